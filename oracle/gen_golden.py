@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE'S OWN code (oracle/_ref/libwbref.so).
+
+Run in the container that has /root/reference:   python oracle/gen_golden.py
+The fixtures are data only — seeds/parameters of the synthetic inputs and the outputs the reference's
+translation units produced for them; no reference source is stored.  Block sequencing for the session
+fixtures comes from the oracle's restated sequencer (the reference's engine.cpp/track.cpp cannot be
+built here); every sample value in the fixtures was computed by reference code."""
+import ctypes as C
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_ffi as O          # noqa: E402
+from refmix import RefMixer     # noqa: E402
+from whitebox_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+SAMPLER_CASES = [(fmt, rate, speed) for fmt in ("f32", "i16", "i24", "i32")
+                 for rate, speed in ((48000, 1.0), (44100, 1.0), (48000, 0.5), (48000, 1.75), (96000, 1.0))]
+
+SESSIONS = {
+    "c1": dict(n_tracks=8, clip_channels=1, unity_gain=True, seed=0x5EED0001),
+    "c2": dict(n_tracks=48, seed=0x5EED0002),
+    "c3": dict(n_tracks=40, src_rate=44100, seed=0x5EED0003),
+    "c4": dict(n_tracks=64, n_buses=8, seed=0x5EED0004),
+    "seek": dict(n_tracks=24, seek=True, seed=0x5EED0005),
+    "seek441": dict(n_tracks=24, seek=True, src_rate=44100, seed=0x5EED0006),
+    "hot": dict(n_tracks=16, amp=0.5, seed=0x5EED0007),
+    "i16": dict(n_tracks=12, fmt="i16", seed=0x5EED0008),
+    "i24_441": dict(n_tracks=12, fmt="i24", src_rate=44100, seed=0x5EED0009),
+}
+N_BLOCKS = 6
+
+
+def sampler_ops(fmt, rate, speed):
+    rng = np.random.default_rng(zlib.crc32(repr((fmt, rate, speed)).encode()))
+    start = float(rng.integers(0, 40))
+    ops = []
+    for _ in range(8):
+        n = int(rng.choice([512, 512, 1, 0, 37, 255, 300]))
+        boff = int(rng.integers(0, 512 - n + 1)) if n < 512 else 0
+        gain = float(np.float32(rng.choice([1.0, 0.5, 0.3333])))
+        ops.append((n, boff, gain))
+    return start, ops
+
+
+def main():
+    R = O.ref()
+    if R is None:
+        raise SystemExit("oracle/_ref is not built (needs /root/reference)")
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---- scalars ---------------------------------------------------------------------------------
+    pans = np.linspace(-1, 1, 257).astype(np.float32)
+    pan_bits = np.zeros((5, len(pans), 2), np.uint32)
+    for law in range(5):
+        for i, p in enumerate(pans):
+            l, r = C.c_float(), C.c_float()
+            R.ref_pan_coefs(p, law, C.byref(l), C.byref(r))
+            pan_bits[law, i] = (O.f32_bits(l.value), O.f32_bits(r.value))
+    dbs = np.linspace(-80, 12, 369).astype(np.float32)
+    db_bits = np.array([O.f32_bits(R.ref_db_to_linear(d)) for d in dbs], np.uint32)
+    np.savez_compressed(os.path.join(OUT, "scalars.npz"), pans=pans, pan_bits=pan_bits, dbs=dbs, db_bits=db_bits)
+
+    # ---- Sampler::stream -------------------------------------------------------------------------
+    sam = {}
+    for fmt, rate, speed in SAMPLER_CASES:
+        count = 3000
+        sess = synth.SessionSpec("s", 1, 0xABCD, [synth.SampleSpec(7, 2, rate, count, fmt, 0.7)], [], [0], [0], [False])
+        data = sess.sample_data(0)
+        ptrs = O.void_ptrs(data)
+        start, ops = sampler_ops(fmt, rate, speed)
+        ps, so = C.c_double(), C.c_double()
+        R.ref_sampler_reset(C.byref(ps), C.byref(so), start, speed, float(rate), 48000.0)
+        outs, offs = [], []
+        for n, boff, gain in ops:
+            b = [np.zeros(512, np.float32) for _ in range(2)]
+            R.ref_sampler_stream(C.byref(ps), C.byref(so), O.FMT[fmt], 2, rate, count, C.cast(ptrs, O.c_voidpp), 2, n,
+                                 boff, np.float32(gain), O.planar_ptrs(b))
+            outs.append(np.stack(b))
+            offs.append(so.value)
+        key = f"{fmt}_{rate}_{speed}"
+        sam[key + "_out"] = np.stack(outs)
+        sam[key + "_off"] = np.array(offs, np.float64)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **sam)
+
+    # ---- whole blocks ----------------------------------------------------------------------------
+    manifest = {}
+    for name, kw in SESSIONS.items():
+        kw2 = dict(kw)
+        spec = synth.make_session(name, kw2.pop("n_tracks"), n_blocks=N_BLOCKS, **kw2)
+        e = O.build_oracle_engine(spec)
+        e.enable_seglog()
+        rm = RefMixer(spec)
+        e.play()
+        masters, peaks, buses, gains, segs = [], [], [], [], []
+        for b in range(N_BLOCKS):
+            e.process()
+            log = e.seglog()
+            g = e.gains()
+            m, bu, pk, ends = rm.block(log, g)
+            masters.append(m)
+            peaks.append(pk)
+            gains.append(g)
+            if bu is not None:
+                buses.append(bu)
+            for (t, ds, ln, off, spd, cg, smp), end in zip(log, ends):
+                segs.append((b, t, ds, ln, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(cg), smp, O.f64_bits(end)))
+        e.close()
+        arrs = dict(master=np.stack(masters), peaks=np.stack(peaks), gains=np.stack(gains).view(np.uint32),
+                    segs=np.array(segs, np.uint64))
+        if buses:
+            arrs["buses"] = np.stack(buses)
+        np.savez_compressed(os.path.join(OUT, f"session_{name}.npz"), **arrs)
+        manifest[name] = kw
+    with open(os.path.join(OUT, "sessions.json"), "w") as f:
+        json.dump({"n_blocks": N_BLOCKS, "sessions": manifest}, f, indent=1, sort_keys=True)
+
+    # ---- format conversion -----------------------------------------------------------------------
+    rng = np.random.default_rng(5)
+    src = [np.clip(rng.normal(0, 0.5, 600), -1, 1).astype(np.float32) for _ in range(2)]
+    src[0][:6] = [1.0, -1.0, 0.0, -0.0, 0.9999999, -0.9999999]
+    conv = {"src": np.stack(src)}
+    for name, dt, width in (("i16", np.int16, 1), ("i24_x8", np.int32, 1), ("i32", np.int32, 1), ("f32", np.float32, 1),
+                            ("i24", np.uint8, 3)):
+        b = np.zeros(512 * 2 * width, dt)
+        getattr(R, "ref_f32_to_" + name)(b.ctypes.data, O.planar_ptrs(src), 40, 512, 2)
+        conv[name] = b
+    np.savez_compressed(os.path.join(OUT, "conv.npz"), **conv)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,765 @@
+/*
+ * wb_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY).  See wb_oracle.h for scope and pinning status.
+ * Plain-C restatement of the reference algorithm; each function cites the reference file:line
+ * (relative to /root/reference/src).  Never linked into the product.
+ */
+#include "wb_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * scalar helpers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* core/core_math.h:83-89 — db_to_linear<float>: x <= -72 -> 0, else powf(10, (float)((double)x*0.05)) */
+float wbo_db_to_linear(float db) {
+  if (db <= -72.0f)
+    return 0.0f;
+  return powf(10.0f, (float)((double)db * 0.05));
+}
+
+/* core/panning_law.cpp:9-32 — only Linear and ConstantPower_3db compute anything (Q7). */
+void wbo_pan_coefs(float p, int law, float* left_out, float* right_out) {
+  double boost = 0.0, left = 0.0, right = 0.0;
+  double x = 0.5 * ((double)p + 1.0);
+  const double pi = 3.141592653589793238462643383279502884; /* std::numbers::pi */
+  switch (law) {
+    case WBO_PAN_LINEAR:
+      left = (1.0 - x) * 0.5;
+      right = x * 0.5;
+      boost = 2.0;
+      break;
+    case WBO_PAN_CP_3DB:
+      left = sin(0.5 * pi * (1.0 - x));
+      right = sin(0.5 * pi * x);
+      boost = sqrt(2.0);
+      break;
+    default: break;
+  }
+  *left_out = (float)(left * boost);
+  *right_out = (float)(right * boost);
+}
+
+/* core/core_math.h:209-212 */
+double wbo_beat_to_samples(double beat, double sample_rate, double beat_duration) {
+  double sec = beat * beat_duration;
+  return sec * sample_rate;
+}
+
+/* core/core_math.h:204-207 */
+double wbo_samples_to_beat(double samples, double sample_rate, double beat_duration) {
+  double sec = samples / sample_rate;
+  return sec / beat_duration;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * buffers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* core/audio_buffer.h:67-71 */
+void wbo_clear(float* const* ch, uint32_t n_channels, uint32_t n_samples) {
+  for (uint32_t i = 0; i < n_channels; i++)
+    memset(ch[i], 0, (size_t)n_samples * sizeof(float));
+}
+
+/* core/audio_buffer.h:73-82 */
+void wbo_mix(float* const* dst, const float* const* src, uint32_t n_channels, uint32_t n) {
+  for (uint32_t i = 0; i < n_channels; i++) {
+    const float* o = src[i];
+    float* b = dst[i];
+    for (uint32_t j = 0; j < n; j++)
+      b[j] += o[j];
+  }
+}
+
+/* dsp/dsp_ops.h:27-31 */
+void wbo_apply_gain(float* buf, uint32_t count, float gain) {
+  for (uint32_t i = 0; i < count; i++)
+    buf[i] *= gain;
+}
+
+/* engine/vu_meter.h:20-25: new_level = max(new_level, abs(x)) with math::max(a,b)= b<a?a:b and
+ * math::abs(x)= x<0?-x:x (core_math.h:19-31). */
+float wbo_abs_max(const float* buf, uint32_t count) {
+  float lvl = 0.0f;
+  for (uint32_t i = 0; i < count; i++) {
+    float v = buf[i];
+    float a = v < 0 ? -v : v;
+    lvl = a < lvl ? lvl : a;
+  }
+  return lvl;
+}
+
+/* engine/engine.cpp:1627-1636 (comparison against double literals 1.0 / -1.0) */
+void wbo_master_clamp(float* const* ch, uint32_t n_channels, uint32_t n_samples) {
+  for (uint32_t i = 0; i < n_channels; i++) {
+    float* c = ch[i];
+    for (uint32_t j = 0; j < n_samples; j++) {
+      if (c[j] > 1.0)
+        c[j] = 1.0;
+      else if (c[j] < -1.0)
+        c[j] = -1.0;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * output format conversion, core/audio_format_conv.cpp
+ * ---------------------------------------------------------------------------------------------- */
+
+/* audio_format_conv.cpp:5-20 */
+void wbo_f32_to_interleaved_i16(int16_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
+  const float min_val = -(float)INT16_MIN; /* 32768 */
+  const float max_val = (float)INT16_MAX;  /* 32767 */
+  for (uint32_t c = 0; c < nch; c++) {
+    const float* s = src[c] + off;
+    for (size_t i = 0; i < n; i++) {
+      float v = s[i];
+      dst[i * nch + c] = (int16_t)(v > 0.0f ? v * max_val : v * min_val);
+    }
+  }
+}
+
+/* audio_format_conv.cpp:22-43 — NOTE the reference's destination index ignores the channel and the
+ * channel count (every channel overwrites bytes [0, 3n)); restated as written. */
+void wbo_f32_to_interleaved_i24(uint8_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
+  const float min_val = 8388608.0f, max_val = 8388607.0f;
+  for (uint32_t c = 0; c < nch; c++) {
+    const float* s = src[c] + off;
+    size_t num_bytes = n * 3, j = 0;
+    for (size_t i = 0; i < num_bytes; i += 3) {
+      float v = s[j];
+      int32_t q = v > 0.0f ? (int32_t)(v * max_val) : (int32_t)(v * min_val);
+      dst[i + 0] = (uint8_t)(q);
+      dst[i + 1] = (uint8_t)(q >> 8);
+      dst[i + 2] = (uint8_t)(q >> 16);
+      j++;
+    }
+  }
+}
+
+/* audio_format_conv.cpp:45-60 */
+void wbo_f32_to_interleaved_i24_x8(int32_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
+  const float min_val = 8388608.0f, max_val = 8388607.0f;
+  for (uint32_t c = 0; c < nch; c++) {
+    const float* s = src[c] + off;
+    for (size_t i = 0; i < n; i++) {
+      float v = s[i];
+      int32_t q = v > 0.0f ? (int32_t)(v * max_val) : (int32_t)(v * min_val);
+      dst[i * nch + c] = (int32_t)(q & 0xFFFFFF);
+    }
+  }
+}
+
+/* audio_format_conv.cpp:62-77 */
+void wbo_f32_to_interleaved_i32(int32_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
+  const double min_val = -(double)INT32_MIN, max_val = (double)INT32_MAX;
+  for (uint32_t c = 0; c < nch; c++) {
+    const float* s = src[c] + off;
+    for (size_t i = 0; i < n; i++) {
+      float v = s[i];
+      dst[i * nch + c] = (int32_t)(v > 0.0f ? (double)v * max_val : (double)v * min_val);
+    }
+  }
+}
+
+/* audio_format_conv.cpp:79-91 */
+void wbo_f32_to_interleaved_f32(float* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
+  for (uint32_t c = 0; c < nch; c++) {
+    const float* s = src[c] + off;
+    for (size_t i = 0; i < n; i++)
+      dst[i * nch + c] = s[i];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler
+ * ---------------------------------------------------------------------------------------------- */
+
+/* dsp/sampler.h:18-27 */
+void wbo_sampler_reset(wbo_sampler* s, double sample_offset, double speed, double src_rate, double dst_rate) {
+  s->playback_speed = (src_rate / dst_rate) * speed;
+  s->sample_offset = sample_offset;
+}
+
+static inline float clampf(float x, float lo, float hi) { /* core_math.h:33-37 */
+  float m = x < hi ? x : hi;
+  return m > lo ? m : lo;
+}
+static inline double clampd(double x, double lo, double hi) {
+  double m = x < hi ? x : hi;
+  return m > lo ? m : lo;
+}
+
+/* dsp/sampler.cpp:34-59 sample_linear<T,Fmt>; normalisers from :7-18.
+ * Q1: the reference indexes src_channels[i] with NO "% channels" wrap here (reads out of bounds for
+ * a mono clip into a stereo bus); the build DEFINES the wrap (i % channels) for both paths. */
+static void linear_f32(const wbo_sample* smp, uint32_t nch, uint32_t n, uint32_t boff, float gain, double speed,
+                       double pos, float* const* out) {
+  for (int32_t i = 0; i < (int32_t)nch; i++) {
+    const float* src = (const float*)smp->data[(uint32_t)i % smp->channels];
+    float* dst = out[i] + boff;
+    for (int32_t j = 0; j < (int32_t)n; j++) {
+      const double x = pos + ((double)j * speed);
+      const int64_t ix = (int64_t)x;
+      const float fx = (float)(x - (double)ix);
+      const float a = (float)(1.0f * (float)src[ix]);
+      const float b = (float)(1.0f * (float)src[ix + 1]);
+      const float s = a + fx * (b - a);
+      dst[j] += s * gain;
+    }
+  }
+}
+
+static void linear_i16(const wbo_sample* smp, uint32_t nch, uint32_t n, uint32_t boff, float gain, double speed,
+                       double pos, float* const* out) {
+  const float norm = (float)(1.0 / (double)INT16_MAX); /* sampler.cpp:9-10 */
+  for (int32_t i = 0; i < (int32_t)nch; i++) {
+    const int16_t* src = (const int16_t*)smp->data[(uint32_t)i % smp->channels];
+    float* dst = out[i] + boff;
+    for (int32_t j = 0; j < (int32_t)n; j++) {
+      const double x = pos + ((double)j * speed);
+      const int64_t ix = (int64_t)x;
+      const float fx = (float)(x - (double)ix);
+      const float a = (float)(norm * (float)src[ix]);
+      const float b = (float)(norm * (float)src[ix + 1]);
+      const float s = a + fx * (b - a);
+      dst[j] += s * gain;
+    }
+  }
+}
+
+static void linear_i32c(const wbo_sample* smp, double norm, uint32_t nch, uint32_t n, uint32_t boff, float gain,
+                        double speed, double pos, float* const* out) {
+  for (int32_t i = 0; i < (int32_t)nch; i++) {
+    const int32_t* src = (const int32_t*)smp->data[(uint32_t)i % smp->channels];
+    float* dst = out[i] + boff;
+    for (int32_t j = 0; j < (int32_t)n; j++) {
+      const double x = pos + ((double)j * speed);
+      const int64_t ix = (int64_t)x;
+      const float fx = (float)(x - (double)ix);
+      const float a = (float)(norm * (double)src[ix]);
+      const float b = (float)(norm * (double)src[ix + 1]);
+      const float s = a + fx * (b - a);
+      dst[j] += s * gain;
+    }
+  }
+}
+
+/* dsp/sampler.cpp:88-210 */
+void wbo_sampler_stream(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
+                        uint32_t buffer_offset, float gain, float* const* dst) {
+  const float i16_norm = 1.0f / (float)INT16_MAX;                 /* :95 */
+  const double i24_norm = 1.0 / (double)((1 << 23) - 1);          /* :96 */
+  const double i32_norm = 1.0 / (double)INT32_MAX;                /* :97 */
+
+  if (s->sample_offset >= (double)smp->count)                     /* :99-100 (size_t -> double compare) */
+    return;
+
+  double stream_max_length = ((double)smp->count - s->sample_offset) / s->playback_speed; /* :102 */
+  double next_sample_offset = s->sample_offset + ((double)num_samples * s->playback_speed); /* :103 */
+  double cl = ceil(stream_max_length);
+  uint32_t lim = (uint32_t)cl;                                     /* :104 */
+  uint32_t n = num_samples < lim ? num_samples : lim;
+
+  if (s->playback_speed == 1.0) {                                  /* :106 (Q3) */
+    uint32_t off = (uint32_t)s->sample_offset;                     /* :107 */
+    switch (smp->format) {
+      case WBO_FMT_I16:                                            /* :109-120 */
+        for (uint32_t i = 0; i < num_channels; i++) {
+          const int16_t* d = (const int16_t*)smp->data[i % smp->channels];
+          float* o = dst[i] + buffer_offset;
+          for (uint32_t j = 0; j < n; j++) {
+            float v = (float)d[off + j] * i16_norm;
+            o[j] += clampf(v, -1.0f, 1.0f) * gain;
+          }
+        }
+        break;
+      case WBO_FMT_I24:                                            /* :121-132 */
+        for (uint32_t i = 0; i < num_channels; i++) {
+          const int32_t* d = (const int32_t*)smp->data[i % smp->channels];
+          float* o = dst[i] + buffer_offset;
+          for (uint32_t j = 0; j < n; j++) {
+            double v = (double)d[off + j] * i24_norm;
+            o[j] += (float)clampd(v, -1.0, 1.0) * gain;
+          }
+        }
+        break;
+      case WBO_FMT_I32:                                            /* :133-144 */
+        for (uint32_t i = 0; i < num_channels; i++) {
+          const int32_t* d = (const int32_t*)smp->data[i % smp->channels];
+          float* o = dst[i] + buffer_offset;
+          for (uint32_t j = 0; j < n; j++) {
+            double v = (double)d[off + j] * i32_norm;
+            o[j] += (float)clampd(v, -1.0, 1.0) * gain;
+          }
+        }
+        break;
+      case WBO_FMT_F32:                                            /* :145-156 */
+        for (uint32_t i = 0; i < num_channels; i++) {
+          const float* d = (const float*)smp->data[i % smp->channels];
+          float* o = dst[i] + buffer_offset;
+          for (uint32_t j = 0; j < n; j++) {
+            float v = d[off + j];
+            o[j] += v * gain;
+          }
+        }
+        break;
+      default: break;
+    }
+  } else {                                                         /* :159-207 */
+    switch (smp->format) {
+      case WBO_FMT_I16: linear_i16(smp, num_channels, n, buffer_offset, gain, s->playback_speed, s->sample_offset, dst); break;
+      case WBO_FMT_I24:
+        linear_i32c(smp, (double)(1.0 / (double)((1 << 23) - 1)), num_channels, n, buffer_offset, gain,
+                    s->playback_speed, s->sample_offset, dst);
+        break;
+      case WBO_FMT_I32:
+        linear_i32c(smp, (double)(1.0 / (double)INT32_MAX), num_channels, n, buffer_offset, gain, s->playback_speed,
+                    s->sample_offset, dst);
+        break;
+      case WBO_FMT_F32: linear_f32(smp, num_channels, n, buffer_offset, gain, s->playback_speed, s->sample_offset, dst); break;
+      default: break;
+    }
+  }
+
+  s->sample_offset = next_sample_offset;                           /* :209 */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * engine / tracks
+ * ---------------------------------------------------------------------------------------------- */
+
+enum { PARAM_VOLUME = 0, PARAM_PAN = 1, PARAM_MUTE = 2 }; /* track.h:29-34 */
+
+wbo_engine* wbo_engine_create(uint32_t out_channels, uint32_t buffer_size, uint32_t sample_rate) {
+  wbo_engine* e = (wbo_engine*)calloc(1, sizeof(wbo_engine));
+  e->out_channels = out_channels;
+  e->buffer_size = buffer_size;
+  e->sample_rate = sample_rate;
+  e->ppq = 96.0; /* engine.h:43 */
+  for (uint32_t c = 0; c < out_channels && c < 16; c++)
+    e->mixbuf[c] = (float*)calloc(buffer_size, sizeof(float));
+  return e;
+}
+
+void wbo_engine_destroy(wbo_engine* e) {
+  if (!e) return;
+  for (uint32_t i = 0; i < e->n_tracks; i++) free(e->tracks[i].clips);
+  free(e->tracks);
+  free(e->samples);
+  for (int c = 0; c < 16; c++) free(e->mixbuf[c]);
+  free(e->busbuf);
+  free(e->seglog);
+  free(e);
+}
+
+/* engine.cpp:24-30 */
+void wbo_engine_set_bpm(wbo_engine* e, double bpm) { e->beat_duration = 60.0 / bpm; }
+
+/* engine.cpp:32-41 */
+void wbo_engine_set_playhead(wbo_engine* e, double beat) {
+  e->playhead_start = beat;
+  e->playhead = beat;
+}
+
+void wbo_engine_set_buses(wbo_engine* e, uint32_t n_buses) {
+  e->n_buses = n_buses;
+  free(e->busbuf);
+  e->busbuf = n_buses ? (float*)calloc((size_t)n_buses * e->out_channels * e->buffer_size, sizeof(float)) : NULL;
+}
+
+int wbo_engine_add_sample(wbo_engine* e, int format, uint32_t channels, uint32_t sample_rate, size_t count,
+                          const void* const* planar) {
+  if (e->n_samples_tab == e->cap_samples) {
+    e->cap_samples = e->cap_samples ? e->cap_samples * 2 : 64;
+    e->samples = (wbo_sample*)realloc(e->samples, e->cap_samples * sizeof(wbo_sample));
+  }
+  wbo_sample* s = &e->samples[e->n_samples_tab];
+  s->format = format;
+  s->channels = channels;
+  s->sample_rate = sample_rate;
+  s->count = count;
+  s->data = planar;
+  return (int)e->n_samples_tab++;
+}
+
+static void push_msg(wbo_track* t, uint32_t id, double value) {
+  if (t->n_msgs < WBO_MAX_MSGS) { /* reference ring has capacity 64 and the producer spins when full */
+    t->msgs[t->n_msgs].id = id;
+    t->msgs[t->n_msgs].value = value;
+    t->n_msgs++;
+  }
+}
+
+/* track.cpp:47-57 */
+void wbo_track_set_volume(wbo_engine* e, int track, float db) {
+  float v = wbo_db_to_linear(db);
+  push_msg(&e->tracks[track], PARAM_VOLUME, (double)v);
+}
+/* track.cpp:59-68 */
+void wbo_track_set_pan(wbo_engine* e, int track, float pan) { push_msg(&e->tracks[track], PARAM_PAN, (double)pan); }
+/* track.cpp:70-79 */
+void wbo_track_set_mute(wbo_engine* e, int track, int mute) {
+  push_msg(&e->tracks[track], PARAM_MUTE, (double)(mute ? 1 : 0));
+}
+void wbo_track_set_bus(wbo_engine* e, int track, int bus) { e->tracks[track].bus = bus; }
+
+/* engine.cpp:200-208 + Track::Track() track.cpp:22-27 */
+int wbo_engine_add_track(wbo_engine* e) {
+  if (e->n_tracks == e->cap_tracks) {
+    e->cap_tracks = e->cap_tracks ? e->cap_tracks * 2 : 64;
+    e->tracks = (wbo_track*)realloc(e->tracks, e->cap_tracks * sizeof(wbo_track));
+  }
+  wbo_track* t = &e->tracks[e->n_tracks];
+  memset(t, 0, sizeof(*t));
+  t->current_event.clip = -1;
+  t->bus = -1;
+  int idx = (int)e->n_tracks++;
+  wbo_track_set_volume(e, idx, 0.0f);
+  wbo_track_set_pan(e, idx, 0.0f);
+  wbo_track_set_mute(e, idx, 0);
+  return idx;
+}
+
+/* core/algorithm.h:24-40 with the predicate clip->max_time <= value */
+static uint32_t lower_bound_max_time(const wbo_clip* clips, uint32_t n, double value) {
+  int64_t left = 0, right = (int64_t)n - 1;
+  while (left < right) {
+    int64_t middle = (left + right) >> 1;
+    if (clips[middle].max_time <= value)
+      left = middle + 1;
+    else
+      right = middle;
+  }
+  return (uint32_t)right;
+}
+
+/* track.cpp:182-213 — returns 1 and *idx when a next clip exists */
+static int find_next_clip(const wbo_track* t, double time_pos, uint32_t* idx) {
+  if (t->n_clips == 0) return 0;
+  if (t->clips[t->n_clips - 1].max_time < time_pos) return 0;
+  *idx = lower_bound_max_time(t->clips, t->n_clips, time_pos); /* clips[i].id == i after ordering */
+  return 1;
+}
+
+/* track.cpp:220-232 */
+static void reset_playback_state(wbo_track* t, double time_pos, int refresh_voices) {
+  if (!refresh_voices) {
+    uint32_t idx = 0;
+    int has = find_next_clip(t, time_pos, &idx);
+    t->has_clip_idx = has;
+    t->clip_idx = idx;
+    t->partially_ended = 0;
+  }
+  t->refresh_voice = refresh_voices;
+}
+
+/* track.cpp:112-157 reduced to its "nothing overlaps" answer */
+static int range_is_free(const wbo_track* t, double min, double max) {
+  if (t->n_clips == 0) return 1;
+  if (max <= t->clips[0].min_time) return 1;
+  if (min >= t->clips[t->n_clips - 1].max_time) return 1;
+  uint32_t first = lower_bound_max_time(t->clips, t->n_clips, min);
+  uint32_t last = lower_bound_max_time(t->clips, t->n_clips, max);
+  if (first == last && (max <= t->clips[first].min_time || min >= t->clips[last].max_time)) return 1;
+  return 0;
+}
+
+static int cmp_clip(const void* a, const void* b) {
+  double x = ((const wbo_clip*)a)->min_time, y = ((const wbo_clip*)b)->min_time;
+  return (x > y) - (x < y);
+}
+
+/* engine.cpp:293-309 add_audio_clip -> :409-461 add_to_cliplist (non-overlapping inserts only) */
+int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double max_time, double start_offset,
+                              int sample, double speed, float gain) {
+  wbo_track* t = &e->tracks[track];
+  int back = t->n_clips && t->clips[t->n_clips - 1].max_time < min_time;
+  int front = t->n_clips && t->clips[0].min_time > max_time;
+  if (t->n_clips && !back && !front && !range_is_free(t, min_time, max_time))
+    return -3; /* reserve_track_region trimming: out of scope */
+  if (t->n_clips == t->cap_clips) {
+    t->cap_clips = t->cap_clips ? t->cap_clips * 2 : 4;
+    t->clips = (wbo_clip*)realloc(t->clips, t->cap_clips * sizeof(wbo_clip));
+  }
+  wbo_clip* c = &t->clips[t->n_clips++];
+  c->min_time = min_time;
+  c->max_time = max_time;
+  c->start_offset = start_offset;
+  c->speed = speed;
+  c->gain = gain;
+  c->sample = sample;
+  c->internal_state_changed = 0;
+  /* track.cpp:159-180 update_clip_ordering: sort by min_time (distinct for non-overlapping clips) */
+  qsort(t->clips, t->n_clips, sizeof(wbo_clip), cmp_clip);
+  reset_playback_state(t, e->playhead, 1); /* engine.cpp:416,426,437,449,459 */
+  return 0;
+}
+
+/* engine.cpp:68-80 */
+void wbo_engine_play(wbo_engine* e) {
+  for (uint32_t i = 0; i < e->n_tracks; i++)
+    reset_playback_state(&e->tracks[i], e->playhead_start, 0);
+  e->sample_position = 0;
+  e->playing = 1;
+}
+
+/* engine.cpp:82-93 + Track::stop track.cpp:249-256 */
+void wbo_engine_stop(wbo_engine* e) {
+  e->playing = 0;
+  e->playhead = e->playhead_start;
+  for (uint32_t i = 0; i < e->n_tracks; i++) {
+    wbo_track* t = &e->tracks[i];
+    memset(&t->current_event, 0, sizeof(t->current_event));
+    t->current_event.clip = -1;
+    t->n_events = 0;
+  }
+}
+
+static void push_event(wbo_track* t, int type, uint32_t buffer_offset, double time, double speed,
+                       uint64_t sample_offset, int clip) {
+  if (t->n_events < WBO_MAX_EVENTS) {
+    wbo_event* ev = &t->events[t->n_events++];
+    ev->type = type;
+    ev->buffer_offset = buffer_offset;
+    ev->time = time;
+    ev->speed = speed;
+    ev->sample_offset = sample_offset;
+    ev->clip = clip;
+  }
+}
+
+/* track.cpp:258-451, audio branch (MIDI clips / recording are out of scope) */
+void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, double end_time, double sample_position,
+                             double beat_duration, double buffer_duration, double sample_rate, uint32_t buffer_size) {
+  (void)e;
+  (void)buffer_duration;
+  if (t->n_clips == 0) {                                           /* :268-284 */
+    if (t->refresh_voice) {
+      push_event(t, WBO_EV_STOP, 0, start_time, 0.0, 0, -1);
+      t->has_clip_idx = 0;
+      t->refresh_voice = 0;
+    }
+    return;
+  }
+
+  uint32_t num_clips = t->n_clips;
+  if (t->refresh_voice) {                                          /* :287-340 */
+    uint32_t at = 0;
+    int has_at = find_next_clip(t, start_time, &at);
+    if (has_at) {
+      if (t->has_clip_idx) {
+        uint32_t idx = t->clip_idx;
+        if (idx < num_clips) {
+          const wbo_clip* clip = &t->clips[at];
+          if (at != idx && start_time >= clip->min_time && start_time <= clip->max_time) {
+            push_event(t, WBO_EV_STOP, 0, start_time, 0.0, 0, -1);
+            t->clip_idx = at;
+            t->partially_ended = 0;
+          } else if (at == idx && (start_time < clip->min_time || start_time > clip->max_time)) {
+            push_event(t, WBO_EV_STOP, 0, start_time, 0.0, 0, -1);
+            t->clip_idx = at;
+            t->partially_ended = 0;
+          }
+        }
+      } else {
+        t->has_clip_idx = 1;
+        t->clip_idx = at;
+      }
+    } else {
+      push_event(t, WBO_EV_STOP, 0, start_time, 0.0, 0, -1);
+      t->has_clip_idx = 0;
+    }
+    t->refresh_voice = 0;
+  }
+
+  if (!t->has_clip_idx)                                            /* :342-346 */
+    return;
+
+  uint32_t next_clip = t->clip_idx;
+  while (next_clip < num_clips) {                                  /* :349-446 */
+    wbo_clip* clip = &t->clips[next_clip];
+    double min_time = clip->min_time;
+    double max_time = clip->max_time;
+
+    if (min_time > end_time)
+      break;
+
+    if (min_time >= start_time) {                                  /* :357-374 started from beginning */
+      double offset_from_start = wbo_beat_to_samples(min_time - start_time, sample_rate, beat_duration);
+      double sample_offset = sample_position + offset_from_start;
+      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      push_event(t, WBO_EV_PLAY, buffer_offset, min_time, clip->speed, (uint64_t)clip->start_offset, (int)next_clip);
+      clip->internal_state_changed = 0;
+    } else if (start_time > min_time && !t->partially_ended) {     /* :375-393 started in the middle (Q5) */
+      double relative_start_time = start_time - min_time;
+      double sample_pos = wbo_beat_to_samples(relative_start_time, sample_rate, beat_duration);
+      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      push_event(t, WBO_EV_PLAY, 0, start_time, clip->speed, sample_offset, (int)next_clip);
+      clip->internal_state_changed = 0;
+    } else if (clip->internal_state_changed && t->partially_ended) { /* :394-419 */
+      double relative_start_time = start_time - min_time;
+      double sample_pos = wbo_beat_to_samples(relative_start_time, sample_rate, beat_duration);
+      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      push_event(t, WBO_EV_STOP, 0, start_time, 0.0, 0, -1);
+      push_event(t, WBO_EV_PLAY, 0, start_time, clip->speed, sample_offset, (int)next_clip);
+      clip->internal_state_changed = 0;
+    }
+
+    if (max_time <= end_time) {                                    /* :421-434 */
+      double offset_from_start = wbo_beat_to_samples(max_time - start_time, sample_rate, beat_duration);
+      double sample_offset = sample_position + offset_from_start;
+      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      push_event(t, WBO_EV_STOP, buffer_offset, max_time, 0.0, 0, -1);
+      t->partially_ended = 0;
+    } else {                                                       /* :435-442 */
+      t->partially_ended = 1;
+      break;
+    }
+    next_clip++;
+  }
+  t->clip_idx = next_clip;                                         /* :450 */
+}
+
+void wbo_engine_enable_seglog(wbo_engine* e, int on) { e->seglog_enabled = on; }
+
+static void log_stream(wbo_engine* e, const wbo_track* t, uint32_t dst_start, uint32_t len) {
+  if (!e->seglog_enabled) return;
+  if (e->n_seglog == e->cap_seglog) {
+    e->cap_seglog = e->cap_seglog ? e->cap_seglog * 2 : 256;
+    e->seglog = (wbo_seglog*)realloc(e->seglog, e->cap_seglog * sizeof(wbo_seglog));
+  }
+  wbo_seglog* s = &e->seglog[e->n_seglog++];
+  s->playback_speed = t->sampler.playback_speed;
+  s->sample_offset = t->sampler.sample_offset;
+  s->track = (uint32_t)(t - e->tracks);
+  s->dst_start = dst_start;
+  s->len = len;
+  s->gain = t->cur_gain;
+  s->sample = t->cur_sample;
+}
+
+/* track.cpp:587-736 (no plugin: write_buffer == output_buffer; Q6 fenced off) */
+static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double sample_rate, double beat_duration,
+                          double buffer_duration_in_beats, double sample_position, double start_time, double end_time,
+                          int playing) {
+  const uint32_t n_samples = e->buffer_size, n_channels = e->out_channels;
+
+  /* :602 process_track_messages (:773-779) then :618-643 apply param_queue */
+  if (playing)
+    wbo_track_process_event(e, t, start_time, end_time, sample_position, beat_duration, buffer_duration_in_beats,
+                            sample_rate, n_samples);
+  for (uint32_t i = 0; i < t->n_msgs; i++) {
+    double value = t->msgs[i].value;
+    switch (t->msgs[i].id) {
+      case PARAM_VOLUME: t->volume = (float)value; break;
+      case PARAM_PAN:
+        t->pan = (float)value;
+        wbo_pan_coefs(t->pan, WBO_PAN_CP_3DB, &t->pan_coeffs[0], &t->pan_coeffs[1]);
+        break;
+      case PARAM_MUTE: t->mute = value > 0.0 ? 1 : 0; break;
+      default: break;
+    }
+  }
+  t->n_msgs = 0; /* :735 */
+
+  if (playing) {                                                   /* :664-724 */
+    uint32_t next = 0, end = t->n_events;
+    uint32_t start_sample = 0;
+    while (start_sample < n_samples) {
+      if (next != end) {
+        const wbo_event* ne = &t->events[next];
+        uint32_t event_length = ne->buffer_offset - start_sample;  /* uint32 arithmetic, as in the reference */
+        if (t->current_event.type == WBO_EV_PLAY) {
+          log_stream(e, t, start_sample, event_length);
+          wbo_sampler_stream(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
+                             t->cur_gain, out);
+        }
+        if (ne->type == WBO_EV_PLAY) {                             /* :687-697 */
+          const wbo_clip* clip = &t->clips[ne->clip];
+          const wbo_sample* smp = &e->samples[clip->sample];
+          wbo_sampler_reset(&t->sampler, (double)ne->sample_offset, ne->speed, (double)smp->sample_rate, sample_rate);
+          t->cur_gain = clip->gain;
+          t->cur_sample = clip->sample;
+        }
+        t->current_event = *ne;
+        start_sample += event_length;
+        next++;
+      } else {
+        uint32_t event_length = n_samples - start_sample;
+        if (t->current_event.type == WBO_EV_PLAY) {
+          log_stream(e, t, start_sample, event_length);
+          wbo_sampler_stream(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
+                             t->cur_gain, out);
+        }
+        start_sample = n_samples;
+      }
+    }
+  }
+
+  float volume = t->mute ? 0.0f : t->volume;                       /* :728-733 */
+  for (uint32_t i = 0; i < n_channels; i++) {
+    float g = volume * t->pan_coeffs[i < 2 ? i : 1];
+    wbo_apply_gain(out[i], n_samples, g);
+    float p = wbo_abs_max(out[i], n_samples);
+    if (i < 2) {
+      t->block_peak[i] = p;
+      if (t->level[i] < p) t->level[i] = p;                        /* vu_meter.h:26-29 */
+    }
+  }
+}
+
+/* engine.cpp:1576-1654.  With n_buses > 0 (extension A13, not in the reference): each track's block is
+ * mixed into its bus in track order (AudioBuffer::mix), then buses 0..n-1 are mixed into the output in
+ * bus order, then the clamp. */
+void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) {
+  const uint32_t F = e->buffer_size, C = e->out_channels;
+  double sample_rate = (double)e->sample_rate;
+  double buffer_duration = (double)F / sample_rate;                /* :1578 */
+  double current_beat_duration = e->beat_duration;
+  double current_playhead_position = e->playhead;
+  double buffer_duration_in_beats = buffer_duration / current_beat_duration; /* :1581 */
+  double next_playhead_pos = e->playhead + buffer_duration_in_beats;         /* :1582 */
+  int currently_playing = e->playing;
+
+  for (uint32_t i = 0; i < e->n_tracks; i++)                       /* :1589-1596 */
+    e->tracks[i].n_events = 0;
+  e->n_seglog = 0;
+
+  wbo_clear(out, C, F);                                            /* :1598 */
+  if (e->n_buses)
+    memset(e->busbuf, 0, (size_t)e->n_buses * C * F * sizeof(float));
+
+  for (uint32_t i = 0; i < e->n_tracks; i++) {                     /* :1600-1617 */
+    wbo_track* t = &e->tracks[i];
+    wbo_clear(e->mixbuf, C, F);
+    track_process(e, t, e->mixbuf, sample_rate, current_beat_duration, buffer_duration_in_beats, e->sample_position,
+                  current_playhead_position, next_playhead_pos, currently_playing);
+    if (e->n_buses && t->bus >= 0) {
+      float* b[16];
+      for (uint32_t c = 0; c < C; c++) b[c] = e->busbuf + ((size_t)t->bus * C + c) * F;
+      wbo_mix(b, (const float* const*)e->mixbuf, C, F);
+    } else {
+      wbo_mix(out, (const float* const*)e->mixbuf, C, F);
+    }
+  }
+  if (e->n_buses) {
+    for (uint32_t u = 0; u < e->n_buses; u++) {
+      const float* b[16];
+      for (uint32_t c = 0; c < C; c++) b[c] = e->busbuf + ((size_t)u * C + c) * F;
+      wbo_mix(out, b, C, F);
+    }
+    if (bus_out) memcpy(bus_out, e->busbuf, (size_t)e->n_buses * C * F * sizeof(float));
+  }
+
+  if (currently_playing) {                                         /* :1619-1623 */
+    e->sample_position += wbo_beat_to_samples(buffer_duration_in_beats, sample_rate, current_beat_duration);
+    e->playhead = next_playhead_pos;
+  }
+
+  wbo_master_clamp(out, C, F);                                     /* :1627-1636 */
+}

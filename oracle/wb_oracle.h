@@ -1,0 +1,174 @@
+/*
+ * wb_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY) for the whitebox per-block mix hot path.
+ *
+ * This is a plain-C restatement of the reference's algorithm (native-m/whitebox @ 2025-07-25),
+ * every function citing the reference file:line it follows.  It exists to CHECK the HIP product
+ * path; it is never linked into, imported by, or called from the product (libwbx.so /
+ * whitebox_amd).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - sample-rate arithmetic (Sampler::stream, panning law, dB->linear, beat<->sample, apply_gain,
+ *     abs-max, AudioBuffer::mix/clear, f32->int conversion) is pinned bit-for-bit against the
+ *     reference's OWN translation units compiled into oracle/_ref/libwbref.so (sampler.cpp,
+ *     panning_law.cpp, audio_format_conv.cpp + header-only audio_buffer.h, dsp_ops.h, core_math.h)
+ *     and against golden vectors generated from that build (tests/golden/).
+ *   - the clip sequencer / block driver (Track::process_event, Track::process, Engine::process)
+ *     cannot be compiled here without a stand-in for third-party spdlog (core/debug.h:5-6), so that
+ *     part is pinned only by the known answers the survey recorded from the real engine
+ *     (SURVEY.md §8(c)): PARITY OF THE SEQUENCER IS PARTIALLY PINNED (KATs only).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (no FMA contraction: the reference build has
+ * none, CMakeLists.txt has no -march/-ffast-math).
+ */
+#ifndef WB_ORACLE_H
+#define WB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AudioFormat values, src/core/audio_format.h:7-20 */
+enum {
+  WBO_FMT_UNKNOWN = 0, WBO_FMT_I8 = 1, WBO_FMT_U8 = 2, WBO_FMT_I16 = 3, WBO_FMT_U16 = 4,
+  WBO_FMT_I24 = 5, WBO_FMT_I24_X8 = 6, WBO_FMT_I32 = 7, WBO_FMT_U32 = 8, WBO_FMT_F32 = 9, WBO_FMT_F64 = 10
+};
+
+/* PanningLaw values, src/core/panning_law.h:5-11 */
+enum { WBO_PAN_LINEAR = 0, WBO_PAN_BALANCED = 1, WBO_PAN_CP_3DB = 2, WBO_PAN_CP_4_5DB = 3, WBO_PAN_CP_6DB = 4 };
+
+/* EventType, src/engine/event.h:11-15 */
+enum { WBO_EV_NONE = 0, WBO_EV_STOP = 1, WBO_EV_PLAY = 2 };
+
+/* ---- scalar helpers ------------------------------------------------------------------------ */
+float wbo_db_to_linear(float db);                                  /* core_math.h:83-89 */
+void wbo_pan_coefs(float p, int law, float* left, float* right);   /* panning_law.cpp:9-32 */
+double wbo_beat_to_samples(double beat, double sample_rate, double beat_duration);   /* core_math.h:209-212 */
+double wbo_samples_to_beat(double samples, double sample_rate, double beat_duration); /* core_math.h:204-207 */
+
+/* ---- buffers (planar fp32, AudioBuffer<float> semantics) ------------------------------------ */
+void wbo_clear(float* const* ch, uint32_t n_channels, uint32_t n_samples);                  /* audio_buffer.h:67-71 */
+void wbo_mix(float* const* dst, const float* const* src, uint32_t n_channels, uint32_t n);  /* audio_buffer.h:73-82 */
+void wbo_apply_gain(float* buf, uint32_t count, float gain);                                /* dsp_ops.h:27-31 */
+float wbo_abs_max(const float* buf, uint32_t count);        /* vu_meter.h:20-25 (== dsp_ops.h:10-19) */
+void wbo_master_clamp(float* const* ch, uint32_t n_channels, uint32_t n_samples);           /* engine.cpp:1627-1636 */
+
+/* ---- output format conversion, audio_format_conv.cpp:5-106 ------------- */
+void wbo_f32_to_interleaved_i16(int16_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch);
+void wbo_f32_to_interleaved_i24(uint8_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch);
+void wbo_f32_to_interleaved_i24_x8(int32_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch);
+void wbo_f32_to_interleaved_i32(int32_t* dst, const float* const* src, size_t off, size_t n, uint32_t nch);
+void wbo_f32_to_interleaved_f32(float* dst, const float* const* src, size_t off, size_t n, uint32_t nch);
+
+/* ---- Sample / Sampler, src/dsp/sample.h:18-28, src/dsp/sampler.h:13-36 ----------------------- */
+typedef struct wbo_sample {
+  int format;              /* WBO_FMT_* ; I24 is stored in int32 containers (sample.cpp:20) */
+  uint32_t channels;
+  uint32_t sample_rate;
+  size_t count;            /* frames; each channel array must hold count + 16 readable frames (sample.h:19) */
+  const void* const* data; /* data[channel] planar */
+} wbo_sample;
+
+typedef struct wbo_sampler {
+  double playback_speed;
+  double sample_offset;
+} wbo_sampler;
+
+void wbo_sampler_reset(wbo_sampler* s, double sample_offset, double speed, double src_rate, double dst_rate); /* sampler.h:18-27 */
+void wbo_sampler_stream(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
+                        uint32_t buffer_offset, float gain, float* const* dst);                              /* sampler.cpp:88-210 */
+
+/* ---- clips / events / tracks / engine -------------------------------------------------------- */
+typedef struct wbo_clip {     /* src/engine/clip.h:39-45,55-75 (audio fields only) */
+  double min_time, max_time;  /* beats */
+  double start_offset;        /* samples */
+  double speed;               /* AudioClip::speed */
+  float gain;                 /* AudioClip::gain */
+  int sample;                 /* index into engine sample table */
+  int internal_state_changed;
+} wbo_clip;
+
+typedef struct wbo_event {    /* src/engine/event.h:66-74 */
+  int type;
+  uint32_t buffer_offset;
+  double time;
+  double speed;
+  uint64_t sample_offset;
+  int clip;                   /* index into the track's clip list, -1 if none */
+} wbo_event;
+
+#define WBO_MAX_EVENTS 64
+#define WBO_MAX_MSGS 64
+
+typedef struct wbo_track {
+  wbo_clip* clips; uint32_t n_clips, cap_clips;     /* sorted by min_time (track.cpp:176) */
+  /* TrackEventState, track.h:36-44 */
+  int has_clip_idx; uint32_t clip_idx; int refresh_voice; int partially_ended;
+  wbo_event events[WBO_MAX_EVENTS]; uint32_t n_events;
+  wbo_event current_event;                            /* track.h:112 */
+  float cur_gain; int cur_sample;                     /* resolved from current_event.clip at event time */
+  wbo_sampler sampler;
+  /* TrackParameterState (audio side), track.h:46-53 */
+  float volume, pan, pan_coeffs[2]; int mute;
+  /* pending TrackMessage::ParamChange, track.cpp:47-79,773-779 */
+  struct { uint32_t id; double value; } msgs[WBO_MAX_MSGS]; uint32_t n_msgs;
+  float level[2];                                     /* VUMeter::level (max since last read) */
+  float block_peak[2];                                /* max|m| of the last processed block */
+  int bus;                                            /* extension A13: sub-bus id, -1 = none */
+} wbo_track;
+
+typedef struct wbo_seglog {  /* one Sampler::stream call issued by Track::process (track.cpp:678,718) */
+  double playback_speed;      /* Sampler::playback_speed_ */
+  double sample_offset;       /* Sampler::sample_offset_ before the call */
+  uint32_t track, dst_start, len;
+  float gain;
+  int sample;
+} wbo_seglog;
+
+typedef struct wbo_engine {
+  wbo_track* tracks; uint32_t n_tracks, cap_tracks;
+  wbo_sample* samples; uint32_t n_samples_tab, cap_samples;
+  uint32_t out_channels, buffer_size, sample_rate;    /* set_audio_channel_config, engine.cpp:43-57 */
+  double ppq;                                         /* engine.h:43 */
+  double playhead, playhead_start, sample_position, beat_duration;
+  int playing;
+  uint32_t n_buses;                                   /* 0 = reference behaviour (no buses) */
+  float* mixbuf[16];                                  /* Engine::mixing_buffer */
+  float* busbuf;                                      /* [n_buses][C][F] scratch (extension) */
+  wbo_seglog* seglog; uint32_t n_seglog, cap_seglog;  /* stream calls of the LAST processed block (if enabled) */
+  int seglog_enabled;
+} wbo_engine;
+
+wbo_engine* wbo_engine_create(uint32_t out_channels, uint32_t buffer_size, uint32_t sample_rate);
+void wbo_engine_destroy(wbo_engine* e);
+void wbo_engine_set_bpm(wbo_engine* e, double bpm);                /* engine.cpp:24-30 */
+void wbo_engine_set_playhead(wbo_engine* e, double beat);          /* engine.cpp:32-41 */
+void wbo_engine_set_buses(wbo_engine* e, uint32_t n_buses);        /* extension A13 */
+int wbo_engine_add_sample(wbo_engine* e, int format, uint32_t channels, uint32_t sample_rate, size_t count,
+                          const void* const* planar);             /* borrows the pointers */
+int wbo_engine_add_track(wbo_engine* e);                          /* engine add_track + Track::Track() track.cpp:22-27 */
+void wbo_track_set_volume(wbo_engine* e, int track, float db);    /* track.cpp:47-57 */
+void wbo_track_set_pan(wbo_engine* e, int track, float pan);      /* track.cpp:59-68 */
+void wbo_track_set_mute(wbo_engine* e, int track, int mute);      /* track.cpp:70-79 */
+void wbo_track_set_bus(wbo_engine* e, int track, int bus);        /* extension A13 */
+/* returns 0 ok, -3 if the clip overlaps an existing one (reserve_track_region trimming is out of scope) */
+int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double max_time, double start_offset,
+                              int sample, double speed, float gain); /* engine.cpp:293-309,409-461 */
+void wbo_engine_play(wbo_engine* e);                               /* engine.cpp:68-80 */
+void wbo_engine_stop(wbo_engine* e);                               /* engine.cpp:82-93 */
+void wbo_engine_enable_seglog(wbo_engine* e, int on);
+/* one block; out[c] planar, out_channels x buffer_size.  engine.cpp:1576-1654
+ * bus_out (optional, may be NULL): [n_buses][C][F] planar bus sums (extension A13). */
+void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out);
+
+/* exposed for KAT tests of the seek math */
+void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, double end_time, double sample_position,
+                             double beat_duration, double buffer_duration, double sample_rate, uint32_t buffer_size);
+                                                                   /* track.cpp:258-451 (audio branch) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
