@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the whitebox mix path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+
+A "step" is one device pass of the hot path (clip sequencer + per-track render/gain/pan/resample +
+peaks + group/bus/master sum + clamp) over one batch of `--blocks` consecutive 512-frame blocks of a
+synthetic session that is already resident in HBM.  The default workload is BASELINE.json configs[2]
+("4096 stereo tracks, gain+pan + linear clip resample (44.1->48 kHz), 1 MI355X") — the configuration the
+metric "…4096 tracks @ 512-frame blocks" is quoted on.  With N GPUs every rank mixes its own 4096 tracks
+(weak scaling = configs[4]: 32768 tracks sharded 8-way) and the un-clamped partial masters are reduced
+to rank 0 with one RCCL reduce per step, then clamped there.
+
+Prints ONE JSON line on rank 0.  `value` = 4096-track-equivalent stereo frames mixed per second over the
+whole job = (total tracks / 4096) x master frames / wall time; at N=1 it is exactly master frames/s.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+F = 512
+SR = 48000
+
+WORKLOADS = {
+    # name: (description, src_rate, n_buses)
+    "c2": ("configs[1]: 256 stereo tracks, per-track gain+pan, 512-frame blocks", 48000, 0),
+    "c3": ("configs[2]: 4096 stereo tracks, gain+pan + linear clip resample 44.1k->48k, 512-frame blocks", 44100, 0),
+    "c4": ("configs[3]: 4096 stereo tracks into 64 sub-buses + master sum, 512-frame blocks", 48000, 64),
+}
+
+
+def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2) -> float:
+    """per master frame read N*C*4*r bytes of clip audio (r = src/dst rate) and write
+    C*4 bytes of master; per block additionally N*C*4 B of peaks and N*32 B of segment/gain tables."""
+    r = src_rate / SR
+    return F * (n_tracks * channels * 4 * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
+
+
+def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, stream_ptr, group_size):
+    from whitebox_amd.engine import Engine
+    desc, src_rate, n_buses = WORKLOADS[workload]
+    eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank),
+                 stream=stream_ptr)
+    eng.set_bpm(120.0)
+    if n_buses:
+        eng.set_buses(n_buses)
+    seed = 0x5EED0000 + {"c2": 2, "c3": 3, "c4": 4}[workload]
+    total_tracks = n_tracks * max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    amp = synth.default_amp(total_tracks)
+    frames = int(math.ceil((session_blocks + 2) * F * (src_rate / SR))) + 64
+    beat_frames = SR * 60.0 / 120.0
+    per_bus = max(1, n_tracks // n_buses) if n_buses else 0
+    for t in range(n_tracks):
+        gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
+        sid = eng.add_sample_synth("f32", 2, src_rate, frames, seed, gt, amp)
+        tr = eng.add_track(f"t{gt}")
+        v, p = synth.track_params(seed, gt)
+        tr.set_volume(float(v))
+        tr.set_pan(float(p))
+        if n_buses:
+            tr.set_bus(min(t // per_bus, n_buses - 1))
+        eng.add_audio_clip(tr, "clip", 0.0, (session_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
+    return eng, seed, amp
+
+
+def rank_device(rank):
+    return int(os.environ.get("LOCAL_RANK", rank))
+
+
+def cpu_baseline(workload, n_tracks, budget_s=12.0):
+    """The oracle (C restatement of the reference's single-threaded Engine::process, bit-identical to the
+    reference's own TUs) timed on ONE host core over a bounded sample of the same workload."""
+    import oracle_ffi as O
+    from whitebox_amd import synth
+    _, src_rate, n_buses = WORKLOADS[workload]
+    L = O.lib()
+    L.wbo_synth_f32.argtypes = [O.c_f32p, C.c_size_t, C.c_uint64, C.c_float, C.c_size_t]
+    sample_blocks = 24
+    seed = 0x5EED0000 + {"c2": 2, "c3": 3, "c4": 4}[workload]
+    amp = np.float32(synth.default_amp(n_tracks))
+    frames = int(math.ceil((sample_blocks + 2) * F * (src_rate / SR))) + 64
+    e = O.OracleEngine(2, F, SR)
+    e.set_bpm(120.0)
+    if n_buses:
+        e.set_buses(n_buses)
+    beat_frames = SR * 60.0 / 120.0
+    per_bus = max(1, n_tracks // n_buses) if n_buses else 0
+    keep = []
+    for t in range(n_tracks):
+        chans = []
+        for c in range(2):
+            a = np.empty(frames + 16, np.float32)
+            L.wbo_synth_f32(a.ctypes.data_as(O.c_f32p), frames, int(synth.clip_key(seed, t, c)), amp, 16)
+            chans.append(a)
+        keep.append(chans)
+        sid = e.add_sample("f32", 2, src_rate, frames, chans)
+        e.add_track()
+        v, p = synth.track_params(seed, t)
+        e.set_volume(t, v)
+        e.set_pan(t, p)
+        if n_buses:
+            e.set_bus(t, min(t // per_bus, n_buses - 1))
+        e.add_audio_clip(t, 0.0, (sample_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
+    out = [np.zeros(F, np.float32) for _ in range(2)]
+    ptrs = O.planar_ptrs(out)
+    blocks_done, elapsed, passes = 0, 0.0, 0
+    while elapsed < budget_s and passes < 64:
+        e.play()
+        t0 = time.perf_counter()
+        for _ in range(sample_blocks):
+            L.wbo_engine_process(e.e, ptrs, None)
+        elapsed += time.perf_counter() - t0
+        e.stop()
+        blocks_done += sample_blocks
+        passes += 1
+    e.close()
+    fps = blocks_done * F / elapsed
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_tracks} tracks x {sample_blocks} blocks x {passes} passes ({workload}), "
+                      f"{elapsed:.1f} s of CPU work, single thread like the reference's audio thread",
+            "host_cpu": model, "host_cores_total": os.cpu_count(),
+            "us_per_block": 1e6 * elapsed / blocks_done}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
+    ap.add_argument("--blocks", type=int, default=64, help="512-frame blocks per step (one device pass)")
+    ap.add_argument("--group-size", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import whitebox_amd as W
+    from whitebox_amd import synth
+
+    n_tracks = args.tracks or (256 if args.workload == "c2" else 4096)
+    desc, src_rate, n_buses = WORKLOADS[args.workload]
+    K = args.blocks
+    total_blocks = (args.warmup + args.steps) * K
+    bytes_per_block_src = n_tracks * 2 * 4 * F * src_rate / SR
+    mem_budget = 96e9
+    session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
+    session_blocks = (session_blocks // K) * K
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng, seed, amp = build_device_session(W, synth, args.workload, n_tracks, K, session_blocks, rank,
+                                              stream.cuda_stream, args.group_size)
+        master = torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda")
+        host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
+        eng.ctx.set_master_target(master.data_ptr())
+        if world > 1:
+            eng.ctx.set_clamp(False)          # partials are clamped on the root AFTER the reduce
+
+        done = 0
+
+        def step():
+            nonlocal done
+            if done + K > session_blocks:     # end of the resident session: rewind (Engine::stop + play)
+                eng.stop()
+                eng.play()
+                done = 0
+            eng.render(K)
+            if world > 1:
+                dist.reduce(master, dst=0)    # RCCL sum of the per-GPU partial masters over xGMI
+                if rank == 0:
+                    eng.ctx.finalize_master(master.data_ptr(), K, True)
+            if rank == 0:
+                host_master.copy_(master, non_blocking=True)
+            done += K
+
+        eng.play()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        eng.ctx.kernel_time(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        mix_ms, mix_n = eng.ctx.kernel_time()
+
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+        # K = 1 latency mode (the real-time callback shape): Engine::process one block at a time
+        lat = None
+        if rank == 0 and args.latency_blocks > 0 and world == 1:
+            eng.ctx.set_master_target(None)
+            out = W.AudioBuffer(F, 2)
+            eng.stop()
+            eng.play()
+            for _ in range(5):
+                eng.process(None, out, float(SR))
+            t1 = time.perf_counter()
+            for _ in range(args.latency_blocks):
+                eng.process(None, out, float(SR))
+            lat = (time.perf_counter() - t1) / args.latency_blocks
+
+    master_frames = args.steps * K * F
+    total_tracks = n_tracks * world
+    value = (total_tracks / 4096.0) * master_frames / dt if n_tracks == 4096 else master_frames / dt * world
+    alg = algorithmic_bytes_per_block(n_tracks, src_rate) * K
+    achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{args.workload}_K{K}_N{n_tracks}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "stereo fp32 frames/sec mixed (4096 tracks @ 512-frame blocks)",
+            "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
+                       "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate,
+                       "sub_buses": n_buses, "group_size": args.group_size or 64,
+                       "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}"},
+            "master_frames_per_s": master_frames / dt,
+            "track_frames_per_s": total_tracks * master_frames / dt,
+            "realtime_factor": master_frames / dt / SR,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "wbx::mix_kernel<8>",
+                         "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n),
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if lat is not None:
+            line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * lat, "frames_per_s": F / lat}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, n_tracks, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

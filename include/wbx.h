@@ -1,0 +1,195 @@
+/*
+ * wbx.h — C ABI of the MI355X-native whitebox mix path (libwbx.so).
+ *
+ * Drop-in boundary for the reference's per-block multitrack mix
+ *   Engine::process -> Track::process -> dsp::Sampler::stream / dsp::apply_gain /
+ *   VUMeter::push_samples -> AudioBuffer::mix -> master clamp
+ * (reference: src/engine/engine.cpp:1576-1654, src/engine/track.cpp:587-736,
+ *  src/dsp/sampler.cpp:34-59,88-210, src/dsp/dsp_ops.h:27-31, src/engine/vu_meter.h:20-30,
+ *  src/core/audio_buffer.h:73-82).
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *   Layer 1  wbx_ctx      the device mix runtime.  The HOST keeps the reference's own clip
+ *                         sequencer (Track::process_event) and hands the device, per block and
+ *                         track, the Sampler::stream calls it would have made ("segments") plus
+ *                         the block-rate gains; the device does every per-sample operation.
+ *   Layer 2  wbx_engine   the whole path, sequencer included, resident on the device behind the
+ *                         reference's Engine/Track surface (set_bpm, add_track, add_audio_clip,
+ *                         Track::set_volume/pan/mute, play/stop, process).
+ *
+ * Conventions: every call returns wbx_status (0 = ok; negatives mirror the reference's
+ * PluginResult, src/plughost/plugin_interface.h:24-29, plus device errors); host pointers are
+ * caller-owned, device memory is ctx-owned; one submitting thread per ctx (the reference has exactly
+ * one audio thread, engine.cpp:1587); no callbacks into the host; nothing here falls back to the CPU
+ * — without a gfx950 device wbx_create/wbx_engine_create return WBX_ERR_NO_DEVICE.
+ */
+#ifndef WBX_H
+#define WBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int wbx_status;
+enum {
+  WBX_OK = 0,
+  WBX_ERR_FAILED = -1,        /* PluginResult::Failed        */
+  WBX_ERR_UNIMPLEMENTED = -2, /* PluginResult::Unimplemented */
+  WBX_ERR_UNSUPPORTED = -3,   /* PluginResult::Unsupported   */
+  WBX_ERR_INVALID = -4,       /* bad argument                */
+  WBX_ERR_NO_DEVICE = -5,     /* no HIP device / not gfx950  */
+  WBX_ERR_DEVICE = -6,        /* HIP runtime error (see wbx_last_error) */
+  WBX_ERR_OOM = -7,
+  WBX_ERR_OVERFLOW = -8       /* more segments in one block than the plan can hold */
+};
+
+/* AudioFormat of clip storage — values of the reference enum, src/core/audio_format.h:7-20.
+ * I24 clips are stored in 32-bit containers, as the reference does (src/dsp/sample.cpp:20). */
+enum { WBX_FMT_I16 = 3, WBX_FMT_I24 = 5, WBX_FMT_I32 = 7, WBX_FMT_F32 = 9 };
+
+/* Interleaved device-output formats for wbx_*_fetch_interleaved — reference converters
+ * src/core/audio_format_conv.cpp:5-91 (I24 packed is WBX_ERR_UNSUPPORTED: the reference writer
+ * ignores the channel, audio_format_conv.cpp:22-43). */
+enum { WBX_OUT_I16 = 3, WBX_OUT_I24_X8 = 6, WBX_OUT_I32 = 7, WBX_OUT_F32 = 9 };
+
+typedef struct wbx_config {
+  int32_t device;          /* HIP device ordinal */
+  uint32_t max_tracks;     /* N upper bound */
+  uint32_t max_blocks;     /* K upper bound per submit/render (>= 1) */
+  uint32_t block_frames;   /* F, Engine::audio_buffer_size (reference default 512, src/config.cpp:146); multiple of 4 */
+  uint32_t channels;       /* C, output channels: 1 or 2 (reference: 2, src/config.cpp:224) */
+  uint32_t sample_rate;    /* destination rate, Engine::audio_sample_rate */
+  uint32_t group_size;     /* tracks summed in index order by one workgroup (0 = default 64).  The
+                              master is the in-order sum of the group sums; group_size >= N reproduces
+                              the reference's strictly sequential order bit-for-bit. */
+  uint32_t max_segments;   /* extra (beyond one per track-block) segment slots per launch; 0 = default */
+  void* stream;            /* hipStream_t to launch on, or NULL: the ctx creates its own */
+} wbx_config;
+
+typedef struct wbx_ctx wbx_ctx;
+typedef struct wbx_engine wbx_engine;
+
+/* One Sampler::stream call of one track in one block (dsp/sampler.h:29-35, sampler.cpp:88-210),
+ * with the sampler state the host's sequencer holds at that point. */
+typedef struct wbx_segment {
+  double sample_offset;    /* Sampler::sample_offset_ before the call */
+  double playback_speed;   /* Sampler::playback_speed_ ((src_rate/dst_rate)*clip speed, sampler.h:24) */
+  uint32_t clip;           /* clip id given to wbx_clip_upload */
+  uint32_t buffer_offset;  /* first destination frame in the block */
+  uint32_t num_samples;    /* frames requested (the device applies the clip-tail limit of sampler.cpp:102-104) */
+  float gain;              /* AudioClip::gain */
+} wbx_segment;
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char* wbx_version(void);
+int wbx_device_count(void);                 /* gfx950 devices visible; 0 without a GPU (never an error) */
+const char* wbx_status_string(wbx_status);
+
+/* ---- layer 1: device mix runtime ------------------------------------------------------------
+ * replaces the body of the per-track loop of Engine::process (engine.cpp:1600-1617) and the master
+ * clamp (engine.cpp:1627-1636). */
+wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out);
+void wbx_destroy(wbx_ctx* ctx);
+const char* wbx_last_error(const wbx_ctx* ctx);
+
+/* Clip audio -> HBM (planar, +16 zero frames of tail padding like Sample::sample_padding,
+ * src/dsp/sample.h:19, sample.cpp:127,140).  Replaces the storage half of `struct Sample`
+ * (sample.h:18-28).  frames < 2^31-16. */
+wbx_status wbx_clip_upload(wbx_ctx* ctx, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                           uint64_t frames, const void* const* planar);
+/* Device-side synthetic clip (bench/test helper; integer-hash generator, DESIGN.md "Synthetic input"). */
+wbx_status wbx_clip_synth(wbx_ctx* ctx, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                          uint64_t frames, uint64_t seed, uint32_t key_track, float amp);
+wbx_status wbx_clip_free(wbx_ctx* ctx, uint32_t clip);
+
+/* Track -> sub-bus routing (extension of the reference, which has no buses: SURVEY §8(a) A13).
+ * track_bus[t] in [0, n_buses) or -1 (straight to master).  NULL / n_buses 0 = reference behaviour. */
+wbx_status wbx_set_routing(wbx_ctx* ctx, uint32_t n_tracks, const int32_t* track_bus, uint32_t n_buses);
+
+/* Mix K blocks of n_tracks tracks.  segs[] holds the Sampler::stream calls grouped by (block, track):
+ * those of (b, t) are segs[seg_offsets[b*n_tracks+t] .. seg_offsets[b*n_tracks+t+1]).  gains[(b*n_tracks+t)*2+c]
+ * = fl(volume*pan_coeffs[c]) (0 when muted), the factor of track.cpp:728-731.  Asynchronous. */
+wbx_status wbx_submit(wbx_ctx* ctx, uint32_t n_blocks, uint32_t n_tracks, const wbx_segment* segs,
+                      const uint32_t* seg_offsets, const float* gains);
+
+/* Results of the last submit (blocks until done).  Any pointer may be NULL.
+ *  master_planar[c] : K*F floats, block after block (the AudioBuffer the audio thread hands to process)
+ *  peaks            : [K][N][C]  max|x| per track/channel/block (VUMeter::push_samples, vu_meter.h:20-25)
+ *  buses            : [K][n_buses][C][F] bus sums */
+wbx_status wbx_fetch(wbx_ctx* ctx, float* const* master_planar, float* peaks, float* buses);
+wbx_status wbx_fetch_interleaved(wbx_ctx* ctx, int out_format, void* dst);  /* K*F*C interleaved samples */
+wbx_status wbx_sync(wbx_ctx* ctx);
+
+/* Multi-GPU: the un-clamped partial master of the last submit, on the device, [K][C][F] fp32 ... */
+wbx_status wbx_partial_master(wbx_ctx* ctx, void** device_ptr, size_t* n_floats);
+/* ... and, on the root after the RCCL reduce, the clamp of engine.cpp:1627-1636 over a device buffer. */
+wbx_status wbx_finalize_master(wbx_ctx* ctx, void* device_partial, uint32_t n_blocks, int clamp);
+wbx_status wbx_set_clamp(wbx_ctx* ctx, int clamp_on_submit); /* 0: leave the master un-clamped (shard mode) */
+/* Write the master of later submits/renders into a caller-owned DEVICE buffer of at least
+ * max_blocks*C*F floats (e.g. the send buffer of the RCCL reduce); NULL restores the ctx-owned one. */
+wbx_status wbx_set_master_target(wbx_ctx* ctx, void* device_buffer);
+
+/* Timing of the dominant kernel (HIP events on the ctx stream): average ms per launch since reset. */
+wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t* mix_launches);
+
+/* ---- layer 2: the engine surface -----------------------------------------------------------
+ * Mirrors wb::Engine / wb::Track (src/engine/engine.h, track.h).  Beats are doubles as in the
+ * reference; all seek / sample-index math is done in the reference's order in fp64/int64. */
+wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out);  /* + set_audio_channel_config, engine.cpp:43-57 */
+void wbx_engine_destroy(wbx_engine* e);
+const char* wbx_engine_last_error(const wbx_engine* e);
+wbx_ctx* wbx_engine_ctx(wbx_engine* e);
+
+wbx_status wbx_engine_set_bpm(wbx_engine* e, double bpm);                       /* engine.cpp:24-30 */
+wbx_status wbx_engine_set_playhead_position(wbx_engine* e, double beat);       /* engine.cpp:32-41 */
+wbx_status wbx_engine_add_track(wbx_engine* e, uint32_t* track_out);           /* engine.cpp:200-208 */
+wbx_status wbx_engine_set_buses(wbx_engine* e, uint32_t n_buses);              /* extension A13 */
+wbx_status wbx_track_set_volume(wbx_engine* e, uint32_t track, float db);      /* track.cpp:47-57 */
+wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t track, float pan);        /* track.cpp:59-68 */
+wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t track, int mute);        /* track.cpp:70-79 */
+wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);      /* extension A13 */
+/* Sample assets (SampleAsset, engine/assets_table.h:22-35): upload once, reference by id from clips. */
+wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
+                                 const void* const* planar, uint32_t* sample_out);
+wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                       uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
+                                       uint32_t* sample_out);
+/* Engine::add_audio_clip (engine.cpp:293-309 -> add_to_cliplist :409-461).  A clip that overlaps an
+ * existing one needs reserve_track_region's trimming (engine.cpp:478-569): WBX_ERR_UNSUPPORTED. */
+wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
+                                     double start_offset, uint32_t sample, double speed, float gain);
+wbx_status wbx_engine_play(wbx_engine* e);                                      /* engine.cpp:68-80 */
+wbx_status wbx_engine_stop(wbx_engine* e);                                      /* engine.cpp:82-93 */
+
+/* Engine::process (engine.cpp:1576-1654): one block into out_planar[c][0..F). */
+wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar);
+/* K consecutive blocks in one device pass (render-ahead / offline): sequencing, mixing, summing and
+ * clamping all on the device.  Asynchronous; results via wbx_fetch(wbx_engine_ctx(e), ...). */
+wbx_status wbx_engine_render(wbx_engine* e, uint32_t n_blocks);
+/* Transport after the last process/render (engine.h:44-46), for bit-exact checks. */
+wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing);
+/* VUMeter::level per track/channel: max since the last call (vu_meter.h:20-40). levels: [n_tracks][C]. */
+wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks);
+
+/* The plan the device sequencer produced for the last process/render: one record per Sampler::stream
+ * call, ordered by (block, track, call).  For seek-math parity checks (bit patterns, not tolerances). */
+typedef struct wbx_plan_record {
+  uint32_t block, track;
+  uint32_t buffer_offset, num_samples;   /* as handed to Sampler::stream */
+  uint32_t num_actual;                   /* after the clip-tail limit, sampler.cpp:102-104 */
+  uint32_t sample;
+  double sample_offset;                  /* Sampler::sample_offset_ before the call */
+  double playback_speed;
+  float gain;
+  uint32_t _pad;
+} wbx_plan_record;
+wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out, size_t cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBX_H */

@@ -763,3 +763,20 @@ void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) {
 
   wbo_master_clamp(out, C, F);                                     /* :1627-1636 */
 }
+
+/* synthetic input (not part of the reference): u = splitmix64(key ^ i); v = ((u>>40) - 2^23) * 2^-23; v*amp */
+static uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pad) {
+  for (size_t i = 0; i < frames; i++) {
+    uint64_t u = splitmix64(key ^ (uint64_t)i);
+    float v = (float)((int64_t)(u >> 40) - (1 << 23)) * 1.1920928955078125e-07f;
+    dst[i] = v * amp;
+  }
+  for (size_t i = 0; i < pad; i++) dst[frames + i] = 0.0f;
+}

@@ -163,6 +163,9 @@ void wbo_engine_enable_seglog(wbo_engine* e, int on);
  * bus_out (optional, may be NULL): [n_buses][C][F] planar bus sums (extension A13). */
 void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out);
 
+/* synthetic input generator (integer hash; input generation only, same bits as whitebox_amd/synth.py) */
+void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pad);
+
 /* exposed for KAT tests of the seek math */
 void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, double end_time, double sample_position,
                              double beat_duration, double buffer_duration, double sample_rate, uint32_t buffer_size);

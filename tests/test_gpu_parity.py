@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path (libwbx.so through the C ABI) against the committed golden vectors
+and against the CPU oracle on the same seeded inputs.  Run on a real MI355X:  pytest -m gpu
+
+Bars (BASELINE.json north_star): output within 1e-6 RMS per sample of the CPU reference (fp32); seek /
+sample-index math bit-exact.  What is actually asserted is tighter wherever the design allows it:
+  * every per-track value is computed with the reference's roundings, so per-track peaks are EQUAL;
+  * the master is BIT-EXACT whenever the summation order equals the reference's (group_size >= N, or
+    the bus layout of config 4), and within 1e-6 RMS otherwise (grouped order);
+  * the device sequencer's plan (buffer offsets, lengths, sample offsets as bit patterns) is EQUAL
+    to the oracle's Sampler::stream call log.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_ffi as O
+import whitebox_amd as W
+from whitebox_amd import synth
+from whitebox_amd.engine import build_engine
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-6     # north_star: "within 1e-6 RMS per sample (fp32)"
+
+
+def rms(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def plan_rows(plan):
+    """(block, track, buffer_offset, num_samples, offset_bits, speed_bits, gain_bits, sample)"""
+    return [(b, t, bo, ns, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (b, t, bo, ns, na, smp, off, spd, g, fl) in plan]
+
+
+def oracle_rows(e, block):
+    return [(block, t, ds, min(ln, 0xFFFF), O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (t, ds, ln, off, spd, g, smp) in e.seglog()]
+
+
+def run_oracle(spec, n_blocks, want_buses=False):
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    masters, peaks, buses, rows = [], [], [], []
+    for b in range(n_blocks):
+        m, bu = e.process(want_buses=want_buses)
+        masters.append(m)
+        peaks.append(e.peaks())
+        rows += oracle_rows(e, b)
+        if bu is not None:
+            buses.append(bu)
+    tr = (e.playhead, e.sample_position)
+    e.close()
+    return np.stack(masters), np.stack(peaks), (np.stack(buses) if buses else None), rows, tr
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors (outputs of the reference's own translation units)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", G.session_names())
+def test_golden_sessions_block_by_block(name):
+    """Engine::process one block at a time.  All fixtures have <= 64 tracks per group, so the summation
+    order IS the reference's: master, bus sums and peaks must match the golden bits."""
+    spec, n_blocks, g = G.load_session(name)
+    eng = build_engine(spec, max_blocks=1)
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    for b in range(n_blocks):
+        eng.process(None, out, float(spec.sample_rate))
+        m = np.stack(out.channel_buffers)
+        assert np.array_equal(bits(m), bits(g["master"][b])), (name, b, rms(m, g["master"][b]))
+        _, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        assert np.array_equal(pk[0], g["peaks"][b]), (name, b)
+        if spec.n_buses:
+            assert np.array_equal(bits(bus[0]), bits(g["buses"][b]))
+        rows = [r[1:] for r in plan_rows(eng.fetch_plan())]
+        gold = [(t, ds, min(ln, 0xFFFF), ob, sb, gb, smp) for (t, ds, ln, ob, sb, gb, smp, _e) in G.golden_segments(g, b)]
+        assert rows == gold, (name, b)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "seek", "seek441", "i24_441"])
+def test_golden_sessions_batched(name):
+    """The same sessions rendered as ONE K-block device pass (sequencer on the device for all K blocks)."""
+    spec, n_blocks, g = G.load_session(name)
+    eng = build_engine(spec, max_blocks=n_blocks)
+    eng.play()
+    eng.render(n_blocks)
+    m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+    assert np.array_equal(bits(m), bits(g["master"]))
+    assert np.array_equal(pk, g["peaks"])
+    if spec.n_buses:
+        assert np.array_equal(bits(bus), bits(g["buses"]))
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# oracle on the same seeded inputs — BASELINE.json configs
+# ---------------------------------------------------------------------------------------------------
+def check_against_oracle(spec, n_blocks, group_size=0, expect_exact=False, device_synth=False):
+    om, opk, obus, orows, otr = run_oracle(spec, n_blocks, want_buses=bool(spec.n_buses))
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=group_size, device_synth=device_synth)
+    eng.play()
+    eng.render(n_blocks)
+    m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+    # seek / sample-index math: bit-exact
+    assert plan_rows(eng.fetch_plan()) == orows
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(otr[0]), O.f64_bits(otr[1]))
+    # per-track values carry the reference's roundings -> peaks equal
+    assert np.array_equal(pk, opk[..., :spec.channels])
+    r = rms(m, om)
+    if expect_exact:
+        assert np.array_equal(bits(m), bits(om)), r
+        if bus is not None:
+            assert np.array_equal(bits(bus), bits(obus))
+    else:
+        assert r <= RMS_TOL, r
+    eng.close()
+    return r
+
+
+def test_config1_8_mono_unity():
+    spec = synth.make_session("c1", 8, clip_channels=1, n_blocks=8, unity_gain=True, seed=0x5EED0001)
+    check_against_oracle(spec, 8, expect_exact=True)
+
+
+def test_config2_256_stereo_gain_pan():
+    spec = synth.make_session("c2", 256, n_blocks=8, seed=0x5EED0002)
+    r = check_against_oracle(spec, 8)
+    assert r <= RMS_TOL
+
+
+def test_config2_exact_order_mode():
+    """group_size >= N reproduces the reference's strictly sequential sum: bit-exact master."""
+    spec = synth.make_session("c2", 256, n_blocks=4, seed=0x5EED0002)
+    check_against_oracle(spec, 4, group_size=256, expect_exact=True)
+
+
+def test_config3_4096_resample():
+    """BASELINE config 3 at full size: 4096 stereo tracks, gain+pan, linear 44.1k -> 48k."""
+    spec = synth.make_session("c3", 4096, src_rate=44100, n_blocks=4, seed=0x5EED0003)
+    r = check_against_oracle(spec, 4)
+    print("config3 rms vs oracle:", r)
+
+
+def test_config3_exact_order_mode():
+    spec = synth.make_session("c3", 1024, src_rate=44100, n_blocks=2, seed=0x5EED0003)
+    check_against_oracle(spec, 2, group_size=1024, expect_exact=True)
+
+
+def test_config4_4096_into_64_buses():
+    """BASELINE config 4 at full size: bus = track/64, group_size 64 -> every bus is summed in the
+    oracle's order and the master in bus order: bit-exact, bus sums included."""
+    spec = synth.make_session("c4", 4096, n_buses=64, n_blocks=4, seed=0x5EED0004)
+    check_against_oracle(spec, 4, expect_exact=True)
+
+
+def test_seek_variants_full_width():
+    for rate in (48000, 44100):
+        spec = synth.make_session("seek", 512, seek=True, src_rate=rate, n_blocks=8, seed=0x5EED0005)
+        check_against_oracle(spec, 8)
+
+
+def test_device_synth_equals_host_upload():
+    spec = synth.make_session("c2", 128, n_blocks=3, seed=0x5EED0002)
+    check_against_oracle(spec, 3, device_synth=True)
+    spec = synth.make_session("i16", 16, fmt="i16", n_blocks=3, seed=0x5EED0008)
+    check_against_oracle(spec, 3, device_synth=True, expect_exact=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------------
+def test_empty_and_ragged():
+    """Tracks without clips, a muted track, N not a multiple of the group size, clips that end
+    (tail + finished sampler), silence after the last clip."""
+    spec = synth.make_session("ragged", 70, n_blocks=3, seed=0x77)
+    spec.clips = [c for c in spec.clips if c.track % 5 != 0]          # every 5th track is empty
+    for c in spec.clips:                                               # short clips: end inside block 2
+        c.max_beat = (2 * 512 + 100 + c.track) / 24000.0
+    spec.mutes[3] = True
+    for s in spec.samples:
+        s.frames = 900 + 7 * s.seed_track                              # sample shorter than the clip: tail path
+    check_against_oracle(spec, 6, group_size=16)
+
+
+def test_not_playing_is_silent_and_transport_frozen():
+    spec = synth.make_session("idle", 8, n_blocks=2)
+    eng = build_engine(spec, max_blocks=2)
+    eng.render(2)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert not m.any() and not pk.any()
+    assert eng.transport() == (0.0, 0.0, False)
+    eng.close()
+
+
+def test_stop_then_play_again_matches_oracle():
+    spec = synth.make_session("replay", 12, n_blocks=6, seed=0x99)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    for phase in range(2):
+        e.play()
+        eng.play()
+        for _ in range(3):
+            om, _ = e.process()
+            eng.process(None, out, 48000.0)
+            assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om))
+        e.stop()
+        eng.stop()
+    e.close()
+    eng.close()
+
+
+def test_parameter_changes_are_block_rate():
+    spec = synth.make_session("params", 6, n_blocks=6, seed=0x31)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=1)
+    e.play()
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    for b in range(5):
+        if b == 2:
+            e.set_volume(1, -20.0); eng.tracks[1].set_volume(-20.0)
+            e.set_pan(2, -0.75); eng.tracks[2].set_pan(-0.75)
+        if b == 3:
+            e.set_mute(0, True); eng.tracks[0].set_mute(True)
+            e.set_volume(4, -80.0); eng.tracks[4].set_volume(-80.0)     # <= -72 dB -> exactly 0
+        om, _ = e.process()
+        eng.process(None, out, 48000.0)
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), b
+    e.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("block,channels", [(128, 2), (256, 2), (1024, 2), (2048, 2), (512, 1), (96, 2)])
+def test_other_block_sizes_and_mono_out(block, channels):
+    spec = synth.make_session("blk", 40, n_blocks=3, block=block, seed=0x42, src_rate=44100)
+    spec.channels = channels
+    check_against_oracle(spec, 3, group_size=8)
+
+
+def test_speed_variants_and_formats():
+    """Time-stretched clips (speed != 1 at equal rates), speed > 1, near-unity speed, all PCM formats."""
+    spec = synth.make_session("speeds", 24, n_blocks=4, seed=0x55)
+    speeds = [0.5, 1.75, 0.999999, 1.0000001, 0.25, 2.5]
+    fmts = ["f32", "i16", "i24", "i32"]
+    for i, c in enumerate(spec.clips):
+        c.speed = speeds[i % len(speeds)]
+    for i, s in enumerate(spec.samples):
+        s.fmt = fmts[(i // 6) % 4]
+        s.amp = 0.05 if s.fmt == "f32" else 1.0
+        s.frames = 6000
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -30.0
+    check_against_oracle(spec, 4, expect_exact=True)
+
+
+def test_clamp_and_unclamped_partial():
+    spec = synth.make_session("hot", 16, n_blocks=2, amp=0.5, seed=0x5EED0007)
+    om, _, _, _, _ = run_oracle(spec, 2)
+    assert (np.abs(om) == 1.0).any()
+    eng = build_engine(spec, max_blocks=2)
+    eng.play()
+    eng.render(2)
+    m, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m), bits(om))
+    eng.close()
+    # shard mode: un-clamped partial, then finalize (the clamp after the reduce)
+    eng = build_engine(spec, max_blocks=2)
+    eng.ctx.set_clamp(False)
+    eng.play()
+    eng.render(2)
+    raw, _, _ = eng.ctx.fetch()
+    assert np.abs(raw).max() > 1.0
+    ptr, n = eng.ctx.partial_master()
+    assert n == 2 * 2 * 512
+    eng.ctx.finalize_master(ptr, 2, True)
+    m2, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m2), bits(om))
+    eng.close()
+
+
+def test_levels_running_max():
+    spec = synth.make_session("lv", 10, n_blocks=4, seed=0x61)
+    _, opk, _, _, _ = run_oracle(spec, 4)
+    eng = build_engine(spec, max_blocks=4)
+    eng.play()
+    eng.render(4)
+    lv = eng.levels()
+    assert np.array_equal(lv, opk.max(axis=0))
+    assert not eng.levels().any()          # VUMeter::update exchanges the level with 0
+    eng.close()
+
+
+def test_interleaved_output_formats():
+    """Next-1 row: planar fp32 master -> interleaved device formats (audio_format_conv.cpp)."""
+    spec = synth.make_session("conv", 16, n_blocks=2, amp=0.2, seed=0x71)
+    om, _, _, _, _ = run_oracle(spec, 2)
+    eng = build_engine(spec, max_blocks=2)
+    eng.play()
+    eng.render(2)
+    L = O.lib()
+    for fmt, dt in (("i16", np.int16), ("i24_x8", np.int32), ("i32", np.int32), ("f32", np.float32)):
+        got = eng.ctx.fetch_interleaved(fmt)
+        exp = []
+        for b in range(2):
+            a = np.zeros(512 * 2, dt)
+            src = [np.ascontiguousarray(om[b][c]) for c in range(2)]
+            getattr(L, "wbo_f32_to_interleaved_" + fmt)(a.ctypes.data, O.planar_ptrs(src), 0, 512, 2)
+            exp.append(a)
+        assert np.array_equal(got.view(np.uint8), np.concatenate(exp).view(np.uint8)), fmt
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# layer 1: host-sequenced segments (the reference keeps Track::process_event, the device mixes)
+# ---------------------------------------------------------------------------------------------------
+def test_layer1_submit_host_sequenced():
+    spec = synth.make_session("l1", 96, seek=True, src_rate=44100, n_blocks=5, seed=0x81)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    ctx = W.MixContext(spec.n_tracks, max_blocks=5, group_size=32)
+    for i, s in enumerate(spec.samples):
+        ctx.clip_upload(i, s.fmt, s.rate, [np.ascontiguousarray(a[:s.frames]) for a in spec.sample_data(i)])
+    segs, offs, gains, masters, peaks = [], [0], [], [], []
+    for b in range(5):
+        m, _ = e.process()
+        masters.append(m)
+        peaks.append(e.peaks())
+        log = e.seglog()
+        per_track = {}
+        for (t, ds, ln, off, spd, g, smp) in log:
+            per_track.setdefault(t, []).append((off, spd, smp, ds, ln, g))
+        for t in range(spec.n_tracks):
+            segs += per_track.get(t, [])
+            offs.append(len(segs))
+        gains.append(e.gains())
+    ctx.submit(5, spec.n_tracks, segs, np.array(offs, np.uint32), np.stack(gains))
+    m, pk, _ = ctx.fetch(peaks=True)
+    assert np.array_equal(pk, np.stack(peaks))
+    assert rms(m, np.stack(masters)) <= RMS_TOL
+    ctx.close()
+    e.close()
+
+
+def test_kernel_timer_reports():
+    spec = synth.make_session("t", 64, n_blocks=2)
+    eng = build_engine(spec, max_blocks=2)
+    eng.play()
+    eng.ctx.kernel_time(reset=True)
+    eng.render(2)
+    eng.render(2)
+    ms, n = eng.ctx.kernel_time()
+    assert n == 2 and ms > 0.0
+    eng.close()

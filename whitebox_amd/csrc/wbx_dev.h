@@ -1,0 +1,138 @@
+// wbx_dev.h — data laid out in HBM, shared by the host runtime and the gfx950 kernels.
+//
+// Layout summary (DESIGN.md "Data layout in HBM"):
+//   clip audio     per clip and channel one 256-B aligned planar array of `frames + 16` elements
+//                  (16 zero frames of tail padding = Sample::sample_padding, reference src/dsp/sample.h:19)
+//   DSample[]      sample/clip table: channel base pointers (mono wraps: both point at channel 0)
+//   DClip[]        per-track clip lists, sorted by min_time (CSR: clip_first[t] .. clip_first[t+1])
+//   DTrackState[]  the sequencer + sampler state a Track carries across blocks
+//   DTrackBlock[]  [K][N] one 64-B record per (block, track): what to render — the "plan"
+//   partial        [K][NG][C][F] fp32 group sums,  master [K][C][F],  bus [K][NB][C][F],  peaks [K][N][C]
+#pragma once
+#include <stdint.h>
+
+namespace wbx {
+
+constexpr uint32_t kPad = 16;          // Sample::sample_padding
+constexpr uint32_t kMaxSegs = 16;      // Sampler::stream calls per (block, track)
+constexpr uint32_t kChunk = kMaxSegs - 1;  // overflow-pool chunk: segments 1..15 of one track-block
+constexpr uint32_t kStage = 64;        // track-block records staged in LDS at a time
+
+enum : uint32_t { FMT_I16 = 3, FMT_I24 = 5, FMT_I32 = 7, FMT_F32 = 9 };  // reference AudioFormat values
+
+// kind of a track-block, decided when the plan is made (wave-uniform dispatch in the mix kernel)
+enum : uint8_t {
+  KIND_SILENT = 0,   // nothing to render
+  KIND_UNITY = 1,    // one fp32 segment covering the whole block at playback_speed == 1.0 (sampler.cpp:145-156)
+  KIND_WINDOW = 2,   // one fp32 segment covering the whole block, 0 < playback_speed <= 1 (linear, sampler.cpp:34-59)
+  KIND_GENERIC = 3   // anything else: several segments, partial coverage, integer PCM, speed > 1
+};
+
+enum : uint8_t {
+  SEG_FINISHED = 1,  // Sampler::stream returned early: sample_offset_ >= count (sampler.cpp:99-100)
+  SEG_CLIPPED = 2    // reference would have written past the block (uint32 wrap of event_length, track.cpp:669)
+};
+
+struct DSample {
+  const void* ch[2];
+  uint64_t count;
+  uint32_t format, channels, sample_rate, _pad;
+};
+
+struct DClip {            // reference src/engine/clip.h:39-45,55-75 (audio fields)
+  double min_time, max_time, start_offset, speed;
+  float gain;
+  uint32_t sample;
+  uint32_t internal_state_changed;
+  uint32_t _pad;
+};
+
+struct DTrackState {      // reference TrackEventState track.h:36-44, current_audio_event track.h:112, Sampler sampler.h:13-16
+  uint32_t has_clip_idx, clip_idx, refresh_voice, partially_ended;
+  uint32_t cur_type;      // EventType of current_audio_event
+  uint32_t cur_sample;
+  float cur_gain;
+  uint32_t _pad;
+  double playback_speed, sample_offset;
+};
+
+struct DPatch {           // host-side edits applied to DTrackState before the next plan
+  uint32_t flags;         // PATCH_*
+  uint32_t has_clip_idx, clip_idx;
+  uint32_t refresh_voice;
+};
+enum : uint32_t { PATCH_CLIPIDX = 1, PATCH_REFRESH = 2, PATCH_STOP = 4 };
+
+struct DSeg {             // one Sampler::stream call (48 B)
+  const void* src[2];
+  double pos;             // Sampler::sample_offset_ before the call
+  double speed;           // Sampler::playback_speed_
+  float gain;             // AudioClip::gain
+  uint16_t dst_start;
+  uint16_t len;           // num_actual_samples (sampler.cpp:104)
+  uint16_t req_len;       // num_samples as requested
+  uint8_t format;
+  uint8_t flags;
+  uint32_t sample;
+};
+
+struct DTrackBlock {      // 64 B
+  DSeg s0;
+  float g[2];             // fl(volume * pan_coeffs[c]), 0 when muted (track.cpp:728-731)
+  uint8_t nseg;           // stream calls (including zero-length / finished ones)
+  uint8_t kind;
+  uint16_t _pad;
+  uint32_t extra;         // overflow chunk index (segments 1..nseg-1), valid when nseg > 1
+};
+static_assert(sizeof(DSeg) == 48, "DSeg must be 48 bytes");
+static_assert(sizeof(DTrackBlock) == 64, "DTrackBlock must be 64 bytes");
+
+struct DBlockTime {       // per-block transport scalars computed by the host exactly as engine.cpp:1578-1585
+  double start_time, end_time, sample_position, beat_duration;
+};
+
+struct DGroup {           // tracks order[first .. first+count) are summed in order by one workgroup
+  uint32_t first, count;
+  int32_t bus;            // -1: straight into the master
+  uint32_t _pad;
+};
+
+struct PlanArgs {
+  const DClip* clips;
+  const uint32_t* clip_first;   // [N+1]
+  const DSample* samples;
+  DTrackState* state;           // [N]
+  const DPatch* patch;          // [N] or null
+  const DBlockTime* times;      // [K]
+  const float* gains;           // [N][2]
+  DTrackBlock* tb;              // [K][N]
+  DSeg* pool;                   // [pool_chunks][kChunk]
+  uint32_t* pool_count;         // allocated chunks
+  uint32_t* status;             // bit0: pool overflow, bit1: > kMaxSegs calls, bit2: SEG_CLIPPED happened
+  uint32_t pool_chunks;
+  uint32_t n_tracks, n_blocks, block_frames, channels;
+  double sample_rate;
+  uint32_t playing;
+};
+
+struct MixArgs {
+  const DTrackBlock* tb;        // [K][N]
+  const DSeg* pool;
+  const uint32_t* order;        // [N] track permutation (routing order)
+  const DGroup* groups;         // [NG]
+  float* partial;               // [K][NG][C][F]
+  float* peaks;                 // [K][N][C]
+  uint32_t n_tracks, n_groups, block_frames, channels;
+  uint32_t tiles;               // ceil(C*F/4 / 256)
+};
+
+struct SumArgs {
+  const float* partial;         // [K][NG][C][F]
+  const DGroup* groups;
+  float* master;                // [K][C][F]
+  float* buses;                 // [K][NB][C][F] or null
+  uint32_t n_groups, n_buses, block_frames, channels;
+  uint32_t clamp;
+};
+
+}  // namespace wbx

@@ -1,0 +1,1105 @@
+// wbx_runtime.hip — host side of libwbx.so: the C ABI of include/wbx.h over the gfx950 kernels.
+//
+//   layer 1 (wbx_ctx)     clip pool in HBM, routing, plan upload, launches, result fetch
+//   layer 2 (wbx_engine)  the reference's Engine/Track surface: host keeps what the UI thread edits
+//                         (clip lists, parameters, transport), the device keeps what the audio thread
+//                         mutates per block (sequencer + sampler state) and does all per-block work
+//
+// There is no CPU implementation of the mix in this library: without a gfx950 device the create calls
+// fail with WBX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numbers>
+#include <string>
+#include <vector>
+
+#include "../../include/wbx.h"
+#include "wbx_dev.h"
+#include "wbx_seq.h"
+
+namespace wbx {
+void launch_plan(const PlanArgs& a, hipStream_t s);
+void launch_mix(const MixArgs& a, uint32_t n_blocks, hipStream_t s);
+void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
+void launch_clamp(float* buf, size_t n, hipStream_t s);
+void launch_levels(const float* peaks, float* levels, uint32_t n_blocks, uint32_t nc, hipStream_t s);
+void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
+void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
+}  // namespace wbx
+
+using namespace wbx;
+
+namespace {
+
+constexpr int kEventRing = 64;
+
+struct ClipSlot {
+  void* base = nullptr;     // one allocation holding all channels
+  DSample d{};
+  bool used = false;
+};
+
+template <class T>
+struct DevBuf {             // grow-only device array
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct wbx_ctx {
+  wbx_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  std::vector<ClipSlot> clips;
+  DevBuf<DSample> d_samples;
+  bool samples_dirty = true;
+
+  // routing
+  uint32_t routing_tracks = 0, n_buses = 0;
+  std::vector<int32_t> track_bus;
+  std::vector<uint32_t> order;
+  std::vector<DGroup> groups;
+  DevBuf<uint32_t> d_order;
+  DevBuf<DGroup> d_groups;
+  bool routing_dirty = true;
+
+  // plan + results
+  DevBuf<DTrackBlock> d_tb;
+  DevBuf<DSeg> d_pool;
+  uint32_t pool_chunks = 0;
+  uint32_t* d_pool_count = nullptr;   // [0] chunks allocated, [1] status bits
+  DevBuf<float> d_partial, d_master, d_buses, d_peaks, d_gains;
+  DevBuf<uint8_t> d_conv;
+  std::vector<DTrackBlock> h_tb;      // layer-1 staging
+  std::vector<DSeg> h_pool;
+
+  uint32_t last_K = 0, last_N = 0;
+  bool clamp = true;
+  float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
+
+  // kernel timing (mix kernel)
+  hipEvent_t ev[kEventRing][2]{};
+  int ev_pending = 0;
+  double mix_ms_total = 0.0;
+  uint64_t mix_launches = 0;
+  bool profiling = true;
+};
+
+namespace {
+
+wbx_status fail(wbx_ctx* c, wbx_status s, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return s;
+}
+
+#define WBX_HIP(ctx, call)                                                  \
+  do {                                                                      \
+    hipError_t _e = (call);                                                 \
+    if (_e != hipSuccess) return fail((ctx), WBX_ERR_DEVICE, #call, _e);    \
+  } while (0)
+
+size_t fmt_bytes(int fmt) {
+  switch (fmt) {
+    case WBX_FMT_I16: return 2;
+    case WBX_FMT_I24:
+    case WBX_FMT_I32:
+    case WBX_FMT_F32: return 4;
+    default: return 0;
+  }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void drain_events(wbx_ctx* c) {
+  for (int i = 0; i < c->ev_pending; i++) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) {
+      c->mix_ms_total += ms;
+      c->mix_launches++;
+    }
+  }
+  c->ev_pending = 0;
+}
+
+// default routing: identity order, groups of group_size, everything straight into the master
+void build_routing(wbx_ctx* c, uint32_t n_tracks) {
+  const uint32_t G = c->cfg.group_size;
+  c->order.clear();
+  c->groups.clear();
+  auto emit = [&](const std::vector<uint32_t>& members, int32_t bus) {
+    for (size_t i = 0; i < members.size(); i += G) {
+      DGroup g{};
+      g.first = (uint32_t)c->order.size();
+      g.count = (uint32_t)std::min<size_t>(G, members.size() - i);
+      g.bus = bus;
+      for (uint32_t k = 0; k < g.count; k++) c->order.push_back(members[i + k]);
+      c->groups.push_back(g);
+    }
+  };
+  std::vector<uint32_t> direct;
+  std::vector<std::vector<uint32_t>> per_bus(c->n_buses);
+  for (uint32_t t = 0; t < n_tracks; t++) {
+    int32_t bus = (c->n_buses && t < c->track_bus.size()) ? c->track_bus[t] : -1;
+    if (bus >= 0 && (uint32_t)bus < c->n_buses)
+      per_bus[bus].push_back(t);
+    else
+      direct.push_back(t);
+  }
+  emit(direct, -1);
+  for (uint32_t u = 0; u < c->n_buses; u++) emit(per_bus[u], (int32_t)u);
+  c->routing_tracks = n_tracks;
+  c->routing_dirty = true;
+}
+
+wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
+  if (c->routing_tracks != n_tracks) build_routing(c, n_tracks);
+  if (c->routing_dirty) {
+    WBX_HIP(c, c->d_order.ensure(std::max<size_t>(1, c->order.size())));
+    WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size())));
+    if (!c->order.empty())
+      WBX_HIP(c, hipMemcpyAsync(c->d_order.p, c->order.data(), c->order.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                c->stream));
+    if (!c->groups.empty())
+      WBX_HIP(c, hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(DGroup),
+                                hipMemcpyHostToDevice, c->stream));
+    WBX_HIP(c, hipStreamSynchronize(c->stream));   // host vectors may change right after
+    c->routing_dirty = false;
+  }
+  if (c->samples_dirty) {
+    std::vector<DSample> tab(c->clips.size());
+    for (size_t i = 0; i < c->clips.size(); i++) tab[i] = c->clips[i].d;
+    WBX_HIP(c, c->d_samples.ensure(std::max<size_t>(1, tab.size())));
+    if (!tab.empty()) WBX_HIP(c, hipMemcpy(c->d_samples.p, tab.data(), tab.size() * sizeof(DSample), hipMemcpyHostToDevice));
+    c->samples_dirty = false;
+  }
+  return WBX_OK;
+}
+
+wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
+  const size_t CF = (size_t)c->cfg.channels * c->cfg.block_frames;
+  WBX_HIP(c, c->d_tb.ensure((size_t)K * N));
+  WBX_HIP(c, c->d_partial.ensure((size_t)K * std::max<size_t>(1, c->groups.size()) * CF));
+  WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
+  WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
+  if (c->n_buses) WBX_HIP(c, c->d_buses.ensure((size_t)K * c->n_buses * CF));
+  return WBX_OK;
+}
+
+// mix + sum over a plan that already sits in d_tb / d_pool
+wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  MixArgs m{};
+  m.tb = c->d_tb.p;
+  m.pool = c->d_pool.p;
+  m.order = c->d_order.p;
+  m.groups = c->d_groups.p;
+  m.partial = c->d_partial.p;
+  m.peaks = c->d_peaks.p;
+  m.n_tracks = N;
+  m.n_groups = (uint32_t)c->groups.size();
+  m.block_frames = F;
+  m.channels = C;
+  m.tiles = ((C * F / 4) + 255u) / 256u;
+  if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(c->d_peaks.p, 0, (size_t)K * N * C * sizeof(float), c->stream));
+  if (m.n_groups) {
+    if (c->profiling) {
+      if (c->ev_pending == kEventRing) {
+        WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
+        drain_events(c);
+      }
+      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+    }
+    launch_mix(m, K, c->stream);
+    if (c->profiling) {
+      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
+      c->ev_pending++;
+    }
+  }
+  SumArgs s{};
+  s.partial = c->d_partial.p;
+  s.groups = c->d_groups.p;
+  s.master = c->master_target ? c->master_target : c->d_master.p;
+  s.buses = c->n_buses ? c->d_buses.p : nullptr;
+  s.n_groups = m.n_groups;
+  s.n_buses = c->n_buses;
+  s.block_frames = F;
+  s.channels = C;
+  s.clamp = c->clamp ? 1u : 0u;
+  if (c->n_buses) WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, (size_t)K * c->n_buses * C * F * sizeof(float), c->stream));
+  launch_sum(s, K, c->stream);
+  WBX_HIP(c, hipGetLastError());
+  c->last_K = K;
+  c->last_N = N;
+  return WBX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// library
+// =================================================================================================
+extern "C" const char* wbx_version(void) { return "wbx 0.1 (gfx950)"; }
+
+extern "C" int wbx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; i++) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
+}
+
+extern "C" const char* wbx_status_string(wbx_status s) {
+  switch (s) {
+    case WBX_OK: return "ok";
+    case WBX_ERR_FAILED: return "failed";
+    case WBX_ERR_UNIMPLEMENTED: return "unimplemented";
+    case WBX_ERR_UNSUPPORTED: return "unsupported";
+    case WBX_ERR_INVALID: return "invalid argument";
+    case WBX_ERR_NO_DEVICE: return "no gfx950 device";
+    case WBX_ERR_DEVICE: return "HIP error";
+    case WBX_ERR_OOM: return "out of memory";
+    case WBX_ERR_OVERFLOW: return "segment plan overflow";
+    default: return "unknown";
+  }
+}
+
+// =================================================================================================
+// layer 1
+// =================================================================================================
+extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
+  if (!cfg || !out) return WBX_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->channels < 1 || cfg->channels > 2 || cfg->block_frames < 4 || (cfg->block_frames & 3u) ||
+      cfg->block_frames > 32768 || cfg->max_tracks == 0 || cfg->max_blocks == 0 || cfg->sample_rate == 0)
+    return WBX_ERR_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || cfg->device < 0 || cfg->device >= n) return WBX_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return WBX_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return WBX_ERR_NO_DEVICE;   // kernels exist for gfx950 only
+  if (hipSetDevice(cfg->device) != hipSuccess) return WBX_ERR_NO_DEVICE;
+
+  wbx_ctx* c = new (std::nothrow) wbx_ctx();
+  if (!c) return WBX_ERR_OOM;
+  c->cfg = *cfg;
+  if (c->cfg.group_size == 0) c->cfg.group_size = 64;
+  if (cfg->stream) {
+    c->stream = (hipStream_t)cfg->stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return WBX_ERR_DEVICE;
+    }
+    c->own_stream = true;
+  }
+  for (int i = 0; i < kEventRing; i++) {
+    if (hipEventCreate(&c->ev[i][0]) != hipSuccess || hipEventCreate(&c->ev[i][1]) != hipSuccess) {
+      wbx_destroy(c);
+      return WBX_ERR_DEVICE;
+    }
+  }
+  size_t chunks = cfg->max_segments ? (cfg->max_segments + kChunk - 1) / kChunk
+                                    : std::max<size_t>(1024, (size_t)cfg->max_blocks * cfg->max_tracks / 8);
+  c->pool_chunks = (uint32_t)chunks;
+  if (c->d_pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&c->d_pool_count, 2 * sizeof(uint32_t)) != hipSuccess) {
+    wbx_destroy(c);
+    return WBX_ERR_OOM;
+  }
+  (void)hipMemset(c->d_pool_count, 0, 2 * sizeof(uint32_t));
+  *out = c;
+  return WBX_OK;
+}
+
+extern "C" void wbx_destroy(wbx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->clips)
+    if (s.base) (void)hipFree(s.base);
+  c->d_samples.release();
+  c->d_order.release();
+  c->d_groups.release();
+  c->d_tb.release();
+  c->d_pool.release();
+  c->d_partial.release();
+  c->d_master.release();
+  c->d_buses.release();
+  c->d_peaks.release();
+  c->d_gains.release();
+  c->d_conv.release();
+  if (c->d_pool_count) (void)hipFree(c->d_pool_count);
+  for (int i = 0; i < kEventRing; i++) {
+    if (c->ev[i][0]) (void)hipEventDestroy(c->ev[i][0]);
+    if (c->ev[i][1]) (void)hipEventDestroy(c->ev[i][1]);
+  }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char* wbx_last_error(const wbx_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+static wbx_status clip_alloc(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                             uint64_t frames, size_t* stride_out) {
+  if (!c) return WBX_ERR_INVALID;
+  const size_t eb = fmt_bytes(format);
+  if (!eb) return fail(c, WBX_ERR_UNSUPPORTED, "clip format");
+  if (channels < 1 || channels > 2) return fail(c, WBX_ERR_UNSUPPORTED, "clip channel count (1 or 2)");
+  if (frames >= 2147483632ull) return fail(c, WBX_ERR_UNSUPPORTED, "clip longer than 2^31-16 frames");
+  if (clip >= (1u << 24)) return fail(c, WBX_ERR_INVALID, "clip id");
+  (void)hipSetDevice(c->cfg.device);
+  if (clip >= c->clips.size()) c->clips.resize(clip + 1);
+  ClipSlot& s = c->clips[clip];
+  if (s.base) {
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(s.base);
+    s = ClipSlot{};
+  }
+  const size_t stride = align_up((frames + kPad) * eb, 256);
+  WBX_HIP(c, hipMalloc(&s.base, stride * channels));
+  s.d.ch[0] = s.base;
+  s.d.ch[1] = channels > 1 ? (const void*)((const char*)s.base + stride) : s.base;   // mono wraps (i % channels)
+  s.d.count = frames;
+  s.d.format = (uint32_t)format;
+  s.d.channels = channels;
+  s.d.sample_rate = sample_rate;
+  s.used = true;
+  c->samples_dirty = true;
+  *stride_out = stride;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_upload(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                                      uint64_t frames, const void* const* planar) {
+  if (!c || !planar) return WBX_ERR_INVALID;
+  size_t stride = 0;
+  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
+  if (st != WBX_OK) return st;
+  const size_t eb = fmt_bytes(format);
+  ClipSlot& s = c->clips[clip];
+  WBX_HIP(c, hipMemsetAsync(s.base, 0, stride * channels, c->stream));   // the 16 padding frames read as zero
+  for (uint32_t ch = 0; ch < channels; ch++)
+    WBX_HIP(c, hipMemcpyAsync((char*)s.base + stride * ch, planar[ch], frames * eb, hipMemcpyHostToDevice, c->stream));
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_synth(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                                     uint64_t frames, uint64_t seed, uint32_t key_track, float amp) {
+  if (!c) return WBX_ERR_INVALID;
+  size_t stride = 0;
+  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
+  if (st != WBX_OK) return st;
+  ClipSlot& s = c->clips[clip];
+  for (uint32_t ch = 0; ch < channels; ch++) {
+    const uint64_t key = seed ^ ((uint64_t)key_track << 40) ^ ((uint64_t)ch << 32);
+    launch_synth((char*)s.base + stride * ch, frames, key, amp, format, c->stream);
+  }
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
+  if (!c || clip >= c->clips.size() || !c->clips[clip].base) return WBX_ERR_INVALID;
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->clips[clip].base);
+  c->clips[clip] = ClipSlot{};
+  c->samples_dirty = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_set_routing(wbx_ctx* c, uint32_t n_tracks, const int32_t* track_bus, uint32_t n_buses) {
+  if (!c || n_tracks > c->cfg.max_tracks) return WBX_ERR_INVALID;
+  if (track_bus && n_buses) {
+    c->track_bus.assign(track_bus, track_bus + n_tracks);
+    c->n_buses = n_buses;
+  } else {
+    c->track_bus.clear();
+    c->n_buses = 0;
+  }
+  build_routing(c, n_tracks);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_set_clamp(wbx_ctx* c, int on) {
+  if (!c) return WBX_ERR_INVALID;
+  c->clamp = on != 0;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_set_master_target(wbx_ctx* c, void* device_buffer) {
+  if (!c) return WBX_ERR_INVALID;
+  c->master_target = (float*)device_buffer;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_segment* segs, const uint32_t* seg_offsets,
+                                 const float* gains) {
+  if (!c || !seg_offsets || !gains || K == 0 || N == 0) return WBX_ERR_INVALID;
+  if (K > c->cfg.max_blocks || N > c->cfg.max_tracks) return fail(c, WBX_ERR_INVALID, "K or N above the configured maximum");
+  (void)hipSetDevice(c->cfg.device);
+  wbx_status st = upload_tables(c, N);
+  if (st != WBX_OK) return st;
+  st = ensure_result_buffers(c, K, N);
+  if (st != WBX_OK) return st;
+  WBX_HIP(c, hipStreamSynchronize(c->stream));   // staging vectors are reused
+  const uint32_t F = c->cfg.block_frames, C = c->cfg.channels;
+  c->h_tb.assign((size_t)K * N, DTrackBlock{});
+  c->h_pool.clear();
+  uint32_t chunks = 0;
+  for (size_t bt = 0; bt < (size_t)K * N; bt++) {
+    DTrackBlock& tb = c->h_tb[bt];
+    tb.g[0] = gains[bt * 2 + 0];
+    tb.g[1] = gains[bt * 2 + (C > 1 ? 1 : 0)];
+    const uint32_t s0 = seg_offsets[bt], s1 = seg_offsets[bt + 1];
+    if (s1 < s0) return fail(c, WBX_ERR_INVALID, "seg_offsets not monotone");
+    if (s1 - s0 > kMaxSegs) return fail(c, WBX_ERR_OVERFLOW, "more than 16 segments in one track-block");
+    if (s1 != s0 && !segs) return WBX_ERR_INVALID;
+    for (uint32_t i = s0; i < s1; i++) {
+      const wbx_segment& sg = segs[i];
+      if (sg.clip >= c->clips.size() || !c->clips[sg.clip].used) return fail(c, WBX_ERR_INVALID, "segment names an unknown clip");
+      // the prologue of Sampler::stream (sampler.cpp:99-104) through the shared walker
+      DTrackState ts{};
+      ts.cur_type = EV_PLAY;
+      ts.cur_sample = 0;
+      ts.cur_gain = sg.gain;
+      ts.playback_speed = sg.playback_speed;
+      ts.sample_offset = sg.sample_offset;
+      DSeg d{};
+      BlockWalker w{};
+      DTrackBlock scratch{};
+      uint32_t pc = 0, stbits = 0;
+      w.st = &ts;
+      w.samples = &c->clips[sg.clip].d;
+      w.tb = &scratch;
+      w.pool = &d;
+      w.pool_count = &pc;
+      w.pool_chunks = 0;
+      w.status = &stbits;
+      w.n_samples = F;
+      w.n_channels = C;
+      w.dst_rate = (double)c->cfg.sample_rate;
+      w.start_sample = 0;
+      w.nseg = 0;
+      w.chunk = 0xFFFFFFFFu;
+      w.stream(sg.num_samples, sg.buffer_offset);
+      d = scratch.s0;
+      d.sample = sg.clip;
+      const uint32_t k = i - s0;
+      if (k == 0) {
+        tb.s0 = d;
+      } else {
+        if (k == 1) {
+          tb.extra = chunks++;
+          c->h_pool.resize((size_t)chunks * kChunk);
+        }
+        c->h_pool[(size_t)tb.extra * kChunk + (k - 1)] = d;
+      }
+    }
+    tb.nseg = (uint8_t)(s1 - s0);
+    tb.kind = classify(tb, F);
+  }
+  if (chunks > c->pool_chunks) {
+    WBX_HIP(c, c->d_pool.ensure((size_t)chunks * kChunk));
+    c->pool_chunks = chunks;
+  }
+  WBX_HIP(c, hipMemcpyAsync(c->d_tb.p, c->h_tb.data(), c->h_tb.size() * sizeof(DTrackBlock), hipMemcpyHostToDevice, c->stream));
+  if (!c->h_pool.empty())
+    WBX_HIP(c, hipMemcpyAsync(c->d_pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  return launch_mix_sum(c, K, N);
+}
+
+extern "C" wbx_status wbx_sync(wbx_ctx* c) {
+  if (!c) return WBX_ERR_INVALID;
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* peaks, float* buses) {
+  if (!c) return WBX_ERR_INVALID;
+  if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  const uint32_t K = c->last_K, N = c->last_N, C = c->cfg.channels, F = c->cfg.block_frames;
+  if (master_planar) {
+    // device [K][C][F] -> host planar[c][b*F + j]
+    for (uint32_t ch = 0; ch < C; ch++)
+      WBX_HIP(c, hipMemcpy2DAsync(master_planar[ch], F * sizeof(float), (c->master_target ? c->master_target : c->d_master.p) + (size_t)ch * F,
+                                  (size_t)C * F * sizeof(float), F * sizeof(float), K, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (peaks) WBX_HIP(c, hipMemcpyAsync(peaks, c->d_peaks.p, (size_t)K * N * C * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (buses) {
+    if (!c->n_buses) return fail(c, WBX_ERR_INVALID, "no buses configured");
+    WBX_HIP(c, hipMemcpyAsync(buses, c->d_buses.p, (size_t)K * c->n_buses * C * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  uint32_t pc[2] = {0, 0};
+  WBX_HIP(c, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
+  if (pc[1] & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* dst) {
+  if (!c || !dst) return WBX_ERR_INVALID;
+  if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  size_t eb;
+  switch (out_format) {
+    case WBX_OUT_I16: eb = 2; break;
+    case WBX_OUT_I24_X8:
+    case WBX_OUT_I32:
+    case WBX_OUT_F32: eb = 4; break;
+    default: return fail(c, WBX_ERR_UNSUPPORTED, "interleaved output format");
+  }
+  const uint32_t K = c->last_K, C = c->cfg.channels, F = c->cfg.block_frames;
+  const size_t bytes = (size_t)K * F * C * eb;
+  WBX_HIP(c, c->d_conv.ensure(bytes));
+  launch_convert(c->master_target ? c->master_target : c->d_master.p, c->d_conv.p, K, F, C, out_format, c->stream);
+  WBX_HIP(c, hipMemcpyAsync(dst, c->d_conv.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* n_floats) {
+  if (!c || !device_ptr) return WBX_ERR_INVALID;
+  if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  *device_ptr = c->master_target ? c->master_target : c->d_master.p;
+  if (n_floats) *n_floats = (size_t)c->last_K * c->cfg.channels * c->cfg.block_frames;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_finalize_master(wbx_ctx* c, void* device_partial, uint32_t n_blocks, int clamp) {
+  if (!c || !device_partial || n_blocks == 0) return WBX_ERR_INVALID;
+  if (clamp) launch_clamp((float*)device_partial, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, c->stream);
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
+  if (!c) return WBX_ERR_INVALID;
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  if (mix_ms_avg) *mix_ms_avg = c->mix_launches ? c->mix_ms_total / (double)c->mix_launches : 0.0;
+  if (mix_launches) *mix_launches = c->mix_launches;
+  if (reset) {
+    c->mix_ms_total = 0.0;
+    c->mix_launches = 0;
+  }
+  return WBX_OK;
+}
+
+// =================================================================================================
+// layer 2: the engine surface
+// =================================================================================================
+namespace {
+
+enum : uint32_t { PARAM_VOLUME = 0, PARAM_PAN = 1, PARAM_MUTE = 2 };   // reference TrackParameter, track.h:29-34
+
+struct ParamMsg {
+  uint32_t id;
+  double value;
+};
+
+struct HostTrack {
+  std::vector<DClip> clips;            // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
+  float volume = 0.0f, pan = 0.0f, pan_coeffs[2] = {0.0f, 0.0f};
+  bool mute = false;
+  std::vector<ParamMsg> msgs;          // TrackMessage::ParamChange ring (track.h:131), drained at the next block
+  int32_t bus = -1;
+  DPatch patch{};
+};
+
+// math::db_to_linear<float>, reference core/core_math.h:83-89
+float db_to_linear(float x) {
+  if (x <= -72.0f) return 0.0f;
+  return std::pow(10.0f, (float)((double)x * 0.05));
+}
+
+// calculate_panning_coefs(p, ConstantPower_3db), reference core/panning_law.cpp:9-32
+void pan_constant_power_3db(float p, float* l, float* r) {
+  double x = 0.5 * ((double)p + 1.0);
+  double left = std::sin(0.5 * std::numbers::pi * (1.0 - x));
+  double right = std::sin(0.5 * std::numbers::pi * x);
+  double boost = std::sqrt(2.0);
+  *l = (float)(left * boost);
+  *r = (float)(right * boost);
+}
+
+}  // namespace
+
+struct wbx_engine {
+  wbx_ctx* ctx = nullptr;
+  std::string err;
+  std::vector<HostTrack> tracks;
+  uint32_t n_buses = 0;
+  double ppq = 96.0;                    // engine.h:43
+  double playhead = 0.0, playhead_start = 0.0, sample_position = 0.0, beat_duration = 0.5;
+  bool playing = false;
+  bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
+  uint32_t state_tracks = 0;            // tracks that have device state
+
+  DevBuf<DClip> d_clips;
+  DevBuf<uint32_t> d_clip_first;
+  DevBuf<DTrackState> d_state;
+  DevBuf<DPatch> d_patch;
+  DevBuf<DBlockTime> d_times;
+  DevBuf<float> d_gains, d_levels;
+  std::vector<DBlockTime> h_times;
+};
+
+namespace {
+
+wbx_status efail(wbx_engine* e, wbx_status s, const char* what) {
+  if (e) e->err = what;
+  return s;
+}
+
+#define WBX_EHIP(e, call)                                      \
+  do {                                                         \
+    hipError_t _e = (call);                                    \
+    if (_e != hipSuccess) {                                    \
+      (e)->err = std::string(#call) + ": " + hipGetErrorString(_e); \
+      return WBX_ERR_DEVICE;                                   \
+    }                                                          \
+  } while (0)
+
+// Track::find_next_clip over the host copy (track.cpp:182-213)
+bool host_find_next_clip(const HostTrack& t, double time_pos, uint32_t* idx) {
+  return find_next_clip(t.clips.data(), (uint32_t)t.clips.size(), time_pos, idx);
+}
+
+// Track::reset_playback_state, track.cpp:220-232
+void reset_playback_state(wbx_engine* e, HostTrack& t, double time_pos, bool refresh_voices) {
+  if (!refresh_voices) {
+    uint32_t idx = 0;
+    bool has = host_find_next_clip(t, time_pos, &idx);
+    t.patch.flags |= PATCH_CLIPIDX;
+    t.patch.has_clip_idx = has ? 1u : 0u;
+    t.patch.clip_idx = idx;
+  }
+  t.patch.flags |= PATCH_REFRESH;
+  t.patch.refresh_voice = refresh_voices ? 1u : 0u;
+  e->patches_pending = true;
+}
+
+// Track::query_clip_by_range reduced to "is the range free" (track.cpp:112-157)
+bool range_is_free(const HostTrack& t, double mn, double mx) {
+  const auto& c = t.clips;
+  if (c.empty()) return true;
+  if (mx <= c.front().min_time) return true;
+  if (mn >= c.back().max_time) return true;
+  uint32_t first = lower_bound_max_time(c.data(), (uint32_t)c.size(), mn);
+  uint32_t last = lower_bound_max_time(c.data(), (uint32_t)c.size(), mx);
+  if (first == last && (mx <= c[first].min_time || mn >= c[last].max_time)) return true;
+  return false;
+}
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out) {
+  if (!cfg || !out) return WBX_ERR_INVALID;
+  *out = nullptr;
+  wbx_ctx* c = nullptr;
+  wbx_status st = wbx_create(cfg, &c);
+  if (st != WBX_OK) return st;
+  wbx_engine* e = new (std::nothrow) wbx_engine();
+  if (!e) {
+    wbx_destroy(c);
+    return WBX_ERR_OOM;
+  }
+  e->ctx = c;
+  *out = e;
+  return WBX_OK;
+}
+
+extern "C" void wbx_engine_destroy(wbx_engine* e) {
+  if (!e) return;
+  if (e->ctx) {
+    (void)hipSetDevice(e->ctx->cfg.device);
+    (void)hipStreamSynchronize(e->ctx->stream);
+  }
+  e->d_clips.release();
+  e->d_clip_first.release();
+  e->d_state.release();
+  e->d_patch.release();
+  e->d_times.release();
+  e->d_gains.release();
+  e->d_levels.release();
+  wbx_destroy(e->ctx);
+  delete e;
+}
+
+extern "C" const char* wbx_engine_last_error(const wbx_engine* e) {
+  if (!e) return "null engine";
+  if (!e->err.empty()) return e->err.c_str();
+  return wbx_last_error(e->ctx);
+}
+
+extern "C" wbx_ctx* wbx_engine_ctx(wbx_engine* e) { return e ? e->ctx : nullptr; }
+
+extern "C" wbx_status wbx_engine_set_bpm(wbx_engine* e, double bpm) {   // engine.cpp:24-30
+  if (!e || !(bpm > 0.0)) return WBX_ERR_INVALID;
+  e->beat_duration = 60.0 / bpm;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_set_playhead_position(wbx_engine* e, double beat) {   // engine.cpp:32-41
+  if (!e) return WBX_ERR_INVALID;
+  e->playhead_start = beat;
+  e->playhead = beat;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_add_track(wbx_engine* e, uint32_t* track_out) {   // engine.cpp:200-208, Track::Track track.cpp:22-27
+  if (!e) return WBX_ERR_INVALID;
+  if (e->tracks.size() >= e->ctx->cfg.max_tracks) return efail(e, WBX_ERR_INVALID, "max_tracks reached");
+  e->tracks.emplace_back();
+  const uint32_t t = (uint32_t)e->tracks.size() - 1;
+  wbx_track_set_volume(e, t, 0.0f);
+  wbx_track_set_pan(e, t, 0.0f);
+  wbx_track_set_mute(e, t, 0);
+  e->clips_dirty = e->routing_dirty = e->gains_dirty = true;
+  if (track_out) *track_out = t;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_set_buses(wbx_engine* e, uint32_t n_buses) {
+  if (!e) return WBX_ERR_INVALID;
+  e->n_buses = n_buses;
+  e->routing_dirty = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_volume(wbx_engine* e, uint32_t t, float db) {   // track.cpp:47-57
+  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
+  e->tracks[t].msgs.push_back({PARAM_VOLUME, (double)db_to_linear(db)});
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t t, float pan) {   // track.cpp:59-68
+  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
+  e->tracks[t].msgs.push_back({PARAM_PAN, (double)pan});
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t t, int mute) {   // track.cpp:70-79
+  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
+  e->tracks[t].msgs.push_back({PARAM_MUTE, (double)(mute ? 1 : 0)});
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t t, int32_t bus) {
+  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
+  e->tracks[t].bus = bus;
+  e->routing_dirty = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                            uint64_t frames, const void* const* planar, uint32_t* sample_out) {
+  if (!e || !sample_out) return WBX_ERR_INVALID;
+  const uint32_t id = (uint32_t)e->ctx->clips.size();
+  wbx_status st = wbx_clip_upload(e->ctx, id, format, channels, sample_rate, frames, planar);
+  if (st == WBX_OK) *sample_out = id;
+  return st;
+}
+
+extern "C" wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                                  uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
+                                                  uint32_t* sample_out) {
+  if (!e || !sample_out) return WBX_ERR_INVALID;
+  const uint32_t id = (uint32_t)e->ctx->clips.size();
+  wbx_status st = wbx_clip_synth(e->ctx, id, format, channels, sample_rate, frames, seed, key_track, amp);
+  if (st == WBX_OK) *sample_out = id;
+  return st;
+}
+
+// Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461 (non-overlapping inserts)
+extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
+                                                double start_offset, uint32_t sample, double speed, float gain) {
+  if (!e || track >= e->tracks.size()) return WBX_ERR_INVALID;
+  if (sample >= e->ctx->clips.size() || !e->ctx->clips[sample].used) return efail(e, WBX_ERR_INVALID, "unknown sample");
+  if (!(min_time <= max_time)) return efail(e, WBX_ERR_INVALID, "min_time > max_time");
+  HostTrack& t = e->tracks[track];
+  const bool back = !t.clips.empty() && t.clips.back().max_time < min_time;
+  const bool front = !t.clips.empty() && t.clips.front().min_time > max_time;
+  if (!t.clips.empty() && !back && !front && !range_is_free(t, min_time, max_time))
+    return efail(e, WBX_ERR_UNSUPPORTED, "clip overlaps an existing clip (reserve_track_region is out of scope)");
+  DClip c{};
+  c.min_time = min_time;
+  c.max_time = max_time;
+  c.start_offset = start_offset;
+  c.speed = speed;
+  c.gain = gain;
+  c.sample = sample;
+  c.internal_state_changed = 0;
+  t.clips.push_back(c);
+  std::sort(t.clips.begin(), t.clips.end(), [](const DClip& a, const DClip& b) { return a.min_time < b.min_time; });
+  reset_playback_state(e, t, e->playhead, true);   // engine.cpp:416,426,437,449,459
+  e->clips_dirty = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_play(wbx_engine* e) {   // engine.cpp:68-80
+  if (!e) return WBX_ERR_INVALID;
+  for (auto& t : e->tracks) reset_playback_state(e, t, e->playhead_start, false);
+  e->sample_position = 0;
+  e->playing = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_stop(wbx_engine* e) {   // engine.cpp:82-93, Track::stop track.cpp:249-256
+  if (!e) return WBX_ERR_INVALID;
+  e->playing = false;
+  e->playhead = e->playhead_start;
+  for (auto& t : e->tracks) t.patch.flags |= PATCH_STOP;
+  e->patches_pending = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
+  if (!e || K == 0) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  e->err.clear();
+  if (K > c->cfg.max_blocks) return efail(e, WBX_ERR_INVALID, "n_blocks above wbx_config.max_blocks");
+  const uint32_t N = (uint32_t)e->tracks.size();
+  if (N == 0) return efail(e, WBX_ERR_INVALID, "no tracks");
+  (void)hipSetDevice(c->cfg.device);
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  hipStream_t s = c->stream;
+
+  // -- parameters: drain the message rings (process_track_messages track.cpp:773-779) and apply them
+  //    (track.cpp:618-643); the factor used per sample is fl(volume * pan_coeffs[c]) (track.cpp:728-731)
+  for (auto& t : e->tracks) {
+    if (t.msgs.empty()) continue;
+    for (const ParamMsg& m : t.msgs) {
+      switch (m.id) {
+        case PARAM_VOLUME: t.volume = (float)m.value; break;
+        case PARAM_PAN:
+          t.pan = (float)m.value;
+          pan_constant_power_3db(t.pan, &t.pan_coeffs[0], &t.pan_coeffs[1]);
+          break;
+        case PARAM_MUTE: t.mute = m.value > 0.0; break;
+        default: break;
+      }
+    }
+    t.msgs.clear();
+    e->gains_dirty = true;
+  }
+  if (e->gains_dirty) {
+    std::vector<float> g((size_t)N * 2);
+    for (uint32_t t = 0; t < N; t++) {
+      const HostTrack& tr = e->tracks[t];
+      float volume = tr.mute ? 0.0f : tr.volume;
+      g[2 * t + 0] = volume * tr.pan_coeffs[0];
+      g[2 * t + 1] = volume * tr.pan_coeffs[1];
+    }
+    WBX_EHIP(e, e->d_gains.ensure(g.size()));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, hipMemcpy(e->d_gains.p, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    e->gains_dirty = false;
+  }
+
+  // -- clip lists
+  if (e->clips_dirty) {
+    std::vector<uint32_t> first(N + 1, 0);
+    std::vector<DClip> flat;
+    for (uint32_t t = 0; t < N; t++) {
+      first[t] = (uint32_t)flat.size();
+      flat.insert(flat.end(), e->tracks[t].clips.begin(), e->tracks[t].clips.end());
+    }
+    first[N] = (uint32_t)flat.size();
+    WBX_EHIP(e, e->d_clips.ensure(std::max<size_t>(1, flat.size())));
+    WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    if (!flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, flat.data(), flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
+    WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->clips_dirty = false;
+  }
+
+  // -- per-track device state for tracks added since the last render
+  if (e->state_tracks < N) {
+    DevBuf<DTrackState> grown;
+    WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
+    if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
+    e->d_state.release();
+    e->d_state = grown;
+    WBX_EHIP(e, e->d_levels.ensure((size_t)c->cfg.max_tracks * 2));
+    if (e->state_tracks == 0) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    e->state_tracks = N;
+  }
+
+  // -- pending state edits (play / stop / clip-list changes)
+  const DPatch* d_patch = nullptr;
+  if (e->patches_pending) {
+    std::vector<DPatch> p(N);
+    for (uint32_t t = 0; t < N; t++) {
+      p[t] = e->tracks[t].patch;
+      e->tracks[t].patch = DPatch{};
+    }
+    WBX_EHIP(e, e->d_patch.ensure(N));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, hipMemcpy(e->d_patch.p, p.data(), N * sizeof(DPatch), hipMemcpyHostToDevice));
+    d_patch = e->d_patch.p;
+    e->patches_pending = false;
+  }
+
+  // -- routing
+  if (e->routing_dirty || c->routing_tracks != N) {
+    std::vector<int32_t> tb(N);
+    for (uint32_t t = 0; t < N; t++) tb[t] = e->tracks[t].bus;
+    wbx_status st = wbx_set_routing(c, N, e->n_buses ? tb.data() : nullptr, e->n_buses);
+    if (st != WBX_OK) return st;
+    e->routing_dirty = false;
+  }
+  wbx_status st = upload_tables(c, N);
+  if (st != WBX_OK) return st;
+  st = ensure_result_buffers(c, K, N);
+  if (st != WBX_OK) return st;
+
+  // -- transport: exactly the arithmetic of Engine::process, engine.cpp:1578-1585 and :1619-1623, K times
+  const double sample_rate = (double)c->cfg.sample_rate;
+  e->h_times.resize(K);
+  double playhead = e->playhead, sample_position = e->sample_position;
+  for (uint32_t b = 0; b < K; b++) {
+    double buffer_duration = (double)F / sample_rate;
+    double current_beat_duration = e->beat_duration;
+    double buffer_duration_in_beats = buffer_duration / current_beat_duration;
+    double next_playhead_pos = playhead + buffer_duration_in_beats;
+    e->h_times[b] = DBlockTime{playhead, next_playhead_pos, sample_position, current_beat_duration};
+    if (e->playing) {
+      sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, current_beat_duration);
+      playhead = next_playhead_pos;
+    }
+  }
+  WBX_EHIP(e, e->d_times.ensure(std::max<size_t>(K, c->cfg.max_blocks)));
+  WBX_EHIP(e, hipMemcpyAsync(e->d_times.p, e->h_times.data(), K * sizeof(DBlockTime), hipMemcpyHostToDevice, s));
+
+  // -- plan (sequencer on the device), then mix + sum
+  WBX_EHIP(e, hipMemsetAsync(c->d_pool_count, 0, 2 * sizeof(uint32_t), s));
+  PlanArgs a{};
+  a.clips = e->d_clips.p;
+  a.clip_first = e->d_clip_first.p;
+  a.samples = c->d_samples.p;
+  a.state = e->d_state.p;
+  a.patch = d_patch;
+  a.times = e->d_times.p;
+  a.gains = e->d_gains.p;
+  a.tb = c->d_tb.p;
+  a.pool = c->d_pool.p;
+  a.pool_count = c->d_pool_count;
+  a.status = c->d_pool_count + 1;
+  a.pool_chunks = c->pool_chunks;
+  a.n_tracks = N;
+  a.n_blocks = K;
+  a.block_frames = F;
+  a.channels = C;
+  a.sample_rate = sample_rate;
+  a.playing = e->playing ? 1u : 0u;
+  launch_plan(a, s);
+  st = launch_mix_sum(c, K, N);
+  if (st != WBX_OK) return st;
+  launch_levels(c->d_peaks.p, e->d_levels.p, K, N * C, s);
+  WBX_EHIP(e, hipGetLastError());
+
+  e->playhead = playhead;
+  e->sample_position = sample_position;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar) {   // engine.cpp:1576-1654
+  if (!e || !out_planar) return WBX_ERR_INVALID;
+  wbx_status st = wbx_engine_render(e, 1);
+  if (st != WBX_OK) return st;
+  return wbx_fetch(e->ctx, out_planar, nullptr, nullptr);
+}
+
+extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing) {
+  if (!e) return WBX_ERR_INVALID;
+  if (playhead) *playhead = e->playhead;
+  if (sample_position) *sample_position = e->sample_position;
+  if (playing) *playing = e->playing ? 1 : 0;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks) {
+  if (!e || !levels || n_tracks > e->state_tracks) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  const size_t n = (size_t)n_tracks * c->cfg.channels;
+  WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out, size_t cap, size_t* n_out) {
+  if (!e || !n_out) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  if (c->last_K == 0) return efail(e, WBX_ERR_FAILED, "nothing rendered");
+  const uint32_t K = c->last_K, N = c->last_N;
+  std::vector<DTrackBlock> tb((size_t)K * N);
+  uint32_t pc[2] = {0, 0};
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, hipMemcpy(tb.data(), c->d_tb.p, tb.size() * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+  WBX_EHIP(e, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
+  const uint32_t used = std::min(pc[0], c->pool_chunks);
+  std::vector<DSeg> pool((size_t)used * kChunk);
+  if (used) WBX_EHIP(e, hipMemcpy(pool.data(), c->d_pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
+  size_t n = 0;
+  for (uint32_t b = 0; b < K; b++)
+    for (uint32_t t = 0; t < N; t++) {
+      const DTrackBlock& r = tb[(size_t)b * N + t];
+      for (uint32_t i = 0; i < r.nseg; i++) {
+        const DSeg* sg = (i == 0) ? &r.s0 : (r.extra < used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
+        if (!sg) continue;
+        if (out && n < cap) {
+          wbx_plan_record& o = out[n];
+          o.block = b;
+          o.track = t;
+          o.buffer_offset = sg->dst_start;
+          o.num_samples = sg->req_len;
+          o.num_actual = sg->len;
+          o.sample = sg->sample;
+          o.sample_offset = sg->pos;
+          o.playback_speed = sg->speed;
+          o.gain = sg->gain;
+          o._pad = sg->flags;
+        }
+        n++;
+      }
+    }
+  *n_out = n;
+  if (pc[1] & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow");
+  return WBX_OK;
+}

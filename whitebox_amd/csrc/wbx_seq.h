@@ -1,0 +1,296 @@
+// wbx_seq.h — the clip sequencer and sampler-state arithmetic of one track for one block.
+//
+// Follows, operation for operation and in fp64 / int64, the reference's
+//   Track::process_event (audio branch)       src/engine/track.cpp:258-451
+//   the segment loop of Track::process         src/engine/track.cpp:664-724
+//   Sampler::reset_state / stream prologue     src/dsp/sampler.h:18-27, src/dsp/sampler.cpp:99-104,209
+//   beat_to_samples                            src/core/core_math.h:209-212
+// so that every buffer offset, sample offset and segment length is bit-identical to the reference's.
+// It is compiled for the device (plan kernel: one lane per track) and for the host (layer-1 segment
+// conversion and the CPU-side unit tests of the seek math).  No per-sample work happens here.
+//
+// Build with -ffp-contract=off: a fused multiply-add anywhere in here changes results.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "wbx_dev.h"
+
+namespace wbx {
+
+enum : uint32_t { EV_NONE = 0, EV_STOP = 1, EV_PLAY = 2 };  // reference EventType, src/engine/event.h:11-15
+
+// core_math.h:209-212 — two separately rounded multiplies
+__host__ __device__ inline double beat_to_samples(double beat, double sample_rate, double beat_duration) {
+  double sec = beat * beat_duration;
+  return sec * sample_rate;
+}
+
+// (uint32_t)std::ceil(x) as x86-64 evaluates it: convert through a signed 64-bit integer, keep the low word.
+__host__ __device__ inline uint32_t u32_of_ceil(double x) {
+  double c = ceil(x);
+  return (uint32_t)(uint64_t)(long long)c;
+}
+
+// find_lower_bound with the predicate clip->max_time <= value (core/algorithm.h:24-40, track.cpp:206)
+__host__ __device__ inline uint32_t lower_bound_max_time(const DClip* clips, uint32_t n, double value) {
+  long long left = 0, right = (long long)n - 1;
+  while (left < right) {
+    long long middle = (left + right) >> 1;
+    if (clips[middle].max_time <= value)
+      left = middle + 1;
+    else
+      right = middle;
+  }
+  return (uint32_t)right;
+}
+
+// Track::find_next_clip, track.cpp:182-213
+__host__ __device__ inline bool find_next_clip(const DClip* clips, uint32_t n, double time_pos, uint32_t* idx) {
+  if (n == 0) return false;
+  if (clips[n - 1].max_time < time_pos) return false;
+  *idx = lower_bound_max_time(clips, n, time_pos);
+  return true;
+}
+
+// The walker below receives events as process_event produces them and performs the matching iteration
+// of Track::process's segment loop immediately.  That is equivalent to building the whole event list
+// first (track.cpp:604-615) and walking it afterwards (:664-724): the loop never feeds back into the
+// sequencer, and because start_sample always becomes the event's buffer_offset (< buffer_size) under
+// the reference's uint32 arithmetic, every event of the list is consumed.
+struct BlockWalker {
+  DTrackState* st;
+  const DSample* samples;
+  DTrackBlock* tb;          // record being filled
+  DSeg* pool;
+  uint32_t* pool_count;
+  uint32_t pool_chunks;
+  uint32_t* status;
+  uint32_t n_samples;       // block frames
+  uint32_t n_channels;
+  double dst_rate;
+  uint32_t start_sample;
+  uint32_t nseg;
+  uint32_t chunk;
+
+  __host__ __device__ DSeg* slot() {
+    if (nseg == 0) return &tb->s0;
+    if (nseg >= kMaxSegs) {
+      if (status) status[0] |= 2u;
+      return nullptr;
+    }
+    if (nseg == 1) {
+      uint32_t c;
+#if defined(__HIP_DEVICE_COMPILE__)
+      c = atomicAdd(pool_count, 1u);
+#else
+      c = (*pool_count)++;
+#endif
+      if (c >= pool_chunks) {
+        if (status) status[0] |= 1u;
+        return nullptr;
+      }
+      chunk = c;
+      tb->extra = c;
+    }
+    if (chunk == 0xFFFFFFFFu) return nullptr;
+    return &pool[(size_t)chunk * kChunk + (nseg - 1)];
+  }
+
+  // Sampler::stream up to (not including) the per-sample loops: sampler.cpp:99-104 and :209
+  __host__ __device__ void stream(uint32_t num_samples, uint32_t buffer_offset) {
+    const DSample& smp = samples[st->cur_sample];
+    DSeg* s = slot();
+    DSeg seg;
+    seg.src[0] = smp.ch[0];
+    seg.src[1] = smp.ch[n_channels > 1 ? 1 : 0];
+    seg.pos = st->sample_offset;
+    seg.speed = st->playback_speed;
+    seg.gain = st->cur_gain;
+    seg.dst_start = (uint16_t)buffer_offset;
+    seg.req_len = (uint16_t)(num_samples > 0xFFFFu ? 0xFFFFu : num_samples);
+    seg.format = (uint8_t)smp.format;
+    seg.flags = 0;
+    seg.sample = st->cur_sample;
+    if (st->sample_offset >= (double)smp.count) {          // :99-100 finished streaming
+      seg.len = 0;
+      seg.flags = SEG_FINISHED;
+    } else {
+      double stream_max_length = ((double)smp.count - st->sample_offset) / st->playback_speed;   // :102
+      double next_sample_offset = st->sample_offset + ((double)num_samples * st->playback_speed); // :103
+      uint32_t lim = u32_of_ceil(stream_max_length);                                             // :104
+      uint32_t n = num_samples < lim ? num_samples : lim;
+      if (buffer_offset + (uint64_t)n > n_samples) {       // the reference would write out of bounds here
+        n = buffer_offset < n_samples ? n_samples - buffer_offset : 0;
+        seg.flags |= SEG_CLIPPED;
+        if (status) status[0] |= 4u;
+      }
+      seg.len = (uint16_t)n;
+      st->sample_offset = next_sample_offset;                                                    // :209
+    }
+    if (s) {
+      *s = seg;
+      nseg++;
+    }
+  }
+
+  // one `next_event != end` iteration of the loop at track.cpp:668-709
+  __host__ __device__ void on_event(uint32_t type, uint32_t buffer_offset, double speed, uint64_t sample_offset,
+                                    const DClip* clip) {
+    uint32_t event_length = buffer_offset - start_sample;   // uint32 arithmetic as in the reference
+    if (st->cur_type == EV_PLAY) stream(event_length, start_sample);
+    if (type == EV_PLAY) {                                  // :687-697 Sampler::reset_state (sampler.h:18-27)
+      const DSample& smp = samples[clip->sample];
+      st->playback_speed = ((double)smp.sample_rate / dst_rate) * speed;
+      st->sample_offset = (double)sample_offset;
+      st->cur_gain = clip->gain;
+      st->cur_sample = clip->sample;
+    }
+    st->cur_type = type;
+    start_sample += event_length;
+  }
+
+  // the `else` arm, track.cpp:710-722
+  __host__ __device__ void finish() {
+    uint32_t event_length = n_samples - start_sample;
+    if (st->cur_type == EV_PLAY) stream(event_length, start_sample);
+    start_sample = n_samples;
+  }
+};
+
+// Track::process_event, audio branch — track.cpp:258-451.  MIDI clips and recording are out of scope.
+__host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint32_t num_clips, double start_time,
+                                              double end_time, double sample_position, double beat_duration,
+                                              double sample_rate, uint32_t buffer_size) {
+  DTrackState* st = w.st;
+  if (num_clips == 0) {                                          // :268-284
+    if (st->refresh_voice) {
+      w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
+      st->has_clip_idx = 0;
+      st->refresh_voice = 0;
+    }
+    return;
+  }
+
+  if (st->refresh_voice) {                                       // :287-340
+    uint32_t at = 0;
+    if (find_next_clip(clips, num_clips, start_time, &at)) {
+      if (st->has_clip_idx) {
+        uint32_t idx = st->clip_idx;
+        if (idx < num_clips) {
+          const DClip* clip = &clips[at];
+          if (at != idx && start_time >= clip->min_time && start_time <= clip->max_time) {
+            w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
+            st->clip_idx = at;
+            st->partially_ended = 0;
+          } else if (at == idx && (start_time < clip->min_time || start_time > clip->max_time)) {
+            w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
+            st->clip_idx = at;
+            st->partially_ended = 0;
+          }
+        }
+      } else {
+        st->has_clip_idx = 1;
+        st->clip_idx = at;
+      }
+    } else {
+      w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
+      st->has_clip_idx = 0;
+    }
+    st->refresh_voice = 0;
+  }
+
+  if (!st->has_clip_idx) return;                                 // :342-346
+
+  uint32_t next_clip = st->clip_idx;
+  while (next_clip < num_clips) {                                // :349-446
+    DClip* clip = &clips[next_clip];
+    double min_time = clip->min_time;
+    double max_time = clip->max_time;
+
+    if (min_time > end_time) break;
+
+    if (min_time >= start_time) {                                // :357-374 started from the beginning
+      double offset_from_start = beat_to_samples(min_time - start_time, sample_rate, beat_duration);
+      double sample_offset = sample_position + offset_from_start;
+      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      w.on_event(EV_PLAY, buffer_offset, clip->speed, (uint64_t)clip->start_offset, clip);
+      clip->internal_state_changed = 0;
+    } else if (start_time > min_time && !st->partially_ended) {  // :375-393 started in the middle
+      double relative_start_time = start_time - min_time;
+      double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
+      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
+      clip->internal_state_changed = 0;
+    } else if (clip->internal_state_changed && st->partially_ended) {  // :394-419
+      double relative_start_time = start_time - min_time;
+      double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
+      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
+      w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
+      clip->internal_state_changed = 0;
+    }
+
+    if (max_time <= end_time) {                                  // :421-434 reaching the end of the clip
+      double offset_from_start = beat_to_samples(max_time - start_time, sample_rate, beat_duration);
+      double sample_offset = sample_position + offset_from_start;
+      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      w.on_event(EV_STOP, buffer_offset, 0.0, 0, nullptr);
+      st->partially_ended = 0;
+    } else {                                                     // :435-442
+      st->partially_ended = 1;
+      break;
+    }
+    next_clip++;
+  }
+  st->clip_idx = next_clip;                                      // :450
+}
+
+// classify a finished track-block record for the mix kernel's wave-uniform dispatch
+__host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t block_frames) {
+  if (tb.nseg == 0) return KIND_SILENT;
+  if (tb.nseg == 1) {
+    const DSeg& s = tb.s0;
+    if (s.len == 0) return KIND_SILENT;
+    if (s.format == FMT_F32 && s.dst_start == 0 && s.len == block_frames && s.pos >= 0.0 && s.pos < 2147483000.0) {
+      if (s.speed == 1.0) return KIND_UNITY;                     // sampler.cpp:106
+      if (s.speed > 0.0 && s.speed < 1.0) return KIND_WINDOW;
+    }
+  }
+  return KIND_GENERIC;
+}
+
+// One track, one block: Track::process minus the per-sample work (track.cpp:587-736).
+__host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
+                                                 DClip* clips, uint32_t num_clips) {
+  DTrackBlock* tb = &a.tb[(size_t)b * a.n_tracks + t];
+  BlockWalker w;
+  w.st = st;
+  w.samples = a.samples;
+  w.tb = tb;
+  w.pool = a.pool;
+  w.pool_count = a.pool_count;
+  w.pool_chunks = a.pool_chunks;
+  w.status = a.status;
+  w.n_samples = a.block_frames;
+  w.n_channels = a.channels;
+  w.dst_rate = a.sample_rate;
+  w.start_sample = 0;
+  w.nseg = 0;
+  w.chunk = 0xFFFFFFFFu;
+  tb->extra = 0;
+  tb->s0.len = 0;
+  if (a.playing) {
+    const DBlockTime& bt = a.times[b];
+    process_event(w, clips, num_clips, bt.start_time, bt.end_time, bt.sample_position, bt.beat_duration,
+                  a.sample_rate, a.block_frames);
+    w.finish();
+  }
+  tb->g[0] = a.gains[2 * t + 0];
+  tb->g[1] = a.gains[2 * t + 1];
+  tb->nseg = (uint8_t)w.nseg;
+  tb->_pad = 0;
+  tb->kind = classify(*tb, a.block_frames);
+}
+
+}  // namespace wbx
