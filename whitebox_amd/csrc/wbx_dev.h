@@ -63,7 +63,7 @@ struct DPatch {           // host-side edits applied to DTrackState before the n
 };
 enum : uint32_t { PATCH_CLIPIDX = 1, PATCH_REFRESH = 2, PATCH_STOP = 4 };
 
-struct DSeg {             // one Sampler::stream call (48 B)
+struct DSeg {             // one Sampler::stream call (48 B) — overflow-pool entry
   const void* src[2];
   double pos;             // Sampler::sample_offset_ before the call
   double speed;           // Sampler::playback_speed_
@@ -76,12 +76,24 @@ struct DSeg {             // one Sampler::stream call (48 B)
   uint32_t sample;
 };
 
-struct DTrackBlock {      // 64 B
-  DSeg s0;
+// One (block, track) record, 64 B = four 16-B quads laid out for the mix kernel's LDS reads:
+//   Q0 src[0..1]   Q1 pos, speed   Q2 gain, g[0], g[1], nseg|kind|dst_start   Q3 the rest
+// Segment 0 lives inline; segments 1..nseg-1 (rare: a clip boundary inside the block) in the pool.
+struct DTrackBlock {
+  const void* src[2];     // Q0
+  double pos;             // Q1
+  double speed;
+  float gain;             // Q2
   float g[2];             // fl(volume * pan_coeffs[c]), 0 when muted (track.cpp:728-731)
   uint8_t nseg;           // stream calls (including zero-length / finished ones)
   uint8_t kind;
+  uint16_t dst_start;
+  uint16_t len;           // Q3
+  uint16_t req_len;
+  uint8_t format;
+  uint8_t flags;
   uint16_t _pad;
+  uint32_t sample;
   uint32_t extra;         // overflow chunk index (segments 1..nseg-1), valid when nseg > 1
 };
 static_assert(sizeof(DSeg) == 48, "DSeg must be 48 bytes");
@@ -108,15 +120,30 @@ struct PlanArgs {
   DTrackBlock* tb;              // [K][N]
   DSeg* pool;                   // [pool_chunks][kChunk]
   uint32_t* pool_count;         // allocated chunks
-  uint32_t* status;             // bit0: pool overflow, bit1: > kMaxSegs calls, bit2: SEG_CLIPPED happened
+  uint32_t* status;             // bit0: pool overflow, bit1: > kMaxSegs calls, bit2: SEG_CLIPPED happened,
+                                // bit3: more generic track-blocks than pre-render rows
+  uint32_t* gen_list;           // [gen_cap] index (b*N+t) of every KIND_GENERIC record
+  uint32_t* gen_count;
+  uint32_t gen_cap;
   uint32_t pool_chunks;
   uint32_t n_tracks, n_blocks, block_frames, channels;
   double sample_rate;
   uint32_t playing;
 };
 
+struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows
+  DTrackBlock* tb;              // [K][N]; rewritten in place to KIND_UNITY records that read the row
+  const DSeg* pool;
+  const uint32_t* gen_list;
+  const uint32_t* gen_count;
+  float* rows;                  // [gen_cap][C][F + 8]
+  DTrackBlock* saved;           // [gen_cap] the original records (wbx_engine_fetch_plan)
+  uint32_t gen_cap, block_frames, channels;
+};
+
 struct MixArgs {
   const DTrackBlock* tb;        // [K][N]
+  const float* zero_page;       // >= F + 8 zero floats: what padding / silent records read
   const DSeg* pool;
   const uint32_t* order;        // [N] track permutation (routing order)
   const DGroup* groups;         // [NG]

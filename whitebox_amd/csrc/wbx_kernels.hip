@@ -23,10 +23,24 @@ namespace wbx {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B load at 4-B alignment
 
+// Clip pointers travel through LDS / records as plain 64-bit values; telling the compiler they are
+// GLOBAL (address space 1) makes it emit global_load_* instead of flat_load_* (flat loads also occupy
+// the LDS path and its counter).
+#define WBX_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const T WBX_GLOBAL* as_global(const void* p) {
+  return (const T WBX_GLOBAL*)(uintptr_t)p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
+  // the K per-block transport records are the same for every track: stage them in LDS once
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  DBlockTime* s_times = reinterpret_cast<DBlockTime*>(s_raw);
+  for (uint32_t i = threadIdx.x; i < a.n_blocks; i += blockDim.x) s_times[i] = a.times[i];
+  __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.n_tracks) return;
   DTrackState st = a.state[t];
@@ -43,7 +57,11 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
   const uint32_t c0 = a.clip_first[t];
   const uint32_t nc = a.clip_first[t + 1] - c0;
   DClip* clips = const_cast<DClip*>(a.clips) + c0;
-  for (uint32_t b = 0; b < a.n_blocks; b++) plan_track_block(a, t, b, &st, clips, nc);
+  TrackCache cache;
+  cache.clip_idx = 0xFFFFFFFFu;
+  cache.smp_idx = 0xFFFFFFFFu;
+  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
+  for (uint32_t b = 0; b < a.n_blocks; b++) plan_track_block(a, t, b, &st, clips, nc, &cache, s_times[b], gl, gr);
   a.state[t] = st;
 }
 
@@ -65,21 +83,24 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {
 // unity path sampler.cpp:106-158, linear path sampler.cpp:34-59 (normalisers :7-18 and :95-97).
 __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t jj) {
   const void* base = sg.src[c];
+  const float WBX_GLOBAL* bf = as_global<float>(base);
+  const int16_t WBX_GLOBAL* b16 = as_global<int16_t>(base);
+  const int32_t WBX_GLOBAL* b32 = as_global<int32_t>(base);
   if (sg.speed == 1.0) {
     const uint32_t idx = (uint32_t)sg.pos + jj;                          // :107
     switch (sg.format) {
-      case FMT_F32: return ((const float*)base)[idx];
+      case FMT_F32: return bf[idx];
       case FMT_I16: {
         const float norm = 1.0f / 32767.0f;                              // :95
-        return clampf(__fmul_rn((float)((const int16_t*)base)[idx], norm), -1.0f, 1.0f);
+        return clampf(__fmul_rn((float)b16[idx], norm), -1.0f, 1.0f);
       }
       case FMT_I24: {
         const double norm = 1.0 / 8388607.0;                             // :96
-        return (float)clampd(__dmul_rn((double)((const int32_t*)base)[idx], norm), -1.0, 1.0);
+        return (float)clampd(__dmul_rn((double)b32[idx], norm), -1.0, 1.0);
       }
       default: {
         const double norm = 1.0 / 2147483647.0;                          // :97
-        return (float)clampd(__dmul_rn((double)((const int32_t*)base)[idx], norm), -1.0, 1.0);
+        return (float)clampd(__dmul_rn((double)b32[idx], norm), -1.0, 1.0);
       }
     }
   }
@@ -89,25 +110,25 @@ __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t 
   float a, b;
   switch (sg.format) {
     case FMT_F32:
-      a = ((const float*)base)[ix];
-      b = ((const float*)base)[ix + 1];
+      a = bf[ix];
+      b = bf[ix + 1];
       break;
     case FMT_I16: {
       const float norm = (float)(1.0 / 32767.0);                                   // :9-10
-      a = __fmul_rn(norm, (float)((const int16_t*)base)[ix]);
-      b = __fmul_rn(norm, (float)((const int16_t*)base)[ix + 1]);
+      a = __fmul_rn(norm, (float)b16[ix]);
+      b = __fmul_rn(norm, (float)b16[ix + 1]);
       break;
     }
     case FMT_I24: {
       const double norm = 1.0 / 8388607.0;                                         // :11-12
-      a = (float)__dmul_rn(norm, (double)((const int32_t*)base)[ix]);
-      b = (float)__dmul_rn(norm, (double)((const int32_t*)base)[ix + 1]);
+      a = (float)__dmul_rn(norm, (double)b32[ix]);
+      b = (float)__dmul_rn(norm, (double)b32[ix + 1]);
       break;
     }
     default: {
       const double norm = 1.0 / 2147483647.0;                                      // :13-14
-      a = (float)__dmul_rn(norm, (double)((const int32_t*)base)[ix]);
-      b = (float)__dmul_rn(norm, (double)((const int32_t*)base)[ix + 1]);
+      a = (float)__dmul_rn(norm, (double)b32[ix]);
+      b = (float)__dmul_rn(norm, (double)b32[ix + 1]);
       break;
     }
   }
@@ -117,150 +138,279 @@ __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t 
 // Generic track-block: any number of segments, any coverage, any format.  Returns the track's
 // mixing-buffer value for frame j of channel c BEFORE the track gain (the buffer the reference clears
 // at engine.cpp:1602 and Sampler::stream accumulates into, sampler.cpp:56,152).
-__device__ __forceinline__ float render_generic(const DTrackBlock& tb, const DSeg* pool, uint32_t c, uint32_t j) {
-  float acc = 0.0f;
+// One lane's 4 frames of a generic track-block: the mixing-buffer values BEFORE the track gain.
+__device__ __forceinline__ f4 render_generic(const DTrackBlock& tb, const DSeg* pool, uint32_t c, uint32_t j0) {
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const uint32_t nseg = tb.nseg;
   for (uint32_t s = 0; s < nseg; s++) {
-    const DSeg& sg = (s == 0) ? tb.s0 : pool[(size_t)tb.extra * kChunk + (s - 1)];
+    const DSeg sg = (s == 0) ? get_seg0(tb) : pool[(size_t)tb.extra * kChunk + (s - 1)];
     const uint32_t d0 = sg.dst_start, n = sg.len;
-    if (j >= d0 && j < d0 + n) acc = __fadd_rn(acc, __fmul_rn(sample_at(sg, c, j - d0), sg.gain));
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++) {
+      const uint32_t j = j0 + e;
+      if (j >= d0 && j < d0 + n) acc[e] = __fadd_rn(acc[e], __fmul_rn(sample_at(sg, c, j - d0), sg.gain));
+    }
   }
-  return acc;
+  return f4{acc[0], acc[1], acc[2], acc[3]};
 }
 
-__device__ __forceinline__ float pick(float w0, float w1, float w2, float w3, int k) {
-  return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+// ------------------------------------------------------------------------------------------------
+// gen: pre-render of the KIND_GENERIC track-blocks (clip boundaries inside a block, integer PCM,
+// speed > 0.999 ...).  One workgroup per queued record: render the track's mixing buffer (all segments,
+// sampler.cpp:88-210) into a scratch row, then rewrite the record as a KIND_UNITY read of that row with
+// clip gain 1, so the mix kernel's hot loop only ever sees two shapes.  grid-stride over the queue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
+  __shared__ DTrackBlock s_rec;
+  const uint32_t count = min(*a.gen_count, a.gen_cap);
+  const uint32_t F = a.block_frames, C = a.channels, S4 = F >> 2;
+  const size_t row_floats = (size_t)C * (F + 8);
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const uint32_t idx = a.gen_list[i];
+    __syncthreads();
+    if (threadIdx.x < 4) reinterpret_cast<uint4*>(&s_rec)[threadIdx.x] = reinterpret_cast<const uint4*>(a.tb + idx)[threadIdx.x];
+    __syncthreads();
+    float* row = a.rows + (size_t)i * row_floats;
+    for (uint32_t slot = threadIdx.x; slot < C * S4; slot += 256u) {
+      const uint32_t c = slot / S4, j0 = (slot - c * S4) * 4u;
+      const f4 r = render_generic(s_rec, a.pool, c, j0);
+      *reinterpret_cast<f4*>(row + (size_t)c * (F + 8) + j0) = r;
+    }
+    if (threadIdx.x < 8u * C) {   // the 8 floats behind each channel row that a 5-sample window load may touch
+      const uint32_t c = threadIdx.x >> 3;
+      row[(size_t)c * (F + 8) + F + (threadIdx.x & 7u)] = 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.saved[i] = s_rec;
+      DTrackBlock u = s_rec;
+      u.src[0] = row;
+      u.src[1] = row + (C > 1 ? (F + 8) : 0);
+      u.pos = 0.0;
+      u.speed = 1.0;
+      u.gain = 1.0f;
+      u.kind = KIND_UNITY;
+      a.tb[idx] = u;
+    }
+  }
 }
 
 __device__ __forceinline__ float absmax4(f4 m) {
   return fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
 }
 
-// ------------------------------------------------------------------------------------------------
-// mix: grid = (n_groups, n_blocks, tiles), block = 256 lanes (4 waves).
-// Lane -> (channel c, frames j0..j0+3).  With F = 512, C = 2: waves 0-1 own the left channel, waves
-// 2-3 the right one, every wave-level load is one contiguous 1 KiB row of a clip.
-// ------------------------------------------------------------------------------------------------
-template <int U>
-__global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
-  __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kStage];
-  __shared__ uint32_t s_pk[kStage * 2];
+// Branch-free tap selection for the 5-sample window: returns w[k] / w[k+1] for k in [0, E].
+// Written as a chain of compare+select on purpose — an if/switch here becomes exec-mask control flow.
+template <int E>
+__device__ __forceinline__ void taps(const f4& v, float w4, int k, float& sa, float& sb) {
+  sa = v.x;
+  sb = v.y;
+  if (E >= 1) {
+    const bool p = k >= 1;
+    sa = p ? v.y : sa;
+    sb = p ? v.z : sb;
+  }
+  if (E >= 2) {
+    const bool p = k >= 2;
+    sa = p ? v.z : sa;
+    sb = p ? v.w : sb;
+  }
+  if (E >= 3) {
+    const bool p = k >= 3;
+    sa = p ? v.w : sa;
+    sb = p ? w4 : sb;
+  }
+}
 
-  const uint32_t g = blockIdx.x, b = blockIdx.y, tile = blockIdx.z;
+// max over the 64 lanes of a wave, delivered in lane 63, with DPP row operations only (no LDS crossbar):
+// quad butterflies, row_half_mirror, row_mirror, then row_bcast:15 / row_bcast:31 into the upper rows.
+__device__ __forceinline__ float wave_max_lane63(float x) {
+  int v = __float_as_int(x);
+#define WBX_DPP_MAX(ctrl, rmask)                                                                     \
+  {                                                                                                 \
+    const int o = __builtin_amdgcn_update_dpp(v, v, (ctrl), (rmask), 0xF, false);                    \
+    v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(o)));                                 \
+  }
+  WBX_DPP_MAX(0xB1, 0xF)    // quad_perm [1,0,3,2]
+  WBX_DPP_MAX(0x4E, 0xF)    // quad_perm [2,3,0,1]
+  WBX_DPP_MAX(0x141, 0xF)   // row_half_mirror
+  WBX_DPP_MAX(0x140, 0xF)   // row_mirror: every lane of a 16-lane row now holds the row maximum
+  WBX_DPP_MAX(0x142, 0xA)   // row_bcast:15 -> rows 1 and 3
+  WBX_DPP_MAX(0x143, 0xC)   // row_bcast:31 -> rows 2 and 3: lane 63 holds the wave maximum
+#undef WBX_DPP_MAX
+  return __int_as_float(v);
+}
+
+// the loads of one track that are in flight while other tracks are being rendered
+struct Pre {
+  f4 v;        // UNITY: the 4 source frames; WINDOW: window samples 0..3
+  float w4;    // window sample 4 (loaded for every track so that the load sequence is branch-free)
+  int ix0;     // integer source position of v.x
+};
+
+// ------------------------------------------------------------------------------------------------
+// mix: grid = (n_blocks, n_groups, tiles) — consecutive workgroups take consecutive BLOCKS of the same
+// track group, so the workgroups in flight together read long contiguous runs of the same clips.
+// block = 256 lanes (4 waves).  Lane -> (channel c, frames j0..j0+3).  With F = 512, C = 2: waves 0-1
+// own the left channel, waves 2-3 the right one; every wave-level load is one contiguous ~1 KiB row.
+//
+// By the time this kernel runs every record is KIND_UNITY or KIND_WINDOW (gen_kernel rewrote the generic
+// ones; silent ones and the padding of the last batch read the zero page with zero gain), so the load
+// phase is straight-line code: exactly one 16-B + one 4-B load per track, no branches, which lets the
+// compiler count outstanding loads exactly and keep two batches in flight.
+//
+//   U     tracks per batch; two batches are in flight (software pipeline: the loads of batch i+1 are
+//         issued before batch i is rendered), so 2*U clip rows per wave are outstanding
+//   FULL  every lane owns a slot and every wave is channel-uniform (C*F/4 % 256 == 0, F/4 % 64 == 0):
+//         no lane predicate, the channel index is a scalar
+// ------------------------------------------------------------------------------------------------
+template <int U, bool FULL, int W>
+__global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
+  constexpr uint32_t kRecs = kStage + 2 * U;   // staged records + null padding for the last batches
+  __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kRecs];
+  __shared__ uint32_t s_pk[kRecs * 2];
+
+  const uint32_t b = blockIdx.x, g = blockIdx.y, tile = blockIdx.z;
   const uint32_t tid = threadIdx.x;
   const DGroup grp = a.groups[g];
   const uint32_t F = a.block_frames, C = a.channels, N = a.n_tracks;
   const uint32_t S4 = F >> 2;
   const uint32_t slot = tile * 256u + tid;
-  const bool active = slot < C * S4;
-  const uint32_t c = active ? slot / S4 : 0u;
+  const bool active = FULL ? true : (slot < C * S4);
+  uint32_t c = active ? slot / S4 : 0u;
+  if (FULL) c = __builtin_amdgcn_readfirstlane(c);
   const uint32_t j0 = active ? (slot - c * S4) * 4u : 0u;
   // lanes of an aligned `span`-lane group share a channel (span = largest power of two dividing F/4, <= 64)
-  uint32_t span = S4 & (~S4 + 1u);
-  span = span > 64u ? 64u : span;
+  uint32_t span = 64u;
+  if (!FULL) {
+    span = S4 & (~S4 + 1u);
+    span = span > 64u ? 64u : span;
+  }
   const uint32_t lane = tid & 63u;
+  const double j0d = (double)(int32_t)j0;
 
   f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
-    const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
-    __syncthreads();
-    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record
-    for (uint32_t i = tid; i < cn * 4u; i += 256u) {
-      const uint32_t rec = i >> 2, q = i & 3u;
-      const uint32_t track = a.order[grp.first + chunk0 + rec];
-      reinterpret_cast<uint4*>(s_tb)[i] = reinterpret_cast<const uint4*>(a.tb + (size_t)b * N + track)[q];
+  // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line) ---------
+  auto issue = [&](uint32_t u0, Pre (&pre)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const DTrackBlock& r = s_tb[u0 + u];
+      // frame j0 sits at x0 = pos + j0*speed (sampler.cpp:50); for speed == 1.0 (pos integral) this is the
+      // unity path's (uint32)pos + j0 (sampler.cpp:107,151)
+      const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));
+      const int ix0 = (int)trunc(x0);
+      const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + ix0;
+      if (active) {
+        pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);   // the taps of frames j0..j0+3 lie in p[0..4]
+        pre[u].w4 = p[4];
+      }
+      pre[u].ix0 = ix0;
     }
-    if (tid < kStage * 2u) s_pk[tid] = 0u;
-    __syncthreads();
+  };
 
-    for (uint32_t u0 = 0; u0 < cn; u0 += U) {
-      f4 v[U];
-      float w4[U];
-      int kind[U];
-      // phase A: issue the clip loads of U tracks back to back
+  // ---- phase B: render, scale, accumulate — strictly in track order; then the per-track peaks -----
+  auto render = [&](uint32_t u0, Pre (&pre)[U]) {
+    float pk[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t tl = u0 + u;
-        int k = (tl < cn) ? (int)s_tb[tl].kind : (int)KIND_SILENT;
-        k = __builtin_amdgcn_readfirstlane(k);
-        kind[u] = k;
-        v[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        w4[u] = 0.0f;
-        if (active) {
-          if (k == KIND_UNITY) {
-            const DSeg& sg = s_tb[tl].s0;
-            const float* p = (const float*)sg.src[c] + ((uint32_t)sg.pos + j0);      // sampler.cpp:107,151
-            v[u] = *reinterpret_cast<const f4u*>(p);
-          } else if (k == KIND_WINDOW) {
-            const DSeg& sg = s_tb[tl].s0;
-            const double x0 = __dadd_rn(sg.pos, __dmul_rn((double)(int32_t)j0, sg.speed));
-            const float* p = (const float*)sg.src[c] + (int)trunc(x0);
-            v[u] = *reinterpret_cast<const f4u*>(p);   // taps of 4 consecutive frames lie in p[0..4]
-            w4[u] = p[4];
-          }
-        }
+    for (int u = 0; u < U; u++) {
+      const DTrackBlock& r = s_tb[u0 + u];
+      const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+      const float cg = r.gain;
+      const float gc = r.g[c];
+      f4 m;
+      if (k == KIND_WINDOW) {
+        const double pos = r.pos, speed = r.speed;
+        const int ix0 = pre[u].ix0;
+        float q[4];
+#define WBX_TAP(E)                                                                                      \
+  {                                                                                                     \
+    const double x = __dadd_rn(pos, __dmul_rn(j0d + (double)(E), speed)); /* sampler.cpp:50 */          \
+    const double tx = trunc(x);                                           /* :51 (x >= 0) */            \
+    const float fx = (float)__dsub_rn(x, tx);                             /* :52 */                     \
+    float sa, sb;                                                                                       \
+    taps<E>(pre[u].v, pre[u].w4, (int)tx - ix0, sa, sb);                                                \
+    const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
+    q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
+  }
+        WBX_TAP(0) WBX_TAP(1) WBX_TAP(2) WBX_TAP(3)
+#undef WBX_TAP
+        m = f4{q[0], q[1], q[2], q[3]};
+      } else {   // KIND_UNITY (also: pre-rendered rows, silent and padding records)
+        m.x = __fmul_rn(__fmul_rn(pre[u].v.x, cg), gc);                                   // sampler.cpp:152, track.cpp:731
+        m.y = __fmul_rn(__fmul_rn(pre[u].v.y, cg), gc);
+        m.z = __fmul_rn(__fmul_rn(pre[u].v.z, cg), gc);
+        m.w = __fmul_rn(__fmul_rn(pre[u].v.w, cg), gc);
       }
-      // phase B: render, scale, accumulate — strictly in track order
-      float pk[U];
+      if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      acc.x = __fadd_rn(acc.x, m.x);                                                      // audio_buffer.h:73-82
+      acc.y = __fadd_rn(acc.y, m.y);
+      acc.z = __fadd_rn(acc.z, m.z);
+      acc.w = __fadd_rn(acc.w, m.w);
+      pk[u] = absmax4(m);                                                                 // vu_meter.h:20-25
+    }
+    // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes
+    // that share a channel otherwise; then one LDS atomic per wave / lane group
+    if (FULL) {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t tl = u0 + u;
-        f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int k = kind[u];
-        if (k != KIND_SILENT && active) {
-          const DTrackBlock& tb = s_tb[tl];
-          const float gc = tb.g[c];
-          if (k == KIND_UNITY) {
-            const float cg = tb.s0.gain;
-            m.x = __fmul_rn(__fmul_rn(v[u].x, cg), gc);                             // sampler.cpp:152, track.cpp:731
-            m.y = __fmul_rn(__fmul_rn(v[u].y, cg), gc);
-            m.z = __fmul_rn(__fmul_rn(v[u].z, cg), gc);
-            m.w = __fmul_rn(__fmul_rn(v[u].w, cg), gc);
-          } else if (k == KIND_WINDOW) {
-            const double pos = tb.s0.pos, speed = tb.s0.speed;
-            const float cg = tb.s0.gain;
-            const double x0 = __dadd_rn(pos, __dmul_rn((double)(int32_t)j0, speed));
-            const int ix0 = (int)trunc(x0);
-            float r[4];
+      for (int u = 0; u < U; u++) pk[u] = wave_max_lane63(pk[u]);
+      if (lane == 63u) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              const double x = __dadd_rn(pos, __dmul_rn((double)(int32_t)(j0 + e), speed));   // sampler.cpp:50
-              const double tx = trunc(x);                                                    // :51 (x >= 0)
-              const float fx = (float)__dsub_rn(x, tx);                                      // :52
-              const int kk = (int)tx - ix0;                                                  // 0..e
-              const float sa = pick(v[u].x, v[u].y, v[u].z, v[u].w, kk);
-              const float sb = pick(v[u].y, v[u].z, v[u].w, w4[u], kk);
-              const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));               // :55
-              r[e] = __fmul_rn(__fmul_rn(s, cg), gc);                                        // :56, track.cpp:731
-            }
-            m = f4{r[0], r[1], r[2], r[3]};
-          } else {
-            m.x = __fmul_rn(render_generic(tb, a.pool, c, j0 + 0), gc);
-            m.y = __fmul_rn(render_generic(tb, a.pool, c, j0 + 1), gc);
-            m.z = __fmul_rn(render_generic(tb, a.pool, c, j0 + 2), gc);
-            m.w = __fmul_rn(render_generic(tb, a.pool, c, j0 + 3), gc);
-          }
-          acc.x = __fadd_rn(acc.x, m.x);                                                      // audio_buffer.h:73-82
-          acc.y = __fadd_rn(acc.y, m.y);
-          acc.z = __fadd_rn(acc.z, m.z);
-          acc.w = __fadd_rn(acc.w, m.w);
-        }
-        pk[u] = absmax4(m);                                                                   // vu_meter.h:20-25
+        for (int u = 0; u < U; u++) atomicMax(&s_pk[(u0 + u) * 2u + c], __float_as_uint(pk[u]));
       }
-      // per-track peak: shuffle-max across the lanes that share a channel, then one LDS atomic per group
+    } else {
       for (uint32_t off = 1; off < span; off <<= 1) {
 #pragma unroll
         for (int u = 0; u < U; u++) pk[u] = fmaxf(pk[u], __shfl_xor(pk[u], (int)off, 64));
       }
       if ((lane & (span - 1u)) == 0u && active) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t tl = u0 + u;
-          if (tl < cn && kind[u] != KIND_SILENT) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk[u]));
-        }
+        for (int u = 0; u < U; u++) atomicMax(&s_pk[(u0 + u) * 2u + c], __float_as_uint(pk[u]));
       }
     }
+  };
+
+  for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
+    const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
+    __syncthreads();
+    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record;
+    // silent records and the padding up to a whole number of batches become "read the zero page, gain 0"
+    for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
+      const uint32_t rec = i >> 2, q = i & 3u;
+      uint4 w = {0u, 0u, 0u, 0u};
+      if (rec < cn) {
+        const uint32_t track = a.order[grp.first + chunk0 + rec];
+        w = reinterpret_cast<const uint4*>(a.tb + (size_t)b * N + track)[q];
+      }
+      reinterpret_cast<uint4*>(s_tb)[i] = w;
+    }
+    if (tid < kRecs * 2u) s_pk[tid] = 0u;
+    __syncthreads();
+    if (tid < kRecs) {
+      DTrackBlock& r = s_tb[tid];
+      if (tid >= cn || r.kind == KIND_SILENT) {
+        r.src[0] = a.zero_page;
+        r.src[1] = a.zero_page;
+        r.pos = 0.0;
+        r.speed = 1.0;
+        r.gain = 0.0f;
+        r.g[0] = 0.0f;
+        r.g[1] = 0.0f;
+        r.kind = KIND_UNITY;
+      }
+    }
+    __syncthreads();
+
+    // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records)
+    Pre pa[U], pb[U];
+    issue(0, pa);
+    for (uint32_t u0 = 0; u0 < cn; u0 += 2 * U) {
+      issue(u0 + U, pb);
+      render(u0, pa);
+      issue(u0 + 2 * U, pa);
+      render(u0 + U, pb);
+    }
+
     __syncthreads();
     if (tid < cn * C) {
       const uint32_t rec = tid / C, ch = tid - rec * C;
@@ -280,14 +430,14 @@ __global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sum: grid = (n_blocks, tiles), block = 256.  master = (((direct groups in order) + bus 0) + bus 1) + ...
+// sum: grid = (n_blocks, C*F/4/64), block = 64 (one wave).  master = (((direct groups in order) + bus 0) + bus 1) + ...
 // with bus u = in-order sum of its groups (AudioBuffer::mix order, audio_buffer.h:73-82), then the
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sum_kernel(SumArgs a) {
+__global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t F = a.block_frames, C = a.channels;
-  const uint32_t slot = blockIdx.y * 256u + threadIdx.x;
+  const uint32_t slot = blockIdx.y * 64u + threadIdx.x;
   if (slot >= (C * F) >> 2) return;
   const size_t e0 = (size_t)slot * 4u;
   const size_t stride = (size_t)C * F;
@@ -296,7 +446,7 @@ __global__ __launch_bounds__(256) void sum_kernel(SumArgs a) {
   f4 master = {0.0f, 0.0f, 0.0f, 0.0f};
   f4 busacc = {0.0f, 0.0f, 0.0f, 0.0f};
   int cur = -1;
-  constexpr int PF = 8;
+  constexpr int PF = 16;
   for (uint32_t g0 = 0; g0 < a.n_groups; g0 += PF) {
     f4 v[PF];
 #pragma unroll
@@ -361,9 +511,13 @@ __global__ __launch_bounds__(256) void levels_kernel(const float* peaks, float* 
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= nc) return;
   float m = levels[i];
-  for (uint32_t b = 0; b < n_blocks; b++) {
-    const float p = peaks[(size_t)b * nc + i];
-    m = m < p ? p : m;
+  constexpr int PF = 16;
+  for (uint32_t b0 = 0; b0 < n_blocks; b0 += PF) {
+    float p[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) p[k] = (b0 + k < n_blocks) ? peaks[(size_t)(b0 + k) * nc + i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < PF; k++) m = m < p[k] ? p[k] : m;
   }
   levels[i] = m;
 }
@@ -423,16 +577,38 @@ __global__ __launch_bounds__(256) void synth_kernel(void* dst, uint64_t frames, 
 // ------------------------------------------------------------------------------------------------
 void launch_plan(const PlanArgs& a, hipStream_t s) {
   const uint32_t nb = (a.n_tracks + 63u) / 64u;
-  hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.n_blocks * sizeof(DBlockTime), s, a);
 }
 
-void launch_mix(const MixArgs& a, uint32_t n_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(mix_kernel<8>, dim3(a.n_groups, n_blocks, a.tiles), dim3(256), 0, s, a);
+void launch_gen(const GenArgs& a, hipStream_t s) {
+  const uint32_t grid = a.gen_cap < 2048u ? (a.gen_cap ? a.gen_cap : 1u) : 2048u;
+  hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
+void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s) {
+  const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
+  const uint32_t S4 = a.block_frames >> 2;
+  const bool full = ((a.channels * S4) % 256u == 0u) && (S4 % 64u == 0u);
+  if (!full) {
+    hipLaunchKernelGGL((mix_kernel<2, false, 1>), grid, block, 0, s, a);
+    return;
+  }
+  // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
+  // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
+  switch (variant) {
+#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W>), grid, block, 0, s, a); break;
+    WBX_V(1, 6) WBX_V(1, 8)
+    WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6) WBX_V(2, 8)
+    WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
+    WBX_V(8, 2)
+#undef WBX_V
+    default: hipLaunchKernelGGL((mix_kernel<2, true, 4>), grid, block, 0, s, a); break;
+  }
 }
 
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
-  const uint32_t tiles = (((a.channels * a.block_frames) >> 2) + 255u) / 256u;
-  hipLaunchKernelGGL(sum_kernel, dim3(n_blocks, tiles), dim3(256), 0, s, a);
+  const uint32_t tiles = (((a.channels * a.block_frames) >> 2) + 63u) / 64u;
+  hipLaunchKernelGGL(sum_kernel, dim3(n_blocks, tiles), dim3(64), 0, s, a);
 }
 
 void launch_clamp(float* buf, size_t n, hipStream_t s) {

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numbers>
@@ -24,7 +25,8 @@
 
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
-void launch_mix(const MixArgs& a, uint32_t n_blocks, hipStream_t s);
+void launch_gen(const GenArgs& a, hipStream_t s);
+void launch_mix(const MixArgs& a, uint32_t n_blocks, int unroll, hipStream_t s);
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_levels(const float* peaks, float* levels, uint32_t n_blocks, uint32_t nc, hipStream_t s);
@@ -89,7 +91,12 @@ struct wbx_ctx {
   DevBuf<DTrackBlock> d_tb;
   DevBuf<DSeg> d_pool;
   uint32_t pool_chunks = 0;
-  uint32_t* d_pool_count = nullptr;   // [0] chunks allocated, [1] status bits
+  uint32_t* d_pool_count = nullptr;   // [0] chunks allocated, [1] status bits, [2] generic records queued
+  DevBuf<uint32_t> d_gen_list;        // pre-render queue of KIND_GENERIC records
+  DevBuf<float> d_rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
+  DevBuf<DTrackBlock> d_saved;        // original records of the queue (plan read-back)
+  DevBuf<float> d_zero;               // zero page (F+8 floats)
+  uint32_t gen_cap = 0;
   DevBuf<float> d_partial, d_master, d_buses, d_peaks, d_gains;
   DevBuf<uint8_t> d_conv;
   std::vector<DTrackBlock> h_tb;      // layer-1 staging
@@ -105,6 +112,7 @@ struct wbx_ctx {
   double mix_ms_total = 0.0;
   uint64_t mix_launches = 0;
   bool profiling = true;
+  int mix_unroll = 24;                // WBX_MIX_VARIANT=10*U+W (tuning knob; results are identical)
 };
 
 namespace {
@@ -213,11 +221,36 @@ wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
   return WBX_OK;
 }
 
-// mix + sum over a plan that already sits in d_tb / d_pool
+// room for `rows` pre-rendered generic track-blocks (grow-only)
+wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
+  rows = std::max<size_t>(rows, 64);
+  if (rows <= c->gen_cap) return WBX_OK;
+  const size_t row_floats = (size_t)c->cfg.channels * (c->cfg.block_frames + 8);
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, c->d_gen_list.ensure(rows));
+  WBX_HIP(c, c->d_rows.ensure(rows * row_floats));
+  WBX_HIP(c, c->d_saved.ensure(rows));
+  c->gen_cap = (uint32_t)rows;
+  return WBX_OK;
+}
+
+// gen (pre-render of the queued generic records) + mix + sum over a plan that already sits in d_tb / d_pool
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  GenArgs ga{};
+  ga.tb = c->d_tb.p;
+  ga.pool = c->d_pool.p;
+  ga.gen_list = c->d_gen_list.p;
+  ga.gen_count = c->d_pool_count + 2;
+  ga.rows = c->d_rows.p;
+  ga.saved = c->d_saved.p;
+  ga.gen_cap = c->gen_cap;
+  ga.block_frames = F;
+  ga.channels = C;
+  launch_gen(ga, c->stream);
   MixArgs m{};
   m.tb = c->d_tb.p;
+  m.zero_page = c->d_zero.p;
   m.pool = c->d_pool.p;
   m.order = c->d_order.p;
   m.groups = c->d_groups.p;
@@ -237,7 +270,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
-    launch_mix(m, K, c->stream);
+    launch_mix(m, K, c->mix_unroll, c->stream);
     if (c->profiling) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
       c->ev_pending++;
@@ -301,7 +334,8 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!cfg || !out) return WBX_ERR_INVALID;
   *out = nullptr;
   if (cfg->channels < 1 || cfg->channels > 2 || cfg->block_frames < 4 || (cfg->block_frames & 3u) ||
-      cfg->block_frames > 32768 || cfg->max_tracks == 0 || cfg->max_blocks == 0 || cfg->sample_rate == 0)
+      cfg->block_frames > 32768 || cfg->max_tracks == 0 || cfg->max_blocks == 0 || cfg->max_blocks > 2048 ||
+      cfg->sample_rate == 0)
     return WBX_ERR_INVALID;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || cfg->device < 0 || cfg->device >= n) return WBX_ERR_NO_DEVICE;
@@ -314,6 +348,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
   if (c->cfg.group_size == 0) c->cfg.group_size = 64;
+  if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {
@@ -332,11 +367,13 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   size_t chunks = cfg->max_segments ? (cfg->max_segments + kChunk - 1) / kChunk
                                     : std::max<size_t>(1024, (size_t)cfg->max_blocks * cfg->max_tracks / 8);
   c->pool_chunks = (uint32_t)chunks;
-  if (c->d_pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&c->d_pool_count, 2 * sizeof(uint32_t)) != hipSuccess) {
+  if (c->d_pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&c->d_pool_count, 4 * sizeof(uint32_t)) != hipSuccess ||
+      c->d_zero.ensure(cfg->block_frames + 8) != hipSuccess) {
     wbx_destroy(c);
     return WBX_ERR_OOM;
   }
-  (void)hipMemset(c->d_pool_count, 0, 2 * sizeof(uint32_t));
+  (void)hipMemset(c->d_pool_count, 0, 4 * sizeof(uint32_t));
+  (void)hipMemset(c->d_zero.p, 0, (cfg->block_frames + 8) * sizeof(float));
   *out = c;
   return WBX_OK;
 }
@@ -358,6 +395,10 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   c->d_peaks.release();
   c->d_gains.release();
   c->d_conv.release();
+  c->d_gen_list.release();
+  c->d_rows.release();
+  c->d_saved.release();
+  c->d_zero.release();
   if (c->d_pool_count) (void)hipFree(c->d_pool_count);
   for (int i = 0; i < kEventRing; i++) {
     if (c->ev[i][0]) (void)hipEventDestroy(c->ev[i][0]);
@@ -476,6 +517,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   const uint32_t F = c->cfg.block_frames, C = c->cfg.channels;
   c->h_tb.assign((size_t)K * N, DTrackBlock{});
   c->h_pool.clear();
+  std::vector<uint32_t> gen_idx;
   uint32_t chunks = 0;
   for (size_t bt = 0; bt < (size_t)K * N; bt++) {
     DTrackBlock& tb = c->h_tb[bt];
@@ -498,8 +540,11 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
       DSeg d{};
       BlockWalker w{};
       DTrackBlock scratch{};
+      TrackCache tc{};
+      tc.clip_idx = tc.smp_idx = 0xFFFFFFFFu;
       uint32_t pc = 0, stbits = 0;
       w.st = &ts;
+      w.cache = &tc;
       w.samples = &c->clips[sg.clip].d;
       w.tb = &scratch;
       w.pool = &d;
@@ -513,11 +558,11 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
       w.nseg = 0;
       w.chunk = 0xFFFFFFFFu;
       w.stream(sg.num_samples, sg.buffer_offset);
-      d = scratch.s0;
+      d = get_seg0(scratch);
       d.sample = sg.clip;
       const uint32_t k = i - s0;
       if (k == 0) {
-        tb.s0 = d;
+        set_seg0(&tb, d);
       } else {
         if (k == 1) {
           tb.extra = chunks++;
@@ -528,6 +573,16 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     }
     tb.nseg = (uint8_t)(s1 - s0);
     tb.kind = classify(tb, F);
+    if (tb.kind == KIND_GENERIC) gen_idx.push_back((uint32_t)bt);
+  }
+  st = ensure_gen_capacity(c, gen_idx.size());
+  if (st != WBX_OK) return st;
+  {
+    uint32_t counters[4] = {0u, 0u, (uint32_t)gen_idx.size(), 0u};
+    WBX_HIP(c, hipMemcpyAsync(c->d_pool_count, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
+    if (!gen_idx.empty())
+      WBX_HIP(c, hipMemcpyAsync(c->d_gen_list.p, gen_idx.data(), gen_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    WBX_HIP(c, hipStreamSynchronize(c->stream));   // counters / gen_idx are stack / local storage
   }
   if (chunks > c->pool_chunks) {
     WBX_HIP(c, c->d_pool.ensure((size_t)chunks * kChunk));
@@ -563,9 +618,10 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   }
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
-  uint32_t pc[2] = {0, 0};
+  uint32_t pc[4] = {0, 0, 0, 0};
   WBX_HIP(c, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
   if (pc[1] & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
+  if (pc[1] & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
   return WBX_OK;
 }
 
@@ -665,6 +721,8 @@ struct wbx_engine {
   double playhead = 0.0, playhead_start = 0.0, sample_position = 0.0, beat_duration = 0.5;
   bool playing = false;
   bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
+  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (integer PCM, speed > 0.999, != 1)
+  size_t total_clips = 0;
   uint32_t state_tracks = 0;            // tracks that have device state
 
   DevBuf<DClip> d_clips;
@@ -863,6 +921,12 @@ extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, d
   c.sample = sample;
   c.internal_state_changed = 0;
   t.clips.push_back(c);
+  {
+    const DSample& smp = e->ctx->clips[sample].d;
+    const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * speed;   // sampler.h:24
+    if (smp.format != FMT_F32 || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
+    e->total_clips++;
+  }
   std::sort(t.clips.begin(), t.clips.end(), [](const DClip& a, const DClip& b) { return a.min_time < b.min_time; });
   reset_playback_state(e, t, e->playhead, true);   // engine.cpp:416,426,437,449,459
   e->clips_dirty = true;
@@ -1006,8 +1070,17 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   WBX_EHIP(e, e->d_times.ensure(std::max<size_t>(K, c->cfg.max_blocks)));
   WBX_EHIP(e, hipMemcpyAsync(e->d_times.p, e->h_times.data(), K * sizeof(DBlockTime), hipMemcpyHostToDevice, s));
 
-  // -- plan (sequencer on the device), then mix + sum
-  WBX_EHIP(e, hipMemsetAsync(c->d_pool_count, 0, 2 * sizeof(uint32_t), s));
+  // -- rows for the track-blocks the hot loop cannot stream directly: every clip start / end inside a block,
+  //    and all blocks of integer-PCM or fast-forward clips
+  {
+    const size_t all = (size_t)K * N;
+    const size_t rows = e->any_slow_clip ? all : std::min(all, 4 * e->total_clips + 2 * (size_t)N + 64);
+    st = ensure_gen_capacity(c, rows);
+    if (st != WBX_OK) return st;
+  }
+
+  // -- plan (sequencer on the device), then pre-render + mix + sum
+  WBX_EHIP(e, hipMemsetAsync(c->d_pool_count, 0, 4 * sizeof(uint32_t), s));
   PlanArgs a{};
   a.clips = e->d_clips.p;
   a.clip_first = e->d_clip_first.p;
@@ -1020,6 +1093,9 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   a.pool = c->d_pool.p;
   a.pool_count = c->d_pool_count;
   a.status = c->d_pool_count + 1;
+  a.gen_list = c->d_gen_list.p;
+  a.gen_count = c->d_pool_count + 2;
+  a.gen_cap = c->gen_cap;
   a.pool_chunks = c->pool_chunks;
   a.n_tracks = N;
   a.n_blocks = K;
@@ -1069,10 +1145,21 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   if (c->last_K == 0) return efail(e, WBX_ERR_FAILED, "nothing rendered");
   const uint32_t K = c->last_K, N = c->last_N;
   std::vector<DTrackBlock> tb((size_t)K * N);
-  uint32_t pc[2] = {0, 0};
+  uint32_t pc[4] = {0, 0, 0, 0};
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
   WBX_EHIP(e, hipMemcpy(tb.data(), c->d_tb.p, tb.size() * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
   WBX_EHIP(e, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
+  {   // records the pre-render pass rewrote: put the sequencer's originals back
+    const uint32_t ng = std::min(pc[2], c->gen_cap);
+    if (ng) {
+      std::vector<uint32_t> idx(ng);
+      std::vector<DTrackBlock> saved(ng);
+      WBX_EHIP(e, hipMemcpy(idx.data(), c->d_gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      WBX_EHIP(e, hipMemcpy(saved.data(), c->d_saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < ng; i++)
+        if (idx[i] < tb.size()) tb[idx[i]] = saved[i];
+    }
+  }
   const uint32_t used = std::min(pc[0], c->pool_chunks);
   std::vector<DSeg> pool((size_t)used * kChunk);
   if (used) WBX_EHIP(e, hipMemcpy(pool.data(), c->d_pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
@@ -1081,7 +1168,8 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
     for (uint32_t t = 0; t < N; t++) {
       const DTrackBlock& r = tb[(size_t)b * N + t];
       for (uint32_t i = 0; i < r.nseg; i++) {
-        const DSeg* sg = (i == 0) ? &r.s0 : (r.extra < used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
+        const DSeg s0 = get_seg0(r);
+        const DSeg* sg = (i == 0) ? &s0 : (r.extra < used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
         if (!sg) continue;
         if (out && n < cap) {
           wbx_plan_record& o = out[n];

@@ -32,6 +32,37 @@ __host__ __device__ inline uint32_t u32_of_ceil(double x) {
   return (uint32_t)(uint64_t)(long long)c;
 }
 
+// segment 0 of a track-block lives inline in the record
+__host__ __device__ inline void set_seg0(DTrackBlock* tb, const DSeg& s) {
+  tb->src[0] = s.src[0];
+  tb->src[1] = s.src[1];
+  tb->pos = s.pos;
+  tb->speed = s.speed;
+  tb->gain = s.gain;
+  tb->dst_start = s.dst_start;
+  tb->len = s.len;
+  tb->req_len = s.req_len;
+  tb->format = s.format;
+  tb->flags = s.flags;
+  tb->sample = s.sample;
+}
+
+__host__ __device__ inline DSeg get_seg0(const DTrackBlock& tb) {
+  DSeg s;
+  s.src[0] = tb.src[0];
+  s.src[1] = tb.src[1];
+  s.pos = tb.pos;
+  s.speed = tb.speed;
+  s.gain = tb.gain;
+  s.dst_start = tb.dst_start;
+  s.len = tb.len;
+  s.req_len = tb.req_len;
+  s.format = tb.format;
+  s.flags = tb.flags;
+  s.sample = tb.sample;
+  return s;
+}
+
 // find_lower_bound with the predicate clip->max_time <= value (core/algorithm.h:24-40, track.cpp:206)
 __host__ __device__ inline uint32_t lower_bound_max_time(const DClip* clips, uint32_t n, double value) {
   long long left = 0, right = (long long)n - 1;
@@ -58,9 +89,20 @@ __host__ __device__ inline bool find_next_clip(const DClip* clips, uint32_t n, d
 // first (track.cpp:604-615) and walking it afterwards (:664-724): the loop never feeds back into the
 // sequencer, and because start_sample always becomes the event's buffer_offset (< buffer_size) under
 // the reference's uint32 arithmetic, every event of the list is consumed.
+// Register-resident copies of the clip and sample records a track is currently using: in the steady
+// state (a clip playing through the block) a planned block then touches no global memory except its
+// own 64-B output record.
+struct TrackCache {
+  DClip clip;
+  DSample smp;
+  uint32_t clip_idx;   // index within the track's clip list, 0xFFFFFFFF = empty
+  uint32_t smp_idx;    // sample id, 0xFFFFFFFF = empty
+};
+
 struct BlockWalker {
   DTrackState* st;
   const DSample* samples;
+  TrackCache* cache;
   DTrackBlock* tb;          // record being filled
   DSeg* pool;
   uint32_t* pool_count;
@@ -73,8 +115,8 @@ struct BlockWalker {
   uint32_t nseg;
   uint32_t chunk;
 
+  // where call number `nseg` (>= 1) of this block goes in the overflow pool
   __host__ __device__ DSeg* slot() {
-    if (nseg == 0) return &tb->s0;
     if (nseg >= kMaxSegs) {
       if (status) status[0] |= 2u;
       return nullptr;
@@ -98,9 +140,17 @@ struct BlockWalker {
   }
 
   // Sampler::stream up to (not including) the per-sample loops: sampler.cpp:99-104 and :209
+  __host__ __device__ const DSample& sample_of(uint32_t id) {
+    if (cache->smp_idx != id) {
+      cache->smp = samples[id];
+      cache->smp_idx = id;
+    }
+    return cache->smp;
+  }
+
   __host__ __device__ void stream(uint32_t num_samples, uint32_t buffer_offset) {
-    const DSample& smp = samples[st->cur_sample];
-    DSeg* s = slot();
+    const DSample& smp = sample_of(st->cur_sample);
+    DSeg* s = nseg ? slot() : nullptr;
     DSeg seg;
     seg.src[0] = smp.ch[0];
     seg.src[1] = smp.ch[n_channels > 1 ? 1 : 0];
@@ -128,7 +178,10 @@ struct BlockWalker {
       seg.len = (uint16_t)n;
       st->sample_offset = next_sample_offset;                                                    // :209
     }
-    if (s) {
+    if (nseg == 0) {
+      set_seg0(tb, seg);
+      nseg = 1;
+    } else if (s) {
       *s = seg;
       nseg++;
     }
@@ -140,7 +193,7 @@ struct BlockWalker {
     uint32_t event_length = buffer_offset - start_sample;   // uint32 arithmetic as in the reference
     if (st->cur_type == EV_PLAY) stream(event_length, start_sample);
     if (type == EV_PLAY) {                                  // :687-697 Sampler::reset_state (sampler.h:18-27)
-      const DSample& smp = samples[clip->sample];
+      const DSample& smp = sample_of(clip->sample);
       st->playback_speed = ((double)smp.sample_rate / dst_rate) * speed;
       st->sample_offset = (double)sample_offset;
       st->cur_gain = clip->gain;
@@ -157,6 +210,15 @@ struct BlockWalker {
     start_sample = n_samples;
   }
 };
+
+// clip->internal_state_changed = false (track.cpp:373,392,418): the cached copy always, the clip list in
+// HBM only when the flag was actually set.
+__host__ __device__ inline void clear_state_changed(DClip* cached, DClip* global) {
+  if (cached->internal_state_changed) {
+    cached->internal_state_changed = 0;
+    global->internal_state_changed = 0;
+  }
+}
 
 // Track::process_event, audio branch — track.cpp:258-451.  MIDI clips and recording are out of scope.
 __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint32_t num_clips, double start_time,
@@ -203,8 +265,13 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
   if (!st->has_clip_idx) return;                                 // :342-346
 
   uint32_t next_clip = st->clip_idx;
+  TrackCache* cc = w.cache;
   while (next_clip < num_clips) {                                // :349-446
-    DClip* clip = &clips[next_clip];
+    if (cc->clip_idx != next_clip) {
+      cc->clip = clips[next_clip];
+      cc->clip_idx = next_clip;
+    }
+    DClip* clip = &cc->clip;
     double min_time = clip->min_time;
     double max_time = clip->max_time;
 
@@ -215,20 +282,20 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
       double sample_offset = sample_position + offset_from_start;
       uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
       w.on_event(EV_PLAY, buffer_offset, clip->speed, (uint64_t)clip->start_offset, clip);
-      clip->internal_state_changed = 0;
+      clear_state_changed(clip, &clips[next_clip]);
     } else if (start_time > min_time && !st->partially_ended) {  // :375-393 started in the middle
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
       uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
-      clip->internal_state_changed = 0;
+      clear_state_changed(clip, &clips[next_clip]);
     } else if (clip->internal_state_changed && st->partially_ended) {  // :394-419
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
       uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
-      clip->internal_state_changed = 0;
+      clear_state_changed(clip, &clips[next_clip]);
     }
 
     if (max_time <= end_time) {                                  // :421-434 reaching the end of the clip
@@ -250,11 +317,13 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
 __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t block_frames) {
   if (tb.nseg == 0) return KIND_SILENT;
   if (tb.nseg == 1) {
-    const DSeg& s = tb.s0;
+    const DTrackBlock& s = tb;
     if (s.len == 0) return KIND_SILENT;
     if (s.format == FMT_F32 && s.dst_start == 0 && s.len == block_frames && s.pos >= 0.0 && s.pos < 2147483000.0) {
       if (s.speed == 1.0) return KIND_UNITY;                     // sampler.cpp:106
-      if (s.speed > 0.0 && s.speed < 1.0) return KIND_WINDOW;
+      // taps of 4 consecutive frames fit a 5-sample window only while floor(x_e) - floor(x_0) <= e: keep a
+      // margin below 1.0 so fp64 rounding of j*speed can never push it over
+      if (s.speed > 0.0 && s.speed <= 0.999) return KIND_WINDOW;
     }
   }
   return KIND_GENERIC;
@@ -262,11 +331,13 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
 
 // One track, one block: Track::process minus the per-sample work (track.cpp:587-736).
 __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
-                                                 DClip* clips, uint32_t num_clips) {
+                                                 DClip* clips, uint32_t num_clips, TrackCache* cache,
+                                                 const DBlockTime& bt, float gl, float gr) {
   DTrackBlock* tb = &a.tb[(size_t)b * a.n_tracks + t];
   BlockWalker w;
   w.st = st;
   w.samples = a.samples;
+  w.cache = cache;
   w.tb = tb;
   w.pool = a.pool;
   w.pool_count = a.pool_count;
@@ -279,18 +350,29 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   w.nseg = 0;
   w.chunk = 0xFFFFFFFFu;
   tb->extra = 0;
-  tb->s0.len = 0;
+  tb->len = 0;
   if (a.playing) {
-    const DBlockTime& bt = a.times[b];
     process_event(w, clips, num_clips, bt.start_time, bt.end_time, bt.sample_position, bt.beat_duration,
                   a.sample_rate, a.block_frames);
     w.finish();
   }
-  tb->g[0] = a.gains[2 * t + 0];
-  tb->g[1] = a.gains[2 * t + 1];
+  tb->g[0] = gl;
+  tb->g[1] = gr;
   tb->nseg = (uint8_t)w.nseg;
   tb->_pad = 0;
   tb->kind = classify(*tb, a.block_frames);
+  if (tb->kind == KIND_GENERIC) {   // queue it for the pre-render pass
+    uint32_t row;
+#if defined(__HIP_DEVICE_COMPILE__)
+    row = atomicAdd(a.gen_count, 1u);
+#else
+    row = (*a.gen_count)++;
+#endif
+    if (row < a.gen_cap)
+      a.gen_list[row] = b * a.n_tracks + t;
+    else if (a.status)
+      a.status[0] |= 8u;
+  }
 }
 
 }  // namespace wbx
