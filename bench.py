@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
     ap.add_argument("--blocks", type=int, default=64, help="512-frame blocks per step (one device pass)")
     ap.add_argument("--group-size", type=int, default=0)
+    ap.add_argument("--session-blocks", type=int, default=0, help="length of the resident session in blocks "
+                    "(0 = as long as the run needs, capped by memory); the transport rewinds at its end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
@@ -176,6 +178,8 @@ def main():
     bytes_per_block_src = n_tracks * 2 * 4 * F * src_rate / SR
     mem_budget = 96e9
     session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
+    if args.session_blocks:
+        session_blocks = max(K, min(session_blocks, args.session_blocks))
     session_blocks = (session_blocks // K) * K
 
     stream = torch.cuda.Stream()
@@ -184,9 +188,12 @@ def main():
                                               stream.cuda_stream, args.group_size)
         master = torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda")
         host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
-        eng.ctx.set_master_target(master.data_ptr())
         if world > 1:
-            eng.ctx.set_clamp(False)          # partials are clamped on the root AFTER the reduce
+            eng.ctx.set_master_target(master.data_ptr())   # send buffer of the RCCL reduce
+            eng.ctx.set_clamp(False)                       # partials are clamped on the root AFTER the reduce
+        else:
+            # single GPU: the sum kernel stores the clamped master straight into pinned host memory
+            eng.ctx.set_master_target(host_master.data_ptr())
 
         done = 0
 
@@ -201,8 +208,7 @@ def main():
                 dist.reduce(master, dst=0)    # RCCL sum of the per-GPU partial masters over xGMI
                 if rank == 0:
                     eng.ctx.finalize_master(master.data_ptr(), K, True)
-            if rank == 0:
-                host_master.copy_(master, non_blocking=True)
+                    host_master.copy_(master, non_blocking=True)
             done += K
 
         eng.play()

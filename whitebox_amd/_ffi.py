@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libwbx.so")
+_LIB = os.environ.get("WBX_LIB") or os.path.join(_HERE, "libwbx.so")   # WBX_LIB: A/B another build of the library
 
 
 class WbxError(RuntimeError):

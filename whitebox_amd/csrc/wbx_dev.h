@@ -115,7 +115,6 @@ struct PlanArgs {
   const DSample* samples;
   DTrackState* state;           // [N]
   const DPatch* patch;          // [N] or null
-  const DBlockTime* times;      // [K]
   const float* gains;           // [N][2]
   DTrackBlock* tb;              // [K][N]
   DSeg* pool;                   // [pool_chunks][kChunk]
@@ -128,6 +127,7 @@ struct PlanArgs {
   uint32_t pool_chunks;
   uint32_t n_tracks, n_blocks, block_frames, channels;
   double sample_rate;
+  double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
   uint32_t playing;
 };
 
@@ -149,6 +149,7 @@ struct MixArgs {
   const DGroup* groups;         // [NG]
   float* partial;               // [K][NG][C][F]
   float* peaks;                 // [K][N][C]
+  uint32_t* levels;             // [N][C] running maxima (VUMeter::level) as uint images, or null
   uint32_t n_tracks, n_groups, block_frames, channels;
   uint32_t tiles;               // ceil(C*F/4 / 256)
 };

@@ -15,6 +15,8 @@
 // -ffp-contract=off so that nothing is fused: the reference build has no FMA.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wbx_dev.h"
 #include "wbx_seq.h"
 
@@ -36,10 +38,23 @@ __device__ __forceinline__ const T WBX_GLOBAL* as_global(const void* p) {
 // plan
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
-  // the K per-block transport records are the same for every track: stage them in LDS once
+  // The K per-block transport records are the same for every track: one lane computes them into LDS with
+  // exactly the arithmetic of Engine::process (engine.cpp:1578-1585 per block, :1619-1623 between blocks).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   DBlockTime* s_times = reinterpret_cast<DBlockTime*>(s_raw);
-  for (uint32_t i = threadIdx.x; i < a.n_blocks; i += blockDim.x) s_times[i] = a.times[i];
+  if (threadIdx.x == 0) {
+    double playhead = a.playhead, sample_position = a.sample_position;
+    for (uint32_t i = 0; i < a.n_blocks; i++) {
+      const double buffer_duration = (double)a.block_frames / a.sample_rate;            // :1578
+      const double buffer_duration_in_beats = buffer_duration / a.beat_duration;       // :1581
+      const double next_playhead_pos = playhead + buffer_duration_in_beats;            // :1582
+      s_times[i] = DBlockTime{playhead, next_playhead_pos, sample_position, a.beat_duration};
+      if (a.playing) {
+        sample_position += beat_to_samples(buffer_duration_in_beats, a.sample_rate, a.beat_duration);   // :1620
+        playhead = next_playhead_pos;                                                                   // :1621
+      }
+    }
+  }
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.n_tracks) return;
@@ -61,7 +76,14 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
   cache.clip_idx = 0xFFFFFFFFu;
   cache.smp_idx = 0xFFFFFFFFu;
   const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
-  for (uint32_t b = 0; b < a.n_blocks; b++) plan_track_block(a, t, b, &st, clips, nc, &cache, s_times[b], gl, gr);
+  uint32_t b = 0;
+  while (b < a.n_blocks) {
+    b += plan_steady_run(a, t, b, &st, nc, &cache, s_times, gl, gr);   // tight loop over the common case
+    if (b < a.n_blocks) {
+      plan_track_block(a, t, b, &st, clips, nc, &cache, s_times[b], gl, gr);
+      b++;
+    }
+  }
   a.state[t] = st;
 }
 
@@ -244,8 +266,9 @@ __device__ __forceinline__ float wave_max_lane63(float x) {
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
   f4 v;        // UNITY: the 4 source frames; WINDOW: window samples 0..3
-  float w4;    // window sample 4 (loaded for every track so that the load sequence is branch-free)
-  int ix0;     // integer source position of v.x
+  float w4;    // WINDOW: window sample 4
+  int ix0;     // WINDOW: integer source position of v.x
+  float fx0;   // WINDOW: interpolation fraction of frame j0
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -291,41 +314,60 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 
   f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line) ---------
-  auto issue = [&](uint32_t u0, Pre (&pre)[U]) {
+  // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
+  const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
+
+  // ---- phase A: the clip loads of the U tracks starting at local index u0 -------------------------
+  // WIN = false: every record of the chunk is a unity row (no fp64, one 16-B load per track);
+  // WIN = true : linear-resample rows present; unity rows go through the same address formula (their pos is
+  //              integral and speed 1.0, so trunc(pos + j0*speed) == (uint32)pos + j0 exactly).
+  auto issue = [&](auto win, uint32_t u0, Pre (&pre)[U]) {
+    constexpr bool WIN = decltype(win)::value;
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const DTrackBlock& r = s_tb[u0 + u];
-      // frame j0 sits at x0 = pos + j0*speed (sampler.cpp:50); for speed == 1.0 (pos integral) this is the
-      // unity path's (uint32)pos + j0 (sampler.cpp:107,151)
-      const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));
-      const int ix0 = (int)trunc(x0);
-      const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + ix0;
-      if (active) {
-        pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);   // the taps of frames j0..j0+3 lie in p[0..4]
-        pre[u].w4 = p[4];
+      if (WIN) {
+        const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                    // sampler.cpp:50, frame j0
+        const double t0 = trunc(x0);                                                    // :51 (x >= 0)
+        const int ix0 = (int)t0;
+        const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + ix0;
+        if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
+          pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);   // the taps of frames j0..j0+3 lie in p[0..4]
+          pre[u].w4 = p[4];
+        }
+        pre[u].ix0 = ix0;
+        pre[u].fx0 = (float)__dsub_rn(x0, t0);                                          // :52
+      } else {
+        const uint32_t off = (uint32_t)r.pos + j0;                                      // sampler.cpp:107,151
+        const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + off;
+        if (active) pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);
       }
-      pre[u].ix0 = ix0;
     }
   };
 
   // ---- phase B: render, scale, accumulate — strictly in track order; then the per-track peaks -----
-  auto render = [&](uint32_t u0, Pre (&pre)[U]) {
+  auto render = [&](auto win, uint32_t u0, Pre (&pre)[U]) {
+    constexpr bool WIN = decltype(win)::value;
     float pk[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const DTrackBlock& r = s_tb[u0 + u];
-      const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
       const float cg = r.gain;
       const float gc = r.g[c];
       f4 m;
-      if (k == KIND_WINDOW) {
+      bool is_win = false;
+      if (WIN) is_win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW;
+      if (WIN && is_win) {
         const double pos = r.pos, speed = r.speed;
         const int ix0 = pre[u].ix0;
         float q[4];
-#define WBX_TAP(E)                                                                                      \
+        {   // frame j0: position and fraction already known from phase A; its taps are window samples 0 and 1
+          const float s = __fadd_rn(pre[u].v.x, __fmul_rn(pre[u].fx0, __fsub_rn(pre[u].v.y, pre[u].v.x)));   // :55
+          q[0] = __fmul_rn(__fmul_rn(s, cg), gc);                                       // :56, track.cpp:731
+        }
+#define WBX_TAP(E, JD)                                                                                  \
   {                                                                                                     \
-    const double x = __dadd_rn(pos, __dmul_rn(j0d + (double)(E), speed)); /* sampler.cpp:50 */          \
+    const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
     const double tx = trunc(x);                                           /* :51 (x >= 0) */            \
     const float fx = (float)__dsub_rn(x, tx);                             /* :52 */                     \
     float sa, sb;                                                                                       \
@@ -333,7 +375,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
     q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
   }
-        WBX_TAP(0) WBX_TAP(1) WBX_TAP(2) WBX_TAP(3)
+        WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
 #undef WBX_TAP
         m = f4{q[0], q[1], q[2], q[3]};
       } else {   // KIND_UNITY (also: pre-rendered rows, silent and padding records)
@@ -370,6 +412,18 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   };
 
+  // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records)
+  auto pipeline = [&](auto win, uint32_t cn) {
+    Pre pa[U], pb[U];
+    issue(win, 0, pa);
+    for (uint32_t u0 = 0; u0 < cn; u0 += 2 * U) {
+      issue(win, u0 + U, pb);
+      render(win, u0, pa);
+      issue(win, u0 + 2 * U, pa);
+      render(win, u0 + U, pb);
+    }
+  };
+
   for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
     const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
     __syncthreads();
@@ -386,8 +440,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
     if (tid < kRecs * 2u) s_pk[tid] = 0u;
     __syncthreads();
+    int is_window = 0;
     if (tid < kRecs) {
       DTrackBlock& r = s_tb[tid];
+      is_window = (tid < cn && r.kind == KIND_WINDOW) ? 1 : 0;
       if (tid >= cn || r.kind == KIND_SILENT) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
@@ -399,17 +455,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.kind = KIND_UNITY;
       }
     }
-    __syncthreads();
+    const int any_window = __syncthreads_or(is_window);   // also the barrier after the null-record fill
 
-    // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records)
-    Pre pa[U], pb[U];
-    issue(0, pa);
-    for (uint32_t u0 = 0; u0 < cn; u0 += 2 * U) {
-      issue(u0 + U, pb);
-      render(u0, pa);
-      issue(u0 + 2 * U, pa);
-      render(u0 + U, pb);
-    }
+    if (any_window)
+      pipeline(std::true_type{}, cn);
+    else
+      pipeline(std::false_type{}, cn);
 
     __syncthreads();
     if (tid < cn * C) {
@@ -420,6 +471,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         *dst = s_pk[rec * 2u + ch];
       else
         atomicMax(dst, s_pk[rec * 2u + ch]);   // peaks are non-negative floats: uint order == float order
+      // VUMeter::level keeps the maximum until the UI reads it (vu_meter.h:26-29)
+      if (a.levels && s_pk[rec * 2u + ch] != 0u) atomicMax(a.levels + (size_t)track * C + ch, s_pk[rec * 2u + ch]);
     }
   }
 
@@ -504,22 +557,6 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* buf, size_t n) {
   if (i >= n) return;
   const float v = buf[i];
   buf[i] = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);
-}
-
-// VUMeter::level semantics: running maximum (vu_meter.h:26-29); levels[t][c] = max(levels, max_b peaks[b][t][c])
-__global__ __launch_bounds__(256) void levels_kernel(const float* peaks, float* levels, uint32_t n_blocks, uint32_t nc) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= nc) return;
-  float m = levels[i];
-  constexpr int PF = 16;
-  for (uint32_t b0 = 0; b0 < n_blocks; b0 += PF) {
-    float p[PF];
-#pragma unroll
-    for (int k = 0; k < PF; k++) p[k] = (b0 + k < n_blocks) ? peaks[(size_t)(b0 + k) * nc + i] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < PF; k++) m = m < p[k] ? p[k] : m;
-  }
-  levels[i] = m;
 }
 
 // planar fp32 master [K][C][F] -> interleaved device-format samples [K*F][C]; reference
@@ -613,10 +650,6 @@ void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
 
 void launch_clamp(float* buf, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(clamp_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, buf, n);
-}
-
-void launch_levels(const float* peaks, float* levels, uint32_t n_blocks, uint32_t nc, hipStream_t s) {
-  hipLaunchKernelGGL(levels_kernel, dim3((nc + 255u) / 256u), dim3(256), 0, s, peaks, levels, n_blocks, nc);
 }
 
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s) {

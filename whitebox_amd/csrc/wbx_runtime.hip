@@ -29,7 +29,6 @@ void launch_gen(const GenArgs& a, hipStream_t s);
 void launch_mix(const MixArgs& a, uint32_t n_blocks, int unroll, hipStream_t s);
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
-void launch_levels(const float* peaks, float* levels, uint32_t n_blocks, uint32_t nc, hipStream_t s);
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
 }  // namespace wbx
@@ -87,16 +86,26 @@ struct wbx_ctx {
   DevBuf<DGroup> d_groups;
   bool routing_dirty = true;
 
-  // plan + results
-  DevBuf<DTrackBlock> d_tb;
-  DevBuf<DSeg> d_pool;
-  uint32_t pool_chunks = 0;
-  uint32_t* d_pool_count = nullptr;   // [0] chunks allocated, [1] status bits, [2] generic records queued
-  DevBuf<uint32_t> d_gen_list;        // pre-render queue of KIND_GENERIC records
-  DevBuf<float> d_rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
-  DevBuf<DTrackBlock> d_saved;        // original records of the queue (plan read-back)
+  // The plan of a render (track-block records, overflow pool, pre-render queue + rows) is double-buffered:
+  // the sequencer of step i+1 runs on `plan_stream` while the mix of step i runs on `stream`.
+  struct PlanBuf {
+    DevBuf<DTrackBlock> tb;           // [K][N]
+    DevBuf<DSeg> pool;
+    uint32_t pool_chunks = 0;
+    uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued
+    DevBuf<uint32_t> gen_list;        // pre-render queue of KIND_GENERIC records
+    DevBuf<float> rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
+    DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
+    uint32_t gen_cap = 0;
+    hipEvent_t planned = nullptr;     // recorded on plan_stream when plan + pre-render are done
+    hipEvent_t consumed = nullptr;    // recorded on stream when the mix that read this buffer is done
+    bool consumed_valid = false;
+  } pb[2];
+  int cur = 0;
+  hipStream_t plan_stream = nullptr;
+  bool overlap = true;
   DevBuf<float> d_zero;               // zero page (F+8 floats)
-  uint32_t gen_cap = 0;
+  uint32_t* levels_target = nullptr;  // [N][C] running per-track maxima (VUMeter::level), or null
   DevBuf<float> d_partial, d_master, d_buses, d_peaks, d_gains;
   DevBuf<uint8_t> d_conv;
   std::vector<DTrackBlock> h_tb;      // layer-1 staging
@@ -116,6 +125,8 @@ struct wbx_ctx {
 };
 
 namespace {
+
+inline wbx_ctx::PlanBuf& PB(wbx_ctx* c) { return c->pb[c->cur]; }
 
 wbx_status fail(wbx_ctx* c, wbx_status s, const char* what, hipError_t e = hipSuccess) {
   if (c) {
@@ -213,7 +224,12 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
 
 wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
   const size_t CF = (size_t)c->cfg.channels * c->cfg.block_frames;
-  WBX_HIP(c, c->d_tb.ensure((size_t)K * N));
+  for (auto& B : c->pb)
+    if (B.tb.cap < (size_t)K * N) {
+      WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
+      WBX_HIP(c, hipStreamSynchronize(c->stream));
+      WBX_HIP(c, B.tb.ensure((size_t)K * N));
+    }
   WBX_HIP(c, c->d_partial.ensure((size_t)K * std::max<size_t>(1, c->groups.size()) * CF));
   WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
   WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
@@ -224,38 +240,49 @@ wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
 // room for `rows` pre-rendered generic track-blocks (grow-only)
 wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
   rows = std::max<size_t>(rows, 64);
-  if (rows <= c->gen_cap) return WBX_OK;
   const size_t row_floats = (size_t)c->cfg.channels * (c->cfg.block_frames + 8);
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
-  WBX_HIP(c, c->d_gen_list.ensure(rows));
-  WBX_HIP(c, c->d_rows.ensure(rows * row_floats));
-  WBX_HIP(c, c->d_saved.ensure(rows));
-  c->gen_cap = (uint32_t)rows;
+  for (auto& B : c->pb) {
+    if (rows <= B.gen_cap) continue;
+    WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, B.gen_list.ensure(rows));
+    WBX_HIP(c, B.rows.ensure(rows * row_floats));
+    WBX_HIP(c, B.saved.ensure(rows));
+    B.gen_cap = (uint32_t)rows;
+  }
   return WBX_OK;
 }
 
-// gen (pre-render of the queued generic records) + mix + sum over a plan that already sits in d_tb / d_pool
-wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
+// pre-render of the queued generic records of the current plan buffer
+wbx_status launch_pre_render(wbx_ctx* c, hipStream_t on) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   GenArgs ga{};
-  ga.tb = c->d_tb.p;
-  ga.pool = c->d_pool.p;
-  ga.gen_list = c->d_gen_list.p;
-  ga.gen_count = c->d_pool_count + 2;
-  ga.rows = c->d_rows.p;
-  ga.saved = c->d_saved.p;
-  ga.gen_cap = c->gen_cap;
+  ga.tb = PB(c).tb.p;
+  ga.pool = PB(c).pool.p;
+  ga.gen_list = PB(c).gen_list.p;
+  ga.gen_count = PB(c).counters + 2;
+  ga.rows = PB(c).rows.p;
+  ga.saved = PB(c).saved.p;
+  ga.gen_cap = PB(c).gen_cap;
   ga.block_frames = F;
   ga.channels = C;
-  launch_gen(ga, c->stream);
+  launch_gen(ga, on);
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+// mix + sum over the current plan buffer, on the main stream
+wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   MixArgs m{};
-  m.tb = c->d_tb.p;
+  m.tb = PB(c).tb.p;
   m.zero_page = c->d_zero.p;
-  m.pool = c->d_pool.p;
+  m.pool = PB(c).pool.p;
   m.order = c->d_order.p;
   m.groups = c->d_groups.p;
   m.partial = c->d_partial.p;
   m.peaks = c->d_peaks.p;
+  m.levels = c->levels_target;
   m.n_tracks = N;
   m.n_groups = (uint32_t)c->groups.size();
   m.block_frames = F;
@@ -364,15 +391,34 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
       return WBX_ERR_DEVICE;
     }
   }
+  {
+    // the sequencer runs beside the mix of the previous render; give it the lowest priority so that the
+    // bandwidth-bound mix keeps the machine (WBX_OVERLAP=0 puts everything on the main stream instead)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* ov = std::getenv("WBX_OVERLAP");
+    c->overlap = !(ov && ov[0] == '0');
+    if (hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+      wbx_destroy(c);
+      return WBX_ERR_DEVICE;
+    }
+  }
   size_t chunks = cfg->max_segments ? (cfg->max_segments + kChunk - 1) / kChunk
                                     : std::max<size_t>(1024, (size_t)cfg->max_blocks * cfg->max_tracks / 8);
-  c->pool_chunks = (uint32_t)chunks;
-  if (c->d_pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&c->d_pool_count, 4 * sizeof(uint32_t)) != hipSuccess ||
-      c->d_zero.ensure(cfg->block_frames + 8) != hipSuccess) {
+  for (auto& B : c->pb) {
+    B.pool_chunks = (uint32_t)chunks;
+    if (B.pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&B.counters, 4 * sizeof(uint32_t)) != hipSuccess ||
+        hipEventCreateWithFlags(&B.planned, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&B.consumed, hipEventDisableTiming) != hipSuccess) {
+      wbx_destroy(c);
+      return WBX_ERR_OOM;
+    }
+    (void)hipMemset(B.counters, 0, 4 * sizeof(uint32_t));
+  }
+  if (c->d_zero.ensure(cfg->block_frames + 8) != hipSuccess) {
     wbx_destroy(c);
     return WBX_ERR_OOM;
   }
-  (void)hipMemset(c->d_pool_count, 0, 4 * sizeof(uint32_t));
   (void)hipMemset(c->d_zero.p, 0, (cfg->block_frames + 8) * sizeof(float));
   *out = c;
   return WBX_OK;
@@ -381,25 +427,31 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
 extern "C" void wbx_destroy(wbx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
+  if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->clips)
     if (s.base) (void)hipFree(s.base);
   c->d_samples.release();
   c->d_order.release();
   c->d_groups.release();
-  c->d_tb.release();
-  c->d_pool.release();
+  for (auto& B : c->pb) {
+    B.tb.release();
+    B.pool.release();
+    B.gen_list.release();
+    B.rows.release();
+    B.saved.release();
+    if (B.counters) (void)hipFree(B.counters);
+    if (B.planned) (void)hipEventDestroy(B.planned);
+    if (B.consumed) (void)hipEventDestroy(B.consumed);
+  }
+  if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
   c->d_partial.release();
   c->d_master.release();
   c->d_buses.release();
   c->d_peaks.release();
   c->d_gains.release();
   c->d_conv.release();
-  c->d_gen_list.release();
-  c->d_rows.release();
-  c->d_saved.release();
   c->d_zero.release();
-  if (c->d_pool_count) (void)hipFree(c->d_pool_count);
   for (int i = 0; i < kEventRing; i++) {
     if (c->ev[i][0]) (void)hipEventDestroy(c->ev[i][0]);
     if (c->ev[i][1]) (void)hipEventDestroy(c->ev[i][1]);
@@ -509,6 +561,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (!c || !seg_offsets || !gains || K == 0 || N == 0) return WBX_ERR_INVALID;
   if (K > c->cfg.max_blocks || N > c->cfg.max_tracks) return fail(c, WBX_ERR_INVALID, "K or N above the configured maximum");
   (void)hipSetDevice(c->cfg.device);
+  WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
   wbx_status st = upload_tables(c, N);
   if (st != WBX_OK) return st;
   st = ensure_result_buffers(c, K, N);
@@ -579,18 +632,20 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (st != WBX_OK) return st;
   {
     uint32_t counters[4] = {0u, 0u, (uint32_t)gen_idx.size(), 0u};
-    WBX_HIP(c, hipMemcpyAsync(c->d_pool_count, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
+    WBX_HIP(c, hipMemcpyAsync(PB(c).counters, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
     if (!gen_idx.empty())
-      WBX_HIP(c, hipMemcpyAsync(c->d_gen_list.p, gen_idx.data(), gen_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      WBX_HIP(c, hipMemcpyAsync(PB(c).gen_list.p, gen_idx.data(), gen_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     WBX_HIP(c, hipStreamSynchronize(c->stream));   // counters / gen_idx are stack / local storage
   }
-  if (chunks > c->pool_chunks) {
-    WBX_HIP(c, c->d_pool.ensure((size_t)chunks * kChunk));
-    c->pool_chunks = chunks;
+  if (chunks > PB(c).pool_chunks) {
+    WBX_HIP(c, PB(c).pool.ensure((size_t)chunks * kChunk));
+    PB(c).pool_chunks = chunks;
   }
-  WBX_HIP(c, hipMemcpyAsync(c->d_tb.p, c->h_tb.data(), c->h_tb.size() * sizeof(DTrackBlock), hipMemcpyHostToDevice, c->stream));
+  WBX_HIP(c, hipMemcpyAsync(PB(c).tb.p, c->h_tb.data(), c->h_tb.size() * sizeof(DTrackBlock), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
-    WBX_HIP(c, hipMemcpyAsync(c->d_pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+    WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  st = launch_pre_render(c, c->stream);
+  if (st != WBX_OK) return st;
   return launch_mix_sum(c, K, N);
 }
 
@@ -619,7 +674,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   uint32_t pc[4] = {0, 0, 0, 0};
-  WBX_HIP(c, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
+  WBX_HIP(c, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   if (pc[1] & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
   if (pc[1] & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
   return WBX_OK;
@@ -729,9 +784,7 @@ struct wbx_engine {
   DevBuf<uint32_t> d_clip_first;
   DevBuf<DTrackState> d_state;
   DevBuf<DPatch> d_patch;
-  DevBuf<DBlockTime> d_times;
   DevBuf<float> d_gains, d_levels;
-  std::vector<DBlockTime> h_times;
 };
 
 namespace {
@@ -809,7 +862,6 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
   e->d_clip_first.release();
   e->d_state.release();
   e->d_patch.release();
-  e->d_times.release();
   e->d_gains.release();
   e->d_levels.release();
   wbx_destroy(e->ctx);
@@ -988,6 +1040,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
       g[2 * t + 1] = volume * tr.pan_coeffs[1];
     }
     WBX_EHIP(e, e->d_gains.ensure(g.size()));
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
     WBX_EHIP(e, hipStreamSynchronize(s));
     WBX_EHIP(e, hipMemcpy(e->d_gains.p, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
     e->gains_dirty = false;
@@ -1004,6 +1057,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
     first[N] = (uint32_t)flat.size();
     WBX_EHIP(e, e->d_clips.ensure(std::max<size_t>(1, flat.size())));
     WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
     WBX_EHIP(e, hipStreamSynchronize(s));
     if (!flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, flat.data(), flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
     WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1014,6 +1068,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   if (e->state_tracks < N) {
     DevBuf<DTrackState> grown;
     WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
     WBX_EHIP(e, hipStreamSynchronize(s));
     WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
     if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
@@ -1033,6 +1088,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
       e->tracks[t].patch = DPatch{};
     }
     WBX_EHIP(e, e->d_patch.ensure(N));
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
     WBX_EHIP(e, hipStreamSynchronize(s));
     WBX_EHIP(e, hipMemcpy(e->d_patch.p, p.data(), N * sizeof(DPatch), hipMemcpyHostToDevice));
     d_patch = e->d_patch.p;
@@ -1052,24 +1108,6 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   st = ensure_result_buffers(c, K, N);
   if (st != WBX_OK) return st;
 
-  // -- transport: exactly the arithmetic of Engine::process, engine.cpp:1578-1585 and :1619-1623, K times
-  const double sample_rate = (double)c->cfg.sample_rate;
-  e->h_times.resize(K);
-  double playhead = e->playhead, sample_position = e->sample_position;
-  for (uint32_t b = 0; b < K; b++) {
-    double buffer_duration = (double)F / sample_rate;
-    double current_beat_duration = e->beat_duration;
-    double buffer_duration_in_beats = buffer_duration / current_beat_duration;
-    double next_playhead_pos = playhead + buffer_duration_in_beats;
-    e->h_times[b] = DBlockTime{playhead, next_playhead_pos, sample_position, current_beat_duration};
-    if (e->playing) {
-      sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, current_beat_duration);
-      playhead = next_playhead_pos;
-    }
-  }
-  WBX_EHIP(e, e->d_times.ensure(std::max<size_t>(K, c->cfg.max_blocks)));
-  WBX_EHIP(e, hipMemcpyAsync(e->d_times.p, e->h_times.data(), K * sizeof(DBlockTime), hipMemcpyHostToDevice, s));
-
   // -- rows for the track-blocks the hot loop cannot stream directly: every clip start / end inside a block,
   //    and all blocks of integer-PCM or fast-forward clips
   {
@@ -1079,36 +1117,64 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
     if (st != WBX_OK) return st;
   }
 
-  // -- plan (sequencer on the device), then pre-render + mix + sum
-  WBX_EHIP(e, hipMemsetAsync(c->d_pool_count, 0, 4 * sizeof(uint32_t), s));
+  // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
+  //    while the mix of the previous render is still busy on the main stream
+  c->cur ^= 1;
+  wbx_ctx::PlanBuf& B = PB(c);
+  hipStream_t ps = c->overlap ? c->plan_stream : s;
+  if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
+  WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
+  const double sample_rate = (double)c->cfg.sample_rate;
   PlanArgs a{};
   a.clips = e->d_clips.p;
   a.clip_first = e->d_clip_first.p;
   a.samples = c->d_samples.p;
   a.state = e->d_state.p;
   a.patch = d_patch;
-  a.times = e->d_times.p;
   a.gains = e->d_gains.p;
-  a.tb = c->d_tb.p;
-  a.pool = c->d_pool.p;
-  a.pool_count = c->d_pool_count;
-  a.status = c->d_pool_count + 1;
-  a.gen_list = c->d_gen_list.p;
-  a.gen_count = c->d_pool_count + 2;
-  a.gen_cap = c->gen_cap;
-  a.pool_chunks = c->pool_chunks;
+  a.tb = B.tb.p;
+  a.pool = B.pool.p;
+  a.pool_count = B.counters;
+  a.status = B.counters + 1;
+  a.gen_list = B.gen_list.p;
+  a.gen_count = B.counters + 2;
+  a.gen_cap = B.gen_cap;
+  a.pool_chunks = B.pool_chunks;
   a.n_tracks = N;
   a.n_blocks = K;
   a.block_frames = F;
   a.channels = C;
   a.sample_rate = sample_rate;
   a.playing = e->playing ? 1u : 0u;
-  launch_plan(a, s);
+  a.playhead = e->playhead;
+  a.sample_position = e->sample_position;
+  a.beat_duration = e->beat_duration;
+  launch_plan(a, ps);
+  st = launch_pre_render(c, ps);
+  if (st != WBX_OK) return st;
+  WBX_EHIP(e, hipEventRecord(B.planned, ps));
+
+  // -- mix + sum on the main stream, after the plan
+  WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
+  c->levels_target = std::getenv("WBX_NO_LEVELS") ? nullptr : reinterpret_cast<uint32_t*>(e->d_levels.p);
   st = launch_mix_sum(c, K, N);
   if (st != WBX_OK) return st;
-  launch_levels(c->d_peaks.p, e->d_levels.p, K, N * C, s);
-  WBX_EHIP(e, hipGetLastError());
+  WBX_EHIP(e, hipEventRecord(B.consumed, s));
+  B.consumed_valid = true;
 
+  // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
+  //    the plan kernel performs for its K blocks, so both sides hold the same playhead / sample_position bits
+  double playhead = e->playhead, sample_position = e->sample_position;
+  for (uint32_t b = 0; b < K; b++) {
+    double buffer_duration = (double)F / sample_rate;
+    double current_beat_duration = e->beat_duration;
+    double buffer_duration_in_beats = buffer_duration / current_beat_duration;
+    double next_playhead_pos = playhead + buffer_duration_in_beats;
+    if (e->playing) {
+      sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, current_beat_duration);
+      playhead = next_playhead_pos;
+    }
+  }
   e->playhead = playhead;
   e->sample_position = sample_position;
   return WBX_OK;
@@ -1133,6 +1199,7 @@ extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n
   if (!e || !levels || n_tracks > e->state_tracks) return WBX_ERR_INVALID;
   wbx_ctx* c = e->ctx;
   const size_t n = (size_t)n_tracks * c->cfg.channels;
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
   WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
@@ -1147,22 +1214,22 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   std::vector<DTrackBlock> tb((size_t)K * N);
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  WBX_EHIP(e, hipMemcpy(tb.data(), c->d_tb.p, tb.size() * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
-  WBX_EHIP(e, hipMemcpy(pc, c->d_pool_count, sizeof(pc), hipMemcpyDeviceToHost));
+  WBX_EHIP(e, hipMemcpy(tb.data(), PB(c).tb.p, tb.size() * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+  WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   {   // records the pre-render pass rewrote: put the sequencer's originals back
-    const uint32_t ng = std::min(pc[2], c->gen_cap);
+    const uint32_t ng = std::min(pc[2], PB(c).gen_cap);
     if (ng) {
       std::vector<uint32_t> idx(ng);
       std::vector<DTrackBlock> saved(ng);
-      WBX_EHIP(e, hipMemcpy(idx.data(), c->d_gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      WBX_EHIP(e, hipMemcpy(saved.data(), c->d_saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+      WBX_EHIP(e, hipMemcpy(idx.data(), PB(c).gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      WBX_EHIP(e, hipMemcpy(saved.data(), PB(c).saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
       for (uint32_t i = 0; i < ng; i++)
         if (idx[i] < tb.size()) tb[idx[i]] = saved[i];
     }
   }
-  const uint32_t used = std::min(pc[0], c->pool_chunks);
+  const uint32_t used = std::min(pc[0], PB(c).pool_chunks);
   std::vector<DSeg> pool((size_t)used * kChunk);
-  if (used) WBX_EHIP(e, hipMemcpy(pool.data(), c->d_pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
+  if (used) WBX_EHIP(e, hipMemcpy(pool.data(), PB(c).pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
   size_t n = 0;
   for (uint32_t b = 0; b < K; b++)
     for (uint32_t t = 0; t < N; t++) {

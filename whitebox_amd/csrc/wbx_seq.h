@@ -166,10 +166,20 @@ struct BlockWalker {
       seg.len = 0;
       seg.flags = SEG_FINISHED;
     } else {
-      double stream_max_length = ((double)smp.count - st->sample_offset) / st->playback_speed;   // :102
-      double next_sample_offset = st->sample_offset + ((double)num_samples * st->playback_speed); // :103
-      uint32_t lim = u32_of_ceil(stream_max_length);                                             // :104
-      uint32_t n = num_samples < lim ? num_samples : lim;
+      const double cnt = (double)smp.count, off = st->sample_offset, sp = st->playback_speed;
+      double next_sample_offset = off + ((double)num_samples * sp);                              // :103
+      uint32_t n;
+      // :102,:104  n = min(num_samples, (uint32)ceil((count - offset) / speed)).  The quotient is only needed
+      // near the clip tail: when count - offset exceeds (num_samples + 1) * speed by a whole frame, the
+      // rounded quotient is >= num_samples + 1 and (being below 2^32) survives the uint32 conversion, so
+      // the minimum is num_samples and the fp64 division can be skipped without changing any result.
+      if (sp > 0.0 && off + (double)(num_samples + 1u) * sp + 1.0 <= cnt && (cnt - off) < sp * 4294967040.0) {
+        n = num_samples;
+      } else {
+        double stream_max_length = (cnt - off) / sp;                                             // :102
+        uint32_t lim = u32_of_ceil(stream_max_length);                                           // :104
+        n = num_samples < lim ? num_samples : lim;
+      }
       if (buffer_offset + (uint64_t)n > n_samples) {       // the reference would write out of bounds here
         n = buffer_offset < n_samples ? n_samples - buffer_offset : 0;
         seg.flags |= SEG_CLIPPED;
@@ -333,7 +343,20 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
 __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
                                                  DClip* clips, uint32_t num_clips, TrackCache* cache,
                                                  const DBlockTime& bt, float gl, float gr) {
-  DTrackBlock* tb = &a.tb[(size_t)b * a.n_tracks + t];
+  // the record is assembled in registers and written to HBM once, as four 16-B stores: building it in place
+  // would turn every field update into a global store followed (in classify) by a dependent global load
+  DTrackBlock rec;
+  DTrackBlock* tb = &rec;
+  rec.src[0] = nullptr;
+  rec.src[1] = nullptr;
+  rec.pos = 0.0;
+  rec.speed = 0.0;
+  rec.gain = 0.0f;
+  rec.dst_start = 0;
+  rec.req_len = 0;
+  rec.format = 0;
+  rec.flags = 0;
+  rec.sample = 0;
   BlockWalker w;
   w.st = st;
   w.samples = a.samples;
@@ -352,8 +375,16 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   tb->extra = 0;
   tb->len = 0;
   if (a.playing) {
-    process_event(w, clips, num_clips, bt.start_time, bt.end_time, bt.sample_position, bt.beat_duration,
-                  a.sample_rate, a.block_frames);
+    // Steady state — a clip that started in an earlier block plays through this whole block: process_event
+    // (track.cpp:258-451) would walk to `max_time <= end_time` being false, emit no event and leave every
+    // field as it is, so only the tail of the segment loop (track.cpp:710-722) remains.
+    const bool steady = st->cur_type == EV_PLAY && st->has_clip_idx && !st->refresh_voice && st->partially_ended &&
+                        st->clip_idx < num_clips && cache->clip_idx == st->clip_idx &&
+                        !cache->clip.internal_state_changed && cache->clip.min_time < bt.start_time &&
+                        cache->clip.max_time > bt.end_time;
+    if (!steady)
+      process_event(w, clips, num_clips, bt.start_time, bt.end_time, bt.sample_position, bt.beat_duration,
+                    a.sample_rate, a.block_frames);
     w.finish();
   }
   tb->g[0] = gl;
@@ -361,6 +392,14 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   tb->nseg = (uint8_t)w.nseg;
   tb->_pad = 0;
   tb->kind = classify(*tb, a.block_frames);
+  {
+    const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
+    uint4* dstq = reinterpret_cast<uint4*>(&a.tb[(size_t)b * a.n_tracks + t]);
+    dstq[0] = srcq[0];
+    dstq[1] = srcq[1];
+    dstq[2] = srcq[2];
+    dstq[3] = srcq[3];
+  }
   if (tb->kind == KIND_GENERIC) {   // queue it for the pre-render pass
     uint32_t row;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -373,6 +412,68 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
     else if (a.status)
       a.status[0] |= 8u;
   }
+}
+
+// A run of steady-state blocks: the clip that is playing covers each of them completely and is far from
+// its tail.  For such a block Track::process_event emits nothing and changes nothing, and Sampler::stream
+// (sampler.cpp:99-104,209) reduces to  n = num_samples;  sample_offset_ += (double)num_samples * speed.
+// Everything but the position is loop-invariant, so the run is planned by a short loop: two beat
+// comparisons, the tail guard, one fp64 add and the 64-B store per block.  The records are field-for-field
+// what plan_track_block produces (the parity tests compare them with the oracle's call log).  Returns the
+// number of blocks planned (0: the general path must handle block b).
+__host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
+                                                    uint32_t num_clips, const TrackCache* cache,
+                                                    const DBlockTime* times, float gl, float gr) {
+  if (!(a.playing && st->cur_type == EV_PLAY && st->has_clip_idx && !st->refresh_voice && st->partially_ended &&
+        st->clip_idx < num_clips && cache->clip_idx == st->clip_idx && !cache->clip.internal_state_changed &&
+        cache->smp_idx == st->cur_sample))
+    return 0;
+  const DSample& smp = cache->smp;
+  const double cnt = (double)smp.count, sp = st->playback_speed;
+  if (!(sp > 0.0)) return 0;
+  const uint32_t F = a.block_frames;
+  const double step = (double)F * sp;                      // (double)num_samples * playback_speed_, sampler.cpp:103
+  const double guard = (double)(F + 1u) * sp + 1.0;        // see BlockWalker::stream
+  const double qmax = sp * 4294967040.0;
+  const double min_time = cache->clip.min_time, max_time = cache->clip.max_time;
+  DTrackBlock rec;
+  rec.src[0] = smp.ch[0];
+  rec.src[1] = smp.ch[a.channels > 1 ? 1 : 0];
+  rec.pos = 0.0;
+  rec.speed = sp;
+  rec.gain = st->cur_gain;
+  rec.g[0] = gl;
+  rec.g[1] = gr;
+  rec.nseg = 1;
+  rec.kind = KIND_SILENT;
+  rec.dst_start = 0;
+  rec.len = (uint16_t)F;
+  rec.req_len = (uint16_t)F;
+  rec.format = (uint8_t)smp.format;
+  rec.flags = 0;
+  rec._pad = 0;
+  rec.sample = st->cur_sample;
+  rec.extra = 0;
+  double off = st->sample_offset;
+  uint32_t n = 0;
+  while (b + n < a.n_blocks) {
+    const DBlockTime& bt = times[b + n];
+    if (!(min_time < bt.start_time && max_time > bt.end_time)) break;
+    if (!(off + guard <= cnt && (cnt - off) < qmax)) break;
+    rec.pos = off;
+    rec.kind = classify(rec, F);
+    if (rec.kind == KIND_GENERIC) break;                   // needs the pre-render queue: general path
+    const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
+    uint4* dstq = reinterpret_cast<uint4*>(&a.tb[(size_t)(b + n) * a.n_tracks + t]);
+    dstq[0] = srcq[0];
+    dstq[1] = srcq[1];
+    dstq[2] = srcq[2];
+    dstq[3] = srcq[3];
+    off = off + step;                                      // sampler.cpp:209
+    n++;
+  }
+  st->sample_offset = off;
+  return n;
 }
 
 }  // namespace wbx
