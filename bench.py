@@ -145,13 +145,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
-    ap.add_argument("--blocks", type=int, default=64, help="512-frame blocks per step (one device pass)")
+    ap.add_argument("--blocks", type=int, default=256, help="512-frame blocks per step (one device pass)")
     ap.add_argument("--group-size", type=int, default=0)
     ap.add_argument("--session-blocks", type=int, default=0, help="length of the resident session in blocks "
                     "(0 = as long as the run needs, capped by memory); the transport rewinds at its end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
+    ap.add_argument("--force-dist-path", action="store_true",
+                    help="run the multi-GPU code path (RCCL reduce + clamp on root) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -182,47 +184,78 @@ def main():
         session_blocks = max(K, min(session_blocks, args.session_blocks))
     session_blocks = (session_blocks // K) * K
 
+    use_dist = world > 1 or args.force_dist_path
+    if args.force_dist_path and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+
     stream = torch.cuda.Stream()
+    fin_stream = torch.cuda.Stream()          # root: clamp + D2H of a reduced master, beside the next render
     with torch.cuda.stream(stream):
         eng, seed, amp = build_device_session(W, synth, args.workload, n_tracks, K, session_blocks, rank,
                                               stream.cuda_stream, args.group_size)
-        master = torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda")
         host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
-        if world > 1:
-            eng.ctx.set_master_target(master.data_ptr())   # send buffer of the RCCL reduce
+        if use_dist:
+            from whitebox_amd.dist import MasterReducer
+            masters = [torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda") for _ in range(2)]
+            fin_done = [torch.cuda.Event(), torch.cuda.Event()]
             eng.ctx.set_clamp(False)                       # partials are clamped on the root AFTER the reduce
+            red = MasterReducer(lambda buf: eng.ctx.finalize_master(buf.data_ptr(), K, True,
+                                                                    stream=fin_stream.cuda_stream), root=0)
         else:
             # single GPU: the sum kernel stores the clamped master straight into pinned host memory
             eng.ctx.set_master_target(host_master.data_ptr())
 
         done = 0
+        nstep = 0
+
+        def finish(slot):
+            """root: wait for the reduce of `slot`, clamp, copy to the host — all on fin_stream."""
+            with torch.cuda.stream(fin_stream):
+                red.finish(masters[slot], slot)
+                if rank == 0:
+                    host_master.copy_(masters[slot], non_blocking=True)
+                fin_done[slot].record(fin_stream)
 
         def step():
-            nonlocal done
+            nonlocal done, nstep
             if done + K > session_blocks:     # end of the resident session: rewind (Engine::stop + play)
                 eng.stop()
                 eng.play()
                 done = 0
-            eng.render(K)
-            if world > 1:
-                dist.reduce(master, dst=0)    # RCCL sum of the per-GPU partial masters over xGMI
-                if rank == 0:
-                    eng.ctx.finalize_master(master.data_ptr(), K, True)
-                    host_master.copy_(master, non_blocking=True)
+            if use_dist:
+                slot = nstep & 1
+                if nstep >= 2:
+                    stream.wait_event(fin_done[slot])          # the buffer's previous reduce / copy is over
+                eng.ctx.set_master_target(masters[slot].data_ptr())
+                eng.render(K)
+                red.reduce(masters[slot], slot)                # RCCL sum over xGMI, asynchronous to this stream
+                if nstep >= 1:
+                    finish((nstep - 1) & 1)
+            else:
+                eng.render(K)
             done += K
+            nstep += 1
+
+        def drain():
+            if use_dist and nstep >= 1:
+                finish((nstep - 1) & 1)
+            torch.cuda.synchronize()
 
         eng.play()
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
+        drain()
         eng.ctx.kernel_time(reset=True)
+        nstep = 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -236,7 +269,7 @@ def main():
 
         # K = 1 latency mode (the real-time callback shape): Engine::process one block at a time
         lat = None
-        if rank == 0 and args.latency_blocks > 0 and world == 1:
+        if rank == 0 and args.latency_blocks > 0 and world == 1 and not use_dist:
             eng.ctx.set_master_target(None)
             out = W.AudioBuffer(F, 2)
             eng.stop()
@@ -278,7 +311,7 @@ def main():
             "track_frames_per_s": total_tracks * master_frames / dt,
             "realtime_factor": master_frames / dt / SR,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "wbx::mix_kernel<8>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "wbx::mix_kernel<2,true,4>",
                          "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n),
                          "algorithmic_bytes_per_launch": alg},
         }
@@ -289,7 +322,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

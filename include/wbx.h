@@ -126,8 +126,9 @@ wbx_status wbx_sync(wbx_ctx* ctx);
 
 /* Multi-GPU: the un-clamped partial master of the last submit, on the device, [K][C][F] fp32 ... */
 wbx_status wbx_partial_master(wbx_ctx* ctx, void** device_ptr, size_t* n_floats);
-/* ... and, on the root after the RCCL reduce, the clamp of engine.cpp:1627-1636 over a device buffer. */
-wbx_status wbx_finalize_master(wbx_ctx* ctx, void* device_partial, uint32_t n_blocks, int clamp);
+/* ... and, on the root after the RCCL reduce, the clamp of engine.cpp:1627-1636 over a device buffer.
+ * `stream`: hipStream_t to launch on (e.g. the stream that waited for the collective), NULL = the ctx stream. */
+wbx_status wbx_finalize_master(wbx_ctx* ctx, void* device_partial, uint32_t n_blocks, int clamp, void* stream);
 wbx_status wbx_set_clamp(wbx_ctx* ctx, int clamp_on_submit); /* 0: leave the master un-clamped (shard mode) */
 /* Write the master of later submits/renders into a caller-owned DEVICE buffer of at least
  * max_blocks*C*F floats (e.g. the send buffer of the RCCL reduce); NULL restores the ctx-owned one. */

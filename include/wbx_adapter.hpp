@@ -1,0 +1,149 @@
+// wbx_adapter.hpp — header-only C++ adapter over the C ABI (wbx.h) with the reference's own shapes.
+//
+// A reference maintainer who wants the MI355X path behind the existing C++ host replaces `wb::Engine
+// g_engine` (src/engine/engine.cpp:1715, engine.h:273) by `wbx::Engine`: same method names, argument
+// meaning and buffer type as
+//   wb::AudioBuffer<float>                         src/core/audio_buffer.h:14-175
+//   wb::Engine::set_audio_channel_config/set_bpm/add_track/add_audio_clip/play/stop/process
+//                                                   src/engine/engine.h:68-113,235-239
+//   wb::Track::set_volume/set_pan/set_mute          src/engine/track.h:137-139
+// Compiles with any C++17 compiler (no HIP headers needed); link against libwbx.so.
+#pragma once
+#include <cassert>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "wbx.h"
+
+namespace wbx {
+
+// Planar sample buffer with the reference's fields and semantics (audio_buffer.h:19-23,28-82).
+template <typename T>
+struct AudioBuffer {
+  static_assert(sizeof(T) == 4, "the mix path is fp32");
+  uint32_t n_samples{};
+  uint32_t n_channels{};
+  std::vector<T*> channel_buffers;
+
+  AudioBuffer() = default;
+  AudioBuffer(uint32_t sample_count, uint32_t channel_count) : n_samples(sample_count), n_channels(channel_count) {
+    channel_buffers.resize(channel_count);
+    for (auto& p : channel_buffers) {
+      p = static_cast<T*>(std::aligned_alloc(32, ((sample_count * sizeof(T) + 31) / 32) * 32));
+      std::memset(p, 0, sample_count * sizeof(T));
+    }
+  }
+  AudioBuffer(const AudioBuffer&) = delete;
+  AudioBuffer& operator=(const AudioBuffer&) = delete;
+  ~AudioBuffer() {
+    for (auto p : channel_buffers) std::free(p);
+  }
+  T* get_write_pointer(uint32_t channel, uint32_t sample_offset = 0) {
+    assert(channel < n_channels && "Channel out of range");
+    return channel_buffers[channel] + sample_offset;
+  }
+  const T* get_read_pointer(uint32_t channel, uint32_t sample_offset = 0) const {
+    assert(channel < n_channels && "Channel out of range");
+    return channel_buffers[channel] + sample_offset;
+  }
+  void clear() {
+    for (auto p : channel_buffers) std::memset(p, 0, n_samples * sizeof(T));
+  }
+  void mix(const AudioBuffer<T>& other) {   // audio_buffer.h:73-82
+    assert(n_samples == other.n_samples);
+    for (uint32_t i = 0; i < n_channels; i++)
+      for (uint32_t j = 0; j < n_samples; j++) channel_buffers[i][j] += other.channel_buffers[i][j];
+  }
+};
+
+struct Error : std::runtime_error {
+  wbx_status status;
+  Error(wbx_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+struct Engine;
+
+struct Track {   // track.h:137-139
+  Engine* engine{};
+  uint32_t index{};
+  std::string name;
+  void set_volume(float db);
+  void set_pan(float pan);
+  void set_mute(bool mute);
+};
+
+struct AudioClip {   // clip.h:39-45: the asset is a sample id returned by Engine::add_sample
+  uint32_t asset{};
+  double speed = 1.0;
+  float gain = 1.0f;
+};
+
+struct Engine {
+  wbx_engine* h{};
+  uint32_t num_output_channels = 0, audio_buffer_size = 0, audio_sample_rate = 0;
+  std::vector<std::unique_ptr<Track>> tracks;
+
+  // set_audio_channel_config(in, out, buffer_size, sample_rate), engine.cpp:43-57 (sizes the device context)
+  void set_audio_channel_config(uint32_t /*input_channels*/, uint32_t output_channels, uint32_t buffer_size,
+                                uint32_t sample_rate, uint32_t max_tracks = 4096, uint32_t max_blocks = 1, int device = 0) {
+    if (h) wbx_engine_destroy(h);
+    h = nullptr;
+    wbx_config cfg{};
+    cfg.device = device;
+    cfg.max_tracks = max_tracks;
+    cfg.max_blocks = max_blocks;
+    cfg.block_frames = buffer_size;
+    cfg.channels = output_channels;
+    cfg.sample_rate = sample_rate;
+    check(wbx_engine_create(&cfg, &h), "wbx_engine_create");
+    num_output_channels = output_channels;
+    audio_buffer_size = buffer_size;
+    audio_sample_rate = sample_rate;
+  }
+  ~Engine() {
+    if (h) wbx_engine_destroy(h);
+  }
+  void set_bpm(double bpm) { check(wbx_engine_set_bpm(h, bpm), "set_bpm"); }
+  void set_playhead_position(double beat) { check(wbx_engine_set_playhead_position(h, beat), "set_playhead_position"); }
+  Track* add_track(const std::string& name) {
+    uint32_t idx = 0;
+    check(wbx_engine_add_track(h, &idx), "add_track");
+    tracks.emplace_back(new Track{this, idx, name});
+    return tracks.back().get();
+  }
+  // decoded clip audio -> HBM (what SampleAsset / Sample hold in the reference: assets_table.h:22-35, sample.h:18-28)
+  uint32_t add_sample(int format, uint32_t channels, uint32_t sample_rate, uint64_t frames, const void* const* planar) {
+    uint32_t id = 0;
+    check(wbx_engine_add_sample(h, format, channels, sample_rate, frames, planar, &id), "add_sample");
+    return id;
+  }
+  // Engine::add_audio_clip(track, name, min_time, max_time, start_offset, clip_info), engine.h:106-113
+  void add_audio_clip(Track* track, const std::string& /*name*/, double min_time, double max_time, double start_offset,
+                      const AudioClip& clip_info) {
+    check(wbx_engine_add_audio_clip(h, track->index, min_time, max_time, start_offset, clip_info.asset, clip_info.speed,
+                                    clip_info.gain),
+          "add_audio_clip");
+  }
+  void play() { check(wbx_engine_play(h), "play"); }
+  void stop() { check(wbx_engine_stop(h), "stop"); }
+  // void Engine::process(const AudioBuffer<float>&, AudioBuffer<float>&, double), engine.h:235-239
+  void process(const AudioBuffer<float>& /*input_buffer*/, AudioBuffer<float>& output_buffer, double sample_rate) {
+    assert(output_buffer.n_samples == audio_buffer_size && output_buffer.n_channels == num_output_channels);
+    assert(sample_rate == (double)audio_sample_rate);
+    (void)sample_rate;
+    check(wbx_engine_process(h, output_buffer.channel_buffers.data()), "process");
+  }
+  void check(wbx_status s, const char* where) const {
+    if (s != WBX_OK) throw Error(s, std::string(where) + ": " + (h ? wbx_engine_last_error(h) : wbx_status_string(s)));
+  }
+};
+
+inline void Track::set_volume(float db) { engine->check(wbx_track_set_volume(engine->h, index, db), "Track::set_volume"); }
+inline void Track::set_pan(float pan) { engine->check(wbx_track_set_pan(engine->h, index, pan), "Track::set_pan"); }
+inline void Track::set_mute(bool mute) { engine->check(wbx_track_set_mute(engine->h, index, mute ? 1 : 0), "Track::set_mute"); }
+
+}  // namespace wbx

@@ -716,7 +716,9 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
 /* engine.cpp:1576-1654.  With n_buses > 0 (extension A13, not in the reference): each track's block is
  * mixed into its bus in track order (AudioBuffer::mix), then buses 0..n-1 are mixed into the output in
  * bus order, then the clamp. */
-void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) {
+void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) { wbo_engine_process_ex(e, out, bus_out, 1); }
+
+void wbo_engine_process_ex(wbo_engine* e, float* const* out, float* bus_out, int clamp) {
   const uint32_t F = e->buffer_size, C = e->out_channels;
   double sample_rate = (double)e->sample_rate;
   double buffer_duration = (double)F / sample_rate;                /* :1578 */
@@ -761,7 +763,7 @@ void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) {
     e->playhead = next_playhead_pos;
   }
 
-  wbo_master_clamp(out, C, F);                                     /* :1627-1636 */
+  if (clamp) wbo_master_clamp(out, C, F);                          /* :1627-1636 */
 }
 
 /* synthetic input (not part of the reference): u = splitmix64(key ^ i); v = ((u>>40) - 2^23) * 2^-23; v*amp */

@@ -162,6 +162,9 @@ void wbo_engine_enable_seglog(wbo_engine* e, int on);
 /* one block; out[c] planar, out_channels x buffer_size.  engine.cpp:1576-1654
  * bus_out (optional, may be NULL): [n_buses][C][F] planar bus sums (extension A13). */
 void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out);
+/* same, with the final clamp optional (clamp = 0: the un-clamped sum, what one shard of a multi-GPU
+ * session contributes before the cross-GPU reduce) */
+void wbo_engine_process_ex(wbo_engine* e, float* const* out, float* bus_out, int clamp);
 
 /* synthetic input generator (integer hash; input generation only, same bits as whitebox_amd/synth.py) */
 void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pad);

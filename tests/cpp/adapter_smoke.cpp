@@ -1,0 +1,69 @@
+// C++ host using the reference-shaped adapter (include/wbx_adapter.hpp) over libwbx.so, checked block by
+// block against the CPU oracle (oracle/wb_oracle.h).  Session = the survey's seek-math KAT
+// plus a resampled track: written the way a reference host would write it (engine.h / track.h names).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "wb_oracle.h"
+#include "wbx_adapter.hpp"
+
+int main() {
+  const uint32_t F = 512, C = 2, SR = 48000, NB = 6;
+  const size_t cnt = 6000;
+  std::vector<float> ramp(cnt + 16, 0.0f), ramp2(cnt + 16, 0.0f);
+  for (size_t i = 0; i < cnt; i++) {
+    ramp[i] = 0.001f * (float)(i + 1);
+    ramp2[i] = 0.0005f * (float)((i * 7) % 1000);
+  }
+  const void* planar[2] = {ramp.data(), ramp2.data()};
+
+  // ---- product, through the adapter -------------------------------------------------------------
+  wbx::Engine g_engine;
+  g_engine.set_audio_channel_config(0, C, F, SR, /*max_tracks*/ 8);
+  g_engine.set_bpm(120.0);
+  const uint32_t s48 = g_engine.add_sample(WBX_FMT_F32, 2, 48000, cnt, planar);
+  const uint32_t s44 = g_engine.add_sample(WBX_FMT_F32, 2, 44100, cnt, planar);
+  wbx::Track* t0 = g_engine.add_track("kat");
+  wbx::Track* t1 = g_engine.add_track("resampled");
+  t0->set_volume(0.0f);
+  t1->set_volume(-6.0f);
+  t1->set_pan(0.3f);
+  g_engine.add_audio_clip(t0, "a", 100.0 / 24000, 700.0 / 24000, 10.0, wbx::AudioClip{s48, 1.0, 0.5f});
+  g_engine.add_audio_clip(t0, "b", 812.0 / 24000, 2000.0 / 24000, 0.0, wbx::AudioClip{s48, 1.0, 1.0f});
+  g_engine.add_audio_clip(t1, "c", 40.0 / 24000, 2500.0 / 24000, 3.0, wbx::AudioClip{s44, 1.0, 0.8f});
+  g_engine.play();
+
+  // ---- oracle ------------------------------------------------------------------------------------
+  wbo_engine* o = wbo_engine_create(C, F, SR);
+  wbo_engine_set_bpm(o, 120.0);
+  const int o48 = wbo_engine_add_sample(o, WBO_FMT_F32, 2, 48000, cnt, planar);
+  const int o44 = wbo_engine_add_sample(o, WBO_FMT_F32, 2, 44100, cnt, planar);
+  wbo_engine_add_track(o);
+  wbo_engine_add_track(o);
+  wbo_track_set_volume(o, 0, 0.0f);
+  wbo_track_set_volume(o, 1, -6.0f);
+  wbo_track_set_pan(o, 1, 0.3f);
+  wbo_engine_add_audio_clip(o, 0, 100.0 / 24000, 700.0 / 24000, 10.0, o48, 1.0, 0.5f);
+  wbo_engine_add_audio_clip(o, 0, 812.0 / 24000, 2000.0 / 24000, 0.0, o48, 1.0, 1.0f);
+  wbo_engine_add_audio_clip(o, 1, 40.0 / 24000, 2500.0 / 24000, 3.0, o44, 1.0, 0.8f);
+  wbo_engine_play(o);
+
+  wbx::AudioBuffer<float> in(F, C), out(F, C);
+  std::vector<float> ol(F), orr(F);
+  float* optr[2] = {ol.data(), orr.data()};
+  for (uint32_t b = 0; b < NB; b++) {
+    g_engine.process(in, out, (double)SR);
+    wbo_engine_process(o, optr, nullptr);
+    for (uint32_t c = 0; c < C; c++)
+      if (std::memcmp(out.channel_buffers[c], optr[c], F * sizeof(float)) != 0) {
+        std::printf("MISMATCH block %u channel %u\n", b, c);
+        return 1;
+      }
+  }
+  if (out.n_samples != F || out.n_channels != C) return 2;
+  wbo_engine_destroy(o);
+  std::printf("adapter ok: %u blocks bit-identical to the oracle\n", NB);
+  return 0;
+}

@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
         L.wbo_engine_stop.argtypes = [C.POINTER(_Engine)]
         L.wbo_engine_process.argtypes = [C.POINTER(_Engine), c_f32pp, c_f32p]
         L.wbo_engine_enable_seglog.argtypes = [C.POINTER(_Engine), C.c_int]
+        L.wbo_engine_process_ex.argtypes = [C.POINTER(_Engine), c_f32pp, c_f32p, C.c_int]
+        L.wbo_master_clamp.argtypes = [c_f32pp, C.c_uint32, C.c_uint32]
         for name, t in (("wbo_f32_to_interleaved_i16", C.c_void_p), ("wbo_f32_to_interleaved_i24", C.c_void_p),
                         ("wbo_f32_to_interleaved_i24_x8", C.c_void_p), ("wbo_f32_to_interleaved_i32", C.c_void_p),
                         ("wbo_f32_to_interleaved_f32", C.c_void_p)):
@@ -246,11 +248,12 @@ class OracleEngine:
     def play(self): self.L.wbo_engine_play(self.e)
     def stop(self): self.L.wbo_engine_stop(self.e)
 
-    def process(self, want_buses=False):
+    def process(self, want_buses=False, clamp=True):
         out = [np.zeros(self.F, dtype=np.float32) for _ in range(self.C)]
         nb = self.e.contents.n_buses
         bus = np.zeros((nb, self.C, self.F), dtype=np.float32) if (want_buses and nb) else None
-        self.L.wbo_engine_process(self.e, planar_ptrs(out), bus.ctypes.data_as(c_f32p) if bus is not None else None)
+        self.L.wbo_engine_process_ex(self.e, planar_ptrs(out), bus.ctypes.data_as(c_f32p) if bus is not None else None,
+                                     int(clamp))
         return np.stack(out), bus
 
     def enable_seglog(self, on=True): self.L.wbo_engine_enable_seglog(self.e, int(on))

@@ -362,3 +362,20 @@ def test_kernel_timer_reports():
     ms, n = eng.ctx.kernel_time()
     assert n == 2 and ms > 0.0
     eng.close()
+
+
+def test_cpp_host_through_the_adapter(tmp_path):
+    """A C++ host written against include/wbx_adapter.hpp (reference-shaped Engine/Track/AudioBuffer),
+    compiled with plain g++ and linked to libwbx.so, is bit-identical to the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "adapter_smoke")
+    O.lib()     # makes sure oracle/liboracle.so exists
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "adapter_smoke.cpp"),
+                           "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "oracle"),
+                           "-L" + os.path.join(root, "whitebox_amd"), "-lwbx", "-L" + os.path.join(root, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(root, "whitebox_amd"), "-Wl,-rpath," + os.path.join(root, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert "adapter ok" in out

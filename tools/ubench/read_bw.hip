@@ -1,0 +1,101 @@
+// Micro-benchmark (measurement tool, not product code): HBM read bandwidth on gfx950 for
+//  (a) an ideal contiguous grid-stride float4 read, and
+//  (b) the mix kernel's access pattern: workgroup (block b, group g) reads, for 64 tracks, one 2 KiB row
+//      per channel (4 waves x 1 KiB) from 64 x 2 separate arrays, K blocks contiguous per array.
+// build: hipcc --offload-arch=gfx950 -O3 read_bw.hip -o read_bw ; run: ./read_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_contig(const f4* __restrict__ p, size_t n4, float* out) {
+  f4 acc = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f4 v = p[i];
+    acc += v;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_rows(const float* const* __restrict__ chans, int tracks_per_group, int frames_per_block,
+                                              float* out) {
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int c = threadIdx.x >> 7, j0 = (threadIdx.x & 127) * 4;
+  f4 acc = {0, 0, 0, 0};
+  for (int t0 = 0; t0 < tracks_per_group; t0 += U) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float* base = chans[((size_t)(g * tracks_per_group + t0 + u)) * 2 + c];
+      v[u] = *reinterpret_cast<const f4*>(base + (size_t)b * frames_per_block + j0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += v[u];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// the window (linear resample) load shape: lane L reads 16 B at float offset floor(L*4*0.91875)+off and 4 B behind it
+template <int U, bool W4>
+__global__ __launch_bounds__(256) void k_window(const float* const* __restrict__ chans, int tracks_per_group, int frames_per_block,
+                                                int off, float* out) {
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int c = threadIdx.x >> 7, j0 = (threadIdx.x & 127) * 4;
+  const int src0 = (int)((double)((size_t)b * frames_per_block + j0) * 0.91875) + off;
+  f4 acc = {0, 0, 0, 0};
+  for (int t0 = 0; t0 < tracks_per_group; t0 += U) {
+    f4 v[U]; float w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float* base = chans[((size_t)(g * tracks_per_group + t0 + u)) * 2 + c];
+      v[u] = *reinterpret_cast<const f4u*>(base + src0);
+      w[u] = W4 ? base[src0 + 4] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) { acc += v[u]; acc.x += w[u]; }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+
+int main() {
+  const int N = 4096, K = 256, F = 512, G = 64;
+  const size_t frames = (size_t)K * F;
+  std::vector<float*> h(N * 2);
+  for (auto& p : h) { hipMalloc(&p, frames * 4 + 256); hipMemset(p, 0, frames * 4); }
+  float** d; hipMalloc(&d, h.size() * sizeof(float*)); hipMemcpy(d, h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice);
+  float* big; const size_t bytes = (size_t)N * 2 * frames * 4; hipMalloc(&big, bytes); hipMemset(big, 0, bytes);
+  float* out; hipMalloc(&out, 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char* name, auto launch) {
+    for (int i = 0; i < 3; i++) launch();
+    hipEventRecord(e0);
+    const int R = 20;
+    for (int i = 0; i < R; i++) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s %8.3f ms  %7.1f GB/s\n", name, ms / R, bytes / (ms / R * 1e-3) / 1e9);
+  };
+  timeit("contiguous grid-stride x2048", [&] { hipLaunchKernelGGL(k_contig, dim3(2048), dim3(256), 0, 0, (const f4*)big, bytes / 16, out); });
+  timeit("contiguous grid-stride x8192", [&] { hipLaunchKernelGGL(k_contig, dim3(8192), dim3(256), 0, 0, (const f4*)big, bytes / 16, out); });
+  timeit("rows U=2 (b fastest)", [&] { hipLaunchKernelGGL(k_rows<2>, dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, out); });
+  timeit("rows U=4 (b fastest)", [&] { hipLaunchKernelGGL(k_rows<4>, dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, out); });
+  timeit("rows U=8 (b fastest)", [&] { hipLaunchKernelGGL(k_rows<8>, dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, out); });
+  timeit("rows U=16 (b fastest)", [&] { hipLaunchKernelGGL(k_rows<16>, dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, out); });
+  const double wb = bytes * 0.91875;
+  auto timeit2 = [&](const char* name, auto launch) {
+    for (int i = 0; i < 3; i++) launch();
+    hipEventRecord(e0);
+    const int R = 20;
+    for (int i = 0; i < R; i++) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s %8.3f ms  %7.1f GB/s (unique bytes)\n", name, ms / R, wb / (ms / R * 1e-3) / 1e9);
+  };
+  timeit2("window U=2 no w4", [&] { hipLaunchKernelGGL((k_window<2, false>), dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, 1, out); });
+  timeit2("window U=2 + w4", [&] { hipLaunchKernelGGL((k_window<2, true>), dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, 1, out); });
+  timeit2("window U=4 + w4", [&] { hipLaunchKernelGGL((k_window<4, true>), dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, 1, out); });
+  timeit2("window U=8 + w4", [&] { hipLaunchKernelGGL((k_window<8, true>), dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, 1, out); });
+  return 0;
+}

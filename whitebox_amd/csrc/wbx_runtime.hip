@@ -392,13 +392,18 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     }
   }
   {
-    // the sequencer runs beside the mix of the previous render; give it the lowest priority so that the
-    // bandwidth-bound mix keeps the machine (WBX_OVERLAP=0 puts everything on the main stream instead)
+    // The sequencer runs beside the mix of the previous render.  It is a few dozen latency-bound waves (one
+    // lane per track): at low or equal priority they starve behind the 16 mix waves of their CU and the
+    // plan becomes the critical path, so the plan stream gets the HIGHEST priority — the issue slots it
+    // takes from the bandwidth-bound mix are negligible.  WBX_OVERLAP=0 runs everything on the main stream;
+    // WBX_PLAN_PRIO=lo|hi picks the priority (tuning knobs).
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     const char* ov = std::getenv("WBX_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
-    if (hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+    const char* pp = std::getenv("WBX_PLAN_PRIO");
+    const int prio = (pp && pp[0] == 'l') ? lo : hi;
+    if (hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, prio) != hipSuccess) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
     }
@@ -708,9 +713,10 @@ extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* 
   return WBX_OK;
 }
 
-extern "C" wbx_status wbx_finalize_master(wbx_ctx* c, void* device_partial, uint32_t n_blocks, int clamp) {
+extern "C" wbx_status wbx_finalize_master(wbx_ctx* c, void* device_partial, uint32_t n_blocks, int clamp, void* stream) {
   if (!c || !device_partial || n_blocks == 0) return WBX_ERR_INVALID;
-  if (clamp) launch_clamp((float*)device_partial, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, c->stream);
+  hipStream_t on = stream ? (hipStream_t)stream : c->stream;
+  if (clamp) launch_clamp((float*)device_partial, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
 }

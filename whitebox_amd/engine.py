@@ -168,8 +168,8 @@ class MixContext:
         _check(self.L.wbx_partial_master(self.h, C.byref(p), C.byref(n)), "wbx_partial_master", self.h)
         return p.value, n.value
 
-    def finalize_master(self, device_ptr: int, n_blocks: int, clamp: bool = True):
-        _check(self.L.wbx_finalize_master(self.h, device_ptr, n_blocks, int(clamp)), "wbx_finalize_master", self.h)
+    def finalize_master(self, device_ptr: int, n_blocks: int, clamp: bool = True, stream: Optional[int] = None):
+        _check(self.L.wbx_finalize_master(self.h, device_ptr, n_blocks, int(clamp), stream), "wbx_finalize_master", self.h)
 
     def kernel_time(self, reset: bool = False):
         ms, n = C.c_double(), C.c_uint64()
