@@ -32,10 +32,7 @@ struct AudioBuffer {
   AudioBuffer() = default;
   AudioBuffer(uint32_t sample_count, uint32_t channel_count) : n_samples(sample_count), n_channels(channel_count) {
     channel_buffers.resize(channel_count);
-    for (auto& p : channel_buffers) {
-      p = static_cast<T*>(std::aligned_alloc(32, ((sample_count * sizeof(T) + 31) / 32) * 32));
-      std::memset(p, 0, sample_count * sizeof(T));
-    }
+    for (auto& p : channel_buffers) p = alloc_channel(sample_count);
   }
   AudioBuffer(const AudioBuffer&) = delete;
   AudioBuffer& operator=(const AudioBuffer&) = delete;
@@ -50,9 +47,52 @@ struct AudioBuffer {
     assert(channel < n_channels && "Channel out of range");
     return channel_buffers[channel] + sample_offset;
   }
-  void clear() {
+  void clear() {   // audio_buffer.h:67-71
     for (auto p : channel_buffers) std::memset(p, 0, n_samples * sizeof(T));
   }
+  void set_sample(uint32_t channel, uint32_t sample_offset, T sample) const { channel_buffers[channel][sample_offset] = sample; }
+  void mix_sample(uint32_t channel, uint32_t sample_offset, T sample) const { channel_buffers[channel][sample_offset] += sample; }
+  // resize(samples, clear): keeps the old contents unless `clear`, zero-fills the growth (audio_buffer.h:84-110)
+  void resize(uint32_t samples, bool clear = false) {
+    if (samples == n_samples) return;
+    for (auto& p : channel_buffers) {
+      T* fresh = alloc_channel(samples);
+      if (!clear) std::memcpy(fresh, p, (samples < n_samples ? samples : n_samples) * sizeof(T));
+      std::free(p);
+      p = fresh;
+    }
+    n_samples = samples;
+  }
+  // resize_channel(count): new channels are zeroed, dropped ones freed (audio_buffer.h:112-132)
+  void resize_channel(uint32_t channel_count) {
+    assert(n_samples != 0);
+    if (channel_count == n_channels) return;
+    for (uint32_t i = channel_count; i < n_channels; i++) std::free(channel_buffers[i]);
+    const uint32_t old = n_channels;
+    channel_buffers.resize(channel_count, nullptr);
+    for (uint32_t i = old; i < channel_count; i++) channel_buffers[i] = alloc_channel(n_samples);
+    n_channels = channel_count;
+  }
+  // planar -> interleaved f32 (convert_to_interleaved_f32, audio_format_conv.cpp:79-91); integer device formats
+  // come from the GPU: wbx_fetch_interleaved
+  void interleave_samples_to(float* dst, uint32_t offset, uint32_t count) const {
+    for (uint32_t c = 0; c < n_channels; c++)
+      for (uint32_t i = 0; i < count; i++) dst[(size_t)i * n_channels + c] = channel_buffers[c][offset + i];
+  }
+  // interleaved f32 -> planar (convert_to_deinterleaved_f32, audio_format_conv.cpp:93-105)
+  void deinterleave_samples_from(const float* src, uint32_t dst_offset, uint32_t count) {
+    for (uint32_t c = 0; c < n_channels; c++)
+      for (uint32_t i = 0; i < count; i++) channel_buffers[c][dst_offset + i] = src[(size_t)i * n_channels + c];
+  }
+
+ private:
+  static T* alloc_channel(uint32_t samples) {
+    T* p = static_cast<T*>(std::aligned_alloc(32, ((samples * sizeof(T) + 31) / 32) * 32 + 32));
+    std::memset(p, 0, samples * sizeof(T));
+    return p;
+  }
+
+ public:
   void mix(const AudioBuffer<T>& other) {   // audio_buffer.h:73-82
     assert(n_samples == other.n_samples);
     for (uint32_t i = 0; i < n_channels; i++)

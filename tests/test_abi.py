@@ -78,3 +78,14 @@ def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_ffi, "_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         _ffi.lib()
+
+
+def test_adapter_audio_buffer_host_semantics(tmp_path):
+    """wbx::AudioBuffer keeps the reference's construct / resize / resize_channel behaviour (the cases of the
+    reference's test/test_audio_buffer.cpp).  Host-only: compiled with g++, no device call."""
+    import subprocess
+    exe = str(tmp_path / "audio_buffer_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "audio_buffer_test.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "whitebox_amd"), "-lwbx",
+                           "-Wl,-rpath," + os.path.join(ROOT, "whitebox_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    assert "audio_buffer ok" in subprocess.check_output([exe]).decode()

@@ -328,15 +328,16 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const DTrackBlock& r = s_tb[u0 + u];
       if (WIN) {
         const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                    // sampler.cpp:50, frame j0
-        const double t0 = trunc(x0);                                                    // :51 (x >= 0)
-        const int ix0 = (int)t0;
+        const int ix0 = (int)x0;                                                        // :51 (x >= 0: truncation)
         const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + ix0;
         if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
           pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);   // the taps of frames j0..j0+3 lie in p[0..4]
           pre[u].w4 = p[4];
         }
         pre[u].ix0 = ix0;
-        pre[u].fx0 = (float)__dsub_rn(x0, t0);                                          // :52
+        // :52 fx = (float)(x - (double)ix): for x >= 0 that difference is x - floor(x), which v_fract_f64
+        // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
+        pre[u].fx0 = (float)__builtin_amdgcn_fract(x0);
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                      // sampler.cpp:107,151
         const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + off;
@@ -368,10 +369,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 #define WBX_TAP(E, JD)                                                                                  \
   {                                                                                                     \
     const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
-    const double tx = trunc(x);                                           /* :51 (x >= 0) */            \
-    const float fx = (float)__dsub_rn(x, tx);                             /* :52 */                     \
+    const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
     float sa, sb;                                                                                       \
-    taps<E>(pre[u].v, pre[u].w4, (int)tx - ix0, sa, sb);                                                \
+    taps<E>(pre[u].v, pre[u].w4, (int)x - ix0, sa, sb);                   /* :51 */                     \
     const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
     q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
   }

@@ -121,7 +121,9 @@ struct wbx_ctx {
   double mix_ms_total = 0.0;
   uint64_t mix_launches = 0;
   bool profiling = true;
-  int mix_unroll = 24;                // WBX_MIX_VARIANT=10*U+W (tuning knob; results are identical)
+  int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
+                                      // 0 = chosen per render: 16 when resampled clips are present, else 43
+  bool has_window_clips = true;
 };
 
 namespace {
@@ -297,7 +299,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
-    launch_mix(m, K, c->mix_unroll, c->stream);
+    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : (c->has_window_clips ? 16 : 43), c->stream);
     if (c->profiling) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
       c->ev_pending++;
@@ -783,6 +785,7 @@ struct wbx_engine {
   bool playing = false;
   bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
   bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (integer PCM, speed > 0.999, != 1)
+  bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
   size_t total_clips = 0;
   uint32_t state_tracks = 0;            // tracks that have device state
 
@@ -983,6 +986,7 @@ extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, d
     const DSample& smp = e->ctx->clips[sample].d;
     const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * speed;   // sampler.h:24
     if (smp.format != FMT_F32 || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
+    if (ps != 1.0) e->any_window_clip = true;
     e->total_clips++;
   }
   std::sort(t.clips.begin(), t.clips.end(), [](const DClip& a, const DClip& b) { return a.min_time < b.min_time; });
@@ -1162,7 +1166,8 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
 
   // -- mix + sum on the main stream, after the plan
   WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
-  c->levels_target = std::getenv("WBX_NO_LEVELS") ? nullptr : reinterpret_cast<uint32_t*>(e->d_levels.p);
+  c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
+  c->has_window_clips = e->any_window_clip;
   st = launch_mix_sum(c, K, N);
   if (st != WBX_OK) return st;
   WBX_EHIP(e, hipEventRecord(B.consumed, s));

@@ -454,12 +454,24 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   rec._pad = 0;
   rec.sample = st->cur_sample;
   rec.extra = 0;
+  // How many consecutive blocks lie strictly inside the clip?  The block windows are computed by repeated
+  // fp64 addition of a positive step (engine.cpp:1582,1621), so start_time and end_time are non-decreasing
+  // in the block index: min_time < start_time only needs checking at the first block, and the last block
+  // with max_time > end_time is found by bisection — no per-block LDS read on the critical path below.
+  if (!(min_time < times[b].start_time)) return 0;
+  uint32_t lo = 0, hi = a.n_blocks - b;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (max_time > times[b + mid].end_time)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const uint32_t n_time = lo;
   double off = st->sample_offset;
   uint32_t n = 0;
-  while (b + n < a.n_blocks) {
-    const DBlockTime& bt = times[b + n];
-    if (!(min_time < bt.start_time && max_time > bt.end_time)) break;
-    if (!(off + guard <= cnt && (cnt - off) < qmax)) break;
+  while (n < n_time) {
+    if (!(off + guard <= cnt && (cnt - off) < qmax)) break;   // near the clip tail: general path (exact division)
     rec.pos = off;
     rec.kind = classify(rec, F);
     if (rec.kind == KIND_GENERIC) break;                   // needs the pre-render queue: general path
