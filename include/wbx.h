@@ -159,10 +159,39 @@ wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, u
 wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
                                        uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
                                        uint32_t* sample_out);
-/* Engine::add_audio_clip (engine.cpp:293-309 -> add_to_cliplist :409-461).  A clip that overlaps an
- * existing one needs reserve_track_region's trimming (engine.cpp:478-569): WBX_ERR_UNSUPPORTED. */
+/* Engine::add_audio_clip (engine.cpp:293-309 -> add_to_cliplist :409-461).  A clip that overlaps existing ones
+ * trims / splits / deletes them through reserve_track_region (engine.cpp:478-569), like the reference. */
 wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
                                      double start_offset, uint32_t sample, double speed, float gain);
+
+/* Clip edits (UI thread in the reference).  `clip` is the index in the track's clip list, which is kept sorted
+ * by min_time (Track::update_clip_ordering, track.cpp:159-180): indices change after every edit. */
+typedef struct wbx_clip_info {
+  double min_time, max_time;   /* beats */
+  double start_offset;         /* samples */
+  double speed;                /* AudioClip::speed */
+  float gain;                  /* AudioClip::gain */
+  uint32_t sample;
+} wbx_clip_info;
+wbx_status wbx_engine_move_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos);   /* engine.cpp:346-363 */
+wbx_status wbx_engine_resize_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos, double resize_limit,
+                                  double min_length, int left_side, int shift, int stretch);          /* engine.cpp:365-398 */
+wbx_status wbx_engine_delete_clip(wbx_engine* e, uint32_t track, uint32_t clip);                       /* engine.cpp:400-407 */
+wbx_status wbx_engine_delete_region(wbx_engine* e, uint32_t track, double min_time, double max_time);  /* engine.cpp:463-475 */
+wbx_status wbx_engine_set_clip_gain(wbx_engine* e, uint32_t track, uint32_t clip, float gain);         /* engine.cpp:1460-1464 */
+wbx_status wbx_engine_clip_count(wbx_engine* e, uint32_t track, uint32_t* count);
+wbx_status wbx_engine_get_clip(wbx_engine* e, uint32_t track, uint32_t clip, wbx_clip_info* out);
+/* The clip placement arithmetic by itself (src/engine/clip_edit.h:10-150; audio clips), fp64, host-only. */
+void wbx_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                        double* new_max);
+void wbx_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed, double sample_rate,
+                          double sample_count, double relative_pos, double resize_limit, double min_length,
+                          double min_resize_pos, double beat_duration, int is_min, int shift, int stretch,
+                          int clamp_at_resize_pos, double* out_min, double* out_max, double* out_start_offset,
+                          double* out_speed);
+double wbx_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate);
+double wbx_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                              double beat_duration);
 wbx_status wbx_engine_play(wbx_engine* e);                                      /* engine.cpp:68-80 */
 wbx_status wbx_engine_stop(wbx_engine* e);                                      /* engine.cpp:82-93 */
 

@@ -136,6 +136,27 @@ def main():
         getattr(R, "ref_f32_to_" + name)(b.ctypes.data, O.planar_ptrs(src), 40, 512, 2)
         conv[name] = b
     np.savez_compressed(os.path.join(OUT, "conv.npz"), **conv)
+
+    # ---- clip placement arithmetic (engine/clip_edit.h) -----------------------------------------------
+    rng = np.random.default_rng(11)
+    rows_in, rows_out = [], []
+    d = [C.c_double() for _ in range(4)]
+    for _ in range(400):
+        mn = float(rng.uniform(0, 64)); ln = float(rng.uniform(0.01, 16))
+        k = [mn, mn + ln, float(rng.uniform(0, 50000)), float(rng.choice([1.0, 0.5, 1.25, 0.91875])),
+             float(rng.choice([44100, 48000, 96000])), float(rng.integers(1000, 2000000)), float(rng.uniform(-8, 8)),
+             float(rng.uniform(0, 1)), float(rng.uniform(0.001, 0.5)), float(rng.uniform(0, 4)),
+             60.0 / float(rng.uniform(60, 200))]
+        flags = [int(rng.integers(0, 2)) for _ in range(4)]
+        R.ref_calc_resize_clip(*k, *flags, *[C.byref(x) for x in d])
+        res = [x.value for x in d]
+        R.ref_calc_move_clip(k[0], k[1], k[6], k[9], C.byref(d[0]), C.byref(d[1]))
+        res += [d[0].value, d[1].value, R.ref_calc_clip_shift(k[2], k[6], k[10], k[4]),
+                R.ref_shift_clip_content(k[2], k[3], k[4], k[6], k[10])]
+        rows_in.append(k + [float(f) for f in flags])
+        rows_out.append(res)
+    np.savez_compressed(os.path.join(OUT, "clip_edit.npz"), inputs=np.array(rows_in, np.float64),
+                        outputs=np.array(rows_out, np.float64).view(np.uint64))
     print("golden vectors written to", OUT)
 
 

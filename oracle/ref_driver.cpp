@@ -8,7 +8,7 @@
 // Linked reference translation units (compile unmodified, no third-party headers needed):
 //   dsp/sampler.cpp  core/panning_law.cpp  core/audio_format_conv.cpp
 // Header-only reference code used here: core/audio_buffer.h, dsp/dsp_ops.h, core/core_math.h,
-//   dsp/sampler.h, dsp/sample.h.
+//   dsp/sampler.h, dsp/sample.h, engine/clip_edit.h (+ engine/clip.h, engine/assets_table.h it includes).
 //
 // NOT buildable here (and therefore not in this library): engine/engine.cpp, engine/track.cpp,
 // engine/vu_meter.h — they include core/debug.h which needs third-party spdlog (absent from the
@@ -25,6 +25,7 @@
 #include "core/panning_law.h"
 #include "dsp/dsp_ops.h"
 #include "dsp/sampler.h"
+#include "engine/clip_edit.h"
 
 namespace {
 
@@ -49,9 +50,74 @@ wb::Sample* make_sample(SampleBox& box, int format, uint32_t channels, uint32_t 
   return s;
 }
 
+// A wb::Clip / wb::SampleAsset pair materialised by field assignment in zeroed storage (their out-of-line
+// members live in assets_table.cpp / sample.cpp, which need third-party libraries): only the fields
+// clip_edit.h reads are set, and neither object is ever destroyed.
+struct ClipBox {
+  alignas(wb::Clip) unsigned char clip[sizeof(wb::Clip)];
+  alignas(wb::SampleAsset) unsigned char asset[sizeof(wb::SampleAsset)];
+  wb::Clip* make(double min_time, double max_time, double start_offset, double speed, double sample_rate,
+                 double sample_count) {
+    std::memset(clip, 0, sizeof(clip));
+    std::memset(asset, 0, sizeof(asset));
+    wb::SampleAsset* a = reinterpret_cast<wb::SampleAsset*>(asset);
+    a->sample_instance.sample_rate = (uint32_t)sample_rate;
+    a->sample_instance.count = (size_t)sample_count;
+    wb::Clip* c = reinterpret_cast<wb::Clip*>(clip);
+    c->type = wb::ClipType::Audio;
+    c->min_time = min_time;
+    c->max_time = max_time;
+    c->start_offset = start_offset;
+    c->audio.asset = a;
+    c->audio.speed = speed;
+    c->audio.gain = 1.0f;
+    return c;
+  }
+};
+
 }  // namespace
 
 extern "C" {
+
+// engine/clip_edit.h:10-16
+void ref_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                        double* new_max) {
+  ClipBox box;
+  wb::Clip* c = box.make(clip_min, clip_max, 0.0, 1.0, 48000.0, 0.0);
+  wb::ClipMoveResult r = wb::calc_move_clip(c, relative_pos, min_move);
+  *new_min = r.min;
+  *new_max = r.max;
+}
+
+// engine/clip_edit.h:18-126
+void ref_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                          double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                          double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
+                          int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
+                          double* out_start_offset, double* out_speed) {
+  ClipBox box;
+  wb::Clip* c = box.make(clip_min, clip_max, clip_start_offset, clip_speed, sample_rate, sample_count);
+  wb::ClipResizeResult r = wb::calc_resize_clip(c, relative_pos, resize_limit, min_length, min_resize_pos, beat_duration,
+                                                is_min != 0, shift != 0, stretch != 0, clamp_at_resize_pos != 0);
+  *out_min = r.min;
+  *out_max = r.max;
+  *out_start_offset = r.start_offset;
+  *out_speed = r.speed;
+}
+
+// engine/clip_edit.h:128-137
+double ref_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
+  return wb::calc_clip_shift(true, start_offset, relative_pos, beat_duration, sample_rate);
+}
+
+// engine/clip_edit.h:139-150
+double ref_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                              double beat_duration) {
+  ClipBox box;
+  wb::Clip* c = box.make(0.0, 1.0, start_offset, speed, sample_rate, 1e9);
+  return wb::shift_clip_content(c, relative_pos, beat_duration);
+}
+
 
 // math::db_to_linear<float>, core/core_math.h:83-89
 float ref_db_to_linear(float db) { return wb::math::db_to_linear<float>(db); }

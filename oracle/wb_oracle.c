@@ -6,6 +6,7 @@
 #include "wb_oracle.h"
 
 #include <limits.h>
+#include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -249,9 +250,22 @@ static void linear_i32c(const wbo_sample* smp, double norm, uint32_t nch, uint32
   }
 }
 
+static void sampler_stream_impl(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
+                                uint32_t buffer_offset, float gain, float* const* dst, uint32_t dst_frames);
+
 /* dsp/sampler.cpp:88-210 */
 void wbo_sampler_stream(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
                         uint32_t buffer_offset, float gain, float* const* dst) {
+  sampler_stream_impl(s, smp, num_channels, num_samples, buffer_offset, gain, dst, UINT32_MAX);
+}
+
+/* dst_frames: size of the destination buffers.  When Track::process hands Sampler::stream an event_length that
+ * wrapped around (uint32 arithmetic at track.cpp:669 with events out of buffer order — possible after edits
+ * while playing), the reference writes past the end of the block buffer: undefined behaviour.  Oracle and
+ * product both DEFINE that case: the write is clipped to the block, the sampler offset still advances by
+ * the full (wrapped) length exactly as sampler.cpp:103,209 compute it. */
+static void sampler_stream_impl(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
+                                uint32_t buffer_offset, float gain, float* const* dst, uint32_t dst_frames) {
   const float i16_norm = 1.0f / (float)INT16_MAX;                 /* :95 */
   const double i24_norm = 1.0 / (double)((1 << 23) - 1);          /* :96 */
   const double i32_norm = 1.0 / (double)INT32_MAX;                /* :97 */
@@ -264,6 +278,8 @@ void wbo_sampler_stream(wbo_sampler* s, const wbo_sample* smp, uint32_t num_chan
   double cl = ceil(stream_max_length);
   uint32_t lim = (uint32_t)cl;                                     /* :104 */
   uint32_t n = num_samples < lim ? num_samples : lim;
+  if (dst_frames != UINT32_MAX && (uint64_t)buffer_offset + n > dst_frames)
+    n = buffer_offset < dst_frames ? dst_frames - buffer_offset : 0;
 
   if (s->playback_speed == 1.0) {                                  /* :106 (Q3) */
     uint32_t off = (uint32_t)s->sample_offset;                     /* :107 */
@@ -458,15 +474,121 @@ static void reset_playback_state(wbo_track* t, double time_pos, int refresh_voic
   t->refresh_voice = refresh_voices;
 }
 
-/* track.cpp:112-157 reduced to its "nothing overlaps" answer */
-static int range_is_free(const wbo_track* t, double min, double max) {
-  if (t->n_clips == 0) return 1;
-  if (max <= t->clips[0].min_time) return 1;
-  if (min >= t->clips[t->n_clips - 1].max_time) return 1;
+/* ---- clip placement arithmetic, engine/clip_edit.h ------------------------------------------------ */
+
+static inline double dmax(double a, double b) { return b < a ? a : b; }   /* math::max, core_math.h:28-31 */
+static inline double dmin(double a, double b) { return a < b ? a : b; }   /* math::min, core_math.h:23-26 */
+
+/* clip_edit.h:10-16 */
+void wbo_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                        double* new_max) {
+  const double new_pos = dmax(clip_min + relative_pos, min_move);
+  *new_min = new_pos;
+  *new_max = new_pos + (clip_max - clip_min);
+}
+
+/* clip_edit.h:18-126 (audio clip with an asset) */
+void wbo_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                          double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                          double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
+                          int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
+                          double* out_start_offset, double* out_speed) {
+  if (!is_min) {                                                   /* :29-75 */
+    const double old_max = clip_max;
+    const double actual_min_length = resize_limit + min_length - clip_min;
+    double new_max = dmax(clip_max + relative_pos, 0.0);
+    double length = new_max - clip_min;
+    if (length < actual_min_length)
+      new_max = clip_min + actual_min_length;
+    double start_offset = clip_start_offset;
+    double new_speed = 1.0;
+    if (shift) {
+      double mult = clip_speed;
+      start_offset = wbo_samples_to_beat(start_offset, sample_rate, beat_duration);
+      if (old_max < new_max)
+        start_offset -= (new_max - old_max) * mult;
+      else
+        start_offset += (old_max - new_max) * mult;
+      start_offset = dmax(start_offset, 0.0);
+      start_offset = dmin(start_offset, sample_count);
+      start_offset = wbo_beat_to_samples(start_offset, sample_rate, beat_duration);
+    }
+    if (stretch) {
+      double old_length = sample_count / clip_speed;
+      double num_samples = wbo_beat_to_samples(relative_pos, sample_rate, beat_duration);
+      new_speed = sample_count / (old_length + num_samples);
+    }
+    *out_min = clip_min;
+    *out_max = new_max;
+    *out_start_offset = start_offset;
+    *out_speed = new_speed;
+    return;
+  }
+  const double old_min = clip_min;                                 /* :77-125 */
+  const double actual_min_length = clip_max - resize_limit + min_length;
+  double new_min = dmax(clip_min + relative_pos, 0.0);
+  double length = clip_max - new_min;
+  if (length < actual_min_length)
+    new_min = clip_max - actual_min_length;
+  if (clamp_at_resize_pos && new_min < min_resize_pos)
+    new_min = min_resize_pos;
+  double start_offset = clip_start_offset;
+  double new_speed = 1.0;
+  if (!shift) {
+    start_offset = wbo_samples_to_beat(start_offset, sample_rate, beat_duration);
+    if (old_min < new_min)
+      start_offset -= old_min - new_min;
+    else
+      start_offset += new_min - old_min;
+    if (start_offset < 0.0)
+      new_min = new_min - start_offset;
+    start_offset = dmax(start_offset, 0.0);
+    start_offset = wbo_beat_to_samples(start_offset, sample_rate, beat_duration);
+  }
+  if (stretch) {
+    double old_length = sample_count / clip_speed;
+    double num_samples = wbo_beat_to_samples(old_min - new_min, sample_rate, beat_duration);
+    new_speed = sample_count / (old_length + num_samples);
+  }
+  *out_min = new_min;
+  *out_max = clip_max;
+  *out_start_offset = start_offset;
+  *out_speed = new_speed;
+}
+
+/* clip_edit.h:128-137, audio branch */
+double wbo_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
+  const double offset_in_beat = wbo_samples_to_beat(start_offset, sample_rate, beat_duration);
+  return wbo_beat_to_samples(dmax(offset_in_beat - relative_pos, 0.0), sample_rate, beat_duration);
+}
+
+/* clip_edit.h:139-150, audio branch */
+double wbo_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                              double beat_duration) {
+  relative_pos *= speed;
+  return wbo_calc_clip_shift(start_offset, relative_pos, beat_duration, sample_rate);
+}
+
+/* ---- clip list edits ---------------------------------------------------------------------------- */
+
+/* Track::query_clip_by_range, track.cpp:112-157 */
+static int query_clip_by_range(const wbo_track* t, double min, double max, uint32_t* first_out, uint32_t* last_out) {
+  if (t->n_clips == 0) return 0;
+  if (max <= t->clips[0].min_time) return 0;
+  if (min >= t->clips[t->n_clips - 1].max_time) return 0;
   uint32_t first = lower_bound_max_time(t->clips, t->n_clips, min);
   uint32_t last = lower_bound_max_time(t->clips, t->n_clips, max);
-  if (first == last && (max <= t->clips[first].min_time || min >= t->clips[last].max_time)) return 1;
-  return 0;
+  uint32_t first_clip = first, last_clip = last;
+  if (first == last && (max <= t->clips[first].min_time || min >= t->clips[last].max_time)) return 0;
+  if (min > t->clips[first].max_time) first_clip++;
+  if (!(max > t->clips[last].min_time)) last_clip--;
+  *first_out = first_clip;
+  *last_out = last_clip;
+  return 1;
+}
+
+int wbo_track_query_clip_by_range(const wbo_engine* e, int track, double min, double max, uint32_t* first, uint32_t* last) {
+  return query_clip_by_range(&e->tracks[track], min, max, first, last);
 }
 
 static int cmp_clip(const void* a, const void* b) {
@@ -474,31 +596,177 @@ static int cmp_clip(const void* a, const void* b) {
   return (x > y) - (x < y);
 }
 
-/* engine.cpp:293-309 add_audio_clip -> :409-461 add_to_cliplist (non-overlapping inserts only) */
-int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double max_time, double start_offset,
-                              int sample, double speed, float gain) {
-  wbo_track* t = &e->tracks[track];
-  int back = t->n_clips && t->clips[t->n_clips - 1].max_time < min_time;
-  int front = t->n_clips && t->clips[0].min_time > max_time;
-  if (t->n_clips && !back && !front && !range_is_free(t, min_time, max_time))
-    return -3; /* reserve_track_region trimming: out of scope */
+/* Track::update_clip_ordering, track.cpp:159-180: drop deleted clips, sort by min_time */
+static void update_clip_ordering(wbo_track* t) {
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < t->n_clips; i++)
+    if (!t->clips[i].deleted) t->clips[n++] = t->clips[i];
+  t->n_clips = n;
+  qsort(t->clips, t->n_clips, sizeof(wbo_clip), cmp_clip);
+}
+
+static wbo_clip* push_clip(wbo_engine* e, wbo_track* t) {
   if (t->n_clips == t->cap_clips) {
     t->cap_clips = t->cap_clips ? t->cap_clips * 2 : 4;
     t->clips = (wbo_clip*)realloc(t->clips, t->cap_clips * sizeof(wbo_clip));
   }
   wbo_clip* c = &t->clips[t->n_clips++];
+  memset(c, 0, sizeof(*c));
+  c->uid = ++e->next_clip_uid;
+  return c;
+}
+
+static double clip_shift(const wbo_engine* e, const wbo_clip* c, double relative_pos) {
+  return wbo_shift_clip_content(c->start_offset, c->speed, (double)e->samples[c->sample].sample_rate, relative_pos,
+                                e->beat_duration);
+}
+
+/* Engine::reserve_track_region, engine.cpp:478-569.  ignore_uid = 0: no clip is ignored. */
+static void reserve_track_region(wbo_engine* e, wbo_track* t, uint32_t first_clip, uint32_t last_clip, double min,
+                                 double max, uint32_t ignore_uid) {
+  if (t->n_clips == 0) return;
+  if (first_clip == last_clip) {                                   /* :493-533 */
+    wbo_clip* clip = &t->clips[first_clip];
+    if (clip->uid == ignore_uid) return;
+    if (min > clip->min_time && max < clip->max_time) {            /* split into two parts */
+      wbo_clip copy = *clip;
+      wbo_clip* nc = push_clip(e, t);                              /* may move t->clips */
+      clip = &t->clips[first_clip];
+      uint32_t uid = nc->uid;
+      *nc = copy;
+      nc->uid = uid;
+      nc->min_time = max;
+      nc->start_offset = clip_shift(e, nc, clip->min_time - max);
+      clip->max_time = min;
+    } else if (min > clip->min_time) {
+      clip->max_time = min;
+    } else if (max < clip->max_time) {
+      clip->start_offset = clip_shift(e, clip, clip->min_time - max);
+      clip->min_time = max;
+    } else {
+      clip->deleted = 1;
+    }
+    return;
+  }
+  wbo_clip* first = &t->clips[first_clip];                         /* :535-568 */
+  wbo_clip* last = &t->clips[last_clip];
+  if (first->uid != ignore_uid && min > first->min_time) {
+    first->max_time = min;
+    first_clip++;
+  }
+  if (last->uid != ignore_uid && max < last->max_time) {
+    last->start_offset = clip_shift(e, last, last->min_time - max);
+    last->min_time = max;
+    last_clip--;
+  }
+  if (first_clip <= last_clip && last_clip < t->n_clips)
+    for (uint32_t i = first_clip; i <= last_clip; i++)
+      if (t->clips[i].uid != ignore_uid) t->clips[i].deleted = 1;
+}
+
+/* engine.cpp:293-309 add_audio_clip -> :409-461 add_to_cliplist */
+int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double max_time, double start_offset,
+                              int sample, double speed, float gain) {
+  wbo_track* t = &e->tracks[track];
+  const int empty = t->n_clips == 0;
+  const int back = !empty && t->clips[t->n_clips - 1].max_time < min_time;
+  const int front = !empty && !back && t->clips[0].min_time > max_time;
+  uint32_t qf = 0, ql = 0;
+  const int hit = (!empty && !back && !front) ? query_clip_by_range(t, min_time, max_time, &qf, &ql) : 0;
+  if (hit) reserve_track_region(e, t, qf, ql, min_time, max_time, 0);
+  wbo_clip* c = push_clip(e, t);
   c->min_time = min_time;
   c->max_time = max_time;
   c->start_offset = start_offset;
   c->speed = speed;
   c->gain = gain;
   c->sample = sample;
-  c->internal_state_changed = 0;
-  /* track.cpp:159-180 update_clip_ordering: sort by min_time (distinct for non-overlapping clips) */
-  qsort(t->clips, t->n_clips, sizeof(wbo_clip), cmp_clip);
-  reset_playback_state(t, e->playhead, 1); /* engine.cpp:416,426,437,449,459 */
+  update_clip_ordering(t);
+  reset_playback_state(t, e->playhead, 1);                         /* engine.cpp:416,426,437,449,459 */
   return 0;
 }
+
+/* engine.cpp:346-363 */
+int wbo_engine_move_clip(wbo_engine* e, int track, uint32_t clip, double relative_pos) {
+  wbo_track* t = &e->tracks[track];
+  if (clip >= t->n_clips) return -4;
+  if (relative_pos == 0.0) return 0;
+  const uint32_t uid = t->clips[clip].uid;
+  double mn, mx;
+  wbo_calc_move_clip(t->clips[clip].min_time, t->clips[clip].max_time, relative_pos, 0.0, &mn, &mx);
+  uint32_t qf, ql;
+  if (query_clip_by_range(t, mn, mx, &qf, &ql)) reserve_track_region(e, t, qf, ql, mn, mx, uid);
+  for (uint32_t i = 0; i < t->n_clips; i++)
+    if (t->clips[i].uid == uid) {
+      t->clips[i].min_time = mn;
+      t->clips[i].max_time = mx;
+      t->clips[i].internal_state_changed = 1;
+    }
+  update_clip_ordering(t);
+  reset_playback_state(t, e->playhead, 1);
+  return 0;
+}
+
+/* engine.cpp:365-398 */
+int wbo_engine_resize_clip(wbo_engine* e, int track, uint32_t clip, double relative_pos, double resize_limit,
+                           double min_length, int left_side, int shift, int stretch) {
+  wbo_track* t = &e->tracks[track];
+  if (clip >= t->n_clips) return -4;
+  if (relative_pos == 0.0) return 0;
+  const wbo_clip c0 = t->clips[clip];
+  const wbo_sample* smp = &e->samples[c0.sample];
+  double mn, mx, so, sp;
+  wbo_calc_resize_clip(c0.min_time, c0.max_time, c0.start_offset, c0.speed, (double)smp->sample_rate, (double)smp->count,
+                       relative_pos, resize_limit, min_length, c0.min_time, e->beat_duration, left_side, shift, stretch,
+                       0, &mn, &mx, &so, &sp);
+  uint32_t qf, ql;
+  if (query_clip_by_range(t, mn, mx, &qf, &ql)) reserve_track_region(e, t, qf, ql, mn, mx, c0.uid);
+  for (uint32_t i = 0; i < t->n_clips; i++)
+    if (t->clips[i].uid == c0.uid) {
+      if (left_side)
+        t->clips[i].min_time = mn;
+      else
+        t->clips[i].max_time = mx;
+      t->clips[i].start_offset = so;
+      if (stretch) t->clips[i].speed = sp;
+      t->clips[i].internal_state_changed = (shift || stretch) ? 1 : 0;
+    }
+  update_clip_ordering(t);
+  reset_playback_state(t, e->playhead, 1);
+  return 0;
+}
+
+/* engine.cpp:400-407 */
+int wbo_engine_delete_clip(wbo_engine* e, int track, uint32_t clip) {
+  wbo_track* t = &e->tracks[track];
+  if (clip >= t->n_clips) return -4;
+  t->clips[clip].deleted = 1;
+  update_clip_ordering(t);
+  reset_playback_state(t, e->playhead, 1);
+  return 0;
+}
+
+/* engine.cpp:1460-1464 */
+int wbo_engine_set_clip_gain(wbo_engine* e, int track, uint32_t clip, float gain) {
+  wbo_track* t = &e->tracks[track];
+  if (clip >= t->n_clips) return -4;
+  t->clips[clip].gain = gain;
+  return 0;
+}
+
+/* engine.cpp:463-475 */
+int wbo_engine_delete_region(wbo_engine* e, int track, double min, double max) {
+  wbo_track* t = &e->tracks[track];
+  uint32_t qf, ql;
+  if (!query_clip_by_range(t, min, max, &qf, &ql)) return 0;
+  reserve_track_region(e, t, qf, ql, min, max, 0);
+  update_clip_ordering(t);
+  reset_playback_state(t, e->playhead, 1);
+  return 0;
+}
+
+uint32_t wbo_track_clip_count(const wbo_engine* e, int track) { return e->tracks[track].n_clips; }
+const wbo_clip* wbo_track_clip(const wbo_engine* e, int track, uint32_t i) { return &e->tracks[track].clips[i]; }
 
 /* engine.cpp:68-80 */
 void wbo_engine_play(wbo_engine* e) {
@@ -643,6 +911,17 @@ static void log_stream(wbo_engine* e, const wbo_track* t, uint32_t dst_start, ui
   s->sample = t->cur_sample;
 }
 
+/* current_audio_event.clip->audio.gain is read at every stream call (track.cpp:676,716): follow the clip by
+ * identity so that set_clip_gain takes effect on the clip that is already playing */
+static void refresh_current_gain(wbo_track* t) {
+  if (t->current_event.type != WBO_EV_PLAY) return;
+  for (uint32_t i = 0; i < t->n_clips; i++)
+    if (t->clips[i].uid == t->cur_clip_uid) {
+      t->cur_gain = t->clips[i].gain;
+      return;
+    }
+}
+
 /* track.cpp:587-736 (no plugin: write_buffer == output_buffer; Q6 fenced off) */
 static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double sample_rate, double beat_duration,
                           double buffer_duration_in_beats, double sample_position, double start_time, double end_time,
@@ -668,6 +947,7 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
   t->n_msgs = 0; /* :735 */
 
   if (playing) {                                                   /* :664-724 */
+    refresh_current_gain(t);
     uint32_t next = 0, end = t->n_events;
     uint32_t start_sample = 0;
     while (start_sample < n_samples) {
@@ -676,8 +956,8 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
         uint32_t event_length = ne->buffer_offset - start_sample;  /* uint32 arithmetic, as in the reference */
         if (t->current_event.type == WBO_EV_PLAY) {
           log_stream(e, t, start_sample, event_length);
-          wbo_sampler_stream(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
-                             t->cur_gain, out);
+          sampler_stream_impl(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
+                              t->cur_gain, out, n_samples);
         }
         if (ne->type == WBO_EV_PLAY) {                             /* :687-697 */
           const wbo_clip* clip = &t->clips[ne->clip];
@@ -685,6 +965,7 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
           wbo_sampler_reset(&t->sampler, (double)ne->sample_offset, ne->speed, (double)smp->sample_rate, sample_rate);
           t->cur_gain = clip->gain;
           t->cur_sample = clip->sample;
+          t->cur_clip_uid = clip->uid;
         }
         t->current_event = *ne;
         start_sample += event_length;
@@ -693,8 +974,8 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
         uint32_t event_length = n_samples - start_sample;
         if (t->current_event.type == WBO_EV_PLAY) {
           log_stream(e, t, start_sample, event_length);
-          wbo_sampler_stream(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
-                             t->cur_gain, out);
+          sampler_stream_impl(&t->sampler, &e->samples[t->cur_sample], n_channels, event_length, start_sample,
+                              t->cur_gain, out, n_samples);
         }
         start_sample = n_samples;
       }

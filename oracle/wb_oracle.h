@@ -88,6 +88,8 @@ typedef struct wbo_clip {     /* src/engine/clip.h:39-45,55-75 (audio fields onl
   float gain;                 /* AudioClip::gain */
   int sample;                 /* index into engine sample table */
   int internal_state_changed;
+  int deleted;                /* Clip::deleted (clip.h:63), swept by update_clip_ordering */
+  uint32_t uid;               /* stable identity: the reference holds Clip* pointers across re-sorts */
 } wbo_clip;
 
 typedef struct wbo_event {    /* src/engine/event.h:66-74 */
@@ -109,6 +111,7 @@ typedef struct wbo_track {
   wbo_event events[WBO_MAX_EVENTS]; uint32_t n_events;
   wbo_event current_event;                            /* track.h:112 */
   float cur_gain; int cur_sample;                     /* resolved from current_event.clip at event time */
+  uint32_t cur_clip_uid;                              /* current_audio_event.clip (gain is read through it, track.cpp:676,716) */
   wbo_sampler sampler;
   /* TrackParameterState (audio side), track.h:46-53 */
   float volume, pan, pan_coeffs[2]; int mute;
@@ -139,6 +142,7 @@ typedef struct wbo_engine {
   float* busbuf;                                      /* [n_buses][C][F] scratch (extension) */
   wbo_seglog* seglog; uint32_t n_seglog, cap_seglog;  /* stream calls of the LAST processed block (if enabled) */
   int seglog_enabled;
+  uint32_t next_clip_uid;
 } wbo_engine;
 
 wbo_engine* wbo_engine_create(uint32_t out_channels, uint32_t buffer_size, uint32_t sample_rate);
@@ -153,9 +157,35 @@ void wbo_track_set_volume(wbo_engine* e, int track, float db);    /* track.cpp:4
 void wbo_track_set_pan(wbo_engine* e, int track, float pan);      /* track.cpp:59-68 */
 void wbo_track_set_mute(wbo_engine* e, int track, int mute);      /* track.cpp:70-79 */
 void wbo_track_set_bus(wbo_engine* e, int track, int bus);        /* extension A13 */
-/* returns 0 ok, -3 if the clip overlaps an existing one (reserve_track_region trimming is out of scope) */
+/* returns 0 ok; overlapping clips are trimmed / split / deleted by reserve_track_region (engine.cpp:478-569) */
 int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double max_time, double start_offset,
                               int sample, double speed, float gain); /* engine.cpp:293-309,409-461 */
+/* ---- clip placement arithmetic and list edits -------------------------------- */
+/* engine/clip_edit.h:10-16 */
+void wbo_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min, double* new_max);
+/* engine/clip_edit.h:18-126.  sample_rate / sample_count describe the clip's asset. */
+void wbo_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                          double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                          double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
+                          int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
+                          double* out_start_offset, double* out_speed);
+/* engine/clip_edit.h:128-137 (audio) */
+double wbo_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate);
+/* engine/clip_edit.h:139-150 (audio) */
+double wbo_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos, double beat_duration);
+/* Track::query_clip_by_range, track.cpp:112-157: returns 1 and fills first/last when the range touches clips */
+int wbo_track_query_clip_by_range(const wbo_engine* e, int track, double min, double max, uint32_t* first, uint32_t* last);
+/* Engine::move_clip engine.cpp:346-363, resize_clip :365-398, delete_clip :400-407, set_clip_gain :1460-1464,
+ * delete_region :463-475.  `clip` = index in the track's current (sorted) clip list. */
+int wbo_engine_move_clip(wbo_engine* e, int track, uint32_t clip, double relative_pos);
+int wbo_engine_resize_clip(wbo_engine* e, int track, uint32_t clip, double relative_pos, double resize_limit,
+                           double min_length, int left_side, int shift, int stretch);
+int wbo_engine_delete_clip(wbo_engine* e, int track, uint32_t clip);
+int wbo_engine_set_clip_gain(wbo_engine* e, int track, uint32_t clip, float gain);
+int wbo_engine_delete_region(wbo_engine* e, int track, double min, double max);
+uint32_t wbo_track_clip_count(const wbo_engine* e, int track);
+const wbo_clip* wbo_track_clip(const wbo_engine* e, int track, uint32_t i);
+
 void wbo_engine_play(wbo_engine* e);                               /* engine.cpp:68-80 */
 void wbo_engine_stop(wbo_engine* e);                               /* engine.cpp:82-93 */
 void wbo_engine_enable_seglog(wbo_engine* e, int on);

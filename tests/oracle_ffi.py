@@ -55,11 +55,17 @@ class _Track(C.Structure):
                 ("has_clip_idx", C.c_int), ("clip_idx", C.c_uint32), ("refresh_voice", C.c_int),
                 ("partially_ended", C.c_int),
                 ("events", _Event * 64), ("n_events", C.c_uint32),
-                ("current_event", _Event), ("cur_gain", C.c_float), ("cur_sample", C.c_int),
+                ("current_event", _Event), ("cur_gain", C.c_float), ("cur_sample", C.c_int), ("cur_clip_uid", C.c_uint32),
                 ("sampler", _Sampler),
                 ("volume", C.c_float), ("pan", C.c_float), ("pan_coeffs", C.c_float * 2), ("mute", C.c_int),
                 ("msgs", _Msg * 64), ("n_msgs", C.c_uint32),
                 ("level", C.c_float * 2), ("block_peak", C.c_float * 2), ("bus", C.c_int)]
+
+
+class Clip(C.Structure):
+    _fields_ = [("min_time", C.c_double), ("max_time", C.c_double), ("start_offset", C.c_double), ("speed", C.c_double),
+                ("gain", C.c_float), ("sample", C.c_int), ("internal_state_changed", C.c_int), ("deleted", C.c_int),
+                ("uid", C.c_uint32)]
 
 
 class SegLog(C.Structure):
@@ -75,7 +81,7 @@ class _Engine(C.Structure):
                 ("sample_position", C.c_double), ("beat_duration", C.c_double), ("playing", C.c_int),
                 ("n_buses", C.c_uint32), ("mixbuf", c_f32p * 16), ("busbuf", c_f32p),
                 ("seglog", C.POINTER(SegLog)), ("n_seglog", C.c_uint32), ("cap_seglog", C.c_uint32),
-                ("seglog_enabled", C.c_int)]
+                ("seglog_enabled", C.c_int), ("next_clip_uid", C.c_uint32)]
 
 
 _lib = None
@@ -115,6 +121,23 @@ def lib() -> C.CDLL:
         L.wbo_engine_add_audio_clip.restype = C.c_int
         L.wbo_engine_add_audio_clip.argtypes = [C.POINTER(_Engine), C.c_int, C.c_double, C.c_double, C.c_double,
                                                 C.c_int, C.c_double, C.c_float]
+        dp = C.POINTER(C.c_double)
+        L.wbo_calc_move_clip.argtypes = [C.c_double] * 4 + [dp, dp]
+        L.wbo_calc_resize_clip.argtypes = [C.c_double] * 11 + [C.c_int] * 4 + [dp] * 4
+        L.wbo_calc_clip_shift.restype = C.c_double
+        L.wbo_calc_clip_shift.argtypes = [C.c_double] * 4
+        L.wbo_shift_clip_content.restype = C.c_double
+        L.wbo_shift_clip_content.argtypes = [C.c_double] * 5
+        L.wbo_engine_move_clip.argtypes = [C.POINTER(_Engine), C.c_int, C.c_uint32, C.c_double]
+        L.wbo_engine_resize_clip.argtypes = [C.POINTER(_Engine), C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double,
+                                             C.c_int, C.c_int, C.c_int]
+        L.wbo_engine_delete_clip.argtypes = [C.POINTER(_Engine), C.c_int, C.c_uint32]
+        L.wbo_engine_set_clip_gain.argtypes = [C.POINTER(_Engine), C.c_int, C.c_uint32, C.c_float]
+        L.wbo_engine_delete_region.argtypes = [C.POINTER(_Engine), C.c_int, C.c_double, C.c_double]
+        L.wbo_track_clip_count.restype = C.c_uint32
+        L.wbo_track_clip_count.argtypes = [C.POINTER(_Engine), C.c_int]
+        L.wbo_track_clip.restype = C.POINTER(Clip)
+        L.wbo_track_clip.argtypes = [C.POINTER(_Engine), C.c_int, C.c_uint32]
         L.wbo_engine_play.argtypes = [C.POINTER(_Engine)]
         L.wbo_engine_stop.argtypes = [C.POINTER(_Engine)]
         L.wbo_engine_process.argtypes = [C.POINTER(_Engine), c_f32pp, c_f32p]
@@ -158,6 +181,13 @@ def ref() -> Optional[C.CDLL]:
                                     C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_size_t), C.POINTER(c_voidpp), c_f32p, C.POINTER(C.c_int), C.c_uint32,
                                     c_f32pp, c_f32p, c_f32p, C.POINTER(C.c_double), C.c_int]
+        dp = C.POINTER(C.c_double)
+        R.ref_calc_move_clip.argtypes = [C.c_double] * 4 + [dp, dp]
+        R.ref_calc_resize_clip.argtypes = [C.c_double] * 11 + [C.c_int] * 4 + [dp] * 4
+        R.ref_calc_clip_shift.restype = C.c_double
+        R.ref_calc_clip_shift.argtypes = [C.c_double] * 4
+        R.ref_shift_clip_content.restype = C.c_double
+        R.ref_shift_clip_content.argtypes = [C.c_double] * 5
         for name in ("ref_f32_to_i16", "ref_f32_to_i24", "ref_f32_to_i24_x8", "ref_f32_to_i32", "ref_f32_to_f32"):
             getattr(R, name).argtypes = [C.c_void_p, c_f32pp, C.c_size_t, C.c_size_t, C.c_uint32]
         _ref = R
@@ -244,6 +274,25 @@ class OracleEngine:
 
     def add_audio_clip(self, t, mn, mx, start_offset, sample, speed=1.0, gain=1.0) -> int:
         return self.L.wbo_engine_add_audio_clip(self.e, t, mn, mx, start_offset, sample, speed, np.float32(gain))
+
+    def move_clip(self, t, clip, rel): return self.L.wbo_engine_move_clip(self.e, t, clip, rel)
+
+    def resize_clip(self, t, clip, rel, resize_limit, min_length, left_side, shift=False, stretch=False):
+        return self.L.wbo_engine_resize_clip(self.e, t, clip, rel, resize_limit, min_length, int(left_side), int(shift),
+                                             int(stretch))
+
+    def delete_clip(self, t, clip): return self.L.wbo_engine_delete_clip(self.e, t, clip)
+    def set_clip_gain(self, t, clip, gain): return self.L.wbo_engine_set_clip_gain(self.e, t, clip, np.float32(gain))
+    def delete_region(self, t, mn, mx): return self.L.wbo_engine_delete_region(self.e, t, mn, mx)
+
+    def clips(self, t):
+        """(min_time, max_time, start_offset, speed, gain, sample) of the track's sorted clip list"""
+        n = self.L.wbo_track_clip_count(self.e, t)
+        out = []
+        for i in range(n):
+            c = self.L.wbo_track_clip(self.e, t, i).contents
+            out.append((c.min_time, c.max_time, c.start_offset, c.speed, c.gain, c.sample))
+        return out
 
     def play(self): self.L.wbo_engine_play(self.e)
     def stop(self): self.L.wbo_engine_stop(self.e)

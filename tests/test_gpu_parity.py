@@ -379,3 +379,81 @@ def test_cpp_host_through_the_adapter(tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert "adapter ok" in out
+
+
+# ---------------------------------------------------------------------------------------------------
+# clip edits: add with overlap / move / resize / delete / gain, while playing
+# ---------------------------------------------------------------------------------------------------
+def _clip_rows(clips):
+    return [(O.f64_bits(a), O.f64_bits(b), O.f64_bits(c), O.f64_bits(d), O.f32_bits(g), s) for (a, b, c, d, g, s) in clips]
+
+
+def test_clip_edits_match_oracle_lists_and_audio():
+    """Random edit scripts applied to both engines through their reference-shaped APIs, between rendered
+    blocks: the sorted clip lists (fp64 bit patterns), the sequencer's plan and the audio must stay equal."""
+    rng = np.random.default_rng(2024)
+    n_tracks, beat = 6, 24000.0
+    spec = synth.make_session("edits", n_tracks, n_blocks=40, seed=0xED17, amp=0.05)
+    spec.clips = []
+    for s in spec.samples:
+        s.frames = 40000
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=2)
+    e.enable_seglog()
+    out = W.AudioBuffer(spec.block, spec.channels)
+
+    def both(fn_o, fn_p):
+        ro = fn_o()
+        fn_p()
+        return ro
+
+    # overlapping adds: the new clip trims / splits / deletes what it covers (reserve_track_region)
+    for t in range(n_tracks):
+        for _ in range(6):
+            mn = float(rng.uniform(0, 8000)) / beat
+            mx = mn + float(rng.uniform(300, 5000)) / beat
+            so = float(rng.integers(0, 500))
+            sp = float(rng.choice([1.0, 1.0, 0.5, 1.5]))
+            g = float(np.float32(rng.choice([1.0, 0.5, 0.25])))
+            smp = int(rng.integers(0, n_tracks))
+            both(lambda: e.add_audio_clip(t, mn, mx, so, smp, sp, g),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, so, smp, sp, g))
+        assert _clip_rows(eng.clips(eng.tracks[t])) == _clip_rows(e.clips(t)), t
+    e.play()
+    eng.play()
+    for step in range(24):
+        # one edit per step on a random track, then one block
+        t = int(rng.integers(0, n_tracks))
+        n = len(e.clips(t))
+        op = int(rng.integers(0, 6))
+        if n and op == 0:
+            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 1500)) / beat
+            both(lambda: e.move_clip(t, i, rel), lambda: eng.move_clip(eng.tracks[t], i, rel))
+        elif n and op == 1:
+            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 800)) / beat
+            left, shift, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            both(lambda: e.resize_clip(t, i, rel, 0.0, 1.0 / 96.0, left, shift, stretch),
+                 lambda: eng.resize_clip(eng.tracks[t], i, rel, 0.0, 1.0 / 96.0, left, shift, stretch))
+        elif n and op == 2:
+            i = int(rng.integers(0, n))
+            both(lambda: e.delete_clip(t, i), lambda: eng.delete_clip(eng.tracks[t], i))
+        elif n and op == 3:
+            i, g = int(rng.integers(0, n)), float(np.float32(rng.uniform(0.1, 1.5)))
+            both(lambda: e.set_clip_gain(t, i, g), lambda: eng.set_clip_gain(eng.tracks[t], i, g))
+        elif op == 4:
+            mn = float(rng.uniform(0, 12000)) / beat
+            mx = mn + float(rng.uniform(100, 3000)) / beat
+            both(lambda: e.delete_region(t, mn, mx), lambda: eng.delete_region(eng.tracks[t], mn, mx))
+        else:
+            mn = float(rng.uniform(0, 14000)) / beat
+            mx = mn + float(rng.uniform(200, 4000)) / beat
+            both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, 1.0),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, 1.0))
+        for tt in range(n_tracks):
+            assert _clip_rows(eng.clips(eng.tracks[tt])) == _clip_rows(e.clips(tt)), (step, op, tt)
+        om, _ = e.process()
+        eng.process(None, out, 48000.0)
+        assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), (step, op)
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), (step, op)
+    e.close()
+    eng.close()

@@ -1,0 +1,49 @@
+"""Host-side logic of the product (libwbx.so entry points that need no device): the clip placement
+arithmetic of src/engine/clip_edit.h, against the committed golden vectors (outputs of the reference's
+own header) and against the oracle on random inputs — fp64 bit patterns."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import golden_util as G
+import oracle_ffi as O
+import whitebox_amd as W
+
+
+def _product(vals, flags):
+    L = W.lib()
+    d = [C.c_double() for _ in range(4)]
+    L.wbx_calc_resize_clip(*vals, *flags, *[C.byref(x) for x in d])
+    got = [O.f64_bits(x.value) for x in d]
+    L.wbx_calc_move_clip(vals[0], vals[1], vals[6], vals[9], C.byref(d[0]), C.byref(d[1]))
+    got += [O.f64_bits(d[0].value), O.f64_bits(d[1].value),
+            O.f64_bits(L.wbx_calc_clip_shift(vals[2], vals[6], vals[10], vals[4])),
+            O.f64_bits(L.wbx_shift_clip_content(vals[2], vals[3], vals[4], vals[6], vals[10]))]
+    return got
+
+
+def test_clip_edit_arithmetic_matches_reference_golden():
+    g = np.load(os.path.join(G.GOLDEN, "clip_edit.npz"))
+    for k, want in zip(g["inputs"], g["outputs"]):
+        assert _product([float(x) for x in k[:11]], [int(x) for x in k[11:]]) == [int(x) for x in want]
+
+
+def test_clip_edit_arithmetic_matches_oracle_random(oracle):
+    Lo = oracle.lib()
+    rng = np.random.default_rng(77)
+    d = [C.c_double() for _ in range(4)]
+    for _ in range(2000):
+        mn = float(rng.uniform(0, 200))
+        vals = [mn, mn + float(rng.uniform(1e-3, 40)), float(rng.uniform(0, 1e6)), float(rng.uniform(0.1, 3.0)),
+                float(rng.choice([22050, 44100, 48000, 96000, 192000])), float(rng.integers(1, 10_000_000)),
+                float(rng.normal(0, 6)), float(rng.uniform(0, 2)), float(rng.uniform(1e-4, 1)), float(rng.uniform(0, 8)),
+                60.0 / float(rng.uniform(30, 300))]
+        flags = [int(rng.integers(0, 2)) for _ in range(4)]
+        Lo.wbo_calc_resize_clip(*vals, *flags, *[C.byref(x) for x in d])
+        want = [O.f64_bits(x.value) for x in d]
+        Lo.wbo_calc_move_clip(vals[0], vals[1], vals[6], vals[9], C.byref(d[0]), C.byref(d[1]))
+        want += [O.f64_bits(d[0].value), O.f64_bits(d[1].value),
+                 O.f64_bits(Lo.wbo_calc_clip_shift(vals[2], vals[6], vals[10], vals[4])),
+                 O.f64_bits(Lo.wbo_shift_clip_content(vals[2], vals[3], vals[4], vals[6], vals[10]))]
+        assert _product(vals, flags) == want

@@ -133,3 +133,38 @@ def test_format_conversion_bit_exact(oracle, reflib, conv, dt, width):
     getattr(L, "wbo_f32_to_interleaved_" + conv)(a.ctypes.data, O.planar_ptrs(src), off, n, 2)
     getattr(reflib, "ref_f32_to_" + conv)(b.ctypes.data, O.planar_ptrs(src), off, n, 2)
     assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def _clip_edit_cases(n=3000, seed=11):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        mn = float(rng.uniform(0, 64))
+        ln = float(rng.uniform(0.01, 16))
+        yield dict(mn=mn, mx=mn + ln, so=float(rng.uniform(0, 50000)), sp=float(rng.choice([1.0, 0.5, 1.25, 0.91875])),
+                   sr=float(rng.choice([44100, 48000, 96000])), cnt=float(rng.integers(1000, 2000000)),
+                   rel=float(rng.uniform(-8, 8)), lim=float(rng.uniform(0, 1)), minlen=float(rng.uniform(0.001, 0.5)),
+                   mrp=float(rng.uniform(0, 4)), bd=60.0 / float(rng.uniform(60, 200)),
+                   is_min=int(rng.integers(0, 2)), shift=int(rng.integers(0, 2)), stretch=int(rng.integers(0, 2)),
+                   clampp=int(rng.integers(0, 2)))
+
+
+def test_clip_edit_arithmetic_bit_exact(oracle, reflib):
+    """calc_move_clip / calc_resize_clip / calc_clip_shift / shift_clip_content against the reference's
+    header-only engine/clip_edit.h, bit patterns of every fp64 result."""
+    L = oracle.lib()
+    d = [C.c_double() for _ in range(8)]
+    for k in _clip_edit_cases():
+        L.wbo_calc_move_clip(k["mn"], k["mx"], k["rel"], k["mrp"], C.byref(d[0]), C.byref(d[1]))
+        reflib.ref_calc_move_clip(k["mn"], k["mx"], k["rel"], k["mrp"], C.byref(d[2]), C.byref(d[3]))
+        assert (O.f64_bits(d[0].value), O.f64_bits(d[1].value)) == (O.f64_bits(d[2].value), O.f64_bits(d[3].value))
+        args = (k["mn"], k["mx"], k["so"], k["sp"], k["sr"], k["cnt"], k["rel"], k["lim"], k["minlen"], k["mrp"], k["bd"],
+                k["is_min"], k["shift"], k["stretch"], k["clampp"])
+        L.wbo_calc_resize_clip(*args, *[C.byref(x) for x in d[:4]])
+        reflib.ref_calc_resize_clip(*args, *[C.byref(x) for x in d[4:]])
+        assert [O.f64_bits(x.value) for x in d[:4]] == [O.f64_bits(x.value) for x in d[4:]], k
+        a = L.wbo_calc_clip_shift(k["so"], k["rel"], k["bd"], k["sr"])
+        b = reflib.ref_calc_clip_shift(k["so"], k["rel"], k["bd"], k["sr"])
+        assert O.f64_bits(a) == O.f64_bits(b)
+        a = L.wbo_shift_clip_content(k["so"], k["sp"], k["sr"], k["rel"], k["bd"])
+        b = reflib.ref_shift_clip_content(k["so"], k["sp"], k["sr"], k["rel"], k["bd"])
+        assert O.f64_bits(a) == O.f64_bits(b)

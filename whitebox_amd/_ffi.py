@@ -25,6 +25,11 @@ class Segment(C.Structure):
                 ("buffer_offset", C.c_uint32), ("num_samples", C.c_uint32), ("gain", C.c_float)]
 
 
+class ClipInfo(C.Structure):
+    _fields_ = [("min_time", C.c_double), ("max_time", C.c_double), ("start_offset", C.c_double), ("speed", C.c_double),
+                ("gain", C.c_float), ("sample", C.c_uint32)]
+
+
 class PlanRecord(C.Structure):
     _fields_ = [("block", C.c_uint32), ("track", C.c_uint32), ("buffer_offset", C.c_uint32),
                 ("num_samples", C.c_uint32), ("num_actual", C.c_uint32), ("sample", C.c_uint32),
@@ -75,6 +80,17 @@ SYMBOLS = {
     "wbx_engine_add_sample_synth": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, C.c_uint64, _u32, _f,
                                               C.POINTER(_u32)]),
     "wbx_engine_add_audio_clip": (C.c_int, [_vp, _u32, _d, _d, _d, _u32, _d, _f]),
+    "wbx_engine_move_clip": (C.c_int, [_vp, _u32, _u32, _d]),
+    "wbx_engine_resize_clip": (C.c_int, [_vp, _u32, _u32, _d, _d, _d, C.c_int, C.c_int, C.c_int]),
+    "wbx_engine_delete_clip": (C.c_int, [_vp, _u32, _u32]),
+    "wbx_engine_delete_region": (C.c_int, [_vp, _u32, _d, _d]),
+    "wbx_engine_set_clip_gain": (C.c_int, [_vp, _u32, _u32, _f]),
+    "wbx_engine_clip_count": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    "wbx_engine_get_clip": (C.c_int, [_vp, _u32, _u32, C.POINTER(ClipInfo)]),
+    "wbx_calc_move_clip": (None, [_d] * 4 + [C.POINTER(_d)] * 2),
+    "wbx_calc_resize_clip": (None, [_d] * 11 + [C.c_int] * 4 + [C.POINTER(_d)] * 4),
+    "wbx_calc_clip_shift": (_d, [_d] * 4),
+    "wbx_shift_clip_content": (_d, [_d] * 5),
     "wbx_engine_play": (C.c_int, [_vp]),
     "wbx_engine_stop": (C.c_int, [_vp]),
     "wbx_engine_process": (C.c_int, [_vp, _fpp]),

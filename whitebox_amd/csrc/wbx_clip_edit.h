@@ -1,0 +1,203 @@
+// wbx_clip_edit.h — host-side clip placement arithmetic and clip-list edits of the engine adapter.
+//
+// Follows the reference's
+//   calc_move_clip / calc_resize_clip / calc_clip_shift / shift_clip_content     src/engine/clip_edit.h:10-150
+//   Track::query_clip_by_range                                                     src/engine/track.cpp:112-157
+//   Track::update_clip_ordering                                                    src/engine/track.cpp:159-180
+//   Engine::reserve_track_region                                                   src/engine/engine.cpp:478-569
+// in fp64, operation for operation (this is the arithmetic that produces the
+// min_time / max_time / start_offset / speed values the sequencer consumes).  UI-rate code: plain C++.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "wbx_dev.h"
+
+namespace wbx {
+
+struct HostClip {
+  DClip d;
+  bool deleted = false;      // Clip::deleted, swept by update_clip_ordering
+  bool flag_dirty = false;   // internal_state_changed was set by an edit since the last upload
+};
+
+struct ClipQuery {
+  uint32_t first, last;
+};
+
+namespace edit {
+
+inline double samples_to_beat(double samples, double sample_rate, double beat_duration) {   // core_math.h:204-207
+  double sec = samples / sample_rate;
+  return sec / beat_duration;
+}
+inline double beat_to_samples_h(double beat, double sample_rate, double beat_duration) {     // core_math.h:209-212
+  double sec = beat * beat_duration;
+  return sec * sample_rate;
+}
+inline double maxd(double a, double b) { return b < a ? a : b; }   // math::max
+inline double mind(double a, double b) { return a < b ? a : b; }   // math::min
+
+// clip_edit.h:10-16
+inline void calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                           double* new_max) {
+  const double new_pos = maxd(clip_min + relative_pos, min_move);
+  *new_min = new_pos;
+  *new_max = new_pos + (clip_max - clip_min);
+}
+
+struct ResizeResult {
+  double min, max, start_offset, speed;
+};
+
+// clip_edit.h:18-126 for an audio clip whose asset has `sample_rate` / `sample_count`
+inline ResizeResult calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                                     double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                                     double min_length, double min_resize_pos, double beat_duration, bool is_min,
+                                     bool shift, bool stretch, bool clamp_at_resize_pos) {
+  ResizeResult r{};
+  r.speed = 1.0;
+  if (!is_min) {   // right edge, :29-75
+    const double old_max = clip_max;
+    const double actual_min_length = resize_limit + min_length - clip_min;
+    double new_max = maxd(clip_max + relative_pos, 0.0);
+    if (new_max - clip_min < actual_min_length) new_max = clip_min + actual_min_length;
+    double so = clip_start_offset;
+    if (shift) {
+      so = samples_to_beat(so, sample_rate, beat_duration);
+      if (old_max < new_max)
+        so -= (new_max - old_max) * clip_speed;
+      else
+        so += (old_max - new_max) * clip_speed;
+      so = maxd(so, 0.0);
+      so = mind(so, sample_count);
+      so = beat_to_samples_h(so, sample_rate, beat_duration);
+    }
+    if (stretch) {
+      const double old_length = sample_count / clip_speed;
+      const double num_samples = beat_to_samples_h(relative_pos, sample_rate, beat_duration);
+      r.speed = sample_count / (old_length + num_samples);
+    }
+    r.min = clip_min;
+    r.max = new_max;
+    r.start_offset = so;
+    return r;
+  }
+  const double old_min = clip_min;   // left edge, :77-125
+  const double actual_min_length = clip_max - resize_limit + min_length;
+  double new_min = maxd(clip_min + relative_pos, 0.0);
+  if (clip_max - new_min < actual_min_length) new_min = clip_max - actual_min_length;
+  if (clamp_at_resize_pos && new_min < min_resize_pos) new_min = min_resize_pos;
+  double so = clip_start_offset;
+  if (!shift) {
+    so = samples_to_beat(so, sample_rate, beat_duration);
+    if (old_min < new_min)
+      so -= old_min - new_min;
+    else
+      so += new_min - old_min;
+    if (so < 0.0) new_min = new_min - so;
+    so = maxd(so, 0.0);
+    so = beat_to_samples_h(so, sample_rate, beat_duration);
+  }
+  if (stretch) {
+    const double old_length = sample_count / clip_speed;
+    const double num_samples = beat_to_samples_h(old_min - new_min, sample_rate, beat_duration);
+    r.speed = sample_count / (old_length + num_samples);
+  }
+  r.min = new_min;
+  r.max = clip_max;
+  r.start_offset = so;
+  return r;
+}
+
+// clip_edit.h:128-137 (audio)
+inline double calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
+  const double offset_in_beat = samples_to_beat(start_offset, sample_rate, beat_duration);
+  return beat_to_samples_h(maxd(offset_in_beat - relative_pos, 0.0), sample_rate, beat_duration);
+}
+
+// clip_edit.h:139-150 (audio)
+inline double shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                                 double beat_duration) {
+  relative_pos *= speed;
+  return calc_clip_shift(start_offset, relative_pos, beat_duration, sample_rate);
+}
+
+// find_lower_bound with `clip->max_time <= value` (core/algorithm.h:24-40)
+inline uint32_t lower_bound_max(const std::vector<HostClip>& c, double value) {
+  long long left = 0, right = (long long)c.size() - 1;
+  while (left < right) {
+    long long middle = (left + right) >> 1;
+    if (c[(size_t)middle].d.max_time <= value)
+      left = middle + 1;
+    else
+      right = middle;
+  }
+  return (uint32_t)right;
+}
+
+// Track::query_clip_by_range, track.cpp:112-157
+inline bool query_clip_by_range(const std::vector<HostClip>& c, double min, double max, ClipQuery* q) {
+  if (c.empty()) return false;
+  if (max <= c.front().d.min_time) return false;
+  if (min >= c.back().d.max_time) return false;
+  const uint32_t first = lower_bound_max(c, min), last = lower_bound_max(c, max);
+  if (first == last && (max <= c[first].d.min_time || min >= c[last].d.max_time)) return false;
+  q->first = first;
+  q->last = last;
+  if (min > c[first].d.max_time) q->first++;
+  if (!(max > c[last].d.min_time)) q->last--;
+  return true;
+}
+
+// Track::update_clip_ordering, track.cpp:159-180
+inline void update_clip_ordering(std::vector<HostClip>& c) {
+  c.erase(std::remove_if(c.begin(), c.end(), [](const HostClip& x) { return x.deleted; }), c.end());
+  std::sort(c.begin(), c.end(), [](const HostClip& a, const HostClip& b) { return a.d.min_time < b.d.min_time; });
+}
+
+// Engine::reserve_track_region, engine.cpp:478-569.  `rate_of(sample)` gives the asset's sample rate;
+// ignore_uid = 0 ignores nothing; `next_uid` numbers a clip created by a split.
+template <class RateOf>
+inline void reserve_track_region(std::vector<HostClip>& c, uint32_t first_clip, uint32_t last_clip, double min, double max,
+                                 uint32_t ignore_uid, double beat_duration, RateOf rate_of, uint32_t* next_uid) {
+  if (c.empty()) return;
+  auto shifted = [&](const HostClip& k, double rel) {
+    return shift_clip_content(k.d.start_offset, k.d.speed, rate_of(k.d.sample), rel, beat_duration);
+  };
+  if (first_clip == last_clip) {   // :493-533
+    if (c[first_clip].d.uid == ignore_uid) return;
+    if (min > c[first_clip].d.min_time && max < c[first_clip].d.max_time) {   // the region splits the clip in two
+      HostClip right = c[first_clip];
+      right.d.uid = ++*next_uid;
+      right.d.min_time = max;
+      right.d.start_offset = shifted(right, c[first_clip].d.min_time - max);
+      c[first_clip].d.max_time = min;
+      c.push_back(right);
+    } else if (min > c[first_clip].d.min_time) {
+      c[first_clip].d.max_time = min;
+    } else if (max < c[first_clip].d.max_time) {
+      c[first_clip].d.start_offset = shifted(c[first_clip], c[first_clip].d.min_time - max);
+      c[first_clip].d.min_time = max;
+    } else {
+      c[first_clip].deleted = true;
+    }
+    return;
+  }
+  if (c[first_clip].d.uid != ignore_uid && min > c[first_clip].d.min_time) {   // :535-568
+    c[first_clip].d.max_time = min;
+    first_clip++;
+  }
+  if (c[last_clip].d.uid != ignore_uid && max < c[last_clip].d.max_time) {
+    c[last_clip].d.start_offset = shifted(c[last_clip], c[last_clip].d.min_time - max);
+    c[last_clip].d.min_time = max;
+    last_clip--;
+  }
+  if (first_clip <= last_clip && last_clip < c.size())
+    for (uint32_t i = first_clip; i <= last_clip; i++)
+      if (c[i].d.uid != ignore_uid) c[i].deleted = true;
+}
+
+}  // namespace edit
+}  // namespace wbx

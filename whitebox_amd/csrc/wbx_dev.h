@@ -44,7 +44,7 @@ struct DClip {            // reference src/engine/clip.h:39-45,55-75 (audio fiel
   float gain;
   uint32_t sample;
   uint32_t internal_state_changed;
-  uint32_t _pad;
+  uint32_t uid;           // stable identity across re-sorts (the reference holds Clip* pointers)
 };
 
 struct DTrackState {      // reference TrackEventState track.h:36-44, current_audio_event track.h:112, Sampler sampler.h:13-16
@@ -52,7 +52,7 @@ struct DTrackState {      // reference TrackEventState track.h:36-44, current_au
   uint32_t cur_type;      // EventType of current_audio_event
   uint32_t cur_sample;
   float cur_gain;
-  uint32_t _pad;
+  uint32_t cur_clip_uid;  // current_audio_event.clip: its gain is re-read every block (track.cpp:676,716)
   double playback_speed, sample_offset;
 };
 
@@ -129,6 +129,7 @@ struct PlanArgs {
   double sample_rate;
   double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
   uint32_t playing;
+  uint32_t clips_changed;       // the clip lists were edited since the previous plan: re-read the current clip's gain
 };
 
 struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
   const uint32_t c0 = a.clip_first[t];
   const uint32_t nc = a.clip_first[t + 1] - c0;
   DClip* clips = const_cast<DClip*>(a.clips) + c0;
+  if (a.clips_changed && st.cur_type == EV_PLAY) {
+    // the reference reads current_audio_event.clip->audio.gain at every stream call (track.cpp:676,716):
+    // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity
+    for (uint32_t i = 0; i < nc; i++)
+      if (clips[i].uid == st.cur_clip_uid) st.cur_gain = clips[i].gain;
+  }
   TrackCache cache;
   cache.clip_idx = 0xFFFFFFFFu;
   cache.smp_idx = 0xFFFFFFFFu;

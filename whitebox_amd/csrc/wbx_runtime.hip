@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/wbx.h"
+#include "wbx_clip_edit.h"
 #include "wbx_dev.h"
 #include "wbx_seq.h"
 
@@ -749,7 +750,7 @@ struct ParamMsg {
 };
 
 struct HostTrack {
-  std::vector<DClip> clips;            // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
+  std::vector<HostClip> clips;         // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
   float volume = 0.0f, pan = 0.0f, pan_coeffs[2] = {0.0f, 0.0f};
   bool mute = false;
   std::vector<ParamMsg> msgs;          // TrackMessage::ParamChange ring (track.h:131), drained at the next block
@@ -787,6 +788,10 @@ struct wbx_engine {
   bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (integer PCM, speed > 0.999, != 1)
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
   size_t total_clips = 0;
+  uint32_t next_clip_uid = 0;
+  size_t d_clips_count = 0;
+  bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
+  bool clips_edited = false;            // a clip list changed since the previous plan (PlanArgs::clips_changed)
   uint32_t state_tracks = 0;            // tracks that have device state
 
   DevBuf<DClip> d_clips;
@@ -814,7 +819,10 @@ wbx_status efail(wbx_engine* e, wbx_status s, const char* what) {
 
 // Track::find_next_clip over the host copy (track.cpp:182-213)
 bool host_find_next_clip(const HostTrack& t, double time_pos, uint32_t* idx) {
-  return find_next_clip(t.clips.data(), (uint32_t)t.clips.size(), time_pos, idx);
+  if (t.clips.empty()) return false;
+  if (t.clips.back().d.max_time < time_pos) return false;
+  *idx = edit::lower_bound_max(t.clips, time_pos);
+  return true;
 }
 
 // Track::reset_playback_state, track.cpp:220-232
@@ -831,17 +839,11 @@ void reset_playback_state(wbx_engine* e, HostTrack& t, double time_pos, bool ref
   e->patches_pending = true;
 }
 
-// Track::query_clip_by_range reduced to "is the range free" (track.cpp:112-157)
-bool range_is_free(const HostTrack& t, double mn, double mx) {
-  const auto& c = t.clips;
-  if (c.empty()) return true;
-  if (mx <= c.front().min_time) return true;
-  if (mn >= c.back().max_time) return true;
-  uint32_t first = lower_bound_max_time(c.data(), (uint32_t)c.size(), mn);
-  uint32_t last = lower_bound_max_time(c.data(), (uint32_t)c.size(), mx);
-  if (first == last && (mx <= c[first].min_time || mn >= c[last].max_time)) return true;
-  return false;
-}
+// bookkeeping shared by every clip-list edit: which clips the hot loop can stream directly
+void note_clip(wbx_engine* e, const DClip& c);
+
+// after a clip-list edit: Track::update_clip_ordering + reset_playback_state(playhead, true)
+void finish_edit(wbx_engine* e, HostTrack& t);
 
 }  // namespace
 
@@ -962,37 +964,190 @@ extern "C" wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uin
   return st;
 }
 
-// Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461 (non-overlapping inserts)
+namespace {
+
+void note_clip(wbx_engine* e, const DClip& c) {
+  const DSample& smp = e->ctx->clips[c.sample].d;
+  const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * c.speed;   // sampler.h:24
+  if (smp.format != FMT_F32 || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
+  if (ps != 1.0) e->any_window_clip = true;
+}
+
+void finish_edit(wbx_engine* e, HostTrack& t) {
+  edit::update_clip_ordering(t.clips);
+  reset_playback_state(e, t, e->playhead, true);   // engine.cpp:360,395,405,416,426,437,449,459,473
+  e->clips_dirty = true;
+  e->clips_edited = true;
+  e->total_clips = 0;
+  for (auto& tr : e->tracks) e->total_clips += tr.clips.size();
+}
+
+double rate_of_sample(const wbx_engine* e, uint32_t sample) { return (double)e->ctx->clips[sample].d.sample_rate; }
+
+}  // namespace
+
+// Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461.  A clip that overlaps existing ones
+// trims, splits or deletes them through reserve_track_region (engine.cpp:478-569), as the reference does.
 extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
                                                 double start_offset, uint32_t sample, double speed, float gain) {
   if (!e || track >= e->tracks.size()) return WBX_ERR_INVALID;
   if (sample >= e->ctx->clips.size() || !e->ctx->clips[sample].used) return efail(e, WBX_ERR_INVALID, "unknown sample");
   if (!(min_time <= max_time)) return efail(e, WBX_ERR_INVALID, "min_time > max_time");
   HostTrack& t = e->tracks[track];
-  const bool back = !t.clips.empty() && t.clips.back().max_time < min_time;
-  const bool front = !t.clips.empty() && t.clips.front().min_time > max_time;
-  if (!t.clips.empty() && !back && !front && !range_is_free(t, min_time, max_time))
-    return efail(e, WBX_ERR_UNSUPPORTED, "clip overlaps an existing clip (reserve_track_region is out of scope)");
-  DClip c{};
-  c.min_time = min_time;
-  c.max_time = max_time;
-  c.start_offset = start_offset;
-  c.speed = speed;
-  c.gain = gain;
-  c.sample = sample;
-  c.internal_state_changed = 0;
+  const bool empty = t.clips.empty();
+  const bool back = !empty && t.clips.back().d.max_time < min_time;
+  const bool front = !empty && !back && t.clips.front().d.min_time > max_time;
+  ClipQuery q{};
+  if (!empty && !back && !front && edit::query_clip_by_range(t.clips, min_time, max_time, &q))
+    edit::reserve_track_region(t.clips, q.first, q.last, min_time, max_time, 0u, e->beat_duration,
+                               [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
+  HostClip c{};
+  c.d.min_time = min_time;
+  c.d.max_time = max_time;
+  c.d.start_offset = start_offset;
+  c.d.speed = speed;
+  c.d.gain = gain;
+  c.d.sample = sample;
+  c.d.internal_state_changed = 0;
+  c.d.uid = ++e->next_clip_uid;
   t.clips.push_back(c);
-  {
-    const DSample& smp = e->ctx->clips[sample].d;
-    const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * speed;   // sampler.h:24
-    if (smp.format != FMT_F32 || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
-    if (ps != 1.0) e->any_window_clip = true;
-    e->total_clips++;
-  }
-  std::sort(t.clips.begin(), t.clips.end(), [](const DClip& a, const DClip& b) { return a.min_time < b.min_time; });
-  reset_playback_state(e, t, e->playhead, true);   // engine.cpp:416,426,437,449,459
-  e->clips_dirty = true;
+  note_clip(e, c.d);
+  finish_edit(e, t);
   return WBX_OK;
+}
+
+// Engine::move_clip, engine.cpp:346-363
+extern "C" wbx_status wbx_engine_move_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos) {
+  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
+  if (relative_pos == 0.0) return WBX_OK;
+  HostTrack& t = e->tracks[track];
+  const uint32_t uid = t.clips[clip].d.uid;
+  double mn, mx;
+  edit::calc_move_clip(t.clips[clip].d.min_time, t.clips[clip].d.max_time, relative_pos, 0.0, &mn, &mx);
+  ClipQuery q{};
+  if (edit::query_clip_by_range(t.clips, mn, mx, &q))
+    edit::reserve_track_region(t.clips, q.first, q.last, mn, mx, uid, e->beat_duration,
+                               [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
+  for (auto& c : t.clips)
+    if (c.d.uid == uid) {
+      c.d.min_time = mn;
+      c.d.max_time = mx;
+      c.d.internal_state_changed = 1;
+      c.flag_dirty = true;
+    }
+  finish_edit(e, t);
+  return WBX_OK;
+}
+
+// Engine::resize_clip, engine.cpp:365-398
+extern "C" wbx_status wbx_engine_resize_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos,
+                                             double resize_limit, double min_length, int left_side, int shift,
+                                             int stretch) {
+  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
+  if (relative_pos == 0.0) return WBX_OK;
+  HostTrack& t = e->tracks[track];
+  const DClip c0 = t.clips[clip].d;
+  const DSample& smp = e->ctx->clips[c0.sample].d;
+  const edit::ResizeResult r =
+      edit::calc_resize_clip(c0.min_time, c0.max_time, c0.start_offset, c0.speed, (double)smp.sample_rate, (double)smp.count,
+                             relative_pos, resize_limit, min_length, c0.min_time, e->beat_duration, left_side != 0,
+                             shift != 0, stretch != 0, false);
+  ClipQuery q{};
+  if (edit::query_clip_by_range(t.clips, r.min, r.max, &q))
+    edit::reserve_track_region(t.clips, q.first, q.last, r.min, r.max, c0.uid, e->beat_duration,
+                               [&](uint32_t s2) { return rate_of_sample(e, s2); }, &e->next_clip_uid);
+  for (auto& c : t.clips)
+    if (c.d.uid == c0.uid) {
+      if (left_side)
+        c.d.min_time = r.min;
+      else
+        c.d.max_time = r.max;
+      c.d.start_offset = r.start_offset;
+      if (stretch) c.d.speed = r.speed;
+      c.d.internal_state_changed = (shift || stretch) ? 1u : 0u;
+      c.flag_dirty = true;
+      note_clip(e, c.d);
+    }
+  finish_edit(e, t);
+  return WBX_OK;
+}
+
+// Engine::delete_clip, engine.cpp:400-407
+extern "C" wbx_status wbx_engine_delete_clip(wbx_engine* e, uint32_t track, uint32_t clip) {
+  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
+  HostTrack& t = e->tracks[track];
+  t.clips[clip].deleted = true;
+  finish_edit(e, t);
+  return WBX_OK;
+}
+
+// Engine::delete_region, engine.cpp:463-475
+extern "C" wbx_status wbx_engine_delete_region(wbx_engine* e, uint32_t track, double min, double max) {
+  if (!e || track >= e->tracks.size() || !(min <= max)) return WBX_ERR_INVALID;
+  HostTrack& t = e->tracks[track];
+  ClipQuery q{};
+  if (!edit::query_clip_by_range(t.clips, min, max, &q)) return WBX_OK;
+  edit::reserve_track_region(t.clips, q.first, q.last, min, max, 0u, e->beat_duration,
+                             [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
+  finish_edit(e, t);
+  return WBX_OK;
+}
+
+// Engine::set_clip_gain, engine.cpp:1460-1464
+extern "C" wbx_status wbx_engine_set_clip_gain(wbx_engine* e, uint32_t track, uint32_t clip, float gain) {
+  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
+  e->tracks[track].clips[clip].d.gain = gain;
+  e->clips_dirty = true;
+  e->clips_edited = true;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_clip_count(wbx_engine* e, uint32_t track, uint32_t* count) {
+  if (!e || track >= e->tracks.size() || !count) return WBX_ERR_INVALID;
+  *count = (uint32_t)e->tracks[track].clips.size();
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_get_clip(wbx_engine* e, uint32_t track, uint32_t clip, wbx_clip_info* out) {
+  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size() || !out) return WBX_ERR_INVALID;
+  const DClip& d = e->tracks[track].clips[clip].d;
+  out->min_time = d.min_time;
+  out->max_time = d.max_time;
+  out->start_offset = d.start_offset;
+  out->speed = d.speed;
+  out->gain = d.gain;
+  out->sample = d.sample;
+  return WBX_OK;
+}
+
+// the clip placement arithmetic on its own (engine/clip_edit.h:10-150), for hosts that preview an edit
+extern "C" void wbx_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                                   double* new_max) {
+  edit::calc_move_clip(clip_min, clip_max, relative_pos, min_move, new_min, new_max);
+}
+
+extern "C" void wbx_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                                     double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                                     double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
+                                     int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
+                                     double* out_start_offset, double* out_speed) {
+  const edit::ResizeResult r = edit::calc_resize_clip(clip_min, clip_max, clip_start_offset, clip_speed, sample_rate,
+                                                      sample_count, relative_pos, resize_limit, min_length, min_resize_pos,
+                                                      beat_duration, is_min != 0, shift != 0, stretch != 0,
+                                                      clamp_at_resize_pos != 0);
+  *out_min = r.min;
+  *out_max = r.max;
+  *out_start_offset = r.start_offset;
+  *out_speed = r.speed;
+}
+
+extern "C" double wbx_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
+  return edit::calc_clip_shift(start_offset, relative_pos, beat_duration, sample_rate);
+}
+
+extern "C" double wbx_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                                         double beat_duration) {
+  return edit::shift_clip_content(start_offset, speed, sample_rate, relative_pos, beat_duration);
 }
 
 extern "C" wbx_status wbx_engine_play(wbx_engine* e) {   // engine.cpp:68-80
@@ -1058,17 +1213,34 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
 
   // -- clip lists
   if (e->clips_dirty) {
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    // Clip::internal_state_changed is cleared by the sequencer on the device (track.cpp:373,392,418): before
+    // the table is replaced, take the live flags back for every clip no edit has touched since the last upload
+    if (e->clips_uploaded && e->d_clips_count) {
+      std::vector<DClip> live(e->d_clips_count);
+      WBX_EHIP(e, hipMemcpy(live.data(), e->d_clips.p, live.size() * sizeof(DClip), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> flag(e->next_clip_uid + 1, 2u);
+      for (const DClip& d : live)
+        if (d.uid < flag.size()) flag[d.uid] = d.internal_state_changed;
+      for (auto& tr : e->tracks)
+        for (auto& hc : tr.clips)
+          if (!hc.flag_dirty && hc.d.uid < flag.size() && flag[hc.d.uid] != 2u) hc.d.internal_state_changed = flag[hc.d.uid];
+    }
     std::vector<uint32_t> first(N + 1, 0);
     std::vector<DClip> flat;
     for (uint32_t t = 0; t < N; t++) {
       first[t] = (uint32_t)flat.size();
-      flat.insert(flat.end(), e->tracks[t].clips.begin(), e->tracks[t].clips.end());
+      for (auto& hc : e->tracks[t].clips) {
+        flat.push_back(hc.d);
+        hc.flag_dirty = false;
+      }
     }
     first[N] = (uint32_t)flat.size();
     WBX_EHIP(e, e->d_clips.ensure(std::max<size_t>(1, flat.size())));
     WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
+    e->d_clips_count = flat.size();
+    e->clips_uploaded = true;
     if (!flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, flat.data(), flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
     WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     e->clips_dirty = false;
@@ -1156,6 +1328,8 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   a.channels = C;
   a.sample_rate = sample_rate;
   a.playing = e->playing ? 1u : 0u;
+  a.clips_changed = e->clips_edited ? 1u : 0u;
+  e->clips_edited = false;
   a.playhead = e->playhead;
   a.sample_position = e->sample_position;
   a.beat_duration = e->beat_duration;

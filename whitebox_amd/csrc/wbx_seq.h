@@ -208,6 +208,7 @@ struct BlockWalker {
       st->sample_offset = (double)sample_offset;
       st->cur_gain = clip->gain;
       st->cur_sample = clip->sample;
+      st->cur_clip_uid = clip->uid;
     }
     st->cur_type = type;
     start_sample += event_length;

@@ -264,6 +264,35 @@ class Engine:
         _check(self.L.wbx_engine_add_audio_clip(self.h, track.index, min_time, max_time, start_offset, sample, speed,
                                                 np.float32(gain)), "Engine::add_audio_clip", self.h, True)
 
+    # ---- clip edits (engine.cpp:346-407,463-475,1460-1464); `clip` = index in the track's sorted clip list ----
+    def move_clip(self, track: Track, clip: int, relative_pos: float):
+        _check(self.L.wbx_engine_move_clip(self.h, track.index, clip, relative_pos), "Engine::move_clip", self.h, True)
+
+    def resize_clip(self, track: Track, clip: int, relative_pos: float, resize_limit: float, min_length: float,
+                    left_side: bool, shift: bool = False, stretch: bool = False):
+        _check(self.L.wbx_engine_resize_clip(self.h, track.index, clip, relative_pos, resize_limit, min_length,
+                                             int(left_side), int(shift), int(stretch)), "Engine::resize_clip", self.h, True)
+
+    def delete_clip(self, track: Track, clip: int):
+        _check(self.L.wbx_engine_delete_clip(self.h, track.index, clip), "Engine::delete_clip", self.h, True)
+
+    def delete_region(self, track: Track, min_time: float, max_time: float):
+        _check(self.L.wbx_engine_delete_region(self.h, track.index, min_time, max_time), "Engine::delete_region", self.h, True)
+
+    def set_clip_gain(self, track: Track, clip: int, gain: float):
+        _check(self.L.wbx_engine_set_clip_gain(self.h, track.index, clip, np.float32(gain)), "Engine::set_clip_gain", self.h, True)
+
+    def clips(self, track: Track):
+        """(min_time, max_time, start_offset, speed, gain, sample) of the track's sorted clip list"""
+        n = C.c_uint32()
+        _check(self.L.wbx_engine_clip_count(self.h, track.index, C.byref(n)), "wbx_engine_clip_count", self.h, True)
+        out = []
+        for i in range(n.value):
+            ci = _ffi.ClipInfo()
+            _check(self.L.wbx_engine_get_clip(self.h, track.index, i, C.byref(ci)), "wbx_engine_get_clip", self.h, True)
+            out.append((ci.min_time, ci.max_time, ci.start_offset, ci.speed, ci.gain, ci.sample))
+        return out
+
     def play(self):
         _check(self.L.wbx_engine_play(self.h), "Engine::play", self.h, True)
 
