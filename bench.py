@@ -34,29 +34,33 @@ F = 512
 SR = 48000
 
 WORKLOADS = {
-    # name: (description, src_rate, n_buses)
-    "c2": ("configs[1]: 256 stereo tracks, per-track gain+pan, 512-frame blocks", 48000, 0),
-    "c3": ("configs[2]: 4096 stereo tracks, gain+pan + linear clip resample 44.1k->48k, 512-frame blocks", 44100, 0),
-    "c4": ("configs[3]: 4096 stereo tracks into 64 sub-buses + master sum, 512-frame blocks", 48000, 64),
+    # name: (description, src_rate, n_buses, clip storage format)
+    "c2": ("configs[1]: 256 stereo tracks, per-track gain+pan, 512-frame blocks", 48000, 0, "f32"),
+    "c3": ("configs[2]: 4096 stereo tracks, gain+pan + linear clip resample 44.1k->48k, 512-frame blocks", 44100, 0, "f32"),
+    "c4": ("configs[3]: 4096 stereo tracks into 64 sub-buses + master sum, 512-frame blocks", 48000, 64, "f32"),
+    "i16": ("next-2 (SURVEY 8f): 4096 stereo 16-bit PCM tracks, gain+pan, unity rate, 512-frame blocks", 48000, 0, "i16"),
 }
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5}
+FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4}
 
 
-def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2) -> float:
-    """per master frame read N*C*4*r bytes of clip audio (r = src/dst rate) and write
-    C*4 bytes of master; per block additionally N*C*4 B of peaks and N*32 B of segment/gain tables."""
+def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2, fmt: str = "f32") -> float:
+    """per master frame read N*C*B*r bytes of clip audio (B = bytes per stored sample, r =
+    src/dst rate) and write C*4 bytes of master; per block additionally N*C*4 B of peaks and N*32 B of
+    segment/gain tables."""
     r = src_rate / SR
-    return F * (n_tracks * channels * 4 * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
+    return F * (n_tracks * channels * FMT_BYTES[fmt] * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
 
 
 def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, stream_ptr, group_size):
     from whitebox_amd.engine import Engine
-    desc, src_rate, n_buses = WORKLOADS[workload]
+    desc, src_rate, n_buses, fmt = WORKLOADS[workload]
     eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank),
                  stream=stream_ptr)
     eng.set_bpm(120.0)
     if n_buses:
         eng.set_buses(n_buses)
-    seed = 0x5EED0000 + {"c2": 2, "c3": 3, "c4": 4}[workload]
+    seed = 0x5EED0000 + SEEDS[workload]
     total_tracks = n_tracks * max(1, int(os.environ.get("WORLD_SIZE", "1")))
     amp = synth.default_amp(total_tracks)
     frames = int(math.ceil((session_blocks + 2) * F * (src_rate / SR))) + 64
@@ -64,9 +68,11 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
     per_bus = max(1, n_tracks // n_buses) if n_buses else 0
     for t in range(n_tracks):
         gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
-        sid = eng.add_sample_synth("f32", 2, src_rate, frames, seed, gt, amp)
+        sid = eng.add_sample_synth(fmt, 2, src_rate, frames, seed, gt, amp)
         tr = eng.add_track(f"t{gt}")
         v, p = synth.track_params(seed, gt)
+        if fmt != "f32":
+            v = v - 20.0 * math.log10(0.25 / amp)     # integer clips are full scale: the session level goes into the faders
         tr.set_volume(float(v))
         tr.set_pan(float(p))
         if n_buses:
@@ -84,11 +90,11 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
     reference's own TUs) timed on ONE host core over a bounded sample of the same workload."""
     import oracle_ffi as O
     from whitebox_amd import synth
-    _, src_rate, n_buses = WORKLOADS[workload]
+    _, src_rate, n_buses, fmt = WORKLOADS[workload]
     L = O.lib()
     L.wbo_synth_f32.argtypes = [O.c_f32p, C.c_size_t, C.c_uint64, C.c_float, C.c_size_t]
     sample_blocks = 24
-    seed = 0x5EED0000 + {"c2": 2, "c3": 3, "c4": 4}[workload]
+    seed = 0x5EED0000 + SEEDS[workload]
     amp = np.float32(synth.default_amp(n_tracks))
     frames = int(math.ceil((sample_blocks + 2) * F * (src_rate / SR))) + 64
     e = O.OracleEngine(2, F, SR)
@@ -101,13 +107,18 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
     for t in range(n_tracks):
         chans = []
         for c in range(2):
-            a = np.empty(frames + 16, np.float32)
-            L.wbo_synth_f32(a.ctypes.data_as(O.c_f32p), frames, int(synth.clip_key(seed, t, c)), amp, 16)
+            if fmt == "f32":
+                a = np.empty(frames + 16, np.float32)
+                L.wbo_synth_f32(a.ctypes.data_as(O.c_f32p), frames, int(synth.clip_key(seed, t, c)), amp, 16)
+            else:
+                a = np.concatenate([synth.clip_channel_i16(seed, t, c, frames), np.zeros(16, np.int16)])
             chans.append(a)
         keep.append(chans)
-        sid = e.add_sample("f32", 2, src_rate, frames, chans)
+        sid = e.add_sample(fmt, 2, src_rate, frames, chans)
         e.add_track()
         v, p = synth.track_params(seed, t)
+        if fmt != "f32":
+            v = v - 20.0 * math.log10(0.25 / float(amp))
         e.set_volume(t, v)
         e.set_pan(t, p)
         if n_buses:
@@ -174,10 +185,10 @@ def main():
     from whitebox_amd import synth
 
     n_tracks = args.tracks or (256 if args.workload == "c2" else 4096)
-    desc, src_rate, n_buses = WORKLOADS[args.workload]
+    desc, src_rate, n_buses, fmt = WORKLOADS[args.workload]
     K = args.blocks
     total_blocks = (args.warmup + args.steps) * K
-    bytes_per_block_src = n_tracks * 2 * 4 * F * src_rate / SR
+    bytes_per_block_src = n_tracks * 2 * FMT_BYTES[fmt] * F * src_rate / SR
     mem_budget = 96e9
     session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
     if args.session_blocks:
@@ -284,7 +295,7 @@ def main():
     master_frames = args.steps * K * F
     total_tracks = n_tracks * world
     value = (total_tracks / 4096.0) * master_frames / dt if n_tracks == 4096 else master_frames / dt * world
-    alg = algorithmic_bytes_per_block(n_tracks, src_rate) * K
+    alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
     achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
 
     if rank == 0:
@@ -302,9 +313,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
             "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
-                       "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate,
+                       "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate, "clip_format": fmt,
                        "sub_buses": n_buses, "group_size": args.group_size or 64,
                        "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}"},
             "master_frames_per_s": master_frames / dt,

@@ -457,3 +457,31 @@ def test_clip_edits_match_oracle_lists_and_audio():
         assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), (step, op)
     e.close()
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# integer PCM streamed directly by the hot loop
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", ["i16", "i24", "i32"])
+def test_integer_pcm_unity_fast_path(fmt):
+    """All tracks in one storage format at unity speed: the mix kernel streams the integers itself
+    (8 B per lane for 16-bit), with the reference's normalise-clamp-scale roundings (sampler.cpp:109-144)."""
+    spec = synth.make_session("pcm_" + fmt, 192, fmt=fmt, n_blocks=4, seed=0xA16)
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -40.0 + (t % 7)
+    check_against_oracle(spec, 4)                                     # grouped order: 3 groups of 64
+    check_against_oracle(spec, 4, group_size=192, expect_exact=True)  # reference order: bit-exact
+
+
+def test_mixed_storage_formats_in_one_group():
+    """fp32, 16-bit, 24-bit, 32-bit and resampled tracks interleaved in the same group, with clip boundaries
+    inside blocks (pre-rendered fp32 rows among integer rows): the per-row dispatch path."""
+    spec = synth.make_session("mixfmt", 48, seek=True, n_blocks=6, seed=0xA17)
+    fmts = ["f32", "i16", "i24", "i32"]
+    for i, s in enumerate(spec.samples):
+        s.fmt = fmts[i % 4]
+        s.amp = 0.02 if s.fmt == "f32" else 1.0
+        s.rate = 44100 if i % 5 == 0 else 48000
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -42.0
+    check_against_oracle(spec, 6, expect_exact=True)

@@ -269,6 +269,8 @@ __device__ __forceinline__ float wave_max_lane63(float x) {
   return __int_as_float(v);
 }
 
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4 };   // row shapes of a staged chunk
+
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
   f4 v;        // UNITY: the 4 source frames; WINDOW: window samples 0..3
@@ -323,38 +325,127 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
 
-  // ---- phase A: the clip loads of the U tracks starting at local index u0 -------------------------
-  // WIN = false: every record of the chunk is a unity row (no fp64, one 16-B load per track);
-  // WIN = true : linear-resample rows present; unity rows go through the same address formula (their pos is
-  //              integral and speed 1.0, so trunc(pos + j0*speed) == (uint32)pos + j0 exactly).
-  auto issue = [&](auto win, uint32_t u0, Pre (&pre)[U]) {
-    constexpr bool WIN = decltype(win)::value;
+  // ---- per-row arithmetic (each returns the 4 frames of one track AFTER clip gain and track gain) ----
+  // fp32 row at unity speed: sampler.cpp:151-152, track.cpp:731
+  auto row_f32 = [&](const f4& v, float cg, float gc) {
+    f4 m;
+    m.x = __fmul_rn(__fmul_rn(v.x, cg), gc);
+    m.y = __fmul_rn(__fmul_rn(v.y, cg), gc);
+    m.z = __fmul_rn(__fmul_rn(v.z, cg), gc);
+    m.w = __fmul_rn(__fmul_rn(v.w, cg), gc);
+    return m;
+  };
+  // 16-bit PCM row at unity speed, sampler.cpp:109-120: clamp((float)d * (1.0f/32767), -1, 1) * gain
+  auto row_i16 = [&](int lo, int hi, float cg, float gc) {
+    const float norm = 1.0f / 32767.0f;                                                   // :95
+    const float d0 = (float)(short)(lo & 0xFFFF), d1 = (float)(short)((unsigned)lo >> 16);
+    const float d2 = (float)(short)(hi & 0xFFFF), d3 = (float)(short)((unsigned)hi >> 16);
+    f4 m;
+    m.x = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d0, norm), -1.0f, 1.0f), cg), gc);
+    m.y = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d1, norm), -1.0f, 1.0f), cg), gc);
+    m.z = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d2, norm), -1.0f, 1.0f), cg), gc);
+    m.w = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d3, norm), -1.0f, 1.0f), cg), gc);
+    return m;
+  };
+  // 24-bit (32-bit containers) / 32-bit PCM row at unity speed, sampler.cpp:121-144: (float)clamp((double)d * norm, -1, 1) * gain
+  auto row_i32 = [&](const f4& bits, uint32_t format, float cg, float gc) {
+    const double norm = format == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;         // :96-97
+    f4 m;
+    m.x = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.x), norm), -1.0, 1.0), cg), gc);
+    m.y = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.y), norm), -1.0, 1.0), cg), gc);
+    m.z = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.z), norm), -1.0, 1.0), cg), gc);
+    m.w = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.w), norm), -1.0, 1.0), cg), gc);
+    return m;
+  };
+  // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
+  auto row_window = [&](const Pre& p, double pos, double speed, float cg, float gc) {
+    const int ix0 = p.ix0;
+    float q[4];
+    {   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
+      const float s = __fadd_rn(p.v.x, __fmul_rn(p.fx0, __fsub_rn(p.v.y, p.v.x)));        // :55
+      q[0] = __fmul_rn(__fmul_rn(s, cg), gc);                                             // :56, track.cpp:731
+    }
+#define WBX_TAP(E, JD)                                                                                  \
+  {                                                                                                     \
+    const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
+    const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
+    float sa, sb;                                                                                       \
+    taps<E>(p.v, p.w4, (int)x - ix0, sa, sb);                             /* :51 */                     \
+    const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
+    q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
+  }
+    WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
+#undef WBX_TAP
+    return f4{q[0], q[1], q[2], q[3]};
+  };
+  // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
+  auto load_window = [&](const DTrackBlock& r, Pre& p) {
+    const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                          // sampler.cpp:50, frame j0
+    const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
+    const float WBX_GLOBAL* src = as_global<float>(r.src[c]) + ix0;
+    if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
+      p.v = *reinterpret_cast<const f4u WBX_GLOBAL*>(src);   // the taps of frames j0..j0+3 lie in src[0..4]
+      p.w4 = src[4];
+    }
+    p.ix0 = ix0;
+    // :52 fx = (float)(x - (double)ix): for x >= 0 that difference is x - floor(x), which v_fract_f64
+    // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
+    p.fx0 = (float)__builtin_amdgcn_fract(x0);
+  };
+  auto add_row = [&](const f4& m0) {
+    f4 m = m0;
+    if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc.x = __fadd_rn(acc.x, m.x);                                                        // audio_buffer.h:73-82
+    acc.y = __fadd_rn(acc.y, m.y);
+    acc.z = __fadd_rn(acc.z, m.z);
+    acc.w = __fadd_rn(acc.w, m.w);
+    return absmax4(m);                                                                    // vu_meter.h:20-25
+  };
+  // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes that
+  // share a channel otherwise; then one LDS atomic per wave / lane group
+  auto post_peak = [&](float pk, uint32_t tl) {
+    if (FULL) {
+      pk = wave_max_lane63(pk);
+      if (lane == 63u) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
+    } else {
+      for (uint32_t off = 1; off < span; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
+      if ((lane & (span - 1u)) == 0u && active) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
+    }
+  };
+
+  // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line per mode) ----
+  //  MODE_U    every row is an fp32 unity row: one 16-B load per track, no fp64
+  //  MODE_W    fp32 rows, some linearly resampled: 16-B + 4-B load per track (unity rows use the same formula)
+  //  MODE_I16  every row is 16-bit PCM at unity speed: one 8-B load per track (half the bytes of fp32)
+  //  MODE_I32  every row is 24/32-bit PCM at unity speed: one 16-B load per track
+  auto issue = [&](auto mode, uint32_t u0, Pre (&pre)[U]) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const DTrackBlock& r = s_tb[u0 + u];
-      if (WIN) {
-        const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                    // sampler.cpp:50, frame j0
-        const int ix0 = (int)x0;                                                        // :51 (x >= 0: truncation)
-        const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + ix0;
-        if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
-          pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);   // the taps of frames j0..j0+3 lie in p[0..4]
-          pre[u].w4 = p[4];
-        }
-        pre[u].ix0 = ix0;
-        // :52 fx = (float)(x - (double)ix): for x >= 0 that difference is x - floor(x), which v_fract_f64
-        // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
-        pre[u].fx0 = (float)__builtin_amdgcn_fract(x0);
+      if (MODE == MODE_W) {
+        load_window(r, pre[u]);
       } else {
-        const uint32_t off = (uint32_t)r.pos + j0;                                      // sampler.cpp:107,151
-        const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + off;
-        if (active) pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);
+        const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
+        if (MODE == MODE_I16) {
+          typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
+          const short WBX_GLOBAL* p = as_global<short>(r.src[c]) + off;
+          if (active) {
+            const i2u w = *reinterpret_cast<const i2u WBX_GLOBAL*>(p);
+            pre[u].v.x = __int_as_float(w.x);
+            pre[u].v.y = __int_as_float(w.y);
+          }
+        } else {   // MODE_U, MODE_I32: 4 x 32-bit
+          const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + off;
+          if (active) pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);
+        }
       }
     }
   };
 
   // ---- phase B: render, scale, accumulate — strictly in track order; then the per-track peaks -----
-  auto render = [&](auto win, uint32_t u0, Pre (&pre)[U]) {
-    constexpr bool WIN = decltype(win)::value;
+  auto render = [&](auto mode, uint32_t u0, Pre (&pre)[U]) {
+    constexpr int MODE = decltype(mode)::value;
     float pk[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -362,79 +453,67 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const float cg = r.gain;
       const float gc = r.g[c];
       f4 m;
-      bool is_win = false;
-      if (WIN) is_win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW;
-      if (WIN && is_win) {
-        const double pos = r.pos, speed = r.speed;
-        const int ix0 = pre[u].ix0;
-        float q[4];
-        {   // frame j0: position and fraction already known from phase A; its taps are window samples 0 and 1
-          const float s = __fadd_rn(pre[u].v.x, __fmul_rn(pre[u].fx0, __fsub_rn(pre[u].v.y, pre[u].v.x)));   // :55
-          q[0] = __fmul_rn(__fmul_rn(s, cg), gc);                                       // :56, track.cpp:731
-        }
-#define WBX_TAP(E, JD)                                                                                  \
-  {                                                                                                     \
-    const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
-    const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
-    float sa, sb;                                                                                       \
-    taps<E>(pre[u].v, pre[u].w4, (int)x - ix0, sa, sb);                   /* :51 */                     \
-    const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
-    q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
-  }
-        WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
-#undef WBX_TAP
-        m = f4{q[0], q[1], q[2], q[3]};
-      } else {   // KIND_UNITY (also: pre-rendered rows, silent and padding records)
-        m.x = __fmul_rn(__fmul_rn(pre[u].v.x, cg), gc);                                   // sampler.cpp:152, track.cpp:731
-        m.y = __fmul_rn(__fmul_rn(pre[u].v.y, cg), gc);
-        m.z = __fmul_rn(__fmul_rn(pre[u].v.z, cg), gc);
-        m.w = __fmul_rn(__fmul_rn(pre[u].v.w, cg), gc);
+      if (MODE == MODE_W) {
+        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
+          m = row_window(pre[u], r.pos, r.speed, cg, gc);
+        else
+          m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
+      } else if (MODE == MODE_I16) {
+        m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+      } else if (MODE == MODE_I32) {
+        m = row_i32(pre[u].v, r.format, cg, gc);
+      } else {
+        m = row_f32(pre[u].v, cg, gc);
       }
-      if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
-      acc.x = __fadd_rn(acc.x, m.x);                                                      // audio_buffer.h:73-82
-      acc.y = __fadd_rn(acc.y, m.y);
-      acc.z = __fadd_rn(acc.z, m.z);
-      acc.w = __fadd_rn(acc.w, m.w);
-      pk[u] = absmax4(m);                                                                 // vu_meter.h:20-25
+      pk[u] = add_row(m);
     }
-    // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes
-    // that share a channel otherwise; then one LDS atomic per wave / lane group
-    if (FULL) {
 #pragma unroll
-      for (int u = 0; u < U; u++) pk[u] = wave_max_lane63(pk[u]);
-      if (lane == 63u) {
-#pragma unroll
-        for (int u = 0; u < U; u++) atomicMax(&s_pk[(u0 + u) * 2u + c], __float_as_uint(pk[u]));
-      }
-    } else {
-      for (uint32_t off = 1; off < span; off <<= 1) {
-#pragma unroll
-        for (int u = 0; u < U; u++) pk[u] = fmaxf(pk[u], __shfl_xor(pk[u], (int)off, 64));
-      }
-      if ((lane & (span - 1u)) == 0u && active) {
-#pragma unroll
-        for (int u = 0; u < U; u++) atomicMax(&s_pk[(u0 + u) * 2u + c], __float_as_uint(pk[u]));
-      }
-    }
+    for (int u = 0; u < U; u++) post_peak(pk[u], u0 + u);
   };
 
   // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records)
-  auto pipeline = [&](auto win, uint32_t cn) {
+  auto pipeline = [&](auto mode, uint32_t cn) {
     Pre pa[U], pb[U];
-    issue(win, 0, pa);
+    issue(mode, 0, pa);
     for (uint32_t u0 = 0; u0 < cn; u0 += 2 * U) {
-      issue(win, u0 + U, pb);
-      render(win, u0, pa);
-      issue(win, u0 + 2 * U, pa);
-      render(win, u0 + U, pb);
+      issue(mode, u0 + U, pb);
+      render(mode, u0, pa);
+      issue(mode, u0 + 2 * U, pa);
+      render(mode, u0 + U, pb);
+    }
+  };
+
+  // a chunk that mixes storage formats (e.g. a pre-rendered fp32 boundary row among 16-bit tracks): one row at
+  // a time with a wave-uniform dispatch on the row kind — correct for any combination, not software-pipelined
+  auto mixed = [&](uint32_t cn) {
+    for (uint32_t tl = 0; tl < cn; tl++) {
+      const DTrackBlock& r = s_tb[tl];
+      const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+      const float cg = r.gain, gc = r.g[c];
+      const uint32_t off = (uint32_t)r.pos + j0;
+      f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (k == KIND_WINDOW) {
+        Pre p;
+        load_window(r, p);
+        m = row_window(p, r.pos, r.speed, cg, gc);
+      } else if (k == KIND_UNITY_I16) {
+        typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
+        i2u w = {0, 0};
+        if (active) w = *reinterpret_cast<const i2u WBX_GLOBAL*>(as_global<short>(r.src[c]) + off);
+        m = row_i16(w.x, w.y, cg, gc);
+      } else {
+        f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) v = *reinterpret_cast<const f4u WBX_GLOBAL*>(as_global<float>(r.src[c]) + off);
+        m = (k == KIND_UNITY_I32) ? row_i32(v, r.format, cg, gc) : row_f32(v, cg, gc);
+      }
+      post_peak(add_row(m), tl);
     }
   };
 
   for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
     const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
     __syncthreads();
-    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record;
-    // silent records and the padding up to a whole number of batches become "read the zero page, gain 0"
+    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record
     for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
       const uint32_t rec = i >> 2, q = i & 3u;
       uint4 w = {0u, 0u, 0u, 0u};
@@ -446,10 +525,21 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
     if (tid < kRecs * 2u) s_pk[tid] = 0u;
     __syncthreads();
-    int is_window = 0;
+    // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
+    int shape = 0;
+    if (tid < cn) {
+      const int k = s_tb[tid].kind;
+      shape = k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : 0;
+    }
+    const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
+    const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
+    const int mode = (!has_i16 && !has_i32) ? (has_win ? MODE_W : MODE_U)
+                     : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
+                     : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
+    // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
+    // of the chunk's own shape, so that the load phase stays straight-line
     if (tid < kRecs) {
       DTrackBlock& r = s_tb[tid];
-      is_window = (tid < cn && r.kind == KIND_WINDOW) ? 1 : 0;
       if (tid >= cn || r.kind == KIND_SILENT) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
@@ -458,15 +548,19 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.gain = 0.0f;
         r.g[0] = 0.0f;
         r.g[1] = 0.0f;
-        r.kind = KIND_UNITY;
+        r.format = mode == MODE_I16 ? FMT_I16 : mode == MODE_I32 ? FMT_I32 : FMT_F32;
+        r.kind = mode == MODE_I16 ? KIND_UNITY_I16 : mode == MODE_I32 ? KIND_UNITY_I32 : KIND_UNITY;
       }
     }
-    const int any_window = __syncthreads_or(is_window);   // also the barrier after the null-record fill
+    __syncthreads();
 
-    if (any_window)
-      pipeline(std::true_type{}, cn);
-    else
-      pipeline(std::false_type{}, cn);
+    switch (mode) {
+      case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn); break;
+      case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn); break;
+      case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
+      case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
+      default: mixed(cn); break;
+    }
 
     __syncthreads();
     if (tid < cn * C) {

@@ -969,7 +969,8 @@ namespace {
 void note_clip(wbx_engine* e, const DClip& c) {
   const DSample& smp = e->ctx->clips[c.sample].d;
   const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * c.speed;   // sampler.h:24
-  if (smp.format != FMT_F32 || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
+  // every block of such a clip goes through the pre-render pass: resampled integer PCM, fast-forward
+  if ((smp.format != FMT_F32 && ps != 1.0) || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
   if (ps != 1.0) e->any_window_clip = true;
 }
 

@@ -330,6 +330,9 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
   if (tb.nseg == 1) {
     const DTrackBlock& s = tb;
     if (s.len == 0) return KIND_SILENT;
+    if (s.format != FMT_F32 && s.dst_start == 0 && s.len == block_frames && s.pos >= 0.0 && s.pos < 2147483000.0 &&
+        s.speed == 1.0)                                          // integer PCM streamed at unity speed, sampler.cpp:109-144
+      return s.format == FMT_I16 ? KIND_UNITY_I16 : KIND_UNITY_I32;
     if (s.format == FMT_F32 && s.dst_start == 0 && s.len == block_frames && s.pos >= 0.0 && s.pos < 2147483000.0) {
       if (s.speed == 1.0) return KIND_UNITY;                     // sampler.cpp:106
       // taps of 4 consecutive frames fit a 5-sample window only while floor(x_e) - floor(x_0) <= e: keep a
