@@ -485,3 +485,25 @@ def test_mixed_storage_formats_in_one_group():
     for t in range(spec.n_tracks):
         spec.volumes_db[t] = -42.0
     check_against_oracle(spec, 6, expect_exact=True)
+
+
+def test_long_batches_and_ragged_track_counts():
+    """K up to the configured maximum, track counts that do not fill the last 64-lane plan workgroup, and
+    batches of odd length."""
+    for n_tracks, n_blocks in ((70, 13), (5, 1), (130, 27)):
+        spec = synth.make_session("ragK", n_tracks, seek=True, src_rate=44100, n_blocks=n_blocks, seed=0xB00 + n_tracks)
+        check_against_oracle(spec, n_blocks, group_size=32)
+    spec = synth.make_session("bigK", 3, n_blocks=2048, seed=0xB10, src_rate=44100)
+    e = O.build_oracle_engine(spec)
+    e.play()
+    eng = build_engine(spec, max_blocks=2048)
+    eng.play()
+    eng.render(2048)
+    m, _, _ = eng.ctx.fetch()
+    for b in range(2048):
+        om, _ = e.process()
+        if b % 97 == 0 or b > 2040:
+            assert np.array_equal(bits(m[b]), bits(om)), b
+    assert O.f64_bits(eng.transport()[0]) == O.f64_bits(e.playhead)
+    e.close()
+    eng.close()

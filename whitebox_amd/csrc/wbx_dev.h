@@ -101,6 +101,22 @@ struct DTrackBlock {
 static_assert(sizeof(DSeg) == 48, "DSeg must be 48 bytes");
 static_assert(sizeof(DTrackBlock) == 64, "DTrackBlock must be 64 bytes");
 
+// The plan a render hands from the sequencer to the mix kernel is two-level.  Per (block, track) there is one
+// 16-B DRow; the 64-B DTrackBlock records it refers to ("templates") are shared: a clip playing through many
+// blocks produces ONE template (everything but the position) and a row per block that carries the sampler
+// position, while a block with events owns a complete template.  Rows of consecutive tracks are adjacent, so
+// the sequencer's stores are coalesced and a steady track-block costs 16 B of plan traffic, not 64.
+struct DRow {
+  double pos;        // Sampler::sample_offset_ at the start of the block (valid with ROW_POS)
+  uint32_t tmpl;     // index of the DTrackBlock template; unused for ROW_SILENT
+  uint32_t flags;    // ROW_*
+};
+enum : uint32_t {
+  ROW_SILENT = 1,    // nothing to render for this track in this block
+  ROW_POS = 2        // the template is shared by a run of blocks: take the position from the row
+};
+static_assert(sizeof(DRow) == 16, "DRow must be 16 bytes");
+
 struct DBlockTime {       // per-block transport scalars computed by the host exactly as engine.cpp:1578-1585
   double start_time, end_time, sample_position, beat_duration;
 };
@@ -118,12 +134,15 @@ struct PlanArgs {
   DTrackState* state;           // [N]
   const DPatch* patch;          // [N] or null
   const float* gains;           // [N][2]
-  DTrackBlock* tb;              // [K][N]
+  DRow* rows;                   // [K][N]
+  DTrackBlock* tmpl;            // [tmpl_cap] templates, allocated with tmpl_count
+  uint32_t* tmpl_count;
+  uint32_t tmpl_cap;
   DSeg* pool;                   // [pool_chunks][kChunk]
   uint32_t* pool_count;         // allocated chunks
   uint32_t* status;             // bit0: pool overflow, bit1: > kMaxSegs calls, bit2: SEG_CLIPPED happened,
-                                // bit3: more generic track-blocks than pre-render rows
-  uint32_t* gen_list;           // [gen_cap] index (b*N+t) of every KIND_GENERIC record
+                                // bit3: more generic track-blocks than pre-render rows, bit4: out of templates
+  uint32_t* gen_list;           // [gen_cap] template index of every KIND_GENERIC record
   uint32_t* gen_count;
   uint32_t gen_cap;
   uint32_t pool_chunks;
@@ -135,7 +154,7 @@ struct PlanArgs {
 };
 
 struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows
-  DTrackBlock* tb;              // [K][N]; rewritten in place to KIND_UNITY records that read the row
+  DTrackBlock* tmpl;            // templates; the queued ones are rewritten in place to KIND_UNITY reads of their row
   const DSeg* pool;
   const uint32_t* gen_list;
   const uint32_t* gen_count;
@@ -145,7 +164,8 @@ struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into 
 };
 
 struct MixArgs {
-  const DTrackBlock* tb;        // [K][N]
+  const DRow* rows;             // [K][N]
+  const DTrackBlock* tmpl;      // templates
   const float* zero_page;       // >= F + 8 zero floats: what padding / silent records read
   const DSeg* pool;
   const uint32_t* order;        // [N] track permutation (routing order)

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
     const uint32_t idx = a.gen_list[i];
     __syncthreads();
-    if (threadIdx.x < 4) reinterpret_cast<uint4*>(&s_rec)[threadIdx.x] = reinterpret_cast<const uint4*>(a.tb + idx)[threadIdx.x];
+    if (threadIdx.x < 4) reinterpret_cast<uint4*>(&s_rec)[threadIdx.x] = reinterpret_cast<const uint4*>(a.tmpl + idx)[threadIdx.x];
     __syncthreads();
     float* row = a.rows + (size_t)i * row_floats;
     for (uint32_t slot = threadIdx.x; slot < C * S4; slot += 256u) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
       u.speed = 1.0;
       u.gain = 1.0f;
       u.kind = KIND_UNITY;
-      a.tb[idx] = u;
+      a.tmpl[idx] = u;
     }
   }
 }
@@ -513,13 +513,23 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
     const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
     __syncthreads();
-    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record
+    // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
+    // A record = the template its 16-B plan row points at, with the row's position patched in when the template
+    // is shared by a run of blocks; silent rows become all-zero records (kind 0).
     for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
       const uint32_t rec = i >> 2, q = i & 3u;
       uint4 w = {0u, 0u, 0u, 0u};
       if (rec < cn) {
         const uint32_t track = a.order[grp.first + chunk0 + rec];
-        w = reinterpret_cast<const uint4*>(a.tb + (size_t)b * N + track)[q];
+        const DRow row = a.rows[(size_t)b * N + track];
+        if (!(row.flags & ROW_SILENT)) {
+          w = reinterpret_cast<const uint4*>(a.tmpl + row.tmpl)[q];
+          if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
+            const uint2 pb = *reinterpret_cast<const uint2*>(&row.pos);
+            w.x = pb.x;
+            w.y = pb.y;
+          }
+        }
       }
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }

@@ -90,10 +90,13 @@ struct wbx_ctx {
   // The plan of a render (track-block records, overflow pool, pre-render queue + rows) is double-buffered:
   // the sequencer of step i+1 runs on `plan_stream` while the mix of step i runs on `stream`.
   struct PlanBuf {
-    DevBuf<DTrackBlock> tb;           // [K][N]
+    DevBuf<DRow> prows;               // [K][N] 16-B plan rows
+    DevBuf<DTrackBlock> tmpl;         // templates the rows point at (one per steady run / per block with events)
+    uint32_t tmpl_cap = 0;
     DevBuf<DSeg> pool;
     uint32_t pool_chunks = 0;
-    uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued
+    uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued,
+                                      // [3] templates allocated
     DevBuf<uint32_t> gen_list;        // pre-render queue of KIND_GENERIC records
     DevBuf<float> rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
     DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
@@ -110,6 +113,7 @@ struct wbx_ctx {
   DevBuf<float> d_partial, d_master, d_buses, d_peaks, d_gains;
   DevBuf<uint8_t> d_conv;
   std::vector<DTrackBlock> h_tb;      // layer-1 staging
+  std::vector<DRow> h_rows;
   std::vector<DSeg> h_pool;
 
   uint32_t last_K = 0, last_N = 0;
@@ -228,15 +232,28 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
 wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
   const size_t CF = (size_t)c->cfg.channels * c->cfg.block_frames;
   for (auto& B : c->pb)
-    if (B.tb.cap < (size_t)K * N) {
+    if (B.prows.cap < (size_t)K * N) {
       WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
       WBX_HIP(c, hipStreamSynchronize(c->stream));
-      WBX_HIP(c, B.tb.ensure((size_t)K * N));
+      WBX_HIP(c, B.prows.ensure((size_t)K * N));
     }
   WBX_HIP(c, c->d_partial.ensure((size_t)K * std::max<size_t>(1, c->groups.size()) * CF));
   WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
   WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
   if (c->n_buses) WBX_HIP(c, c->d_buses.ensure((size_t)K * c->n_buses * CF));
+  return WBX_OK;
+}
+
+// room for `n` templates in both plan buffers (grow-only)
+wbx_status ensure_template_capacity(wbx_ctx* c, size_t n) {
+  n = std::max<size_t>(n, 64);
+  for (auto& B : c->pb) {
+    if (n <= B.tmpl_cap) continue;
+    WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, B.tmpl.ensure(n));
+    B.tmpl_cap = (uint32_t)n;
+  }
   return WBX_OK;
 }
 
@@ -260,7 +277,7 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
 wbx_status launch_pre_render(wbx_ctx* c, hipStream_t on) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   GenArgs ga{};
-  ga.tb = PB(c).tb.p;
+  ga.tmpl = PB(c).tmpl.p;
   ga.pool = PB(c).pool.p;
   ga.gen_list = PB(c).gen_list.p;
   ga.gen_count = PB(c).counters + 2;
@@ -278,7 +295,8 @@ wbx_status launch_pre_render(wbx_ctx* c, hipStream_t on) {
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   MixArgs m{};
-  m.tb = PB(c).tb.p;
+  m.rows = PB(c).prows.p;
+  m.tmpl = PB(c).tmpl.p;
   m.zero_page = c->d_zero.p;
   m.pool = PB(c).pool.p;
   m.order = c->d_order.p;
@@ -443,7 +461,8 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   c->d_order.release();
   c->d_groups.release();
   for (auto& B : c->pb) {
-    B.tb.release();
+    B.prows.release();
+    B.tmpl.release();
     B.pool.release();
     B.gen_list.release();
     B.rows.release();
@@ -577,6 +596,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipStreamSynchronize(c->stream));   // staging vectors are reused
   const uint32_t F = c->cfg.block_frames, C = c->cfg.channels;
   c->h_tb.assign((size_t)K * N, DTrackBlock{});
+  c->h_rows.assign((size_t)K * N, DRow{});
   c->h_pool.clear();
   std::vector<uint32_t> gen_idx;
   uint32_t chunks = 0;
@@ -635,11 +655,18 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     tb.nseg = (uint8_t)(s1 - s0);
     tb.kind = classify(tb, F);
     if (tb.kind == KIND_GENERIC) gen_idx.push_back((uint32_t)bt);
+    // host-sequenced plans use one template per track-block: row bt -> template bt, position inside the template
+    DRow& row = c->h_rows[bt];
+    row.pos = tb.pos;
+    row.tmpl = tb.nseg ? (uint32_t)bt : 0xFFFFFFFFu;
+    row.flags = tb.kind == KIND_SILENT ? ROW_SILENT : 0u;
   }
   st = ensure_gen_capacity(c, gen_idx.size());
   if (st != WBX_OK) return st;
+  st = ensure_template_capacity(c, (size_t)K * N);
+  if (st != WBX_OK) return st;
   {
-    uint32_t counters[4] = {0u, 0u, (uint32_t)gen_idx.size(), 0u};
+    uint32_t counters[4] = {0u, 0u, (uint32_t)gen_idx.size(), (uint32_t)((size_t)K * N)};
     WBX_HIP(c, hipMemcpyAsync(PB(c).counters, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
     if (!gen_idx.empty())
       WBX_HIP(c, hipMemcpyAsync(PB(c).gen_list.p, gen_idx.data(), gen_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -649,7 +676,8 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     WBX_HIP(c, PB(c).pool.ensure((size_t)chunks * kChunk));
     PB(c).pool_chunks = chunks;
   }
-  WBX_HIP(c, hipMemcpyAsync(PB(c).tb.p, c->h_tb.data(), c->h_tb.size() * sizeof(DTrackBlock), hipMemcpyHostToDevice, c->stream));
+  WBX_HIP(c, hipMemcpyAsync(PB(c).tmpl.p, c->h_tb.data(), c->h_tb.size() * sizeof(DTrackBlock), hipMemcpyHostToDevice, c->stream));
+  WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   st = launch_pre_render(c, c->stream);
@@ -685,6 +713,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   WBX_HIP(c, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   if (pc[1] & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
   if (pc[1] & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
+  if (pc[1] & 16u) return fail(c, WBX_ERR_OVERFLOW, "plan template array full");
   return WBX_OK;
 }
 
@@ -1298,6 +1327,9 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
     const size_t rows = e->any_slow_clip ? all : std::min(all, 4 * e->total_clips + 2 * (size_t)N + 64);
     st = ensure_gen_capacity(c, rows);
     if (st != WBX_OK) return st;
+    // templates: one per block with events (same bound as above) + one per steady run (a run ends at every event)
+    st = ensure_template_capacity(c, std::min(all, rows + 2 * (size_t)N + 64) + (size_t)N);
+    if (st != WBX_OK) return st;
   }
 
   // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
@@ -1315,7 +1347,10 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   a.state = e->d_state.p;
   a.patch = d_patch;
   a.gains = e->d_gains.p;
-  a.tb = B.tb.p;
+  a.rows = B.prows.p;
+  a.tmpl = B.tmpl.p;
+  a.tmpl_count = B.counters + 3;
+  a.tmpl_cap = B.tmpl_cap;
   a.pool = B.pool.p;
   a.pool_count = B.counters;
   a.status = B.counters + 1;
@@ -1400,9 +1435,15 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   std::vector<DTrackBlock> tb((size_t)K * N);
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  WBX_EHIP(e, hipMemcpy(tb.data(), PB(c).tb.p, tb.size() * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
   WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
-  {   // records the pre-render pass rewrote: put the sequencer's originals back
+  {
+    // rebuild the per-(block, track) records from the 16-B rows and the templates they point at
+    std::vector<DRow> rows((size_t)K * N);
+    const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);
+    std::vector<DTrackBlock> tmpl(nt);
+    WBX_EHIP(e, hipMemcpy(rows.data(), PB(c).prows.p, rows.size() * sizeof(DRow), hipMemcpyDeviceToHost));
+    if (nt) WBX_EHIP(e, hipMemcpy(tmpl.data(), PB(c).tmpl.p, nt * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+    // templates the pre-render pass rewrote: put the sequencer's originals back
     const uint32_t ng = std::min(pc[2], PB(c).gen_cap);
     if (ng) {
       std::vector<uint32_t> idx(ng);
@@ -1410,7 +1451,13 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
       WBX_EHIP(e, hipMemcpy(idx.data(), PB(c).gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
       WBX_EHIP(e, hipMemcpy(saved.data(), PB(c).saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
       for (uint32_t i = 0; i < ng; i++)
-        if (idx[i] < tb.size()) tb[idx[i]] = saved[i];
+        if (idx[i] < tmpl.size()) tmpl[idx[i]] = saved[i];
+    }
+    for (size_t i = 0; i < rows.size(); i++) {
+      tb[i] = DTrackBlock{};
+      if (rows[i].tmpl >= tmpl.size()) continue;   // no stream call at all in this track-block
+      tb[i] = tmpl[rows[i].tmpl];
+      if (rows[i].flags & ROW_POS) tb[i].pos = rows[i].pos;
     }
   }
   const uint32_t used = std::min(pc[0], PB(c).pool_chunks);

@@ -343,6 +343,21 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
   return KIND_GENERIC;
 }
 
+// a slot in the render's template array (0xFFFFFFFF + status bit 4 when the array is full)
+__host__ __device__ inline uint32_t alloc_template(const PlanArgs& a) {
+  uint32_t i;
+#if defined(__HIP_DEVICE_COMPILE__)
+  i = atomicAdd(a.tmpl_count, 1u);
+#else
+  i = (*a.tmpl_count)++;
+#endif
+  if (i >= a.tmpl_cap) {
+    if (a.status) a.status[0] |= 16u;
+    return 0xFFFFFFFFu;
+  }
+  return i;
+}
+
 // One track, one block: Track::process minus the per-sample work (track.cpp:587-736).
 __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
                                                  DClip* clips, uint32_t num_clips, TrackCache* cache,
@@ -396,15 +411,29 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   tb->nseg = (uint8_t)w.nseg;
   tb->_pad = 0;
   tb->kind = classify(*tb, a.block_frames);
+  uint32_t tmpl_index = 0xFFFFFFFFu;
   {
     const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
-    uint4* dstq = reinterpret_cast<uint4*>(&a.tb[(size_t)b * a.n_tracks + t]);
-    dstq[0] = srcq[0];
-    dstq[1] = srcq[1];
-    dstq[2] = srcq[2];
-    dstq[3] = srcq[3];
+    DRow row;
+    row.pos = rec.pos;
+    row.tmpl = 0xFFFFFFFFu;
+    row.flags = ROW_SILENT;
+    if (rec.nseg != 0) {   // also for calls that render nothing (finished clip): the plan keeps every stream call
+      const uint32_t ti = alloc_template(a);
+      if (ti != 0xFFFFFFFFu) {
+        uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
+        dstq[0] = srcq[0];
+        dstq[1] = srcq[1];
+        dstq[2] = srcq[2];
+        dstq[3] = srcq[3];
+        row.tmpl = ti;
+        row.flags = rec.kind == KIND_SILENT ? ROW_SILENT : 0u;
+      }
+    }
+    *reinterpret_cast<uint4*>(&a.rows[(size_t)b * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
+    tmpl_index = row.tmpl;
   }
-  if (tb->kind == KIND_GENERIC) {   // queue it for the pre-render pass
+  if (tb->kind == KIND_GENERIC && tmpl_index != 0xFFFFFFFFu) {   // queue it for the pre-render pass
     uint32_t row;
 #if defined(__HIP_DEVICE_COMPILE__)
     row = atomicAdd(a.gen_count, 1u);
@@ -412,7 +441,7 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
     row = (*a.gen_count)++;
 #endif
     if (row < a.gen_cap)
-      a.gen_list[row] = b * a.n_tracks + t;
+      a.gen_list[row] = tmpl_index;
     else if (a.status)
       a.status[0] |= 8u;
   }
@@ -473,18 +502,30 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   }
   const uint32_t n_time = lo;
   double off = st->sample_offset;
-  uint32_t n = 0;
-  while (n < n_time) {
-    if (!(off + guard <= cnt && (cnt - off) < qmax)) break;   // near the clip tail: general path (exact division)
-    rec.pos = off;
-    rec.kind = classify(rec, F);
-    if (rec.kind == KIND_GENERIC) break;                   // needs the pre-render queue: general path
+  // the shape of every record of the run (classify only looks at the position through its range check)
+  if (n_time == 0 || !(off + guard <= cnt && (cnt - off) < qmax)) return 0;
+  rec.pos = off;
+  rec.kind = classify(rec, F);
+  if (rec.kind == KIND_GENERIC || rec.kind == KIND_SILENT) return 0;   // general path (pre-render queue)
+  const uint32_t ti = alloc_template(a);
+  if (ti == 0xFFFFFFFFu) return 0;
+  {
     const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
-    uint4* dstq = reinterpret_cast<uint4*>(&a.tb[(size_t)(b + n) * a.n_tracks + t]);
+    uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
     dstq[0] = srcq[0];
     dstq[1] = srcq[1];
     dstq[2] = srcq[2];
     dstq[3] = srcq[3];
+  }
+  DRow row;
+  row.tmpl = ti;
+  row.flags = ROW_POS;
+  uint32_t n = 0;
+  while (n < n_time) {
+    // near the clip tail the general path takes over (exact division); 2147483000 is classify's position bound
+    if (!(off + guard <= cnt && (cnt - off) < qmax && off < 2147483000.0)) break;
+    row.pos = off;
+    *reinterpret_cast<uint4*>(&a.rows[(size_t)(b + n) * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
     off = off + step;                                      // sampler.cpp:209
     n++;
   }
