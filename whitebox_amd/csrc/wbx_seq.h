@@ -521,6 +521,26 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   row.tmpl = ti;
   row.flags = ROW_POS;
   uint32_t n = 0;
+  {
+    // Most of the run is far from the clip tail.  The tail / position guards below hold for block i as long as
+    // off_i <= lim; off_i grows by one rounded addition per block, so off_i <= (off_0 + i*step) + i*ulp and a
+    // whole frame of slack covers the accumulated rounding of any batch (i <= 2048, values < 2^31).  Those
+    // blocks need no per-block test: the loop carries nothing but the fp64 addition.
+    const double lim = (cnt - guard < 2147482999.0 ? cnt - guard : 2147482999.0) - 1.0;
+    uint32_t n_safe = 0;
+    if (off <= lim) {
+      const double q = (lim - off) / step;
+      n_safe = q >= 4096.0 ? 4096u : (uint32_t)q;
+    }
+    if (n_safe > n_time) n_safe = n_time;
+    DRow* dst = &a.rows[(size_t)b * a.n_tracks + t];
+    for (; n < n_safe; n++) {
+      row.pos = off;
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&row);
+      dst += a.n_tracks;
+      off = off + step;                                    // sampler.cpp:209
+    }
+  }
   while (n < n_time) {
     // near the clip tail the general path takes over (exact division); 2147483000 is classify's position bound
     if (!(off + guard <= cnt && (cnt - off) < qmax && off < 2147483000.0)) break;
