@@ -252,12 +252,15 @@ __device__ __forceinline__ void taps(const f4& v, float w4, int k, float& sa, fl
 
 // max over the 64 lanes of a wave, delivered in lane 63, with DPP row operations only (no LDS crossbar):
 // quad butterflies, row_half_mirror, row_mirror, then row_bcast:15 / row_bcast:31 into the upper rows.
+// The values are non-negative floats, so the comparison is done on their bit patterns as unsigned integers:
+// 0 is the identity (what a masked-out row keeps), no NaN canonicalisation is needed, and each step folds into
+// one v_max_u32 with a DPP source operand.
 __device__ __forceinline__ float wave_max_lane63(float x) {
-  int v = __float_as_int(x);
-#define WBX_DPP_MAX(ctrl, rmask)                                                                     \
-  {                                                                                                 \
-    const int o = __builtin_amdgcn_update_dpp(v, v, (ctrl), (rmask), 0xF, false);                    \
-    v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(o)));                                 \
+  uint32_t v = __float_as_uint(x);
+#define WBX_DPP_MAX(ctrl, rmask)                                                                      \
+  {                                                                                                  \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, (ctrl), (rmask), 0xF, true);  \
+    v = v > o ? v : o;                                                                               \
   }
   WBX_DPP_MAX(0xB1, 0xF)    // quad_perm [1,0,3,2]
   WBX_DPP_MAX(0x4E, 0xF)    // quad_perm [2,3,0,1]
@@ -266,7 +269,7 @@ __device__ __forceinline__ float wave_max_lane63(float x) {
   WBX_DPP_MAX(0x142, 0xA)   // row_bcast:15 -> rows 1 and 3
   WBX_DPP_MAX(0x143, 0xC)   // row_bcast:31 -> rows 2 and 3: lane 63 holds the wave maximum
 #undef WBX_DPP_MAX
-  return __int_as_float(v);
+  return __uint_as_float(v);
 }
 
 enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4 };   // row shapes of a staged chunk
@@ -299,7 +302,8 @@ template <int U, bool FULL, int W>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   constexpr uint32_t kRecs = kStage + 2 * U;   // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kRecs];
-  __shared__ uint32_t s_pk[kRecs * 2];
+  __shared__ uint32_t s_pk[kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
+  __shared__ uint32_t s_wc[4];           // FULL: the channel each wave works on
 
   const uint32_t b = blockIdx.x, g = blockIdx.y, tile = blockIdx.z;
   const uint32_t tid = threadIdx.x;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   auto post_peak = [&](float pk, uint32_t tl) {
     if (FULL) {
       pk = wave_max_lane63(pk);
-      if (lane == 63u) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
+      if (lane == 63u) s_pk[tl * 4u + (tid >> 6)] = __float_as_uint(pk);   // this wave's own slot: no atomic
     } else {
       for (uint32_t off = 1; off < span; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
       if ((lane & (span - 1u)) == 0u && active) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
@@ -533,7 +537,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }
-    if (tid < kRecs * 2u) s_pk[tid] = 0u;
+    for (uint32_t i = tid; i < kRecs * 4u; i += 256u) s_pk[i] = 0u;
+    if (FULL && lane == 0u) s_wc[tid >> 6] = c;
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
@@ -577,12 +582,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const uint32_t rec = tid / C, ch = tid - rec * C;
       const uint32_t track = a.order[grp.first + chunk0 + rec];
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)b * N + track) * C + ch;
+      uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
+      if (FULL) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++)
+          if (s_wc[w] == ch) pk = pk > s_pk[rec * 4u + w] ? pk : s_pk[rec * 4u + w];
+      } else {
+        pk = s_pk[rec * 2u + ch];
+      }
       if (a.tiles == 1u)
-        *dst = s_pk[rec * 2u + ch];
+        *dst = pk;
       else
-        atomicMax(dst, s_pk[rec * 2u + ch]);   // peaks are non-negative floats: uint order == float order
+        atomicMax(dst, pk);
       // VUMeter::level keeps the maximum until the UI reads it (vu_meter.h:26-29)
-      if (a.levels && s_pk[rec * 2u + ch] != 0u) atomicMax(a.levels + (size_t)track * C + ch, s_pk[rec * 2u + ch]);
+      if (a.levels && pk != 0u) atomicMax(a.levels + (size_t)track * C + ch, pk);
     }
   }
 
