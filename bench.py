@@ -149,6 +149,12 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
             "us_per_block": 1e6 * elapsed / blocks_done}
 
 
+def mix_kernel_name(resampled):
+    """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides)."""
+    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (16 if resampled else 43)
+    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,7 +328,7 @@ def main():
             "track_frames_per_s": total_tracks * master_frames / dt,
             "realtime_factor": master_frames / dt / SR,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "wbx::mix_kernel<2,true,4>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate != SR),
                          "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n),
                          "algorithmic_bytes_per_launch": alg},
         }
