@@ -223,30 +223,60 @@ __global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
   }
 }
 
+// max |m| over the 4 frames of a lane (vu_meter.h:20-25).  The operands are results of fp32 multiplies (never
+// signalling NaNs), so the source modifiers can be used directly: two instructions instead of the four that
+// fmaxf's canonicalisation rules cost.
 __device__ __forceinline__ float absmax4(f4 m) {
-  return fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
+  float t;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(m.x), "v"(m.y), "v"(m.z));
+  asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(t) : "v"(m.w), "v"(t));
+  return t;
 }
 
 // Branch-free tap selection for the 5-sample window: returns w[k] / w[k+1] for k in [0, E].
-// Written as a chain of compare+select on purpose — an if/switch here becomes exec-mask control flow.
+// Selection is done with sign masks and v_bfi_b32 ((m & a) | (~m & b)) rather than compare + v_cndmask_b32: on
+// gfx950 a VCC-conditioned v_cndmask_b32 issues at about a fifth of the rate of a plain VALU op
+// (tools/ubench/valu_rate.hip), and an if/switch would become exec-mask control flow.
+__device__ __forceinline__ float sel_neg(int t, float a, float b) {   // t < 0 ? a : b
+  const int m = t >> 31;
+  float r;   // inline asm: the optimiser would fold the mask form back into compare + v_cndmask_b32
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
 template <int E>
 __device__ __forceinline__ void taps(const f4& v, float w4, int k, float& sa, float& sb) {
   sa = v.x;
   sb = v.y;
   if (E >= 1) {
-    const bool p = k >= 1;
-    sa = p ? v.y : sa;
-    sb = p ? v.z : sb;
+    sa = sel_neg(k - 1, sa, v.y);
+    sb = sel_neg(k - 1, sb, v.z);
   }
   if (E >= 2) {
-    const bool p = k >= 2;
-    sa = p ? v.z : sa;
-    sb = p ? v.w : sb;
+    sa = sel_neg(k - 2, sa, v.z);
+    sb = sel_neg(k - 2, sb, v.w);
   }
   if (E >= 3) {
-    const bool p = k >= 3;
-    sa = p ? v.w : sa;
-    sb = p ? w4 : sb;
+    sa = sel_neg(k - 3, sa, v.w);
+    sb = sel_neg(k - 3, sb, w4);
+  }
+}
+
+// The same selection when the playback speed lies in [kNarrowSpeed, 0.999]: frame j0+E then starts at window
+// sample E-1 or E (E*speed + frac(x0) lies in (E-1, E+1) with margin far above the fp64 rounding of the
+// positions), so one mask and two selects per frame are enough.
+constexpr double kNarrowSpeed = 0.67;
+template <int E>
+__device__ __forceinline__ void taps_narrow(const f4& v, float w4, int k, float& sa, float& sb) {
+  const int t = k - E;   // negative: the frame starts at window sample E-1
+  if (E == 1) {
+    sa = sel_neg(t, v.x, v.y);
+    sb = sel_neg(t, v.y, v.z);
+  } else if (E == 2) {
+    sa = sel_neg(t, v.y, v.z);
+    sb = sel_neg(t, v.z, v.w);
+  } else {
+    sa = sel_neg(t, v.z, v.w);
+    sb = sel_neg(t, v.w, w4);
   }
 }
 
@@ -272,7 +302,30 @@ __device__ __forceinline__ float wave_max_lane63(float x) {
   return __uint_as_float(v);
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4 };   // row shapes of a staged chunk
+// The wave maxima of FOUR tracks at once (values non-negative floats compared as unsigned integers).  gfx950's
+// v_permlane32_swap / v_permlane16_swap transpose while reducing: after two levels the four 16-lane rows of one
+// register hold the partial maxima of tracks 0, 2, 1, 3, and the four DPP row steps finish all of them together
+// — 10 VALU instructions per four tracks instead of 24.  Every lane of row r returns the maximum of track
+// kQuadRowTrack[r].
+__device__ __forceinline__ uint32_t wave_max_quad(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+  const u2v a = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);   // {p0.lo | p1.lo}, {p0.hi | p1.hi}
+  const uint32_t m01 = a.x > a.y ? a.x : a.y;                             // lanes 0-31: track 0, lanes 32-63: track 1
+  const u2v b = __builtin_amdgcn_permlane32_swap(p2, p3, false, false);
+  const uint32_t m23 = b.x > b.y ? b.x : b.y;
+  const u2v c = __builtin_amdgcn_permlane16_swap(m01, m23, false, false); // rows {0:t0 2:t2 1:t1 3:t3} x two halves
+  uint32_t v = c.x > c.y ? c.x : c.y;
+#define WBX_DPP_MAX(ctrl)                                                                         \
+  {                                                                                               \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, (ctrl), 0xF, 0xF, true);  \
+    v = v > o ? v : o;                                                                            \
+  }
+  WBX_DPP_MAX(0xB1) WBX_DPP_MAX(0x4E) WBX_DPP_MAX(0x141) WBX_DPP_MAX(0x140)
+#undef WBX_DPP_MAX
+  return v;
+}
+
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -300,7 +353,7 @@ struct Pre {
 // ------------------------------------------------------------------------------------------------
 template <int U, bool FULL, int W>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
-  constexpr uint32_t kRecs = kStage + 2 * U;   // staged records + null padding for the last batches
+  constexpr uint32_t kRecs = kStage + 2 * U + 4;   // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kRecs];
   __shared__ uint32_t s_pk[kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[4];           // FULL: the channel each wave works on
@@ -362,7 +415,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return m;
   };
   // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
-  auto row_window = [&](const Pre& p, double pos, double speed, float cg, float gc) {
+  auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+    constexpr bool NARROW = decltype(narrow)::value;
     const int ix0 = p.ix0;
     float q[4];
     {   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
@@ -374,7 +428,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
     const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
     float sa, sb;                                                                                       \
-    taps<E>(p.v, p.w4, (int)x - ix0, sa, sb);                             /* :51 */                     \
+    if (NARROW)                                                           /* :51 */                     \
+      taps_narrow<E>(p.v, p.w4, (int)x - ix0, sa, sb);                                                  \
+    else                                                                                                \
+      taps<E>(p.v, p.w4, (int)x - ix0, sa, sb);                                                         \
     const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
     q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
   }
@@ -417,6 +474,15 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   };
 
+  // the same for four consecutive tracks tl..tl+3 at once (FULL only): lane 0 of row r stores the wave maximum
+  // of track tl + kQuadRowTrack[r] into this wave's slot
+  const uint32_t quad_slot = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * 4u + (tid >> 6);   // rows hold tracks 0,2,1,3
+  const bool quad_writer = (lane & 15u) == 0u;
+  auto post_peak4 = [&](const float (&pk)[4], uint32_t tl) {
+    const uint32_t v = wave_max_quad(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]));
+    if (quad_writer) s_pk[tl * 4u + quad_slot] = v;
+  };
+
   // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line per mode) ----
   //  MODE_U    every row is an fp32 unity row: one 16-B load per track, no fp64
   //  MODE_W    fp32 rows, some linearly resampled: 16-B + 4-B load per track (unity rows use the same formula)
@@ -427,7 +493,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const DTrackBlock& r = s_tb[u0 + u];
-      if (MODE == MODE_W) {
+      if (MODE == MODE_W || MODE == MODE_WN) {
         load_window(r, pre[u]);
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
@@ -447,19 +513,18 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   };
 
-  // ---- phase B: render, scale, accumulate — strictly in track order; then the per-track peaks -----
-  auto render = [&](auto mode, uint32_t u0, Pre (&pre)[U]) {
+  // ---- phase B: render, scale, accumulate — strictly in track order; pk[u] = per-lane max |m| of track u0+u
+  auto render = [&](auto mode, uint32_t u0, Pre (&pre)[U], float* pk) {
     constexpr int MODE = decltype(mode)::value;
-    float pk[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const DTrackBlock& r = s_tb[u0 + u];
       const float cg = r.gain;
       const float gc = r.g[c];
       f4 m;
-      if (MODE == MODE_W) {
+      if (MODE == MODE_W || MODE == MODE_WN) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
-          m = row_window(pre[u], r.pos, r.speed, cg, gc);
+          m = row_window(std::integral_constant<bool, MODE == MODE_WN>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
       } else if (MODE == MODE_I16) {
@@ -471,19 +536,33 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       pk[u] = add_row(m);
     }
-#pragma unroll
-    for (int u = 0; u < U; u++) post_peak(pk[u], u0 + u);
   };
 
-  // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records)
+  // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records);
+  // one iteration covers kIter = lcm(2U, 4) tracks so that the peaks can be reduced four tracks at a time
   auto pipeline = [&](auto mode, uint32_t cn) {
+    constexpr int kIter = (2 * U) % 4 == 0 ? 2 * U : 4;
     Pre pa[U], pb[U];
     issue(mode, 0, pa);
-    for (uint32_t u0 = 0; u0 < cn; u0 += 2 * U) {
-      issue(mode, u0 + U, pb);
-      render(mode, u0, pa);
-      issue(mode, u0 + 2 * U, pa);
-      render(mode, u0 + U, pb);
+    for (uint32_t u0 = 0; u0 < cn; u0 += kIter) {
+      float pk[kIter];
+#pragma unroll
+      for (int h = 0; h < kIter; h += 2 * U) {
+        issue(mode, u0 + h + U, pb);
+        render(mode, u0 + h, pa, pk + h);
+        issue(mode, u0 + h + 2 * U, pa);
+        render(mode, u0 + h + U, pb, pk + h + U);
+      }
+      if (FULL) {
+#pragma unroll
+        for (int q = 0; q < kIter; q += 4) {
+          const float quad[4] = {pk[q], pk[q + 1], pk[q + 2], pk[q + 3]};
+          post_peak4(quad, u0 + q);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kIter; q++) post_peak(pk[q], u0 + q);
+      }
     }
   };
 
@@ -499,7 +578,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       if (k == KIND_WINDOW) {
         Pre p;
         load_window(r, p);
-        m = row_window(p, r.pos, r.speed, cg, gc);
+        m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
         i2u w = {0, 0};
@@ -545,10 +624,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     if (tid < cn) {
       const int k = s_tb[tid].kind;
       shape = k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : 0;
+      if (k == KIND_WINDOW && !(s_tb[tid].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
     const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
-    const int mode = (!has_i16 && !has_i32) ? (has_win ? MODE_W : MODE_U)
+    const int has_wide = __syncthreads_or(shape & 16);
+    const int mode = (!has_i16 && !has_i32) ? (has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
                      : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
@@ -572,6 +653,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     switch (mode) {
       case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn); break;
       case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn); break;
+      case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn); break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
       case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
       default: mixed(cn); break;
