@@ -151,7 +151,7 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
 
 def mix_kernel_name(resampled):
     """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides)."""
-    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (16 if resampled else 43)
+    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if resampled else 43)
     return f"wbx::mix_kernel<{v // 10}, true, {v % 10}>"
 
 

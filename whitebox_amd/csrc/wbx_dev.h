@@ -16,7 +16,10 @@ namespace wbx {
 constexpr uint32_t kPad = 16;          // Sample::sample_padding
 constexpr uint32_t kMaxSegs = 16;      // Sampler::stream calls per (block, track)
 constexpr uint32_t kChunk = kMaxSegs - 1;  // overflow-pool chunk: segments 1..15 of one track-block
-constexpr uint32_t kStage = 64;        // track-block records staged in LDS at a time
+#ifndef WBX_KSTAGE
+#define WBX_KSTAGE 64
+#endif
+constexpr uint32_t kStage = WBX_KSTAGE;        // track-block records staged in LDS at a time
 
 enum : uint32_t { FMT_I16 = 3, FMT_I24 = 5, FMT_I32 = 7, FMT_F32 = 9 };  // reference AudioFormat values
 

@@ -127,7 +127,7 @@ struct wbx_ctx {
   uint64_t mix_launches = 0;
   bool profiling = true;
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
-                                      // 0 = chosen per render: 16 when resampled clips are present, else 43
+                                      // 0 = chosen per render: 24 when resampled clips are present, else 43
   bool has_window_clips = true;
 };
 
@@ -318,7 +318,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
-    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : (c->has_window_clips ? 16 : 43), c->stream);
+    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : (c->has_window_clips ? 24 : 43), c->stream);
     if (c->profiling) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
       c->ev_pending++;
