@@ -106,6 +106,30 @@ wbx_status wbx_clip_synth(wbx_ctx* ctx, uint32_t clip, int format, uint32_t chan
                           uint64_t frames, uint64_t seed, uint32_t key_track, float amp);
 wbx_status wbx_clip_free(wbx_ctx* ctx, uint32_t clip);
 
+/* Clip ingest: interleaved frames as a decoder delivers them (sf_readf_short/int/float, drmp3_read_pcm_frames_f32)
+ * -> the same planar storage.  Replaces deinterleave_samples<T> + the allocation/padding of Sample::load_file
+ * (src/dsp/sample.cpp:29-43, :127-142, :154-183); the transposition runs on the GPU.
+ *   wbx_clip_upload_interleaved  `interleaved` is host memory ([frames][channels]); staged through pinned chunks
+ *   wbx_clip_ingest_device       `interleaved` is device memory, 16-byte aligned (a GPU decoder / own staging) */
+wbx_status wbx_clip_upload_interleaved(wbx_ctx* ctx, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                                       uint64_t frames, const void* interleaved);
+wbx_status wbx_clip_ingest_device(wbx_ctx* ctx, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                                  uint64_t frames, const void* device_interleaved);
+/* planar clip audio back to the host (tests; also Sample::get_read_pointer's role for host-side tools) */
+wbx_status wbx_clip_download(wbx_ctx* ctx, uint32_t clip, uint32_t channel, void* dst);
+
+/* Waveform peak mip-maps of a resident clip: WaveformVisual::create + summarize_for_mipmaps_impl<T>
+ * (src/gfx/waveform_visual.cpp:9-246).  quality: 0 = Low (int8_t), 1 = High (int16_t) (waveform_visual.h:11-14).
+ * Level l holds, per channel, mip_data_count(l) values = ordered (first, second) min/max pairs of chunks of
+ * 2^(2l+1) samples; layout of a level [channels][mip_data_count] like the reference's upload buffer (:206-226).
+ * Formats: I16, I32, F32 (the reference's switch has no other case). */
+uint32_t wbx_mip_levels(uint64_t frames);                          /* number of levels (:195 while count/4^l > 64) */
+uint64_t wbx_mip_data_count(uint64_t frames, uint32_t level);      /* :197-199 */
+wbx_status wbx_clip_build_mipmaps(wbx_ctx* ctx, uint32_t clip, int quality);
+wbx_status wbx_clip_fetch_mipmap(wbx_ctx* ctx, uint32_t clip, uint32_t level, void* dst);
+/* device pointer + element count of a level (what WaveformMipmap{data, count} holds for the renderer) */
+wbx_status wbx_clip_mipmap_device(wbx_ctx* ctx, uint32_t clip, uint32_t level, const void** data, uint64_t* count);
+
 /* Track -> sub-bus routing (extension of the reference, which has no buses: SURVEY §8(a) A13).
  * track_bus[t] in [0, n_buses) or -1 (straight to master).  NULL / n_buses 0 = reference behaviour. */
 wbx_status wbx_set_routing(wbx_ctx* ctx, uint32_t n_tracks, const int32_t* track_bus, uint32_t n_buses);
@@ -156,6 +180,9 @@ wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);      /
 /* Sample assets (SampleAsset, engine/assets_table.h:22-35): upload once, reference by id from clips. */
 wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
                                  const void* const* planar, uint32_t* sample_out);
+/* the same from interleaved decoder output (wbx_clip_upload_interleaved) */
+wbx_status wbx_engine_add_sample_interleaved(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                             uint64_t frames, const void* interleaved, uint32_t* sample_id);
 wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
                                        uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
                                        uint32_t* sample_out);

@@ -1063,3 +1063,126 @@ void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pa
   }
   for (size_t i = 0; i < pad; i++) dst[frames + i] = 0.0f;
 }
+
+
+/* ================================================================================================
+ * next rows: clip ingest + waveform mip-maps (parity unpinned, see wb_oracle.h)
+ * ================================================================================================ */
+
+/* dsp/sample.cpp:29-43 */
+size_t wbo_deinterleave(void* const* dst, const void* src, size_t num_read, size_t written, int channels, size_t elem) {
+  for (int i = 0; i < channels; i++) {
+    unsigned char* channel_data = (unsigned char*)dst[i];
+    const unsigned char* s = (const unsigned char*)src;
+    for (size_t j = 0; j < num_read; j++)
+      memcpy(channel_data + (written + j) * elem, s + ((size_t)channels * j + (size_t)i) * elem, elem);
+  }
+  return written + num_read;
+}
+
+/* gfx/waveform_visual.cpp:195-239: while (sample_count > 64) { ...; sample_count /= 4; current_mip += 2; } */
+uint32_t wbo_mip_levels(size_t count) {
+  uint32_t n = 0;
+  size_t sample_count = count;
+  while (sample_count > 64) {
+    n++;
+    sample_count /= 4;
+  }
+  return n;
+}
+
+/* :197-199 */
+size_t wbo_mip_data_count(size_t count, uint32_t level) {
+  const uint32_t current_mip = 1u + 2u * level;
+  const size_t block_count = (size_t)1 << (current_mip - 1);
+  size_t mip_data_count = count / block_count;
+  mip_data_count += mip_data_count % 2;
+  return mip_data_count;
+}
+
+/* (T)conv as gcc/x86-64 evaluates it: float/double -> int32 with truncation (cvttss2si / cvttsd2si return
+ * 0x80000000 for NaN and out-of-range), then the low bits of that int */
+static int32_t x86_cvtt_f32(float v) {
+  if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
+  return (int32_t)v;
+}
+static int32_t x86_cvtt_f64(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+  return (int32_t)v;
+}
+
+#define WBO_MIP_BODY(T, TMIN, TMAX, CONVERT)                                                          \
+  for (size_t i = 0; i < output_count; i += 2) {                                                      \
+    size_t idx = i * block_count;                                                                     \
+    size_t chunk_length = chunk_count < sample_count - idx ? chunk_count : sample_count - idx;        \
+    T min_val = TMAX;                                                                                 \
+    T max_val = TMIN;                                                                                 \
+    size_t min_idx = 0, max_idx = 0;                                                                  \
+    for (size_t j = 0; j < chunk_length; j++) {                                                       \
+      T value = (T)(CONVERT);                                                                         \
+      if (value < min_val) {                                                                          \
+        min_val = value;                                                                              \
+        min_idx = j;                                                                                  \
+      }                                                                                               \
+      if (value > max_val) {                                                                          \
+        max_val = value;                                                                              \
+        max_idx = j;                                                                                  \
+      }                                                                                               \
+    }                                                                                                 \
+    if (max_idx < min_idx) {                                                                          \
+      o[i] = max_val;                                                                                 \
+      o[i + 1] = min_val;                                                                             \
+    } else {                                                                                          \
+      o[i] = min_val;                                                                                 \
+      o[i + 1] = max_val;                                                                             \
+    }                                                                                                 \
+  }
+
+/* gfx/waveform_visual.cpp:9-173 */
+void wbo_mip_summarize(int format, size_t count, const void* data, uint32_t level, int out_bits, void* out) {
+  const uint32_t current_mip = 1u + 2u * level;
+  const size_t chunk_count = (size_t)1 << current_mip;
+  const size_t block_count = (size_t)1 << (current_mip - 1);
+  const size_t output_count = wbo_mip_data_count(count, level);
+  const size_t sample_count = count;
+  const double tmin = out_bits == 8 ? -128.0 : -32768.0, tmax = out_bits == 8 ? 127.0 : 32767.0;
+  if (format == 3) {   /* I16, :58-97 */
+    const int16_t* sample = (const int16_t*)data;
+    const float conv_div_min = (float)tmin / (float)-32768.0f;
+    const float conv_div_max = (float)tmax / (float)32767.0f;
+#define CV x86_cvtt_f32((float)sample[idx + j] * (sample[idx + j] >= 0 ? conv_div_max : conv_div_min))
+    if (out_bits == 8) {
+      int8_t* o = (int8_t*)out;
+      WBO_MIP_BODY(int8_t, INT8_MIN, INT8_MAX, CV)
+    } else {
+      int16_t* o = (int16_t*)out;
+      WBO_MIP_BODY(int16_t, INT16_MIN, INT16_MAX, CV)
+    }
+#undef CV
+  } else if (format == 7 || format == 5) {   /* I32, :98-137 (double arithmetic) */
+    const int32_t* sample = (const int32_t*)data;
+    const double conv_div_min = tmin / (double)INT32_MIN;
+    const double conv_div_max = tmax / (double)INT32_MAX;
+#define CV x86_cvtt_f64((double)sample[idx + j] * (sample[idx + j] >= 0 ? conv_div_max : conv_div_min))
+    if (out_bits == 8) {
+      int8_t* o = (int8_t*)out;
+      WBO_MIP_BODY(int8_t, INT8_MIN, INT8_MAX, CV)
+    } else {
+      int16_t* o = (int16_t*)out;
+      WBO_MIP_BODY(int16_t, INT16_MIN, INT16_MAX, CV)
+    }
+#undef CV
+  } else if (format == 9) {   /* F32, :138-170: x * (x >= 0 ? T max : -T min) */
+    const float* sample = (const float*)data;
+    const float kpos = (float)tmax, kneg = (float)(-tmin);
+#define CV x86_cvtt_f32((float)sample[idx + j] * (sample[idx + j] >= 0.0f ? kpos : kneg))
+    if (out_bits == 8) {
+      int8_t* o = (int8_t*)out;
+      WBO_MIP_BODY(int8_t, INT8_MIN, INT8_MAX, CV)
+    } else {
+      int16_t* o = (int16_t*)out;
+      WBO_MIP_BODY(int16_t, INT16_MIN, INT16_MAX, CV)
+    }
+#undef CV
+  }
+}

@@ -204,6 +204,26 @@ void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, dou
                              double beat_duration, double buffer_duration, double sample_rate, uint32_t buffer_size);
                                                                    /* track.cpp:258-451 (audio branch) */
 
+/* ---- next rows: clip ingest and waveform mip-maps ---------------------------------
+ * PARITY UNPINNED for these two: dsp/sample.cpp needs libsndfile/vorbis/dr_mp3 and gfx/waveform_visual.cpp needs
+ * spdlog + the renderer, none of which is in the image, so the reference TUs cannot be compiled here and the
+ * reference holds no test or golden vector for them.  The restatements below follow the cited lines. */
+
+/* deinterleave_samples<T>, dsp/sample.cpp:29-43: dst[c][written + j] = src[channels*j + c]; returns written + n.
+ * elem = bytes per sample (2: I16, 4: I32/F32). */
+size_t wbo_deinterleave(void* const* dst, const void* src, size_t num_read, size_t written, int channels, size_t elem);
+
+/* WaveformVisual::create, gfx/waveform_visual.cpp:181-246: the mip chain of one sample.
+ * level l = 0,1,..: current_mip = 1 + 2l, chunk_count = 2^mip, block_count = 2^(mip-1),
+ * mip_data_count = count/block_count rounded up to even; levels exist while count / 4^l > 64. */
+uint32_t wbo_mip_levels(size_t count);
+size_t wbo_mip_data_count(size_t count, uint32_t level);
+/* summarize_for_mipmaps_impl<T>, gfx/waveform_visual.cpp:9-173, one channel, one level.
+ * format: 3 = I16, 7 = I32 (also 24-bit in 32-bit containers), 9 = F32; out_bits: 8 (Low quality) or 16 (High).
+ * out receives mip_data_count values (int8_t or int16_t). Out-of-range float->int conversions follow x86-64
+ * (cvttss2si / cvttsd2si "integer indefinite", then truncation to T). */
+void wbo_mip_summarize(int format, size_t count, const void* data, uint32_t level, int out_bits, void* out);
+
 #ifdef __cplusplus
 }
 #endif

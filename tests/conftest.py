@@ -9,6 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# torch first: it ships its own HIP runtime, and libwbx.so must bind to that copy (same soname) when a test uses
+# both in one process — loaded the other way round, torch finds "no HIP GPUs"
+try:
+    import torch  # noqa: F401
+except Exception:   # pragma: no cover
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref built from /root/reference (this container only)")

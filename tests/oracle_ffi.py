@@ -100,6 +100,13 @@ def lib() -> C.CDLL:
         L.wbo_beat_to_samples.argtypes = [C.c_double] * 3
         L.wbo_samples_to_beat.restype = C.c_double
         L.wbo_samples_to_beat.argtypes = [C.c_double] * 3
+        L.wbo_deinterleave.restype = C.c_size_t
+        L.wbo_deinterleave.argtypes = [c_voidpp, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]
+        L.wbo_mip_levels.restype = C.c_uint32
+        L.wbo_mip_levels.argtypes = [C.c_size_t]
+        L.wbo_mip_data_count.restype = C.c_size_t
+        L.wbo_mip_data_count.argtypes = [C.c_size_t, C.c_uint32]
+        L.wbo_mip_summarize.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.wbo_abs_max.restype = C.c_float
         L.wbo_abs_max.argtypes = [c_f32p, C.c_uint32]
         L.wbo_apply_gain.argtypes = [c_f32p, C.c_uint32, C.c_float]
@@ -367,3 +374,30 @@ def build_oracle_engine(spec) -> OracleEngine:
         rc = eng.add_audio_clip(c.track, c.min_beat, c.max_beat, c.start_offset, ids[sidx], c.speed, c.gain)
         assert rc == 0, f"oracle add_audio_clip failed rc={rc}"
     return eng
+
+
+# ---- next rows: clip ingest + waveform mip-maps (restatements of dsp/sample.cpp:29-43, gfx/waveform_visual.cpp:9-246)
+def oracle_deinterleave(interleaved: np.ndarray, chunk: int = 1024) -> List[np.ndarray]:
+    """Sample::load_file's loop: the decoder hands `chunk` frames at a time (buffer_len_per_channel = 1024)."""
+    a = np.ascontiguousarray(interleaved)
+    frames, ch = a.shape
+    out = [np.zeros(frames, dtype=a.dtype) for _ in range(ch)]
+    ptrs = (C.c_void_p * ch)(*[o.ctypes.data for o in out])
+    written = 0
+    while written < frames:
+        n = min(chunk, frames - written)
+        part = np.ascontiguousarray(a[written:written + n])
+        written = lib().wbo_deinterleave(ptrs, part.ctypes.data, n, written, ch, a.dtype.itemsize)
+    return out
+
+
+def oracle_mip_levels(count: int) -> int:
+    return lib().wbo_mip_levels(count)
+
+
+def oracle_mip(fmt: str, data: np.ndarray, level: int, quality: int) -> np.ndarray:
+    n = lib().wbo_mip_data_count(len(data), level)
+    out = np.zeros(n, dtype=np.int16 if quality else np.int8)
+    d = np.ascontiguousarray(data)
+    lib().wbo_mip_summarize(FMT[fmt], len(d), d.ctypes.data, level, 16 if quality else 8, out.ctypes.data)
+    return out

@@ -54,6 +54,14 @@ SYMBOLS = {
     "wbx_clip_upload": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _pp]),
     "wbx_clip_synth": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, C.c_uint64, _u32, _f]),
     "wbx_clip_free": (C.c_int, [_vp, _u32]),
+    "wbx_clip_upload_interleaved": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _vp]),
+    "wbx_clip_ingest_device": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _vp]),
+    "wbx_clip_download": (C.c_int, [_vp, _u32, _u32, _vp]),
+    "wbx_mip_levels": (_u32, [C.c_uint64]),
+    "wbx_mip_data_count": (C.c_uint64, [C.c_uint64, _u32]),
+    "wbx_clip_build_mipmaps": (C.c_int, [_vp, _u32, C.c_int]),
+    "wbx_clip_fetch_mipmap": (C.c_int, [_vp, _u32, _u32, _vp]),
+    "wbx_clip_mipmap_device": (C.c_int, [_vp, _u32, _u32, _pp, C.POINTER(C.c_uint64)]),
     "wbx_set_routing": (C.c_int, [_vp, _u32, C.POINTER(_i32), _u32]),
     "wbx_submit": (C.c_int, [_vp, _u32, _u32, C.POINTER(Segment), C.POINTER(_u32), C.POINTER(_f)]),
     "wbx_fetch": (C.c_int, [_vp, _fpp, C.POINTER(_f), C.POINTER(_f)]),
@@ -77,6 +85,7 @@ SYMBOLS = {
     "wbx_track_set_mute": (C.c_int, [_vp, _u32, C.c_int]),
     "wbx_track_set_bus": (C.c_int, [_vp, _u32, _i32]),
     "wbx_engine_add_sample": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, _pp, C.POINTER(_u32)]),
+    "wbx_engine_add_sample_interleaved": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, _vp, C.POINTER(_u32)]),
     "wbx_engine_add_sample_synth": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, C.c_uint64, _u32, _f,
                                               C.POINTER(_u32)]),
     "wbx_engine_add_audio_clip": (C.c_int, [_vp, _u32, _d, _d, _d, _u32, _d, _f]),

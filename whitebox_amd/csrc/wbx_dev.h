@@ -189,4 +189,24 @@ struct SumArgs {
   uint32_t clamp;
 };
 
+// ---- waveform mip-maps (wbx_media.hip) ----
+struct MipNode {
+  int mn, mx;        // T-valued
+  int ord;           // 1: maximum first
+  int empty;
+};
+
+constexpr uint32_t kMipTile = 2048;       // samples per workgroup = the chunk of level 5
+constexpr uint32_t kMipTileLevels = 6;    // levels 0..5 are complete inside a tile
+
+struct MipArgs {
+  const void* src;            // one channel of a clip
+  uint64_t count;
+  void* level_out[24];        // this channel's output row of every level
+  uint64_t data_count[24];    // mip_data_count per level
+  uint32_t n_levels;
+  MipNode* tile_nodes;        // [tiles] the level-5 node of every tile (input of the upper levels)
+  uint32_t n_tiles;
+};
+
 }  // namespace wbx

@@ -32,6 +32,9 @@ void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
+void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
+                         hipStream_t s);
+void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s);
 }  // namespace wbx
 
 using namespace wbx;
@@ -42,8 +45,14 @@ constexpr int kEventRing = 64;
 
 struct ClipSlot {
   void* base = nullptr;     // one allocation holding all channels
+  size_t stride = 0;        // bytes between channel rows
   DSample d{};
   bool used = false;
+  // waveform mip-maps (built on request): one allocation, level l at mip_off[l], [channels][mip_count[l]] elements
+  void* mip = nullptr;
+  int mip_bits = 0;
+  std::vector<size_t> mip_off;
+  std::vector<uint64_t> mip_count;
 };
 
 template <class T>
@@ -455,8 +464,10 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto& s : c->clips)
+  for (auto& s : c->clips) {
     if (s.base) (void)hipFree(s.base);
+    if (s.mip) (void)hipFree(s.mip);
+  }
   c->d_samples.release();
   c->d_order.release();
   c->d_groups.release();
@@ -503,6 +514,7 @@ static wbx_status clip_alloc(wbx_ctx* c, uint32_t clip, int format, uint32_t cha
   if (s.base) {
     WBX_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(s.base);
+    if (s.mip) (void)hipFree(s.mip);
     s = ClipSlot{};
   }
   const size_t stride = align_up((frames + kPad) * eb, 256);
@@ -514,6 +526,7 @@ static wbx_status clip_alloc(wbx_ctx* c, uint32_t clip, int format, uint32_t cha
   s.d.channels = channels;
   s.d.sample_rate = sample_rate;
   s.used = true;
+  s.stride = stride;
   c->samples_dirty = true;
   *stride_out = stride;
   return WBX_OK;
@@ -549,10 +562,168 @@ extern "C" wbx_status wbx_clip_synth(wbx_ctx* c, uint32_t clip, int format, uint
   return WBX_OK;
 }
 
+
+// ---- clip ingest (dsp/sample.cpp:29-43, :112-197) ------------------------------------------------
+extern "C" wbx_status wbx_clip_ingest_device(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
+                                             uint64_t frames, const void* device_interleaved) {
+  if (!c || (!device_interleaved && frames)) return WBX_ERR_INVALID;
+  if ((uintptr_t)device_interleaved & 15u) return fail(c, WBX_ERR_INVALID, "interleaved device buffer must be 16-byte aligned");
+  size_t stride = 0;
+  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
+  if (st != WBX_OK) return st;
+  const size_t eb = fmt_bytes(format);
+  ClipSlot& s = c->clips[clip];
+  // the 16 padding frames (and the alignment slack) read as zero: sample.cpp:127,140
+  for (uint32_t ch = 0; ch < channels; ch++)
+    WBX_HIP(c, hipMemsetAsync((char*)s.base + stride * ch + frames * eb, 0, stride - frames * eb, c->stream));
+  launch_deinterleave(device_interleaved, s.base, (char*)s.base + (channels > 1 ? stride : 0), frames, channels, (uint32_t)eb,
+                      c->stream);
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_upload_interleaved(wbx_ctx* c, uint32_t clip, int format, uint32_t channels,
+                                                  uint32_t sample_rate, uint64_t frames, const void* interleaved) {
+  if (!c || (!interleaved && frames)) return WBX_ERR_INVALID;
+  size_t stride = 0;
+  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
+  if (st != WBX_OK) return st;
+  const size_t eb = fmt_bytes(format);
+  ClipSlot& s = c->clips[clip];
+  for (uint32_t ch = 0; ch < channels; ch++)
+    WBX_HIP(c, hipMemsetAsync((char*)s.base + stride * ch + frames * eb, 0, stride - frames * eb, c->stream));
+  // chunks of the decoder's interleaved output go host -> device staging -> transposed into the channel rows;
+  // two staging buffers so the copy of chunk i+1 overlaps the transposition of chunk i
+  const uint64_t chunk_frames = (uint64_t)4 << 20;   // a multiple of 4 frames: lane groups never straddle chunks
+  const size_t chunk_bytes = (size_t)chunk_frames * channels * eb;
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t freed[2] = {nullptr, nullptr};
+  const int nstage = frames > chunk_frames ? 2 : 1;
+  for (int i = 0; i < nstage; i++) {
+    WBX_HIP(c, hipMalloc(&stage[i], std::min<size_t>(chunk_bytes, std::max<size_t>(16, (size_t)frames * channels * eb))));
+    WBX_HIP(c, hipEventCreateWithFlags(&freed[i], hipEventDisableTiming));
+  }
+  hipError_t err = hipSuccess;
+  uint64_t done = 0;
+  for (int i = 0; done < frames && err == hipSuccess; i++) {
+    const uint64_t n = std::min<uint64_t>(chunk_frames, frames - done);
+    const int b = i % nstage;
+    if (i >= nstage) err = hipEventSynchronize(freed[b]);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(stage[b], (const char*)interleaved + (size_t)done * channels * eb, (size_t)n * channels * eb,
+                           hipMemcpyHostToDevice, c->stream);
+    if (err == hipSuccess) {
+      launch_deinterleave(stage[b], (char*)s.base + (size_t)done * eb, (char*)s.base + (channels > 1 ? stride : 0) + (size_t)done * eb,
+                          n, channels, (uint32_t)eb, c->stream);
+      err = hipEventRecord(freed[b], c->stream);
+    }
+    done += n;
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+  for (int i = 0; i < nstage; i++) {
+    (void)hipFree(stage[i]);
+    (void)hipEventDestroy(freed[i]);
+  }
+  if (err != hipSuccess) return fail(c, WBX_ERR_DEVICE, "clip ingest", err);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_download(wbx_ctx* c, uint32_t clip, uint32_t channel, void* dst) {
+  if (!c || !dst || clip >= c->clips.size() || !c->clips[clip].used) return WBX_ERR_INVALID;
+  const ClipSlot& s = c->clips[clip];
+  if (channel >= s.d.channels) return fail(c, WBX_ERR_INVALID, "channel out of range");
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, hipMemcpy(dst, (const char*)s.base + s.stride * channel, (size_t)s.d.count * fmt_bytes((int)s.d.format), hipMemcpyDeviceToHost));
+  return WBX_OK;
+}
+
+// ---- waveform mip-maps (gfx/waveform_visual.cpp:9-246) -------------------------------------------
+extern "C" uint32_t wbx_mip_levels(uint64_t frames) {
+  uint32_t n = 0;
+  for (uint64_t sample_count = frames; sample_count > 64; sample_count /= 4) n++;   // :195, :236
+  return n;
+}
+
+extern "C" uint64_t wbx_mip_data_count(uint64_t frames, uint32_t level) {
+  const uint64_t block_count = (uint64_t)1 << (2u * level);   // 2^(current_mip - 1), current_mip = 1 + 2*level
+  uint64_t n = frames / block_count;                           // :198
+  n += n % 2;                                                  // :199
+  return n;
+}
+
+extern "C" wbx_status wbx_clip_build_mipmaps(wbx_ctx* c, uint32_t clip, int quality) {
+  if (!c || clip >= c->clips.size() || !c->clips[clip].used) return WBX_ERR_INVALID;
+  if (quality != 0 && quality != 1) return fail(c, WBX_ERR_INVALID, "quality: 0 (Low, int8) or 1 (High, int16)");
+  ClipSlot& s = c->clips[clip];
+  const int fmt = (int)s.d.format;
+  if (fmt != FMT_I16 && fmt != FMT_I32 && fmt != FMT_F32) return fail(c, WBX_ERR_UNSUPPORTED, "mip-maps: clip format");
+  (void)hipSetDevice(c->cfg.device);
+  const uint32_t levels = wbx_mip_levels(s.d.count);
+  if (levels > 24) return fail(c, WBX_ERR_UNSUPPORTED, "mip-maps: too many levels");
+  const int bits = quality ? 16 : 8;
+  const size_t esz = bits / 8;
+  if (s.mip) {
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(s.mip);
+    s.mip = nullptr;
+  }
+  s.mip_off.assign(levels, 0);
+  s.mip_count.assign(levels, 0);
+  s.mip_bits = bits;
+  size_t total = 0;
+  for (uint32_t l = 0; l < levels; l++) {
+    s.mip_count[l] = wbx_mip_data_count(s.d.count, l);
+    s.mip_off[l] = total;
+    total += align_up((size_t)s.mip_count[l] * s.d.channels * esz, 256);
+  }
+  if (!levels) return WBX_OK;
+  const uint32_t tiles = (uint32_t)((s.d.count + kMipTile - 1) / kMipTile);
+  const size_t nodes_off = total;
+  total += (size_t)tiles * s.d.channels * sizeof(MipNode);
+  WBX_HIP(c, hipMalloc(&s.mip, total));
+  for (uint32_t ch = 0; ch < s.d.channels; ch++) {
+    MipArgs a{};
+    a.src = (const char*)s.base + s.stride * ch;
+    a.count = s.d.count;
+    a.n_levels = levels;
+    a.n_tiles = tiles;
+    a.tile_nodes = (MipNode*)((char*)s.mip + nodes_off) + (size_t)tiles * ch;
+    for (uint32_t l = 0; l < levels; l++) {
+      a.level_out[l] = (char*)s.mip + s.mip_off[l] + (size_t)s.mip_count[l] * ch * esz;
+      a.data_count[l] = s.mip_count[l];
+    }
+    launch_mip(a, fmt, bits, c->stream);
+  }
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_mipmap_device(wbx_ctx* c, uint32_t clip, uint32_t level, const void** data, uint64_t* count) {
+  if (!c || clip >= c->clips.size() || !c->clips[clip].used) return WBX_ERR_INVALID;
+  const ClipSlot& s = c->clips[clip];
+  if (!s.mip_bits || level >= s.mip_off.size()) return fail(c, WBX_ERR_INVALID, "no such mip level (call wbx_clip_build_mipmaps)");
+  if (data) *data = (const char*)s.mip + s.mip_off[level];
+  if (count) *count = s.mip_count[level];
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_clip_fetch_mipmap(wbx_ctx* c, uint32_t clip, uint32_t level, void* dst) {
+  const void* p = nullptr;
+  uint64_t n = 0;
+  wbx_status st = wbx_clip_mipmap_device(c, clip, level, &p, &n);
+  if (st != WBX_OK) return st;
+  if (!dst) return WBX_ERR_INVALID;
+  const ClipSlot& s = c->clips[clip];
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, hipMemcpy(dst, p, (size_t)n * s.d.channels * (s.mip_bits / 8), hipMemcpyDeviceToHost));
+  return WBX_OK;
+}
+
 extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
   if (!c || clip >= c->clips.size() || !c->clips[clip].base) return WBX_ERR_INVALID;
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   (void)hipFree(c->clips[clip].base);
+  if (c->clips[clip].mip) (void)hipFree(c->clips[clip].mip);
   c->clips[clip] = ClipSlot{};
   c->samples_dirty = true;
   return WBX_OK;
@@ -979,6 +1150,15 @@ extern "C" wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t 
   if (!e || !sample_out) return WBX_ERR_INVALID;
   const uint32_t id = (uint32_t)e->ctx->clips.size();
   wbx_status st = wbx_clip_upload(e->ctx, id, format, channels, sample_rate, frames, planar);
+  if (st == WBX_OK) *sample_out = id;
+  return st;
+}
+
+extern "C" wbx_status wbx_engine_add_sample_interleaved(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                                        uint64_t frames, const void* interleaved, uint32_t* sample_out) {
+  if (!e || !sample_out) return WBX_ERR_INVALID;
+  const uint32_t id = (uint32_t)e->ctx->clips.size();
+  wbx_status st = wbx_clip_upload_interleaved(e->ctx, id, format, channels, sample_rate, frames, interleaved);
   if (st == WBX_OK) *sample_out = id;
   return st;
 }

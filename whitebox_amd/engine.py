@@ -110,6 +110,31 @@ class MixContext:
         ptrs = (C.c_void_p * len(data))(*[a.ctypes.data for a in data])
         _check(self.L.wbx_clip_upload(self.h, clip, _ffi.FMT[fmt], len(data), rate, frames, ptrs), "wbx_clip_upload", self.h)
 
+    def clip_upload_interleaved(self, clip: int, fmt: str, rate: int, frames_by_channels: np.ndarray):
+        """Decoder output [frames][channels] -> planar clip storage (deinterleave_samples, dsp/sample.cpp:29-43)."""
+        a = np.ascontiguousarray(frames_by_channels)
+        _check(self.L.wbx_clip_upload_interleaved(self.h, clip, _ffi.FMT[fmt], a.shape[1], rate, a.shape[0], a.ctypes.data),
+               "wbx_clip_upload_interleaved", self.h)
+
+    def clip_ingest_device(self, clip: int, fmt: str, channels: int, rate: int, frames: int, device_ptr: int):
+        _check(self.L.wbx_clip_ingest_device(self.h, clip, _ffi.FMT[fmt], channels, rate, frames, device_ptr),
+               "wbx_clip_ingest_device", self.h)
+
+    def clip_download(self, clip: int, channel: int, frames: int, dtype) -> np.ndarray:
+        out = np.empty(frames, dtype=dtype)
+        _check(self.L.wbx_clip_download(self.h, clip, channel, out.ctypes.data), "wbx_clip_download", self.h)
+        return out
+
+    def build_mipmaps(self, clip: int, quality: int):
+        """WaveformVisual::create (gfx/waveform_visual.cpp:181-246): quality 0 = Low (int8), 1 = High (int16)."""
+        _check(self.L.wbx_clip_build_mipmaps(self.h, clip, quality), "wbx_clip_build_mipmaps", self.h)
+
+    def fetch_mipmap(self, clip: int, level: int, channels: int, frames: int, quality: int) -> np.ndarray:
+        n = self.L.wbx_mip_data_count(frames, level)
+        out = np.empty((channels, n), dtype=np.int16 if quality else np.int8)
+        _check(self.L.wbx_clip_fetch_mipmap(self.h, clip, level, out.ctypes.data), "wbx_clip_fetch_mipmap", self.h)
+        return out
+
     def clip_synth(self, clip: int, fmt: str, channels: int, rate: int, frames: int, seed: int, key_track: int, amp: float):
         _check(self.L.wbx_clip_synth(self.h, clip, _ffi.FMT[fmt], channels, rate, frames, seed, key_track,
                                      np.float32(amp)), "wbx_clip_synth", self.h)
@@ -253,6 +278,14 @@ class Engine:
                "wbx_engine_add_sample", self.h, True)
         return sid.value
 
+    def add_sample_interleaved(self, fmt: str, rate: int, frames_by_channels: np.ndarray) -> int:
+        """The same from a decoder's interleaved [frames][channels] buffer (Sample::load_file, dsp/sample.cpp:112-197)."""
+        a = np.ascontiguousarray(frames_by_channels)
+        sid = C.c_uint32()
+        _check(self.L.wbx_engine_add_sample_interleaved(self.h, _ffi.FMT[fmt], a.shape[1], rate, a.shape[0], a.ctypes.data,
+                                                        C.byref(sid)), "wbx_engine_add_sample_interleaved", self.h, True)
+        return sid.value
+
     def add_sample_synth(self, fmt: str, channels: int, rate: int, frames: int, seed: int, key_track: int, amp: float) -> int:
         sid = C.c_uint32()
         _check(self.L.wbx_engine_add_sample_synth(self.h, _ffi.FMT[fmt], channels, rate, frames, seed, key_track,
@@ -331,7 +364,8 @@ class Engine:
                  r.playback_speed, r.gain, r.flags) for r in arr[:n.value]]
 
 
-def build_engine(spec, max_blocks: int = 8, group_size: int = 0, device: int = 0, device_synth: bool = False) -> Engine:
+def build_engine(spec, max_blocks: int = 8, group_size: int = 0, device: int = 0, device_synth: bool = False,
+                 interleaved_ingest: bool = False) -> Engine:
     """Build a product Engine from a synth.SessionSpec through the reference-shaped API."""
     eng = Engine(max(spec.n_tracks, 1), spec.block, spec.sample_rate, spec.channels, max_blocks=max_blocks,
                  group_size=group_size, device=device)
@@ -346,7 +380,10 @@ def build_engine(spec, max_blocks: int = 8, group_size: int = 0, device: int = 0
             ids.append(eng.add_sample_synth(s.fmt, s.channels, s.rate, s.frames, spec.seed, s.seed_track, s.amp))
         else:
             data = [np.ascontiguousarray(a[:s.frames]) for a in spec.sample_data(i)]
-            ids.append(eng.add_sample(s.fmt, s.rate, data, s.frames))
+            if interleaved_ingest:   # as a decoder would deliver the file: [frames][channels]
+                ids.append(eng.add_sample_interleaved(s.fmt, s.rate, np.stack(data, axis=1)))
+            else:
+                ids.append(eng.add_sample(s.fmt, s.rate, data, s.frames))
     for t in range(spec.n_tracks):
         tr = eng.add_track(f"t{t}")
         tr.set_volume(spec.volumes_db[t])
