@@ -205,7 +205,7 @@ struct MipArgs {
   void* level_out[24];        // this channel's output row of every level
   uint64_t data_count[24];    // mip_data_count per level
   uint32_t n_levels;
-  MipNode* tile_nodes;        // [tiles] the level-5 node of every tile (input of the upper levels)
+  MipNode* tile_nodes;        // [tiles + tiles/4 + 1] the level-5 node of every tile, then scratch of the upper levels
   uint32_t n_tiles;
 };
 

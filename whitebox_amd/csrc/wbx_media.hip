@@ -217,19 +217,32 @@ __global__ __launch_bounds__(256) void mip_tile_kernel(MipArgs a) {
   if (tid == 0) a.tile_nodes[tile] = s_nodes[0];
 }
 
-// levels >= 6: one lane per output pair, merging its 4^(l-5) tile nodes in order (a few thousand nodes per clip)
+// levels >= 6 from the per-tile nodes: ONE workgroup of 1024 lanes walks up the tree, four nodes into one per
+// level, ping-ponging between the two halves of the node scratch (a few thousand nodes per clip — latency, not
+// bandwidth; a chain of 4^(l-5) dependent loads per output, the obvious formulation, costs 10x more).
 template <int BITS>
-__global__ __launch_bounds__(256) void mip_upper_kernel(MipArgs a) {
+__global__ __launch_bounds__(1024) void mip_upper_kernel(MipArgs a) {
   typedef typename std::conditional<BITS == 8, int8_t, int16_t>::type OT;
-  const uint32_t lvl = kMipTileLevels + blockIdx.y;
-  if (lvl >= a.n_levels) return;
-  const uint64_t pair = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  const uint64_t span = (uint64_t)1 << (2u * (lvl - (kMipTileLevels - 1u)));   // tiles per chunk
-  const uint64_t t0 = pair * span;
-  if (t0 >= a.n_tiles) return;
-  MipNode n = mip_empty();
-  for (uint64_t t = t0; t < t0 + span && t < a.n_tiles; t++) n = mip_merge(n, a.tile_nodes[t]);
-  mip_store<OT>((OT*)a.level_out[lvl], pair, a.data_count[lvl], n);
+  MipNode* cur = a.tile_nodes;
+  MipNode* nxt = a.tile_nodes + a.n_tiles;
+  uint64_t n = a.n_tiles;
+  for (uint32_t lvl = kMipTileLevels; lvl < a.n_levels; lvl++) {
+    const uint64_t m = (n + 3u) >> 2;
+    for (uint64_t g = threadIdx.x; g < m; g += 1024u) {
+      MipNode r = cur[4 * g];
+      if (4 * g + 1 < n) r = mip_merge(r, cur[4 * g + 1]);
+      if (4 * g + 2 < n) r = mip_merge(r, cur[4 * g + 2]);
+      if (4 * g + 3 < n) r = mip_merge(r, cur[4 * g + 3]);
+      nxt[g] = r;
+      mip_store<OT>((OT*)a.level_out[lvl], g, a.data_count[lvl], r);
+    }
+    __threadfence_block();
+    __syncthreads();
+    MipNode* t = cur;
+    cur = nxt;
+    nxt = t;
+    n = m;
+  }
 }
 
 void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s) {
@@ -245,12 +258,10 @@ void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s) {
   }
 #undef WBX_MIP
   if (a.n_levels > kMipTileLevels) {
-    // level 6 has ceil(n_tiles / 4) pairs; higher levels fewer — one grid row per level
-    const dim3 ugrid((uint32_t)((a.n_tiles / 4u + 256u) / 256u), a.n_levels - kMipTileLevels);
     if (bits == 8)
-      hipLaunchKernelGGL((mip_upper_kernel<8>), ugrid, block, 0, s, a);
+      hipLaunchKernelGGL((mip_upper_kernel<8>), dim3(1), dim3(1024), 0, s, a);
     else
-      hipLaunchKernelGGL((mip_upper_kernel<16>), ugrid, block, 0, s, a);
+      hipLaunchKernelGGL((mip_upper_kernel<16>), dim3(1), dim3(1024), 0, s, a);
   }
 }
 

@@ -679,7 +679,8 @@ extern "C" wbx_status wbx_clip_build_mipmaps(wbx_ctx* c, uint32_t clip, int qual
   if (!levels) return WBX_OK;
   const uint32_t tiles = (uint32_t)((s.d.count + kMipTile - 1) / kMipTile);
   const size_t nodes_off = total;
-  total += (size_t)tiles * s.d.channels * sizeof(MipNode);
+  const size_t nodes_per_ch = (size_t)tiles + tiles / 4 + 1;   // tile nodes + ping-pong scratch of the upper levels
+  total += nodes_per_ch * s.d.channels * sizeof(MipNode);
   WBX_HIP(c, hipMalloc(&s.mip, total));
   for (uint32_t ch = 0; ch < s.d.channels; ch++) {
     MipArgs a{};
@@ -687,7 +688,7 @@ extern "C" wbx_status wbx_clip_build_mipmaps(wbx_ctx* c, uint32_t clip, int qual
     a.count = s.d.count;
     a.n_levels = levels;
     a.n_tiles = tiles;
-    a.tile_nodes = (MipNode*)((char*)s.mip + nodes_off) + (size_t)tiles * ch;
+    a.tile_nodes = (MipNode*)((char*)s.mip + nodes_off) + nodes_per_ch * ch;
     for (uint32_t l = 0; l < levels; l++) {
       a.level_out[l] = (char*)s.mip + s.mip_off[l] + (size_t)s.mip_count[l] * ch * esz;
       a.data_count[l] = s.mip_count[l];
