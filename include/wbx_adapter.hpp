@@ -161,6 +161,13 @@ struct Engine {
     check(wbx_engine_add_sample(h, format, channels, sample_rate, frames, planar, &id), "add_sample");
     return id;
   }
+  // the same from a decoder's interleaved frames (what Sample::load_file reads: sample.cpp:154-183); the
+  // deinterleave of sample.cpp:29-43 runs on the GPU
+  uint32_t add_sample_interleaved(int format, uint32_t channels, uint32_t sample_rate, uint64_t frames, const void* interleaved) {
+    uint32_t id = 0;
+    check(wbx_engine_add_sample_interleaved(h, format, channels, sample_rate, frames, interleaved, &id), "add_sample_interleaved");
+    return id;
+  }
   // Engine::add_audio_clip(track, name, min_time, max_time, start_offset, clip_info), engine.h:106-113
   void add_audio_clip(Track* track, const std::string& /*name*/, double min_time, double max_time, double start_offset,
                       const AudioClip& clip_info) {
