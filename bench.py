@@ -277,6 +277,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        tail_ms = eng.ctx.tail_time()
         mix_ms, mix_n = eng.ctx.kernel_time()
 
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -329,7 +330,7 @@ def main():
             "realtime_factor": master_frames / dt / SR,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate != SR),
-                         "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n),
+                         "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n), "sum_tail_ms_avg": tail_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
         if lat is not None:

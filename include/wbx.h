@@ -160,6 +160,9 @@ wbx_status wbx_set_master_target(wbx_ctx* ctx, void* device_buffer);
 
 /* Timing of the dominant kernel (HIP events on the ctx stream): average ms per launch since reset. */
 wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t* mix_launches);
+/* Average ms from the end of the mix kernel to the end of the sum kernel over the same launches (launch gap + the
+ * group/bus/master sum including its stores to a host-resident master target); read before resetting. */
+wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
 
 /* ---- layer 2: the engine surface -----------------------------------------------------------
  * Mirrors wb::Engine / wb::Track (src/engine/engine.h, track.h).  Beats are doubles as in the

@@ -72,6 +72,7 @@ SYMBOLS = {
     "wbx_set_clamp": (C.c_int, [_vp, C.c_int]),
     "wbx_set_master_target": (C.c_int, [_vp, _vp]),
     "wbx_kernel_time": (C.c_int, [_vp, C.c_int, C.POINTER(_d), C.POINTER(C.c_uint64)]),
+    "wbx_tail_time": (C.c_int, [_vp, C.POINTER(_d)]),
     "wbx_engine_create": (C.c_int, [C.POINTER(Config), _pp]),
     "wbx_engine_destroy": (None, [_vp]),
     "wbx_engine_last_error": (C.c_char_p, [_vp]),

@@ -336,8 +336,8 @@ struct Pre {
 };
 
 // ------------------------------------------------------------------------------------------------
-// mix: grid = (n_blocks, n_groups, tiles) — consecutive workgroups take consecutive BLOCKS of the same
-// track group, so the workgroups in flight together read long contiguous runs of the same clips.
+// mix: grid = (n_blocks, n_groups, tiles) — the workgroups in flight together work on neighbouring BLOCKS of the
+// same track group (XCD-aware order, see below), so they read long contiguous runs of the same clips.
 // block = 256 lanes (4 waves).  Lane -> (channel c, frames j0..j0+3).  With F = 512, C = 2: waves 0-1
 // own the left channel, waves 2-3 the right one; every wave-level load is one contiguous ~1 KiB row.
 //
@@ -358,7 +358,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   __shared__ uint32_t s_pk[kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[4];           // FULL: the channel each wave works on
 
-  const uint32_t b = blockIdx.x, g = blockIdx.y, tile = blockIdx.z;
+  // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
+  // of a group read adjacent pieces of the same clip rows (they share the cache line at the seam), so give every
+  // XCD a contiguous run of blocks: id x -> block (x % 8) * K/8 + x / 8.
+  uint32_t b = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t g = blockIdx.y, tile = blockIdx.z;
   const uint32_t tid = threadIdx.x;
   const DGroup grp = a.groups[g];
   const uint32_t F = a.block_frames, C = a.channels, N = a.n_tracks;

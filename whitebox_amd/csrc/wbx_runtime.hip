@@ -130,9 +130,10 @@ struct wbx_ctx {
   float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
 
   // kernel timing (mix kernel)
-  hipEvent_t ev[kEventRing][2]{};
+  hipEvent_t ev[kEventRing][3]{};       // before the mix, after the mix, after the sum
   int ev_pending = 0;
   double mix_ms_total = 0.0;
+  double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
   uint64_t mix_launches = 0;
   bool profiling = true;
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
@@ -179,6 +180,7 @@ void drain_events(wbx_ctx* c) {
     if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) {
       c->mix_ms_total += ms;
       c->mix_launches++;
+      if (hipEventElapsedTime(&ms, c->ev[i][1], c->ev[i][2]) == hipSuccess) c->tail_ms_total += ms;
     }
   }
   c->ev_pending = 0;
@@ -330,7 +332,6 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     launch_mix(m, K, c->mix_unroll ? c->mix_unroll : (c->has_window_clips ? 24 : 43), c->stream);
     if (c->profiling) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
-      c->ev_pending++;
     }
   }
   SumArgs s{};
@@ -345,6 +346,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.clamp = c->clamp ? 1u : 0u;
   if (c->n_buses) WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, (size_t)K * c->n_buses * C * F * sizeof(float), c->stream));
   launch_sum(s, K, c->stream);
+  if (m.n_groups && c->profiling) {
+    WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], c->stream));
+    c->ev_pending++;
+  }
   WBX_HIP(c, hipGetLastError());
   c->last_K = K;
   c->last_N = N;
@@ -416,7 +421,8 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     c->own_stream = true;
   }
   for (int i = 0; i < kEventRing; i++) {
-    if (hipEventCreate(&c->ev[i][0]) != hipSuccess || hipEventCreate(&c->ev[i][1]) != hipSuccess) {
+    if (hipEventCreate(&c->ev[i][0]) != hipSuccess || hipEventCreate(&c->ev[i][1]) != hipSuccess ||
+        hipEventCreate(&c->ev[i][2]) != hipSuccess) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
     }
@@ -493,6 +499,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   for (int i = 0; i < kEventRing; i++) {
     if (c->ev[i][0]) (void)hipEventDestroy(c->ev[i][0]);
     if (c->ev[i][1]) (void)hipEventDestroy(c->ev[i][1]);
+    if (c->ev[i][2]) (void)hipEventDestroy(c->ev[i][2]);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -933,8 +940,17 @@ extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg,
   if (mix_launches) *mix_launches = c->mix_launches;
   if (reset) {
     c->mix_ms_total = 0.0;
+    c->tail_ms_total = 0.0;
     c->mix_launches = 0;
   }
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_tail_time(wbx_ctx* c, double* tail_ms_avg) {
+  if (!c || !tail_ms_avg) return WBX_ERR_INVALID;
+  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  *tail_ms_avg = c->mix_launches ? c->tail_ms_total / (double)c->mix_launches : 0.0;
   return WBX_OK;
 }
 

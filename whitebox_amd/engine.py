@@ -202,6 +202,12 @@ class MixContext:
         return ms.value, n.value
 
 
+    def tail_time(self) -> float:
+        ms = C.c_double()
+        _check(self.L.wbx_tail_time(self.h, C.byref(ms)), "wbx_tail_time", self.h)
+        return ms.value
+
+
 class Track:
     """wb::Track surface used by the mix path (track.h:137-139)."""
 
