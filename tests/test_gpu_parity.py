@@ -508,3 +508,31 @@ def test_long_batches_and_ragged_track_counts():
     assert O.f64_bits(eng.transport()[0]) == O.f64_bits(e.playhead)
     e.close()
     eng.close()
+
+
+def test_config5_32768_tracks_sharded_8way_on_one_gpu():
+    """BASELINE config 5 at full size, the 8 shards rendered one after the other on this GPU: every shard's peaks
+    equal the oracle's for its tracks, and the rank-ordered sum of the un-clamped partial masters, clamped after
+    the sum (what the RCCL reduce + wbx_finalize_master do on a node), is within the RMS budget of the
+    single-engine oracle over all 32768 tracks."""
+    from test_dist_gloo import _shard_spec
+    from whitebox_amd.dist import shard_tracks
+    n_tracks, world, K = 32768, 8, 2
+    spec = synth.make_session("c5", n_tracks, n_blocks=K, seed=0x5EED0006)
+    om, opk, _, _, _ = run_oracle(spec, K)
+    total = np.zeros_like(om)
+    for rank in range(world):
+        first, count = shard_tracks(n_tracks, world, rank)
+        assert count == 4096
+        eng = build_engine(_shard_spec(spec, first, count), max_blocks=K)
+        eng.ctx.set_clamp(False)
+        eng.play()
+        eng.render(K)
+        part, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk, opk[:, first:first + count, :spec.channels])
+        total = (total + part).astype(np.float32)          # fp32 sum in rank order
+        eng.close()
+    clamped = np.where(total > 1.0, np.float32(1.0), np.where(total < -1.0, np.float32(-1.0), total))
+    r = rms(clamped, om)
+    print("config5 (8 shards) rms vs oracle:", r)
+    assert r <= RMS_TOL, r
