@@ -536,3 +536,48 @@ def test_config5_32768_tracks_sharded_8way_on_one_gpu():
     r = rms(clamped, om)
     print("config5 (8 shards) rms vs oracle:", r)
     assert r <= RMS_TOL, r
+
+
+def test_tempo_change_and_playhead_jump_while_playing():
+    """Engine::set_bpm (engine.cpp:24-30) and Engine::set_playhead_position (:32-41) between blocks of a running
+    transport: the next block uses the new beat duration / playhead with the tracks' sequencer state untouched, as
+    in the reference.  Master, peaks, the stream-call log and the transport doubles stay bit-equal to the oracle."""
+    spec = synth.make_session("tempo", 40, seek=True, src_rate=44100, n_blocks=12, seed=0x7E)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    eng = build_engine(spec, max_blocks=3, group_size=64)
+    e.play()
+    eng.play()
+    done = 0
+
+    def run(nblk):
+        nonlocal done
+        oms, opks, orow = [], [], []
+        for b in range(nblk):
+            om, _ = e.process()
+            oms.append(om)
+            opks.append(e.peaks())
+            orow += oracle_rows(e, b)
+        eng.render(nblk)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert plan_rows(eng.fetch_plan()) == orow, done
+        assert np.array_equal(pk, np.stack(opks)), done
+        assert np.array_equal(bits(m), bits(np.stack(oms))), done     # 40 tracks < one group: the oracle's order
+        ph, sp, _ = eng.transport()
+        assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position)), done
+        done += nblk
+
+    run(3)
+    e.set_bpm(97.3)
+    eng.set_bpm(97.3)
+    run(3)
+    e.set_playhead(0.013)          # a jump backwards while playing
+    eng.set_playhead_position(0.013)
+    run(3)
+    e.set_bpm(151.0)
+    eng.set_bpm(151.0)
+    e.set_playhead(0.05)
+    eng.set_playhead_position(0.05)
+    run(2)
+    e.close()
+    eng.close()
