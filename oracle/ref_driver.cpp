@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 
+#include "core/algorithm.h"
 #include "core/audio_buffer.h"
 #include "core/audio_format_conv.h"
 #include "core/core_math.h"
@@ -239,6 +240,21 @@ void ref_mix_block(uint32_t n_tracks, uint32_t n_channels, uint32_t n_frames, co
     }
   }
   for (uint32_t c = 0; c < n_channels; c++) std::memcpy(out[c], output.channel_buffers[c], n_frames * sizeof(float));
+}
+
+// core/algorithm.h:24-40 with the comparator of its call sites in the clip sequencer (track.cpp:126-127, :206):
+// index of the first clip whose max_time is not <= value, clamped to the last clip (right starts at n-1)
+uint32_t ref_find_lower_bound_max_time(const double* max_times, uint32_t n, double value) {
+  ClipBox* boxes = new ClipBox[n];
+  wb::Clip** clips = new wb::Clip*[n];
+  for (uint32_t i = 0; i < n; i++) clips[i] = boxes[i].make(0.0, max_times[i], 0.0, 1.0, 48000.0, 0.0);
+  wb::Clip** begin = clips;
+  wb::Clip** end = clips + n;
+  auto it = wb::find_lower_bound(begin, end, value, [](wb::Clip* clip, double time_pos) { return clip->max_time <= time_pos; });
+  const uint32_t idx = (uint32_t)(it - begin);
+  delete[] clips;
+  delete[] boxes;
+  return idx;
 }
 
 // core/audio_format_conv.cpp:5-106

@@ -454,6 +454,15 @@ static uint32_t lower_bound_max_time(const wbo_clip* clips, uint32_t n, double v
   return (uint32_t)right;
 }
 
+/* exposed so that tests can pin it against the reference's own template (oracle/_ref) */
+uint32_t wbo_lower_bound_max_time(const double* max_times, uint32_t n, double value) {
+  wbo_clip* tmp = (wbo_clip*)calloc(n ? n : 1, sizeof(wbo_clip));
+  for (uint32_t i = 0; i < n; i++) tmp[i].max_time = max_times[i];
+  uint32_t r = lower_bound_max_time(tmp, n, value);
+  free(tmp);
+  return r;
+}
+
 /* track.cpp:182-213 — returns 1 and *idx when a next clip exists */
 static int find_next_clip(const wbo_track* t, double time_pos, uint32_t* idx) {
   if (t->n_clips == 0) return 0;

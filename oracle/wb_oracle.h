@@ -173,6 +173,8 @@ void wbo_calc_resize_clip(double clip_min, double clip_max, double clip_start_of
 double wbo_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate);
 /* engine/clip_edit.h:139-150 (audio) */
 double wbo_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos, double beat_duration);
+/* wb::find_lower_bound with the sequencer's predicate (core/algorithm.h:24-40; track.cpp:126-127,206); n >= 1 */
+uint32_t wbo_lower_bound_max_time(const double* max_times, uint32_t n, double value);
 /* Track::query_clip_by_range, track.cpp:112-157: returns 1 and fills first/last when the range touches clips */
 int wbo_track_query_clip_by_range(const wbo_engine* e, int track, double min, double max, uint32_t* first, uint32_t* last);
 /* Engine::move_clip engine.cpp:346-363, resize_clip :365-398, delete_clip :400-407, set_clip_gain :1460-1464,

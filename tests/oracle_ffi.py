@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
         L.wbo_beat_to_samples.argtypes = [C.c_double] * 3
         L.wbo_samples_to_beat.restype = C.c_double
         L.wbo_samples_to_beat.argtypes = [C.c_double] * 3
+        L.wbo_lower_bound_max_time.restype = C.c_uint32
+        L.wbo_lower_bound_max_time.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_double]
         L.wbo_deinterleave.restype = C.c_size_t
         L.wbo_deinterleave.argtypes = [c_voidpp, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]
         L.wbo_mip_levels.restype = C.c_uint32
@@ -195,6 +197,8 @@ def ref() -> Optional[C.CDLL]:
         R.ref_calc_clip_shift.argtypes = [C.c_double] * 4
         R.ref_shift_clip_content.restype = C.c_double
         R.ref_shift_clip_content.argtypes = [C.c_double] * 5
+        R.ref_find_lower_bound_max_time.restype = C.c_uint32
+        R.ref_find_lower_bound_max_time.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_double]
         for name in ("ref_f32_to_i16", "ref_f32_to_i24", "ref_f32_to_i24_x8", "ref_f32_to_i32", "ref_f32_to_f32"):
             getattr(R, name).argtypes = [C.c_void_p, c_f32pp, C.c_size_t, C.c_size_t, C.c_uint32]
         _ref = R

@@ -168,3 +168,18 @@ def test_clip_edit_arithmetic_bit_exact(oracle, reflib):
         a = L.wbo_shift_clip_content(k["so"], k["sp"], k["sr"], k["rel"], k["bd"])
         b = reflib.ref_shift_clip_content(k["so"], k["sp"], k["sr"], k["rel"], k["bd"])
         assert O.f64_bits(a) == O.f64_bits(b)
+
+
+def test_clip_lower_bound_matches_reference_template(oracle, reflib):
+    """wb::find_lower_bound (core/algorithm.h:24-40) instantiated with the clip sequencer's predicate
+    (track.cpp:126-127, :206), against the oracle's restatement — including its quirk of never returning `end`."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    L = oracle.lib()
+    for n in list(range(1, 12)) + [31, 64, 257]:
+        for _ in range(20):
+            times = np.sort(rng.choice(np.arange(0, 40) * 0.25, size=n, replace=True)).astype(np.float64)   # duplicates on purpose
+            for v in list(rng.choice(times, size=min(n, 4))) + [-1.0, 100.0, float(times[0]), float(times[-1]),
+                                                               float(times[n // 2]) + 0.125]:
+                p = times.ctypes.data_as(C.POINTER(C.c_double))
+                assert L.wbo_lower_bound_max_time(p, n, float(v)) == reflib.ref_find_lower_bound_max_time(p, n, float(v)), (n, v)
