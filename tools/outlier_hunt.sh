@@ -1,10 +1,12 @@
 #!/bin/bash
-# repeat the default bench many times and print step / mix / tail per run: what does a slow run look like?
+# repeat the default bench many times and print step / mix / tail / slowest host enqueue per run
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 N=${1:-30}
 for i in $(seq 1 $N); do
-  python $R/bench.py --steps 10 --no-cpu-baseline --latency-blocks 0 2>/dev/null | python -c "
-import sys,json
-d=json.loads([x for x in sys.stdin if x.startswith('{')][-1]); r=d['roofline']
-print('run $i step %.3f mix %.3f tail %.3f other %.3f'%(d['ms_per_step'],r['kernel_ms_avg'],r['sum_tail_ms_avg'],d['ms_per_step']-r['kernel_ms_avg']-r['sum_tail_ms_avg']))"
+  python $R/bench.py --steps 20 --no-cpu-baseline --latency-blocks 0 2>/dev/null > /tmp/oh.json
+  python - $i <<'PY'
+import sys, json
+d = json.loads([x for x in open('/tmp/oh.json') if x.startswith('{')][-1]); r = d['roofline']
+print('run %s step %.3f mix %.3f tail %.3f enq_max %.3f' % (sys.argv[1], d['ms_per_step'], r['kernel_ms_avg'], r['sum_tail_ms_avg'], d['host_enqueue_ms_max']))
+PY
 done

@@ -136,6 +136,7 @@ struct wbx_ctx {
   double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
   uint64_t mix_launches = 0;
   bool profiling = true;
+  hipEvent_t record_after_mix = nullptr;   // recorded between the mix and the sum launch (plan-buffer release)
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
                                       // 0 = chosen per render: 24 when resampled clips are present, else 43
   bool has_window_clips = true;
@@ -334,6 +335,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
   }
+  // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
+  // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
+  // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
+  if (c->record_after_mix) WBX_HIP(c, hipEventRecord(c->record_after_mix, c->stream));
   SumArgs s{};
   s.partial = c->d_partial.p;
   s.groups = c->d_groups.p;
@@ -1575,9 +1580,10 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = e->any_window_clip;
+  c->record_after_mix = B.consumed;
   st = launch_mix_sum(c, K, N);
+  c->record_after_mix = nullptr;
   if (st != WBX_OK) return st;
-  WBX_EHIP(e, hipEventRecord(B.consumed, s));
   B.consumed_valid = true;
 
   // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
