@@ -270,9 +270,11 @@ def main():
             from whitebox_amd.dist import MasterReducer
             masters = [torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda") for _ in range(2)]
             fin_done = [torch.cuda.Event(), torch.cuda.Event()]
+            rendered = [torch.cuda.Event(), torch.cuda.Event()]
             eng.ctx.set_clamp(False)                       # partials are clamped on the root AFTER the reduce
-            red = MasterReducer(lambda buf: eng.ctx.finalize_master(buf.data_ptr(), K, True,
-                                                                    stream=fin_stream.cuda_stream), root=0)
+            # root: clamp after the reduce, straight into pinned host memory (plain kernel stores, no copy engine)
+            red = MasterReducer(lambda buf: eng.ctx.finalize_master_into(buf.data_ptr(), host_master.data_ptr(), K, True,
+                                                                         stream=fin_stream.cuda_stream), root=0)
         else:
             # single GPU: the sum kernel stores the clamped master straight into pinned host memory
             eng.ctx.set_master_target(host_master.data_ptr())
@@ -283,9 +285,8 @@ def main():
         def finish(slot):
             """root: wait for the reduce of `slot`, clamp, copy to the host — all on fin_stream."""
             with torch.cuda.stream(fin_stream):
-                red.finish(masters[slot], slot)
-                if rank == 0:
-                    host_master.copy_(masters[slot], non_blocking=True)
+                fin_stream.wait_event(rendered[slot])          # (the reduce already orders after the render; this
+                red.finish(masters[slot], slot)                #  also covers a single-rank run of this path)
                 fin_done[slot].record(fin_stream)
 
         def step():
@@ -300,6 +301,7 @@ def main():
                     stream.wait_event(fin_done[slot])          # the buffer's previous reduce / copy is over
                 eng.ctx.set_master_target(masters[slot].data_ptr())
                 eng.render(K)
+                rendered[slot].record(stream)
                 red.reduce(masters[slot], slot)                # RCCL sum over xGMI, asynchronous to this stream
                 if nstep >= 1:
                     finish((nstep - 1) & 1)

@@ -153,6 +153,10 @@ wbx_status wbx_partial_master(wbx_ctx* ctx, void** device_ptr, size_t* n_floats)
 /* ... and, on the root after the RCCL reduce, the clamp of engine.cpp:1627-1636 over a device buffer.
  * `stream`: hipStream_t to launch on (e.g. the stream that waited for the collective), NULL = the ctx stream. */
 wbx_status wbx_finalize_master(wbx_ctx* ctx, void* device_partial, uint32_t n_blocks, int clamp, void* stream);
+/* Out of place: clamp (or just move) the reduced master into `dst`, which may be device memory or pinned,
+ * device-mapped host memory — the final master then leaves the GPU as the kernel's own stores. */
+wbx_status wbx_finalize_master_into(wbx_ctx* ctx, const void* device_partial, void* dst, uint32_t n_blocks, int clamp,
+                                    void* stream);
 wbx_status wbx_set_clamp(wbx_ctx* ctx, int clamp_on_submit); /* 0: leave the master un-clamped (shard mode) */
 /* Write the master of later submits/renders into a caller-owned DEVICE buffer of at least
  * max_blocks*C*F floats (e.g. the send buffer of the RCCL reduce); NULL restores the ctx-owned one. */

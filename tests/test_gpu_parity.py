@@ -286,6 +286,18 @@ def test_clamp_and_unclamped_partial():
     m2, _, _ = eng.ctx.fetch()
     assert np.array_equal(bits(m2), bits(om))
     eng.close()
+    # the same, out of place into pinned host memory (what the root rank of a multi-GPU run does after the reduce)
+    import torch
+    eng = build_engine(spec, max_blocks=2)
+    eng.ctx.set_clamp(False)
+    eng.play()
+    eng.render(2)
+    ptr, n = eng.ctx.partial_master()
+    host = torch.zeros(n, dtype=torch.float32).pin_memory()
+    eng.ctx.finalize_master_into(ptr, host.data_ptr(), 2, True)
+    eng.ctx.sync()
+    assert np.array_equal(bits(host.numpy().reshape(om.shape)), bits(om))
+    eng.close()
 
 
 def test_levels_running_max():

@@ -69,6 +69,7 @@ SYMBOLS = {
     "wbx_sync": (C.c_int, [_vp]),
     "wbx_partial_master": (C.c_int, [_vp, _pp, C.POINTER(_sz)]),
     "wbx_finalize_master": (C.c_int, [_vp, _vp, _u32, C.c_int, _vp]),
+    "wbx_finalize_master_into": (C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp]),
     "wbx_set_clamp": (C.c_int, [_vp, C.c_int]),
     "wbx_set_master_target": (C.c_int, [_vp, _vp]),
     "wbx_kernel_time": (C.c_int, [_vp, C.c_int, C.POINTER(_d), C.POINTER(C.c_uint64)]),

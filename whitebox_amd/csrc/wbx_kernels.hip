@@ -769,6 +769,28 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* buf, size_t n) {
   buf[i] = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);
 }
 
+// the same out of place: dst may be pinned host memory (the root's final master leaves the GPU as plain stores of
+// this kernel — no copy-engine transfer, whose completion latency is erratic next to a bandwidth-bound kernel)
+__global__ __launch_bounds__(256) void clamp_into_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, int clamp) {
+  const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (i >= n) return;
+  if (i + 4u <= n) {
+    f4 v = *reinterpret_cast<const f4*>(src + i);
+    if (clamp) {
+      v.x = v.x > 1.0f ? 1.0f : (v.x < -1.0f ? -1.0f : v.x);
+      v.y = v.y > 1.0f ? 1.0f : (v.y < -1.0f ? -1.0f : v.y);
+      v.z = v.z > 1.0f ? 1.0f : (v.z < -1.0f ? -1.0f : v.z);
+      v.w = v.w > 1.0f ? 1.0f : (v.w < -1.0f ? -1.0f : v.w);
+    }
+    *reinterpret_cast<f4*>(dst + i) = v;
+  } else {
+    for (size_t k = i; k < n; k++) {
+      const float v = src[k];
+      dst[k] = clamp ? (v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v)) : v;
+    }
+  }
+}
+
 // planar fp32 master [K][C][F] -> interleaved device-format samples [K*F][C]; reference
 // core/audio_format_conv.cpp:5-20 (i16), :45-60 (i24 in 32-bit containers), :62-77 (i32), :79-91 (f32)
 __global__ __launch_bounds__(256) void convert_kernel(const float* master, void* dst, uint32_t n_blocks, uint32_t F,
@@ -860,6 +882,10 @@ void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
 
 void launch_clamp(float* buf, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(clamp_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, buf, n);
+}
+
+void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s) {
+  hipLaunchKernelGGL(clamp_into_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, s, src, dst, n, clamp);
 }
 
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s) {

@@ -30,6 +30,7 @@ void launch_gen(const GenArgs& a, hipStream_t s);
 void launch_mix(const MixArgs& a, uint32_t n_blocks, int unroll, hipStream_t s);
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
+void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
 void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
@@ -933,6 +934,16 @@ extern "C" wbx_status wbx_finalize_master(wbx_ctx* c, void* device_partial, uint
   if (!c || !device_partial || n_blocks == 0) return WBX_ERR_INVALID;
   hipStream_t on = stream ? (hipStream_t)stream : c->stream;
   if (clamp) launch_clamp((float*)device_partial, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, on);
+  WBX_HIP(c, hipGetLastError());
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_finalize_master_into(wbx_ctx* c, const void* device_partial, void* dst, uint32_t n_blocks, int clamp,
+                                               void* stream) {
+  if (!c || !device_partial || !dst || n_blocks == 0) return WBX_ERR_INVALID;
+  if (((uintptr_t)device_partial | (uintptr_t)dst) & 15u) return fail(c, WBX_ERR_INVALID, "finalize: buffers must be 16-byte aligned");
+  hipStream_t on = stream ? (hipStream_t)stream : c->stream;
+  launch_clamp_into((const float*)device_partial, (float*)dst, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, clamp, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
 }

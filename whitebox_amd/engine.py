@@ -196,6 +196,11 @@ class MixContext:
     def finalize_master(self, device_ptr: int, n_blocks: int, clamp: bool = True, stream: Optional[int] = None):
         _check(self.L.wbx_finalize_master(self.h, device_ptr, n_blocks, int(clamp), stream), "wbx_finalize_master", self.h)
 
+    def finalize_master_into(self, device_ptr: int, dst_ptr: int, n_blocks: int, clamp: bool = True, stream: Optional[int] = None):
+        """Clamp the reduced master out of place; `dst_ptr` may be pinned host memory."""
+        _check(self.L.wbx_finalize_master_into(self.h, device_ptr, dst_ptr, n_blocks, int(clamp), stream),
+               "wbx_finalize_master_into", self.h)
+
     def kernel_time(self, reset: bool = False):
         ms, n = C.c_double(), C.c_uint64()
         _check(self.L.wbx_kernel_time(self.h, int(reset), C.byref(ms), C.byref(n)), "wbx_kernel_time", self.h)
