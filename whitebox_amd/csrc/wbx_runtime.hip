@@ -127,6 +127,8 @@ struct wbx_ctx {
   std::vector<DSeg> h_pool;
 
   uint32_t last_K = 0, last_N = 0;
+  float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
+  bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
   bool clamp = true;
   float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
 
@@ -344,6 +346,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.partial = c->d_partial.p;
   s.groups = c->d_groups.p;
   s.master = c->master_target ? c->master_target : c->d_master.p;
+  c->last_master = s.master;
+  c->last_master_on_host = false;
   s.buses = c->n_buses ? c->d_buses.p : nullptr;
   s.n_groups = m.n_groups;
   s.n_buses = c->n_buses;
@@ -884,8 +888,14 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   if (master_planar) {
     // device [K][C][F] -> host planar[c][b*F + j]
     for (uint32_t ch = 0; ch < C; ch++)
-      WBX_HIP(c, hipMemcpy2DAsync(master_planar[ch], F * sizeof(float), (c->master_target ? c->master_target : c->d_master.p) + (size_t)ch * F,
-                                  (size_t)C * F * sizeof(float), F * sizeof(float), K, hipMemcpyDeviceToHost, c->stream));
+      if (c->last_master_on_host) {   // Engine::process: the block is already on the host
+        WBX_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint32_t b = 0; b < K; b++)
+          std::memcpy(master_planar[ch] + (size_t)b * F, c->last_master + ((size_t)b * C + ch) * F, F * sizeof(float));
+      } else {
+        WBX_HIP(c, hipMemcpy2DAsync(master_planar[ch], F * sizeof(float), c->last_master + (size_t)ch * F,
+                                    (size_t)C * F * sizeof(float), F * sizeof(float), K, hipMemcpyDeviceToHost, c->stream));
+      }
   }
   if (peaks) WBX_HIP(c, hipMemcpyAsync(peaks, c->d_peaks.p, (size_t)K * N * C * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (buses) {
@@ -916,7 +926,7 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
   const uint32_t K = c->last_K, C = c->cfg.channels, F = c->cfg.block_frames;
   const size_t bytes = (size_t)K * F * C * eb;
   WBX_HIP(c, c->d_conv.ensure(bytes));
-  launch_convert(c->master_target ? c->master_target : c->d_master.p, c->d_conv.p, K, F, C, out_format, c->stream);
+  launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);   // pinned staging is device-readable too
   WBX_HIP(c, hipMemcpyAsync(dst, c->d_conv.p, bytes, hipMemcpyDeviceToHost, c->stream));
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   return WBX_OK;
@@ -925,7 +935,7 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
 extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* n_floats) {
   if (!c || !device_ptr) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
-  *device_ptr = c->master_target ? c->master_target : c->d_master.p;
+  *device_ptr = c->last_master;
   if (n_floats) *n_floats = (size_t)c->last_K * c->cfg.channels * c->cfg.block_frames;
   return WBX_OK;
 }
@@ -1022,6 +1032,10 @@ struct wbx_engine {
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
   size_t total_clips = 0;
   uint32_t next_clip_uid = 0;
+  // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
+  // and the plan status lands in — the callback path then needs no copy-engine transfer at all
+  float* h_block = nullptr;             // [C][F]
+  uint32_t* h_status = nullptr;         // plan counters [4]
   size_t d_clips_count = 0;
   bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
   bool clips_edited = false;            // a clip list changed since the previous plan (PlanArgs::clips_changed)
@@ -1108,6 +1122,8 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
   e->d_patch.release();
   e->d_gains.release();
   e->d_levels.release();
+  if (e->h_block) (void)hipHostFree(e->h_block);
+  if (e->h_status) (void)hipHostFree(e->h_status);
   wbx_destroy(e->ctx);
   delete e;
 }
@@ -1617,9 +1633,31 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
 
 extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar) {   // engine.cpp:1576-1654
   if (!e || !out_planar) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  if (c->master_target) {   // the caller redirected the master: leave it there and fetch the ordinary way
+    wbx_status st = wbx_engine_render(e, 1);
+    if (st != WBX_OK) return st;
+    return wbx_fetch(c, out_planar, nullptr, nullptr);
+  }
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  if (!e->h_block) {
+    WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
+    WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block
   wbx_status st = wbx_engine_render(e, 1);
+  c->master_target = nullptr;
   if (st != WBX_OK) return st;
-  return wbx_fetch(e->ctx, out_planar, nullptr, nullptr);
+  launch_clamp_into(reinterpret_cast<const float*>(PB(c).counters), reinterpret_cast<float*>(e->h_status), 4, 0, c->stream);
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
+  c->last_master_on_host = true;   // set after launch_mix_sum cleared it: the master of this block is e->h_block
+  const uint32_t flags = e->h_status[1];
+  if (flags & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
+  if (flags & 8u) return efail(e, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
+  if (flags & 16u) return efail(e, WBX_ERR_OVERFLOW, "plan template array full");
+  return WBX_OK;
 }
 
 extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing) {
