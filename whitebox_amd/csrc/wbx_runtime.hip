@@ -127,6 +127,7 @@ struct wbx_ctx {
   std::vector<DSeg> h_pool;
 
   uint32_t last_K = 0, last_N = 0;
+  bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation
   float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
   bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
   bool clamp = true;
@@ -221,7 +222,10 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 }
 
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
-  if (c->routing_tracks != n_tracks) build_routing(c, n_tracks);
+  if (c->routing_tracks != n_tracks) {
+    build_routing(c, n_tracks);
+    c->buses_clean = false;
+  }
   if (c->routing_dirty) {
     WBX_HIP(c, c->d_order.ensure(std::max<size_t>(1, c->order.size())));
     WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size())));
@@ -255,7 +259,11 @@ wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
   WBX_HIP(c, c->d_partial.ensure((size_t)K * std::max<size_t>(1, c->groups.size()) * CF));
   WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
   WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
-  if (c->n_buses) WBX_HIP(c, c->d_buses.ensure((size_t)K * c->n_buses * CF));
+  if (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF) {
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, c->d_buses.ensure((size_t)K * c->n_buses * CF));
+    c->buses_clean = false;
+  }
   return WBX_OK;
 }
 
@@ -354,7 +362,12 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.block_frames = F;
   s.channels = C;
   s.clamp = c->clamp ? 1u : 0u;
-  if (c->n_buses) WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, (size_t)K * c->n_buses * C * F * sizeof(float), c->stream));
+  if (c->n_buses && !c->buses_clean) {
+    // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
+    // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
+    WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
+    c->buses_clean = true;
+  }
   launch_sum(s, K, c->stream);
   if (m.n_groups && c->profiling) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], c->stream));
@@ -757,6 +770,7 @@ extern "C" wbx_status wbx_set_routing(wbx_ctx* c, uint32_t n_tracks, const int32
     c->n_buses = 0;
   }
   build_routing(c, n_tracks);
+  c->buses_clean = false;
   return WBX_OK;
 }
 
