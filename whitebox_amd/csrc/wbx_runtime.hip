@@ -43,6 +43,10 @@ using namespace wbx;
 namespace {
 
 constexpr int kEventRing = 64;
+// Plan buffers, partial-sum buffers and their events form a ring of three: the plan of render i may start as soon as
+// the mix of render i-3 and the sum of render i-3 are over, i.e. a full render before its own mix — the one-wave-per-
+// track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
+constexpr int kRing = 3;
 
 struct ClipSlot {
   void* base = nullptr;     // one allocation holding all channels
@@ -112,15 +116,25 @@ struct wbx_ctx {
     DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
     uint32_t gen_cap = 0;
     hipEvent_t planned = nullptr;     // recorded on plan_stream when plan + pre-render are done
-    hipEvent_t consumed = nullptr;    // recorded on stream when the mix that read this buffer is done
+    hipEvent_t consumed = nullptr;    // (not owned) ctx->mix_done[] of the render whose mix read this buffer
     bool consumed_valid = false;
-  } pb[2];
+  } pb[kRing];
   int cur = 0;
   hipStream_t plan_stream = nullptr;
   bool overlap = true;
   DevBuf<float> d_zero;               // zero page (F+8 floats)
   uint32_t* levels_target = nullptr;  // [N][C] running per-track maxima (VUMeter::level), or null
-  DevBuf<float> d_partial, d_master, d_buses, d_peaks, d_gains;
+  DevBuf<float> d_partial2[kRing];    // group partials, one per render in flight (a sum may still read an older one)
+  DevBuf<float> d_master, d_buses, d_peaks, d_gains;
+  // The sum of render i runs on its own stream beside the mix of render i+1 (it is PCIe-bound when the master goes to
+  // host memory and needs few CUs).  sum_pending: a sum has been issued that the main stream has not waited for yet.
+  hipStream_t sum_stream = nullptr;
+  hipEvent_t mix_done[kRing] = {}, sum_done[kRing] = {};
+  bool sum_valid[kRing] = {};
+  int sum_pending = -1;
+  uint32_t render_seq = 0;
+  bool partial_wait_done = false;     // the caller already ordered this render after the sum of two renders ago
+  bool sum_overlap = true;            // WBX_SUM_OVERLAP=0: sum on the main stream
   DevBuf<uint8_t> d_conv;
   std::vector<DTrackBlock> h_tb;      // layer-1 staging
   std::vector<DRow> h_rows;
@@ -140,7 +154,6 @@ struct wbx_ctx {
   double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
   uint64_t mix_launches = 0;
   bool profiling = true;
-  hipEvent_t record_after_mix = nullptr;   // recorded between the mix and the sum launch (plan-buffer release)
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
                                       // 0 = chosen per render: 24 when resampled clips are present, else 43
   bool has_window_clips = true;
@@ -178,6 +191,15 @@ size_t fmt_bytes(int fmt) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// make the main stream wait for the sum that is still running beside it (device-side; a following
+// hipStreamSynchronize(c->stream) then covers it)
+hipError_t join_sum(wbx_ctx* c) {
+  if (c->sum_pending < 0) return hipSuccess;
+  const hipError_t e = hipStreamWaitEvent(c->stream, c->sum_done[c->sum_pending], 0);
+  c->sum_pending = -1;
+  return e;
+}
 
 void drain_events(wbx_ctx* c) {
   for (int i = 0; i < c->ev_pending; i++) {
@@ -227,6 +249,8 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
     c->buses_clean = false;
   }
   if (c->routing_dirty) {
+    WBX_HIP(c, join_sum(c));                          // a sum beside the main stream may still read d_groups
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
     WBX_HIP(c, c->d_order.ensure(std::max<size_t>(1, c->order.size())));
     WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size())));
     if (!c->order.empty())
@@ -256,7 +280,14 @@ wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
       WBX_HIP(c, hipStreamSynchronize(c->stream));
       WBX_HIP(c, B.prows.ensure((size_t)K * N));
     }
-  WBX_HIP(c, c->d_partial.ensure((size_t)K * std::max<size_t>(1, c->groups.size()) * CF));
+  const size_t need_partial = (size_t)K * std::max<size_t>(1, c->groups.size()) * CF;
+  if (c->d_partial2[0].cap < need_partial || c->d_master.cap < (size_t)K * CF ||
+      c->d_peaks.cap < (size_t)K * N * c->cfg.channels || (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF)) {
+    WBX_HIP(c, join_sum(c));                          // a sum may still be using the buffers about to be replaced
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& v : c->sum_valid) v = false;
+  }
+  for (auto& P : c->d_partial2) WBX_HIP(c, P.ensure(need_partial));
   WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
   WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
   if (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF) {
@@ -324,7 +355,12 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.pool = PB(c).pool.p;
   m.order = c->d_order.p;
   m.groups = c->d_groups.p;
-  m.partial = c->d_partial.p;
+  const int pp = (int)(c->render_seq % kRing);
+  // this partial buffer was last read by the sum of kRing renders ago; the engine path has already made the PLAN
+  // stream wait for that sum (the mix waits for the plan), which keeps the barrier off the main stream
+  if (c->sum_valid[pp] && !c->partial_wait_done) WBX_HIP(c, hipStreamWaitEvent(c->stream, c->sum_done[pp], 0));
+  c->partial_wait_done = false;
+  m.partial = c->d_partial2[pp].p;
   m.peaks = c->d_peaks.p;
   m.levels = c->levels_target;
   m.n_tracks = N;
@@ -349,9 +385,9 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
-  if (c->record_after_mix) WBX_HIP(c, hipEventRecord(c->record_after_mix, c->stream));
+  WBX_HIP(c, hipEventRecord(c->mix_done[pp], c->stream));
   SumArgs s{};
-  s.partial = c->d_partial.p;
+  s.partial = c->d_partial2[pp].p;
   s.groups = c->d_groups.p;
   s.master = c->master_target ? c->master_target : c->d_master.p;
   c->last_master = s.master;
@@ -368,11 +404,19 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
     c->buses_clean = true;
   }
-  launch_sum(s, K, c->stream);
+  hipStream_t ss = c->sum_overlap ? c->sum_stream : c->stream;
+  if (c->sum_overlap) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  launch_sum(s, K, ss);
   if (m.n_groups && c->profiling) {
-    WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], c->stream));
+    WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
     c->ev_pending++;
   }
+  if (c->sum_overlap) {
+    WBX_HIP(c, hipEventRecord(c->sum_done[pp], ss));
+    c->sum_valid[pp] = true;
+    c->sum_pending = pp;
+  }
+  c->render_seq++;
   WBX_HIP(c, hipGetLastError());
   c->last_K = K;
   c->last_N = N;
@@ -466,14 +510,26 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
     }
+    // the sum stream: highest priority as well — its few hundred small workgroups start while the next mix floods
+    // the device.  WBX_SUM_OVERLAP=0 keeps the sum on the main stream.
+    const char* so = std::getenv("WBX_SUM_OVERLAP");
+    c->sum_overlap = !(so && so[0] == '0');
+    const char* sp = std::getenv("WBX_SUM_PRIO");
+    bool ok = hipStreamCreateWithPriority(&c->sum_stream, hipStreamNonBlocking, (sp && sp[0] == 'l') ? lo : hi) == hipSuccess;
+    for (int i = 0; i < kRing && ok; i++)
+      ok = hipEventCreateWithFlags(&c->mix_done[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      wbx_destroy(c);
+      return WBX_ERR_DEVICE;
+    }
   }
   size_t chunks = cfg->max_segments ? (cfg->max_segments + kChunk - 1) / kChunk
                                     : std::max<size_t>(1024, (size_t)cfg->max_blocks * cfg->max_tracks / 8);
   for (auto& B : c->pb) {
     B.pool_chunks = (uint32_t)chunks;
     if (B.pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&B.counters, 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipEventCreateWithFlags(&B.planned, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&B.consumed, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&B.planned, hipEventDisableTiming) != hipSuccess) {
       wbx_destroy(c);
       return WBX_ERR_OOM;
     }
@@ -492,6 +548,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
+  if (c->sum_stream) (void)hipStreamSynchronize(c->sum_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->clips) {
     if (s.base) (void)hipFree(s.base);
@@ -509,10 +566,14 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
     B.saved.release();
     if (B.counters) (void)hipFree(B.counters);
     if (B.planned) (void)hipEventDestroy(B.planned);
-    if (B.consumed) (void)hipEventDestroy(B.consumed);
   }
   if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
-  c->d_partial.release();
+  if (c->sum_stream) (void)hipStreamDestroy(c->sum_stream);
+  for (int i = 0; i < kRing; i++) {
+    if (c->mix_done[i]) (void)hipEventDestroy(c->mix_done[i]);
+    if (c->sum_done[i]) (void)hipEventDestroy(c->sum_done[i]);
+  }
+  for (auto& P : c->d_partial2) P.release();
   c->d_master.release();
   c->d_buses.release();
   c->d_peaks.release();
@@ -890,6 +951,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
 
 extern "C" wbx_status wbx_sync(wbx_ctx* c) {
   if (!c) return WBX_ERR_INVALID;
+  WBX_HIP(c, join_sum(c));
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   return WBX_OK;
@@ -898,6 +960,7 @@ extern "C" wbx_status wbx_sync(wbx_ctx* c) {
 extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* peaks, float* buses) {
   if (!c) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  WBX_HIP(c, join_sum(c));
   const uint32_t K = c->last_K, N = c->last_N, C = c->cfg.channels, F = c->cfg.block_frames;
   if (master_planar) {
     // device [K][C][F] -> host planar[c][b*F + j]
@@ -929,6 +992,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
 extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* dst) {
   if (!c || !dst) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  WBX_HIP(c, join_sum(c));
   size_t eb;
   switch (out_format) {
     case WBX_OUT_I16: eb = 2; break;
@@ -949,6 +1013,7 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
 extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* n_floats) {
   if (!c || !device_ptr) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
+  WBX_HIP(c, join_sum(c));
   *device_ptr = c->last_master;
   if (n_floats) *n_floats = (size_t)c->last_K * c->cfg.channels * c->cfg.block_frames;
   return WBX_OK;
@@ -957,6 +1022,7 @@ extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* 
 extern "C" wbx_status wbx_finalize_master(wbx_ctx* c, void* device_partial, uint32_t n_blocks, int clamp, void* stream) {
   if (!c || !device_partial || n_blocks == 0) return WBX_ERR_INVALID;
   hipStream_t on = stream ? (hipStream_t)stream : c->stream;
+  if (c->sum_pending >= 0) WBX_HIP(c, hipStreamWaitEvent(on, c->sum_done[c->sum_pending], 0));
   if (clamp) launch_clamp((float*)device_partial, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
@@ -967,6 +1033,7 @@ extern "C" wbx_status wbx_finalize_master_into(wbx_ctx* c, const void* device_pa
   if (!c || !device_partial || !dst || n_blocks == 0) return WBX_ERR_INVALID;
   if (((uintptr_t)device_partial | (uintptr_t)dst) & 15u) return fail(c, WBX_ERR_INVALID, "finalize: buffers must be 16-byte aligned");
   hipStream_t on = stream ? (hipStream_t)stream : c->stream;
+  if (c->sum_pending >= 0) WBX_HIP(c, hipStreamWaitEvent(on, c->sum_done[c->sum_pending], 0));
   launch_clamp_into((const float*)device_partial, (float*)dst, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, clamp, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
@@ -974,6 +1041,7 @@ extern "C" wbx_status wbx_finalize_master_into(wbx_ctx* c, const void* device_pa
 
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
   if (!c) return WBX_ERR_INVALID;
+  WBX_HIP(c, join_sum(c));
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   if (mix_ms_avg) *mix_ms_avg = c->mix_launches ? c->mix_ms_total / (double)c->mix_launches : 0.0;
@@ -988,6 +1056,7 @@ extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg,
 
 extern "C" wbx_status wbx_tail_time(wbx_ctx* c, double* tail_ms_avg) {
   if (!c || !tail_ms_avg) return WBX_ERR_INVALID;
+  WBX_HIP(c, join_sum(c));
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   *tail_ms_avg = c->mix_launches ? c->tail_ms_total / (double)c->mix_launches : 0.0;
@@ -1577,10 +1646,17 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
 
   // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
   //    while the mix of the previous render is still busy on the main stream
-  c->cur ^= 1;
+  c->cur = (c->cur + 1) % kRing;
   wbx_ctx::PlanBuf& B = PB(c);
   hipStream_t ps = c->overlap ? c->plan_stream : s;
   if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
+  {
+    const int pp = (int)(c->render_seq % kRing);
+    if (c->overlap && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
+      WBX_EHIP(e, hipStreamWaitEvent(ps, c->sum_done[pp], 0));
+      c->partial_wait_done = true;
+    }
+  }
   WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
   const double sample_rate = (double)c->cfg.sample_rate;
   PlanArgs a{};
@@ -1621,10 +1697,10 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = e->any_window_clip;
-  c->record_after_mix = B.consumed;
+  const int mix_parity = (int)(c->render_seq % kRing);
   st = launch_mix_sum(c, K, N);
-  c->record_after_mix = nullptr;
   if (st != WBX_OK) return st;
+  B.consumed = c->mix_done[mix_parity];   // recorded right after the mix: the plan buffer is free before the sum runs
   B.consumed_valid = true;
 
   // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
@@ -1663,6 +1739,7 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
   c->master_target = nullptr;
   if (st != WBX_OK) return st;
   launch_clamp_into(reinterpret_cast<const float*>(PB(c).counters), reinterpret_cast<float*>(e->h_status), 4, 0, c->stream);
+  WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
   drain_events(c);
   for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
