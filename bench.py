@@ -238,7 +238,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True      # the small reduce must not queue behind the next render's mix
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                pg_options=opts)
 
     import whitebox_amd as W
     from whitebox_amd import synth
@@ -261,16 +264,19 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     stream = torch.cuda.Stream()
-    fin_stream = torch.cuda.Stream()          # root: clamp + D2H of a reduced master, beside the next render
+    # root: clamp of a reduced master into host memory, beside the next renders.  Highest priority: at normal
+    # priority its workgroups only get CU slots as the concurrent mix drains, and the step that reuses the buffer waits
+    fin_stream = torch.cuda.Stream(priority=-1)
     with torch.cuda.stream(stream):
         eng, seed, amp = build_device_session(W, synth, args.workload, n_tracks, K, session_blocks, rank,
                                               stream.cuda_stream, args.group_size)
         host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
         if use_dist:
             from whitebox_amd.dist import MasterReducer
-            masters = [torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda") for _ in range(2)]
-            fin_done = [torch.cuda.Event(), torch.cuda.Event()]
-            rendered = [torch.cuda.Event(), torch.cuda.Event()]
+            NS = 3                                             # master buffers in flight (render / reduce / finalize)
+            masters = [torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda") for _ in range(NS)]
+            fin_done = [torch.cuda.Event() for _ in range(NS)]
+            rendered = [torch.cuda.Event() for _ in range(NS)]
             eng.ctx.set_clamp(False)                       # partials are clamped on the root AFTER the reduce
             # root: clamp after the reduce, straight into pinned host memory (plain kernel stores, no copy engine)
             red = MasterReducer(lambda buf: eng.ctx.finalize_master_into(buf.data_ptr(), host_master.data_ptr(), K, True,
@@ -296,15 +302,15 @@ def main():
                 eng.play()
                 done = 0
             if use_dist:
-                slot = nstep & 1
-                if nstep >= 2:
-                    stream.wait_event(fin_done[slot])          # the buffer's previous reduce / copy is over
+                slot = nstep % NS
+                if nstep >= NS:
+                    stream.wait_event(fin_done[slot])          # the buffer's previous reduce / finalize is over
                 eng.ctx.set_master_target(masters[slot].data_ptr())
                 eng.render(K)
                 rendered[slot].record(stream)
                 red.reduce(masters[slot], slot)                # RCCL sum over xGMI, asynchronous to this stream
                 if nstep >= 1:
-                    finish((nstep - 1) & 1)
+                    finish((nstep - 1) % NS)
             else:
                 eng.render(K)
             done += K
@@ -312,7 +318,7 @@ def main():
 
         def drain():
             if use_dist and nstep >= 1:
-                finish((nstep - 1) & 1)
+                finish((nstep - 1) % NS)
             torch.cuda.synchronize()
 
         eng.play()

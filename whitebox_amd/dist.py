@@ -27,8 +27,8 @@ class MasterReducer:
 
     reduce() is asynchronous with respect to the caller's stream: the collective is enqueued with
     async_op=True, so the next render can be issued at once; finish(slot) makes the finalize stream wait
-    for it and runs `finalize(buffer)` (the clamp kernel on the root).  Buffers are double-buffered by the
-    caller (slot = step & 1) so that a render never overwrites a buffer a reduce is still reading.
+    for it and runs `finalize(buffer)` (the clamp kernel on the root).  Buffers are rotated by the caller
+    (slot = step % n_slots) so that a render never overwrites a buffer a reduce is still reading.
     """
 
     def __init__(self, finalize: Callable[[torch.Tensor], None], root: int = 0, group=None):
@@ -37,19 +37,18 @@ class MasterReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._work: List[Optional[object]] = [None, None]
+        self._work = {}             # slot -> outstanding collective
 
     def reduce(self, partial: torch.Tensor, slot: int = 0) -> None:
         if self.world > 1:
-            self._work[slot & 1] = dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True)
+            self._work[slot] = dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
+                                           async_op=True)
         else:
-            self._work[slot & 1] = None
+            self._work[slot] = None
 
     def finish(self, partial: torch.Tensor, slot: int = 0) -> None:
-        w = self._work[slot & 1]
+        w = self._work.pop(slot, None)
         if w is not None:
             w.wait()            # orders the CURRENT stream after the collective (no host block for nccl)
-            self._work[slot & 1] = None
         if self.rank == self.root:
             self.finalize(partial)
