@@ -202,9 +202,9 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
-def mix_kernel_name(resampled):
+def mix_kernel_name(resampled_or_integer):
     """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides)."""
-    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if resampled else 43)
+    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if resampled_or_integer else 43)
     return f"wbx::mix_kernel<{v // 10}, true, {v % 10}>"
 
 
@@ -400,7 +400,7 @@ def main():
             "realtime_factor": master_frames / dt / SR,
             "host_enqueue_ms_max": 1e3 * enq_max,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate != SR),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate != SR or fmt != "f32"),
                          "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n), "sum_tail_ms_avg": tail_ms,
                          "algorithmic_bytes_per_launch": alg},
         }

@@ -155,8 +155,9 @@ struct wbx_ctx {
   uint64_t mix_launches = 0;
   bool profiling = true;
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
-                                      // 0 = chosen per render: 24 when resampled clips are present, else 43
+                                      // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;
+  bool has_integer_clips = false;
 };
 
 namespace {
@@ -264,7 +265,11 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
   }
   if (c->samples_dirty) {
     std::vector<DSample> tab(c->clips.size());
-    for (size_t i = 0; i < c->clips.size(); i++) tab[i] = c->clips[i].d;
+    c->has_integer_clips = false;
+    for (size_t i = 0; i < c->clips.size(); i++) {
+      tab[i] = c->clips[i].d;
+      if (c->clips[i].used && c->clips[i].d.format != FMT_F32) c->has_integer_clips = true;
+    }
     WBX_HIP(c, c->d_samples.ensure(std::max<size_t>(1, tab.size())));
     if (!tab.empty()) WBX_HIP(c, hipMemcpy(c->d_samples.p, tab.data(), tab.size() * sizeof(DSample), hipMemcpyHostToDevice));
     c->samples_dirty = false;
@@ -377,7 +382,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
-    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : (c->has_window_clips ? 24 : 43), c->stream);
+    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43), c->stream);
     if (c->profiling) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
