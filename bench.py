@@ -83,7 +83,11 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
 
 
 def rank_device(rank):
-    return int(os.environ.get("LOCAL_RANK", rank))
+    dev = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":     # debugging aid: several ranks on one device
+        import torch
+        dev %= torch.cuda.device_count()
+    return dev
 
 
 def cpu_baseline(workload, n_tracks, budget_s=12.0):
@@ -235,13 +239,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":     # debugging aid: several ranks on one device
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        opts = dist.ProcessGroupNCCL.Options()
-        opts.is_high_priority_stream = True      # the small reduce must not queue behind the next render's mix
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                pg_options=opts)
+        if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one device
+        else:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True      # the small reduce must not queue behind the next render's mix
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    pg_options=opts)
 
     import whitebox_amd as W
     from whitebox_amd import synth

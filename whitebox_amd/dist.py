@@ -40,7 +40,15 @@ class MasterReducer:
         self._work = {}             # slot -> outstanding collective
 
     def reduce(self, partial: torch.Tensor, slot: int = 0) -> None:
-        if self.world > 1:
+        if self.world > 1 and partial.is_cuda and dist.get_backend(self.group) == "gloo":
+            # debugging aid (several ranks sharing one GPU, where RCCL cannot be used): through the host, synchronously
+            torch.cuda.current_stream().synchronize()
+            host = partial.cpu()
+            dist.reduce(host, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
+            if self.rank == self.root:
+                partial.copy_(host)
+            self._work[slot] = None
+        elif self.world > 1:
             self._work[slot] = dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True)
         else:
