@@ -1,14 +1,16 @@
 // wbx_kernels.hip — gfx950 (CDNA4, wave64) kernels of the whitebox mix path.  HIP only, no other target.
 //
 //   plan_kernel      one lane per track: the reference's clip sequencer + sampler-state update for K
-//                    consecutive blocks (wbx_seq.h), emitting one 64-B DTrackBlock per (block, track)
+//                    consecutive blocks (wbx_seq.h), emitting a 16-B DRow per (block, track) and one 64-B
+//                    DTrackBlock template per run of steady blocks / per block with events
+//   gen_kernel       pre-render of the rare track-blocks the hot loop cannot stream (clip boundaries, ...)
 //   mix_kernel       the hot kernel: workgroup = (track group, block[, frame tile]); the group's
-//                    DTrackBlock records (gain / pan / resample parameters) are staged in LDS, each
-//                    lane owns 4 consecutive output frames of one channel, clip audio is streamed
-//                    with 16-B loads, rendered, scaled and accumulated in registers IN TRACK ORDER;
-//                    per-track peaks via wavefront shuffle-max + LDS
+//                    records (gain / pan / resample parameters) are staged in LDS, each lane owns 4
+//                    consecutive output frames of one channel, clip audio is streamed with 16-B loads
+//                    through a software pipeline, rendered, scaled and accumulated in registers IN TRACK
+//                    ORDER; per-track peaks via permlane-swap / DPP wave maxima, four tracks at a time
 //   sum_kernel       group sums -> bus sums -> master (fixed order), master clamp
-//   finalize/convert/levels/synth: small helpers
+//   clamp / clamp_into / convert / synth: small helpers
 //
 // HBM-bound integer/fp32 streaming: no MFMA (≈3 flop per 4 B).  Parity-critical arithmetic uses the
 // explicitly rounded intrinsics (__fmul_rn, __dadd_rn, ...) and the file is built with
@@ -341,10 +343,11 @@ struct Pre {
 // block = 256 lanes (4 waves).  Lane -> (channel c, frames j0..j0+3).  With F = 512, C = 2: waves 0-1
 // own the left channel, waves 2-3 the right one; every wave-level load is one contiguous ~1 KiB row.
 //
-// By the time this kernel runs every record is KIND_UNITY or KIND_WINDOW (gen_kernel rewrote the generic
-// ones; silent ones and the padding of the last batch read the zero page with zero gain), so the load
-// phase is straight-line code: exactly one 16-B + one 4-B load per track, no branches, which lets the
-// compiler count outstanding loads exactly and keep two batches in flight.
+// By the time this kernel runs every record is a whole-block unity or window row (gen_kernel rewrote the generic
+// ones; silent ones and the padding of the last batch read the zero page with zero gain), and every staged chunk
+// runs in ONE mode chosen from the row shapes it holds (MODE_*), so the load phase is straight-line code — e.g.
+// exactly one 16-B + one 4-B load per track for resampled fp32 rows — with no branches, which lets the compiler
+// count outstanding loads exactly and keep two batches in flight.
 //
 //   U     tracks per batch; two batches are in flight (software pipeline: the loads of batch i+1 are
 //         issued before batch i is rendered), so 2*U clip rows per wave are outstanding
