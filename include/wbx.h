@@ -183,6 +183,12 @@ wbx_status wbx_engine_set_buses(wbx_engine* e, uint32_t n_buses);              /
 wbx_status wbx_track_set_volume(wbx_engine* e, uint32_t track, float db);      /* track.cpp:47-57 */
 wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t track, float pan);        /* track.cpp:59-68 */
 wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t track, int mute);        /* track.cpp:70-79 */
+/* Engine::delete_track (engine.cpp:210-218), move_track (:228-243; the order is the summation order),
+ * solo_track (:245-262; toggles the UI solo flag and mutes / unmutes the other tracks through set_mute).
+ * Track indices above a deleted / between moved slots shift exactly as the reference's vector does. */
+wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot);
+wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot);
+wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot);
 wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);      /* extension A13 */
 /* Sample assets (SampleAsset, engine/assets_table.h:22-35): upload once, reference by id from clips. */
 wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,

@@ -155,6 +155,20 @@ struct Engine {
     tracks.emplace_back(new Track{this, idx, name});
     return tracks.back().get();
   }
+  // engine.cpp:210-262
+  void delete_track(uint32_t slot) {
+    check(wbx_engine_delete_track(h, slot), "delete_track");
+    tracks.erase(tracks.begin() + slot);
+    for (uint32_t i = 0; i < tracks.size(); i++) tracks[i]->index = i;
+  }
+  void move_track(uint32_t from_slot, uint32_t to_slot) {
+    check(wbx_engine_move_track(h, from_slot, to_slot), "move_track");
+    auto t = std::move(tracks[from_slot]);
+    tracks.erase(tracks.begin() + from_slot);
+    tracks.insert(tracks.begin() + to_slot, std::move(t));
+    for (uint32_t i = 0; i < tracks.size(); i++) tracks[i]->index = i;
+  }
+  void solo_track(uint32_t slot) { check(wbx_engine_solo_track(h, slot), "solo_track"); }
   // decoded clip audio -> HBM (what SampleAsset / Sample hold in the reference: assets_table.h:22-35, sample.h:18-28)
   uint32_t add_sample(int format, uint32_t channels, uint32_t sample_rate, uint64_t frames, const void* const* planar) {
     uint32_t id = 0;

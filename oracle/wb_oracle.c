@@ -441,6 +441,42 @@ int wbo_engine_add_track(wbo_engine* e) {
   return idx;
 }
 
+/* engine.cpp:210-218 (the track object goes away with everything it owns) */
+void wbo_engine_delete_track(wbo_engine* e, uint32_t slot) {
+  free(e->tracks[slot].clips);
+  memmove(&e->tracks[slot], &e->tracks[slot + 1], (e->n_tracks - slot - 1) * sizeof(wbo_track));
+  e->n_tracks--;
+}
+
+/* engine.cpp:228-243: the Track objects keep their state, only the order (= summation order) changes */
+void wbo_engine_move_track(wbo_engine* e, uint32_t from_slot, uint32_t to_slot) {
+  if (from_slot == to_slot) return;
+  wbo_track tmp = e->tracks[from_slot];
+  if (from_slot < to_slot) {
+    for (uint32_t i = from_slot; i < to_slot; i++) e->tracks[i] = e->tracks[i + 1];
+  } else {
+    for (uint32_t i = from_slot; i > to_slot; i--) e->tracks[i] = e->tracks[i - 1];
+  }
+  e->tracks[to_slot] = tmp;
+}
+
+/* engine.cpp:245-262 */
+void wbo_engine_solo_track(wbo_engine* e, uint32_t slot) {
+  int mute = 0;
+  if (e->tracks[slot].ui_solo) {
+    e->tracks[slot].ui_solo = 0;
+  } else {
+    e->tracks[slot].ui_solo = 1;
+    wbo_track_set_mute(e, (int)slot, 0);
+    mute = 1;
+  }
+  for (uint32_t i = 0; i < e->n_tracks; i++) {
+    if (i == slot) continue;
+    if (e->tracks[i].ui_solo) e->tracks[i].ui_solo = 0;
+    wbo_track_set_mute(e, (int)i, mute);
+  }
+}
+
 /* core/algorithm.h:24-40 with the predicate clip->max_time <= value */
 static uint32_t lower_bound_max_time(const wbo_clip* clips, uint32_t n, double value) {
   int64_t left = 0, right = (int64_t)n - 1;

@@ -120,6 +120,7 @@ typedef struct wbo_track {
   float level[2];                                     /* VUMeter::level (max since last read) */
   float block_peak[2];                                /* max|m| of the last processed block */
   int bus;                                            /* extension A13: sub-bus id, -1 = none */
+  int ui_solo;                                        /* ui_parameter_state.solo, track.h:52 (UI flag read by solo_track) */
 } wbo_track;
 
 typedef struct wbo_seglog {  /* one Sampler::stream call issued by Track::process (track.cpp:678,718) */
@@ -187,6 +188,11 @@ int wbo_engine_set_clip_gain(wbo_engine* e, int track, uint32_t clip, float gain
 int wbo_engine_delete_region(wbo_engine* e, int track, double min, double max);
 uint32_t wbo_track_clip_count(const wbo_engine* e, int track);
 const wbo_clip* wbo_track_clip(const wbo_engine* e, int track, uint32_t i);
+
+/* Engine::delete_track engine.cpp:210-218, move_track :228-243, solo_track :245-262 */
+void wbo_engine_delete_track(wbo_engine* e, uint32_t slot);
+void wbo_engine_move_track(wbo_engine* e, uint32_t from_slot, uint32_t to_slot);
+void wbo_engine_solo_track(wbo_engine* e, uint32_t slot);
 
 void wbo_engine_play(wbo_engine* e);                               /* engine.cpp:68-80 */
 void wbo_engine_stop(wbo_engine* e);                               /* engine.cpp:82-93 */

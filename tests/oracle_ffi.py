@@ -59,7 +59,7 @@ class _Track(C.Structure):
                 ("sampler", _Sampler),
                 ("volume", C.c_float), ("pan", C.c_float), ("pan_coeffs", C.c_float * 2), ("mute", C.c_int),
                 ("msgs", _Msg * 64), ("n_msgs", C.c_uint32),
-                ("level", C.c_float * 2), ("block_peak", C.c_float * 2), ("bus", C.c_int)]
+                ("level", C.c_float * 2), ("block_peak", C.c_float * 2), ("bus", C.c_int), ("ui_solo", C.c_int)]
 
 
 class Clip(C.Structure):
@@ -304,6 +304,10 @@ class OracleEngine:
             c = self.L.wbo_track_clip(self.e, t, i).contents
             out.append((c.min_time, c.max_time, c.start_offset, c.speed, c.gain, c.sample))
         return out
+
+    def delete_track(self, slot): self.L.wbo_engine_delete_track(self.e, slot)
+    def move_track(self, a, b): self.L.wbo_engine_move_track(self.e, a, b)
+    def solo_track(self, slot): self.L.wbo_engine_solo_track(self.e, slot)
 
     def play(self): self.L.wbo_engine_play(self.e)
     def stop(self): self.L.wbo_engine_stop(self.e)

@@ -635,3 +635,47 @@ def test_random_sessions_match_oracle(seed):
     spec, n_blocks = random_session(seed)
     # fewer tracks than one group and the oracle's bus order: everything bit-equal, including the stream-call log
     check_against_oracle(spec, n_blocks, expect_exact=True)
+
+
+def test_track_management_while_playing():
+    """Engine::move_track / delete_track / solo_track (engine.cpp:210-262) between blocks of a running transport:
+    tracks keep their sequencer and sampler state, only their slots (= the summation order) change; solo goes
+    through set_mute.  Master, peaks and transport stay bit-equal to the oracle."""
+    spec = synth.make_session("tracks", 30, seek=True, src_rate=44100, n_blocks=16, seed=0x7A)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=2)
+    e.play()
+    eng.play()
+
+    def run(tag):
+        oms, opks = [], []
+        for _ in range(2):
+            om, _ = e.process()
+            oms.append(om)
+            opks.append(e.peaks())
+        eng.render(2)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert len(eng.tracks) == e.e.contents.n_tracks, tag
+        assert np.array_equal(pk, np.stack(opks)), tag
+        assert np.array_equal(bits(m), bits(np.stack(oms))), tag
+        ph, sp, _ = eng.transport()
+        assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position)), tag
+
+    run("start")
+    e.move_track(3, 17); eng.move_track(3, 17)
+    run("move forward")
+    e.move_track(20, 2); eng.move_track(20, 2)
+    run("move back")
+    e.solo_track(5); eng.solo_track(5)
+    run("solo")
+    e.solo_track(9); eng.solo_track(9)          # solo moves to another track
+    run("solo other")
+    e.solo_track(9); eng.solo_track(9)          # un-solo: everything audible again
+    run("unsolo")
+    e.delete_track(0); eng.delete_track(0)
+    e.delete_track(11); eng.delete_track(11)
+    run("delete")
+    e.set_volume(4, -9.0); eng.tracks[4].set_volume(-9.0)     # indices follow the new slots
+    run("param after delete")
+    e.close()
+    eng.close()

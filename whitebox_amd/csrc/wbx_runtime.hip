@@ -1084,6 +1084,7 @@ struct HostTrack {
   std::vector<HostClip> clips;         // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
   float volume = 0.0f, pan = 0.0f, pan_coeffs[2] = {0.0f, 0.0f};
   bool mute = false;
+  bool ui_solo = false;                 // ui_parameter_state.solo (track.h:52)
   std::vector<ParamMsg> msgs;          // TrackMessage::ParamChange ring (track.h:131), drained at the next block
   int32_t bus = -1;
   DPatch patch{};
@@ -1272,6 +1273,87 @@ extern "C" wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t t, float pan) { 
 extern "C" wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t t, int mute) {   // track.cpp:70-79
   if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
   e->tracks[t].msgs.push_back({PARAM_MUTE, (double)(mute ? 1 : 0)});
+  return WBX_OK;
+}
+
+namespace {
+
+// new track i = old track order[i] (order.size() = new track count): the per-track device state (sequencer,
+// sampler, running levels) follows its Track object, as the pointers in the reference's vector do
+wbx_status permute_tracks(wbx_engine* e, const std::vector<uint32_t>& order) {
+  wbx_ctx* c = e->ctx;
+  (void)hipSetDevice(c->cfg.device);
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, join_sum(c));
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  const uint32_t old_n = (uint32_t)e->tracks.size(), new_n = (uint32_t)order.size();
+  if (e->state_tracks) {
+    const uint32_t C = c->cfg.channels;
+    std::vector<DTrackState> st(e->state_tracks), st2(std::max<size_t>(new_n, 1));
+    std::vector<float> lv((size_t)e->state_tracks * C), lv2((size_t)std::max<uint32_t>(new_n, 1) * C, 0.0f);
+    WBX_EHIP(e, hipMemcpy(st.data(), e->d_state.p, st.size() * sizeof(DTrackState), hipMemcpyDeviceToHost));
+    WBX_EHIP(e, hipMemcpy(lv.data(), e->d_levels.p, lv.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < new_n; i++) {
+      if (order[i] < e->state_tracks) {
+        st2[i] = st[order[i]];
+        for (uint32_t ch = 0; ch < C; ch++) lv2[(size_t)i * C + ch] = lv[(size_t)order[i] * C + ch];
+      } else {
+        st2[i] = DTrackState{};   // a track added since the last render
+      }
+    }
+    WBX_EHIP(e, hipMemset(e->d_state.p, 0, e->d_state.cap * sizeof(DTrackState)));
+    WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    if (new_n) {
+      WBX_EHIP(e, hipMemcpy(e->d_state.p, st2.data(), (size_t)new_n * sizeof(DTrackState), hipMemcpyHostToDevice));
+      WBX_EHIP(e, hipMemcpy(e->d_levels.p, lv2.data(), (size_t)new_n * C * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->state_tracks = new_n;
+  }
+  std::vector<HostTrack> moved(new_n);
+  for (uint32_t i = 0; i < new_n; i++) moved[i] = std::move(e->tracks[order[i]]);
+  e->tracks = std::move(moved);
+  (void)old_n;
+  e->clips_dirty = e->gains_dirty = e->routing_dirty = true;
+  e->total_clips = 0;
+  for (auto& tr : e->tracks) e->total_clips += tr.clips.size();
+  return WBX_OK;
+}
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:210-218
+  if (!e || slot >= e->tracks.size()) return WBX_ERR_INVALID;
+  std::vector<uint32_t> order;
+  for (uint32_t i = 0; i < e->tracks.size(); i++)
+    if (i != slot) order.push_back(i);
+  return permute_tracks(e, order);
+}
+
+extern "C" wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot) {   // engine.cpp:228-243
+  if (!e || from_slot >= e->tracks.size() || to_slot >= e->tracks.size()) return WBX_ERR_INVALID;
+  if (from_slot == to_slot) return WBX_OK;
+  std::vector<uint32_t> order(e->tracks.size());
+  for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+  order.erase(order.begin() + from_slot);
+  order.insert(order.begin() + to_slot, from_slot);
+  return permute_tracks(e, order);
+}
+
+extern "C" wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:245-262
+  if (!e || slot >= e->tracks.size()) return WBX_ERR_INVALID;
+  bool mute = false;
+  if (e->tracks[slot].ui_solo) {
+    e->tracks[slot].ui_solo = false;
+  } else {
+    e->tracks[slot].ui_solo = true;
+    wbx_track_set_mute(e, slot, 0);
+    mute = true;
+  }
+  for (uint32_t i = 0; i < e->tracks.size(); i++) {
+    if (i == slot) continue;
+    e->tracks[i].ui_solo = false;
+    wbx_track_set_mute(e, i, mute ? 1 : 0);
+  }
   return WBX_OK;
 }
 

@@ -280,6 +280,25 @@ class Engine:
         self.n_buses = n
         self.ctx.n_buses = n
 
+    # ---- track management (engine.cpp:210-262): the Track objects keep their identity, their slots shift ----
+    def _reindex(self):
+        for i, t in enumerate(self.tracks):
+            t.index = i
+
+    def delete_track(self, slot: int):
+        _check(self.L.wbx_engine_delete_track(self.h, slot), "Engine::delete_track", self.h, True)
+        del self.tracks[slot]
+        self._reindex()
+
+    def move_track(self, from_slot: int, to_slot: int):
+        _check(self.L.wbx_engine_move_track(self.h, from_slot, to_slot), "Engine::move_track", self.h, True)
+        t = self.tracks.pop(from_slot)
+        self.tracks.insert(to_slot, t)
+        self._reindex()
+
+    def solo_track(self, slot: int):
+        _check(self.L.wbx_engine_solo_track(self.h, slot), "Engine::solo_track", self.h, True)
+
     def add_sample(self, fmt: str, rate: int, data: Sequence[np.ndarray], frames: Optional[int] = None) -> int:
         """Sample asset -> HBM.  `data` planar channel arrays (padding is added by the library)."""
         frames = len(data[0]) if frames is None else frames
