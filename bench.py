@@ -402,7 +402,7 @@ def main():
             "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
             "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
                        "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate, "clip_format": fmt,
-                       "sub_buses": n_buses, "group_size": args.group_size or 64,
+                       "sub_buses": n_buses, "group_size": args.group_size or (64 if n_buses else 128),
                        "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}"},
             "master_frames_per_s": master_frames / dt,
             "track_frames_per_s": total_tracks * master_frames / dt,

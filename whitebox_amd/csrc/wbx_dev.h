@@ -17,7 +17,7 @@ constexpr uint32_t kPad = 16;          // Sample::sample_padding
 constexpr uint32_t kMaxSegs = 16;      // Sampler::stream calls per (block, track)
 constexpr uint32_t kChunk = kMaxSegs - 1;  // overflow-pool chunk: segments 1..15 of one track-block
 #ifndef WBX_KSTAGE
-#define WBX_KSTAGE 64
+#define WBX_KSTAGE 128
 #endif
 constexpr uint32_t kStage = WBX_KSTAGE;        // track-block records staged in LDS at a time
 

@@ -629,10 +629,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
-    if (tid < cn) {
-      const int k = s_tb[tid].kind;
-      shape = k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : 0;
-      if (k == KIND_WINDOW && !(s_tb[tid].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
+    for (uint32_t i = tid; i < cn; i += 256u) {
+      const int k = s_tb[i].kind;
+      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : 0;
+      if (k == KIND_WINDOW && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
     const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
@@ -642,9 +642,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
     // of the chunk's own shape, so that the load phase stays straight-line
-    if (tid < kRecs) {
-      DTrackBlock& r = s_tb[tid];
-      if (tid >= cn || r.kind == KIND_SILENT) {
+    for (uint32_t i = tid; i < kRecs; i += 256u) {
+      DTrackBlock& r = s_tb[i];
+      if (i >= cn || r.kind == KIND_SILENT) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
 
     __syncthreads();
-    if (tid < cn * C) {
-      const uint32_t rec = tid / C, ch = tid - rec * C;
+    for (uint32_t i = tid; i < cn * C; i += 256u) {
+      const uint32_t rec = i / C, ch = i - rec * C;
       const uint32_t track = a.order[grp.first + chunk0 + rec];
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)b * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order

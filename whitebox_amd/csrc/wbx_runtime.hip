@@ -481,7 +481,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   wbx_ctx* c = new (std::nothrow) wbx_ctx();
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
-  if (c->cfg.group_size == 0) c->cfg.group_size = 64;
+  if (c->cfg.group_size == 0) c->cfg.group_size = kStage;   // 128: one staging round per workgroup
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
