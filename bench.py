@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ramp-steps", type=int, default=40, help="further untimed steps straight before the timed ones: "
+                    "the device needs ~20 ms of continuous load to reach its sustained clocks, and drops them again "
+                    "in any idle gap")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
     ap.add_argument("--blocks", type=int, default=256, help="512-frame blocks per step (one device pass)")
@@ -258,7 +261,7 @@ def main():
     n_tracks = args.tracks or (256 if args.workload == "c2" else 4096)
     desc, src_rate, n_buses, fmt = WORKLOADS[args.workload]
     K = args.blocks
-    total_blocks = (args.warmup + args.steps) * K
+    total_blocks = (args.warmup + args.ramp_steps + args.steps) * K
     bytes_per_block_src = n_tracks * 2 * FMT_BYTES[fmt] * F * src_rate / SR
     mem_budget = 96e9
     session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
@@ -330,17 +333,18 @@ def main():
                 finish((nstep - 1) % NS)
             torch.cuda.synchronize()
 
+        # the submitting thread must not stall inside the timed region: a cyclic-GC pass over the session's Python
+        # objects (thousands of tracks / clips) costs milliseconds — several steps' worth of GPU time.  Done BEFORE the
+        # warm-up so that no idle gap separates the warm-up from the timed steps (the clocks would drop again).
+        gc.collect()
+        gc.freeze()
+        gc.disable()
         eng.play()
-        for _ in range(args.warmup):
+        for _ in range(args.warmup + args.ramp_steps):
             step()
         drain()
         eng.ctx.kernel_time(reset=True)
         nstep = 0
-        # the submitting thread must not stall inside the timed region: a cyclic-GC pass over the session's Python
-        # objects (thousands of tracks / clips) costs milliseconds — several steps' worth of GPU time
-        gc.collect()
-        gc.freeze()
-        gc.disable()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -396,7 +400,7 @@ def main():
         line = {
             "metric": "stereo fp32 frames/sec mixed (4096 tracks @ 512-frame blocks)",
             "value": value, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": args.ramp_steps,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
