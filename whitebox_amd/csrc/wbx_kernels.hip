@@ -390,6 +390,31 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
 
+  // A staged record is wave-uniform.  Instead of broadcast-reading its fields from LDS one by one (every such read
+  // returns 64 x 8..16 B through the LDS data path), each lane reads ONE dword of the 64-B record and the fields
+  // are pulled into scalar registers with v_readlane: one 4-B LDS read per (track, phase), and the values feed the
+  // vector ALU as scalar operands.
+  struct URec {
+    const void* src;   // src[c]
+    double pos, speed;
+    float gain, gc;    // clip gain, fl(volume * pan_c)
+    uint32_t kind, format;
+  };
+  auto load_urec = [&](uint32_t rec) {
+    const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rec])[lane & 15u];
+    auto rl = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(w, (int)i); };
+    URec r;
+    const uint32_t cs = FULL ? c : 0u;   // (only used when FULL: the channel is wave-uniform)
+    r.src = (const void*)(((uint64_t)rl(2u * cs + 1u) << 32) | rl(2u * cs));
+    r.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
+    r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
+    r.gain = __uint_as_float(rl(8));
+    r.gc = __uint_as_float(rl(9u + cs));
+    r.kind = (rl(11) >> 8) & 0xFFu;
+    r.format = rl(13) & 0xFFu;
+    return r;
+  };
+
   // ---- per-row arithmetic (each returns the 4 frames of one track AFTER clip gain and track gain) ----
   // fp32 row at unity speed: sampler.cpp:151-152, track.cpp:731
   auto row_f32 = [&](const f4& v, float cg, float gc) {
@@ -448,10 +473,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return f4{q[0], q[1], q[2], q[3]};
   };
   // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
-  auto load_window = [&](const DTrackBlock& r, Pre& p) {
-    const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                          // sampler.cpp:50, frame j0
+  auto load_window = [&](const void* src_c, double pos, double speed, Pre& p) {
+    const double x0 = __dadd_rn(pos, __dmul_rn(j0d, speed));                              // sampler.cpp:50, frame j0
     const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
-    const float WBX_GLOBAL* src = as_global<float>(r.src[c]) + ix0;
+    const float WBX_GLOBAL* src = as_global<float>(src_c) + ix0;
     if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
       p.v = *reinterpret_cast<const f4u WBX_GLOBAL*>(src);   // the taps of frames j0..j0+3 lie in src[0..4]
       p.w4 = src[4];
@@ -500,21 +525,29 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const DTrackBlock& r = s_tb[u0 + u];
+      URec r;
+      if (FULL) {
+        r = load_urec(u0 + u);
+      } else {
+        const DTrackBlock& t = s_tb[u0 + u];
+        r.src = t.src[c];
+        r.pos = t.pos;
+        r.speed = t.speed;
+      }
       if (MODE == MODE_W || MODE == MODE_WN) {
-        load_window(r, pre[u]);
+        load_window(r.src, r.pos, r.speed, pre[u]);
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
         if (MODE == MODE_I16) {
           typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
-          const short WBX_GLOBAL* p = as_global<short>(r.src[c]) + off;
+          const short WBX_GLOBAL* p = as_global<short>(r.src) + off;
           if (active) {
             const i2u w = *reinterpret_cast<const i2u WBX_GLOBAL*>(p);
             pre[u].v.x = __int_as_float(w.x);
             pre[u].v.y = __int_as_float(w.y);
           }
         } else {   // MODE_U, MODE_I32: 4 x 32-bit
-          const float WBX_GLOBAL* p = as_global<float>(r.src[c]) + off;
+          const float WBX_GLOBAL* p = as_global<float>(r.src) + off;
           if (active) pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);
         }
       }
@@ -526,9 +559,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const DTrackBlock& r = s_tb[u0 + u];
+      URec r;
+      if (FULL) {
+        r = load_urec(u0 + u);
+      } else {
+        const DTrackBlock& t = s_tb[u0 + u];
+        r.pos = t.pos;
+        r.speed = t.speed;
+        r.gain = t.gain;
+        r.gc = t.g[c];
+        r.kind = t.kind;
+        r.format = t.format;
+      }
       const float cg = r.gain;
-      const float gc = r.g[c];
+      const float gc = r.gc;
       f4 m;
       if (MODE == MODE_W || MODE == MODE_WN) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
@@ -585,7 +629,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
       if (k == KIND_WINDOW) {
         Pre p;
-        load_window(r, p);
+        load_window(r.src[c], r.pos, r.speed, p);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
