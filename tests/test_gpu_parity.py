@@ -679,3 +679,56 @@ def test_track_management_while_playing():
     run("param after delete")
     e.close()
     eng.close()
+
+
+def test_pipelined_renders_without_host_sync():
+    """Twelve renders issued back to back (no fetch, no sync in between): plans, mixes and sums of different renders
+    overlap on their three streams and rotate through the ring of plan / partial-sum buffers.  Every render's master
+    goes to its own device buffer; after one final sync all 48 blocks must equal the oracle's bit for bit."""
+    import torch
+    spec = synth.make_session("pipe", 100, seek=True, src_rate=44100, n_blocks=48, seed=0x91E)
+    K, R = 4, 12
+    om, opk, _, _, otr = run_oracle(spec, K * R)
+    eng = build_engine(spec, max_blocks=K)
+    n = K * spec.channels * spec.block
+    outs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    eng.play()
+    for r in range(R):
+        eng.ctx.set_master_target(outs[r].data_ptr())
+        eng.render(K)
+    eng.ctx.sync()
+    torch.cuda.synchronize()
+    got = np.stack([o.cpu().numpy().reshape(K, spec.channels, spec.block) for o in outs]).reshape(K * R, spec.channels, spec.block)
+    assert np.array_equal(bits(got), bits(om))
+    _, pk, _ = eng.ctx.fetch(peaks=True)            # peaks of the last render
+    assert np.array_equal(pk, opk[-K:, :, :spec.channels])
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(otr[0]), O.f64_bits(otr[1]))
+    eng.ctx.set_master_target(None)
+    eng.close()
+
+
+def test_pipelined_renders_large():
+    """The same at a size where renders really overlap on the device (2048 tracks, 8 x 32 blocks)."""
+    import torch
+    spec = synth.make_session("pipeL", 2048, src_rate=44100, n_blocks=256, seed=0x91F)
+    K, R = 32, 8
+    om, opk, _, _, _ = run_oracle(spec, K * R)
+    eng = build_engine(spec, max_blocks=K, device_synth=True)
+    n = K * spec.channels * spec.block
+    outs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    eng.play()
+    for r in range(R):
+        eng.ctx.set_master_target(outs[r].data_ptr())
+        eng.render(K)
+    eng.ctx.sync()
+    torch.cuda.synchronize()
+    got = np.stack([o.cpu().numpy().reshape(K, spec.channels, spec.block) for o in outs]).reshape(K * R, spec.channels, spec.block)
+    assert rms(got, om) <= RMS_TOL
+    assert np.abs(got - om).max() < 1e-5
+    _, pk, _ = eng.ctx.fetch(peaks=True)
+    assert np.array_equal(pk, opk[-K:, :, :spec.channels])
+    eng.ctx.set_master_target(None)
+    eng.close()
