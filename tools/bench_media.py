@@ -47,6 +47,19 @@ for fmt, dt in (("i16", torch.int16), ("f32", torch.float32)):
         out.append({"op": "build_mipmaps", "fmt": fmt, "quality": q, "frames": FRAMES, "channels": 2, "levels": levels,
                     "ms_wall": dt_mip * 1e3, "algorithmic_bytes": alg, "GBps_wall": alg / dt_mip / 1e9})
     del src
+# host-side entry points (what the boundary does when it is handed host buffers): PCIe-inclusive rates
+HF = 32 << 20
+for fmt, npdt in (("i16", np.int16), ("f32", np.float32)):
+    a = (np.arange(HF * 2, dtype=np.int64) % 30011).astype(npdt).reshape(HF, 2)
+    pinned = torch.from_numpy(a).pin_memory()
+    for name, arr in (("pageable", a), ("pinned", pinned.numpy())):
+        ctx.clip_upload_interleaved(1, fmt, 48000, arr)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.clip_upload_interleaved(1, fmt, 48000, arr)
+        dt_up = (time.perf_counter() - t0) / 3
+        out.append({"op": "upload_interleaved", "host_memory": name, "fmt": fmt, "frames": HF, "channels": 2,
+                    "ms_wall": dt_up * 1e3, "host_bytes": arr.nbytes, "GBps_host_to_planar_hbm": arr.nbytes / dt_up / 1e9})
 ctx.close()
 for o in out:
     print(json.dumps(o))
