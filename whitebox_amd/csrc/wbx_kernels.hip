@@ -745,6 +745,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
+  if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) a.status_dst[threadIdx.x] = a.status_src[threadIdx.x];
   const uint32_t b = blockIdx.x;
   const uint32_t F = a.block_frames, C = a.channels;
   const uint32_t slot = blockIdx.y * 64u + threadIdx.x;

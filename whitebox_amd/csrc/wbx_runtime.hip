@@ -47,6 +47,7 @@ constexpr int kEventRing = 64;
 // the mix of render i-3 and the sum of render i-3 are over, i.e. a full render before its own mix — the one-wave-per-
 // track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
 constexpr int kRing = 3;
+constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
 
 struct ClipSlot {
   void* base = nullptr;     // one allocation holding all channels
@@ -141,6 +142,7 @@ struct wbx_ctx {
   std::vector<DSeg> h_pool;
 
   uint32_t last_K = 0, last_N = 0;
+  uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
   bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation
   float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
   bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
@@ -403,20 +405,25 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.block_frames = F;
   s.channels = C;
   s.clamp = c->clamp ? 1u : 0u;
+  s.status_src = c->status_dst ? PB(c).counters : nullptr;
+  s.status_dst = c->status_dst;
   if (c->n_buses && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
     WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
     c->buses_clean = true;
   }
-  hipStream_t ss = c->sum_overlap ? c->sum_stream : c->stream;
-  if (c->sum_overlap) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
+  // hand-overs cost more than the few microseconds of overlap they could buy
+  const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
+  hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
+  if (sum_beside) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   launch_sum(s, K, ss);
   if (m.n_groups && c->profiling) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
     c->ev_pending++;
   }
-  if (c->sum_overlap) {
+  if (sum_beside) {
     WBX_HIP(c, hipEventRecord(c->sum_done[pp], ss));
     c->sum_valid[pp] = true;
     c->sum_pending = pp;
@@ -1735,11 +1742,12 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   //    while the mix of the previous render is still busy on the main stream
   c->cur = (c->cur + 1) % kRing;
   wbx_ctx::PlanBuf& B = PB(c);
-  hipStream_t ps = c->overlap ? c->plan_stream : s;
+  const bool plan_beside = c->overlap && K >= kOverlapMinBlocks;
+  hipStream_t ps = plan_beside ? c->plan_stream : s;
   if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
   {
     const int pp = (int)(c->render_seq % kRing);
-    if (c->overlap && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
+    if (plan_beside && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
       WBX_EHIP(e, hipStreamWaitEvent(ps, c->sum_done[pp], 0));
       c->partial_wait_done = true;
     }
@@ -1781,7 +1789,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   WBX_EHIP(e, hipEventRecord(B.planned, ps));
 
   // -- mix + sum on the main stream, after the plan
-  WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
+  if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = e->any_window_clip;
   const int mix_parity = (int)(c->render_seq % kRing);
@@ -1821,11 +1829,12 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
     WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
     WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
   }
-  c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block
+  c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
+  c->status_dst = e->h_status;            // and it drops the plan status next to it
   wbx_status st = wbx_engine_render(e, 1);
   c->master_target = nullptr;
+  c->status_dst = nullptr;
   if (st != WBX_OK) return st;
-  launch_clamp_into(reinterpret_cast<const float*>(PB(c).counters), reinterpret_cast<float*>(e->h_status), 4, 0, c->stream);
   WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
   drain_events(c);
