@@ -376,8 +376,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.channels = C;
   m.tiles = ((C * F / 4) + 255u) / 256u;
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(c->d_peaks.p, 0, (size_t)K * N * C * sizeof(float), c->stream));
+  // the kernel timer is for batch renders; the one-block callback path skips its three event records
+  const bool timed = c->profiling && K > 1;
   if (m.n_groups) {
-    if (c->profiling) {
+    if (timed) {
       if (c->ev_pending == kEventRing) {
         WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
         drain_events(c);
@@ -385,7 +387,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
     launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43), c->stream);
-    if (c->profiling) {
+    if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
   }
@@ -419,7 +421,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
   if (sum_beside) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   launch_sum(s, K, ss);
-  if (m.n_groups && c->profiling) {
+  if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
     c->ev_pending++;
   }
@@ -1786,7 +1788,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   launch_plan(a, ps);
   st = launch_pre_render(c, ps);
   if (st != WBX_OK) return st;
-  WBX_EHIP(e, hipEventRecord(B.planned, ps));
+  if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
 
   // -- mix + sum on the main stream, after the plan
   if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
