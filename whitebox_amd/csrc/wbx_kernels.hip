@@ -897,8 +897,9 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.n_blocks * sizeof(DBlockTime), s, a);
 }
 
-void launch_gen(const GenArgs& a, hipStream_t s) {
-  const uint32_t grid = a.gen_cap < 2048u ? (a.gen_cap ? a.gen_cap : 1u) : 2048u;
+void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
+  // grid-stride over the queue: the grid only bounds the parallelism (a short render cannot queue many rows)
+  const uint32_t grid = a.gen_cap < max_grid ? (a.gen_cap ? a.gen_cap : 1u) : max_grid;
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 

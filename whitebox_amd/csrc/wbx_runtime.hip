@@ -26,7 +26,7 @@
 
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
-void launch_gen(const GenArgs& a, hipStream_t s);
+void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
 void launch_mix(const MixArgs& a, uint32_t n_blocks, int unroll, hipStream_t s);
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
@@ -335,7 +335,7 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
 }
 
 // pre-render of the queued generic records of the current plan buffer
-wbx_status launch_pre_render(wbx_ctx* c, hipStream_t on) {
+wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   GenArgs ga{};
   ga.tmpl = PB(c).tmpl.p;
@@ -347,7 +347,7 @@ wbx_status launch_pre_render(wbx_ctx* c, hipStream_t on) {
   ga.gen_cap = PB(c).gen_cap;
   ga.block_frames = F;
   ga.channels = C;
-  launch_gen(ga, on);
+  launch_gen(ga, K < kOverlapMinBlocks ? 64u * K : 2048u, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
 }
@@ -958,7 +958,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
-  st = launch_pre_render(c, c->stream);
+  st = launch_pre_render(c, K, c->stream);
   if (st != WBX_OK) return st;
   return launch_mix_sum(c, K, N);
 }
@@ -1786,7 +1786,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   a.sample_position = e->sample_position;
   a.beat_duration = e->beat_duration;
   launch_plan(a, ps);
-  st = launch_pre_render(c, ps);
+  st = launch_pre_render(c, K, ps);
   if (st != WBX_OK) return st;
   if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
 
