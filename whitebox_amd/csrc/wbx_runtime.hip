@@ -143,6 +143,8 @@ struct wbx_ctx {
 
   uint32_t last_K = 0, last_N = 0;
   uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
+  bool buses_alias_partials = false;  // see build_routing
+  const float* last_buses = nullptr;  // where the last render's bus sums are: d_buses or the partial buffer
   bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation
   float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
   bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
@@ -244,6 +246,11 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
   for (uint32_t u = 0; u < c->n_buses; u++) emit(per_bus[u], (int32_t)u);
   c->routing_tracks = n_tracks;
   c->routing_dirty = true;
+  // every bus exactly one group and nothing routed straight to the master: group g's partial sum IS bus g's sum, so
+  // the bus output can alias the partial buffer instead of being written a second time by the sum kernel
+  c->buses_alias_partials = c->n_buses > 0 && c->groups.size() == c->n_buses;
+  for (size_t g = 0; g < c->groups.size() && c->buses_alias_partials; g++)
+    if (c->groups[g].bus != (int32_t)g) c->buses_alias_partials = false;
 }
 
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
@@ -401,7 +408,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.master = c->master_target ? c->master_target : c->d_master.p;
   c->last_master = s.master;
   c->last_master_on_host = false;
-  s.buses = c->n_buses ? c->d_buses.p : nullptr;
+  s.buses = (c->n_buses && !c->buses_alias_partials) ? c->d_buses.p : nullptr;
+  c->last_buses = c->n_buses ? (c->buses_alias_partials ? c->d_partial2[pp].p : c->d_buses.p) : nullptr;
   s.n_groups = m.n_groups;
   s.n_buses = c->n_buses;
   s.block_frames = F;
@@ -409,7 +417,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.clamp = c->clamp ? 1u : 0u;
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
-  if (c->n_buses && !c->buses_clean) {
+  if (c->n_buses && !c->buses_alias_partials && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
     WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
@@ -991,7 +999,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   if (peaks) WBX_HIP(c, hipMemcpyAsync(peaks, c->d_peaks.p, (size_t)K * N * C * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (buses) {
     if (!c->n_buses) return fail(c, WBX_ERR_INVALID, "no buses configured");
-    WBX_HIP(c, hipMemcpyAsync(buses, c->d_buses.p, (size_t)K * c->n_buses * C * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    WBX_HIP(c, hipMemcpyAsync(buses, c->last_buses, (size_t)K * c->n_buses * C * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
