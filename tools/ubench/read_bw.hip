@@ -5,6 +5,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 read_bw.hip -o read_bw ; run: ./read_bw
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(256) void k_lds(const float* const* __restrict__ ch
   if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int WARM = argc > 1 ? atoi(argv[1]) : 3;   // launches before the timed ones (60+: the steady clocks)
+
   const int N = 4096, K = 256, F = 512, G = 64;
   const size_t frames = (size_t)K * F;
   std::vector<float*> h(N * 2);
@@ -126,7 +129,7 @@ int main() {
   float* out; hipMalloc(&out, 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char* name, auto launch) {
-    for (int i = 0; i < 3; i++) launch();
+    for (int i = 0; i < WARM; i++) launch();
     hipEventRecord(e0);
     const int R = 20;
     for (int i = 0; i < R; i++) launch();
@@ -142,7 +145,7 @@ int main() {
   timeit("rows U=16 (b fastest)", [&] { hipLaunchKernelGGL(k_rows<16>, dim3(K, N / G), dim3(256), 0, 0, (const float* const*)d, G, F, out); });
   const double wb = bytes * 0.91875;
   auto timeit2 = [&](const char* name, auto launch) {
-    for (int i = 0; i < 3; i++) launch();
+    for (int i = 0; i < WARM; i++) launch();
     hipEventRecord(e0);
     const int R = 20;
     for (int i = 0; i < R; i++) launch();
