@@ -187,6 +187,7 @@ wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t track, int mute);        /
  * solo_track (:245-262; toggles the UI solo flag and mutes / unmutes the other tracks through set_mute).
  * Track indices above a deleted / between moved slots shift exactly as the reference's vector does. */
 wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot);
+wbx_status wbx_engine_clear_all(wbx_engine* e);                       /* Engine::clear_all, engine.cpp:59-66 */
 wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot);
 wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot);
 wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);      /* extension A13 */

@@ -169,6 +169,10 @@ struct Engine {
     for (uint32_t i = 0; i < tracks.size(); i++) tracks[i]->index = i;
   }
   void solo_track(uint32_t slot) { check(wbx_engine_solo_track(h, slot), "solo_track"); }
+  void clear_all() {   // engine.cpp:59-66
+    check(wbx_engine_clear_all(h), "clear_all");
+    tracks.clear();
+  }
   // decoded clip audio -> HBM (what SampleAsset / Sample hold in the reference: assets_table.h:22-35, sample.h:18-28)
   uint32_t add_sample(int format, uint32_t channels, uint32_t sample_rate, uint64_t frames, const void* const* planar) {
     uint32_t id = 0;

@@ -678,6 +678,14 @@ def test_track_management_while_playing():
     e.set_volume(4, -9.0); eng.tracks[4].set_volume(-9.0)     # indices follow the new slots
     run("param after delete")
     e.close()
+    # Engine::clear_all: no tracks left -> silence, and the engine takes new tracks afterwards
+    eng.clear_all()
+    eng.render(2)
+    m, _, _ = eng.ctx.fetch()
+    assert not m.any()
+    t = eng.add_track("again")
+    assert t.index == 0 and len(eng.tracks) == 1
+    eng.render(1)
     eng.close()
 
 

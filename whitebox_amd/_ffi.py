@@ -87,6 +87,7 @@ SYMBOLS = {
     "wbx_track_set_mute": (C.c_int, [_vp, _u32, C.c_int]),
     "wbx_track_set_bus": (C.c_int, [_vp, _u32, _i32]),
     "wbx_engine_delete_track": (C.c_int, [_vp, _u32]),
+    "wbx_engine_clear_all": (C.c_int, [_vp]),
     "wbx_engine_move_track": (C.c_int, [_vp, _u32, _u32]),
     "wbx_engine_solo_track": (C.c_int, [_vp, _u32]),
     "wbx_engine_add_sample": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, _pp, C.POINTER(_u32)]),

@@ -1346,6 +1346,11 @@ extern "C" wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot) {   
   return permute_tracks(e, order);
 }
 
+extern "C" wbx_status wbx_engine_clear_all(wbx_engine* e) {   // engine.cpp:59-66: every track goes
+  if (!e) return WBX_ERR_INVALID;
+  return permute_tracks(e, std::vector<uint32_t>{});
+}
+
 extern "C" wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot) {   // engine.cpp:228-243
   if (!e || from_slot >= e->tracks.size() || to_slot >= e->tracks.size()) return WBX_ERR_INVALID;
   if (from_slot == to_slot) return WBX_OK;
@@ -1619,10 +1624,30 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   e->err.clear();
   if (K > c->cfg.max_blocks) return efail(e, WBX_ERR_INVALID, "n_blocks above wbx_config.max_blocks");
   const uint32_t N = (uint32_t)e->tracks.size();
-  if (N == 0) return efail(e, WBX_ERR_INVALID, "no tracks");
   (void)hipSetDevice(c->cfg.device);
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   hipStream_t s = c->stream;
+  if (N == 0) {
+    // Engine::process with an empty track list: output_buffer.clear() and the transport advance (engine.cpp:1598,
+    // :1619-1623) — silence
+    WBX_EHIP(e, join_sum(c));
+    WBX_EHIP(e, c->d_master.ensure((size_t)K * C * F));
+    float* master = c->master_target ? c->master_target : c->d_master.p;
+    WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * sizeof(float), s));
+    c->last_master = master;
+    c->last_master_on_host = false;
+    c->last_K = K;
+    c->last_N = 0;
+    const double sample_rate = (double)c->cfg.sample_rate;
+    for (uint32_t b = 0; b < K; b++) {
+      const double buffer_duration_in_beats = ((double)F / sample_rate) / e->beat_duration;
+      if (e->playing) {
+        e->sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, e->beat_duration);
+        e->playhead = e->playhead + buffer_duration_in_beats;
+      }
+    }
+    return WBX_OK;
+  }
 
   // -- parameters: drain the message rings (process_track_messages track.cpp:773-779) and apply them
   //    (track.cpp:618-643); the factor used per sample is fl(volume * pan_coeffs[c]) (track.cpp:728-731)

@@ -290,6 +290,10 @@ class Engine:
         del self.tracks[slot]
         self._reindex()
 
+    def clear_all(self):
+        _check(self.L.wbx_engine_clear_all(self.h), "Engine::clear_all", self.h, True)
+        self.tracks = []
+
     def move_track(self, from_slot: int, to_slot: int):
         _check(self.L.wbx_engine_move_track(self.h, from_slot, to_slot), "Engine::move_track", self.h, True)
         t = self.tracks.pop(from_slot)
