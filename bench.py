@@ -299,6 +299,7 @@ def main():
 
         done = 0
         nstep = 0
+        pace = [torch.cuda.Event() for _ in range(4)]
 
         def finish(slot):
             """root: wait for the reduce of `slot`, clamp, copy to the host — all on fin_stream."""
@@ -325,6 +326,13 @@ def main():
                     finish((nstep - 1) % NS)
             else:
                 eng.render(K)
+            # keep the submitting thread at most ~16 steps ahead of the device: far deeper, the HIP runtime stalls a
+            # launch until its queue has drained (tens of ms) and the device then idles
+            if nstep % 4 == 0:
+                slot4 = (nstep // 4) % len(pace)
+                if nstep >= 16:
+                    pace[(slot4 + 1) % len(pace)].synchronize()      # recorded 12 steps ago
+                pace[slot4].record(stream)
             done += K
             nstep += 1
 

@@ -1140,6 +1140,11 @@ struct wbx_engine {
   uint32_t next_clip_uid = 0;
   // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
   // and the plan status lands in — the callback path then needs no copy-engine transfer at all
+  DPatch* h_patch[kRing] = {};          // pinned patch buffers the plan kernel reads in place
+  uint32_t patch_cap[kRing] = {};
+  hipEvent_t patch_done[kRing] = {};    // the plan kernel that read the buffer
+  bool patch_valid[kRing] = {};
+  uint32_t patch_seq = 0;
   float* h_block = nullptr;             // [C][F]
   uint32_t* h_status = nullptr;         // plan counters [4]
   size_t d_clips_count = 0;
@@ -1228,6 +1233,10 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
   e->d_patch.release();
   e->d_gains.release();
   e->d_levels.release();
+  for (int i = 0; i < kRing; i++) {
+    if (e->h_patch[i]) (void)hipHostFree(e->h_patch[i]);
+    if (e->patch_done[i]) (void)hipEventDestroy(e->patch_done[i]);
+  }
   if (e->h_block) (void)hipHostFree(e->h_block);
   if (e->h_status) (void)hipHostFree(e->h_status);
   wbx_destroy(e->ctx);
@@ -1733,18 +1742,33 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   }
 
   // -- pending state edits (play / stop / clip-list changes)
+  // The patches sit in pinned host memory that the plan kernel reads directly (one 16-B read per lane): no copy, and
+  // above all no stream synchronisation — a drain here would empty the queue of renders the host has run ahead by.
+  // Three buffers in rotation; a buffer is refilled only after the plan kernel that last read it has finished.
   const DPatch* d_patch = nullptr;
+  int patch_slot = -1;
   if (e->patches_pending) {
-    std::vector<DPatch> p(N);
+    patch_slot = (int)(e->patch_seq++ % kRing);
+    if (e->patch_cap[patch_slot] < N) {
+      // (re)allocate all three at once — pinning memory synchronises the device, so it must not happen in mid-run
+      WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+      WBX_EHIP(e, hipStreamSynchronize(s));
+      const uint32_t cap = std::max<uint32_t>(N, c->cfg.max_tracks);
+      for (int i = 0; i < kRing; i++) {
+        if (e->h_patch[i]) WBX_EHIP(e, hipHostFree(e->h_patch[i]));
+        e->h_patch[i] = nullptr;
+        WBX_EHIP(e, hipHostMalloc((void**)&e->h_patch[i], (size_t)cap * sizeof(DPatch), hipHostMallocDefault));
+        e->patch_cap[i] = cap;
+        e->patch_valid[i] = false;
+        if (!e->patch_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->patch_done[i], hipEventDisableTiming));
+      }
+    }
+    if (e->patch_valid[patch_slot]) WBX_EHIP(e, hipEventSynchronize(e->patch_done[patch_slot]));
     for (uint32_t t = 0; t < N; t++) {
-      p[t] = e->tracks[t].patch;
+      e->h_patch[patch_slot][t] = e->tracks[t].patch;
       e->tracks[t].patch = DPatch{};
     }
-    WBX_EHIP(e, e->d_patch.ensure(N));
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
-    WBX_EHIP(e, hipMemcpy(e->d_patch.p, p.data(), N * sizeof(DPatch), hipMemcpyHostToDevice));
-    d_patch = e->d_patch.p;
+    d_patch = e->h_patch[patch_slot];
     e->patches_pending = false;
   }
 
@@ -1819,6 +1843,10 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   a.sample_position = e->sample_position;
   a.beat_duration = e->beat_duration;
   launch_plan(a, ps);
+  if (patch_slot >= 0) {
+    WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
+    e->patch_valid[patch_slot] = true;
+  }
   st = launch_pre_render(c, K, ps);
   if (st != WBX_OK) return st;
   if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
