@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
     const float WBX_GLOBAL* src = as_global<float>(src_c) + ix0;
     if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
-      p.v = *reinterpret_cast<const f4u WBX_GLOBAL*>(src);   // the taps of frames j0..j0+3 lie in src[0..4]
+      p.v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(src));   // the taps of frames j0..j0+3 lie in src[0..4]
       p.w4 = src[4];
     }
     p.ix0 = ix0;
@@ -542,13 +542,13 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
           typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
           const short WBX_GLOBAL* p = as_global<short>(r.src) + off;
           if (active) {
-            const i2u w = *reinterpret_cast<const i2u WBX_GLOBAL*>(p);
+            const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(p));
             pre[u].v.x = __int_as_float(w.x);
             pre[u].v.y = __int_as_float(w.y);
           }
         } else {   // MODE_U, MODE_I32: 4 x 32-bit
           const float WBX_GLOBAL* p = as_global<float>(r.src) + off;
-          if (active) pre[u].v = *reinterpret_cast<const f4u WBX_GLOBAL*>(p);
+          if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(p));
         }
       }
     }
