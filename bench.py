@@ -40,8 +40,10 @@ WORKLOADS = {
     "c3": ("configs[2]: 4096 stereo tracks, gain+pan + linear clip resample 44.1k->48k, 512-frame blocks", 44100, 0, "f32"),
     "c4": ("configs[3]: 4096 stereo tracks into 64 sub-buses + master sum, 512-frame blocks", 48000, 64, "f32"),
     "i16": ("next-2 (SURVEY 8f): 4096 stereo 16-bit PCM tracks, gain+pan, unity rate, 512-frame blocks", 48000, 0, "i16"),
+    "d96": ("4096 stereo 96 kHz tracks played in the 48 kHz session (playback speed 2, per-frame taps), 512-frame blocks",
+            96000, 0, "f32"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6}
 FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4}
 
 

@@ -263,6 +263,29 @@ def test_speed_variants_and_formats():
     check_against_oracle(spec, 4, expect_exact=True)
 
 
+@pytest.mark.parametrize("src_rate,sample_rate", [(48000, 44100), (96000, 48000), (88200, 48000), (192000, 44100)])
+def test_downsampled_clips_hot_loop(src_rate, sample_rate):
+    """Clips recorded at a higher rate than the session (playback speed > 1): whole-block rows are streamed
+    by the mix kernel with per-frame taps; clip boundaries inside blocks stay on the pre-render pass."""
+    spec = synth.make_session("down", 200, seek=True, n_blocks=6, seed=0xD0 + src_rate // 1000, src_rate=src_rate,
+                              sample_rate=sample_rate)
+    check_against_oracle(spec, 6)                                     # grouped order
+    check_against_oracle(spec, 6, group_size=200, expect_exact=True)  # reference order: bit-exact
+    # among unity, up-sampled and 16-bit tracks in the same group
+    spec = synth.make_session("downmix", 96, n_blocks=5, seed=0xD7, src_rate=src_rate, sample_rate=sample_rate)
+    for i, smp in enumerate(spec.samples):
+        if i % 4 == 1:
+            smp.rate = sample_rate
+        elif i % 4 == 2:
+            smp.rate = sample_rate * 3 // 4
+        elif i % 8 == 3:
+            smp.fmt, smp.rate, smp.amp = "i16", sample_rate, 1.0
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -36.0
+    check_against_oracle(spec, 5, group_size=96, expect_exact=True)
+    check_against_oracle(spec, 5, group_size=12, expect_exact=False)
+
+
 def test_clamp_and_unclamped_partial():
     spec = synth.make_session("hot", 16, n_blocks=2, amp=0.5, seed=0x5EED0007)
     om, _, _, _, _ = run_oracle(spec, 2)

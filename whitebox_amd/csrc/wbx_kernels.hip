@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t wave_max_quad(uint32_t p0, uint32_t p1, uint
   return v;
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5 };   // row shapes of a staged chunk
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -335,6 +335,9 @@ struct Pre {
   float w4;    // WINDOW: window sample 4
   int ix0;     // WINDOW: integer source position of v.x
   float fx0;   // WINDOW: interpolation fraction of frame j0
+};
+struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = fraction of each of the lane's 4 frames
+  f4 v, b, fx;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -354,7 +357,7 @@ struct Pre {
 //   FULL  every lane owns a slot and every wave is channel-uniform (C*F/4 % 256 == 0, F/4 % 64 == 0):
 //         no lane predicate, the channel index is a scalar
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W>
+template <int U, bool FULL, int W, bool G>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   constexpr uint32_t kRecs = kStage + 2 * U + 4;   // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kRecs];
@@ -486,6 +489,36 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
     p.fx0 = (float)__builtin_amdgcn_fract(x0);
   };
+  // per-frame taps for any playback speed (sampler.cpp:50-52 for each of the lane's 4 frames): four unaligned 8-B
+  // loads {src[ix], src[ix+1]}; also valid for unity rows (fx = 0, first tap = the sample itself)
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+  auto load_stride = [&](const void* src_c, double pos, double speed, PreG& p) {
+    const float WBX_GLOBAL* base = as_global<float>(src_c);
+    const double jd[4] = {j0d, jd1, jd2, jd3};
+    float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, f4x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double x = __dadd_rn(pos, __dmul_rn(jd[k], speed));                           // :50
+      const int ix = (int)x;                                                              // :51
+      f4x[k] = (float)__builtin_amdgcn_fract(x);                                          // :52
+      if (active) {
+        const f2u t = *reinterpret_cast<const f2u WBX_GLOBAL*>(base + ix);
+        a4[k] = t.x;
+        b4[k] = t.y;
+      }
+    }
+    p.v = f4{a4[0], a4[1], a4[2], a4[3]};
+    p.b = f4{b4[0], b4[1], b4[2], b4[3]};
+    p.fx = f4{f4x[0], f4x[1], f4x[2], f4x[3]};
+  };
+  auto row_stride = [&](const PreG& p, float cg, float gc) {
+    f4 m;
+    m.x = __fmul_rn(__fmul_rn(__fadd_rn(p.v.x, __fmul_rn(p.fx.x, __fsub_rn(p.b.x, p.v.x))), cg), gc);   // :55-56, track.cpp:731
+    m.y = __fmul_rn(__fmul_rn(__fadd_rn(p.v.y, __fmul_rn(p.fx.y, __fsub_rn(p.b.y, p.v.y))), cg), gc);
+    m.z = __fmul_rn(__fmul_rn(__fadd_rn(p.v.z, __fmul_rn(p.fx.z, __fsub_rn(p.b.z, p.v.z))), cg), gc);
+    m.w = __fmul_rn(__fmul_rn(__fadd_rn(p.v.w, __fmul_rn(p.fx.w, __fsub_rn(p.b.w, p.v.w))), cg), gc);
+    return m;
+  };
   auto add_row = [&](const f4& m0) {
     f4 m = m0;
     if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -521,10 +554,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   //  MODE_W    fp32 rows, some linearly resampled: 16-B + 4-B load per track (unity rows use the same formula)
   //  MODE_I16  every row is 16-bit PCM at unity speed: one 8-B load per track (half the bytes of fp32)
   //  MODE_I32  every row is 24/32-bit PCM at unity speed: one 16-B load per track
-  auto issue = [&](auto mode, uint32_t u0, Pre (&pre)[U]) {
+  auto issue = [&](auto mode, uint32_t u0, auto& pre) {
     constexpr int MODE = decltype(mode)::value;
+    constexpr int D = (int)std::extent_v<std::remove_reference_t<decltype(pre)>>;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < D; u++) {
       URec r;
       if (FULL) {
         r = load_urec(u0 + u);
@@ -534,7 +568,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.pos = t.pos;
         r.speed = t.speed;
       }
-      if (MODE == MODE_W || MODE == MODE_WN) {
+      if constexpr (MODE == MODE_G) {
+        load_stride(r.src, r.pos, r.speed, pre[u]);
+      } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
         load_window(r.src, r.pos, r.speed, pre[u]);
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
@@ -555,10 +591,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   };
 
   // ---- phase B: render, scale, accumulate — strictly in track order; pk[u] = per-lane max |m| of track u0+u
-  auto render = [&](auto mode, uint32_t u0, Pre (&pre)[U], float* pk) {
+  auto render = [&](auto mode, uint32_t u0, auto& pre, float* pk) {
     constexpr int MODE = decltype(mode)::value;
+    constexpr int D = (int)std::extent_v<std::remove_reference_t<decltype(pre)>>;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < D; u++) {
       URec r;
       if (FULL) {
         r = load_urec(u0 + u);
@@ -574,14 +611,19 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const float cg = r.gain;
       const float gc = r.gc;
       f4 m;
-      if (MODE == MODE_W || MODE == MODE_WN) {
+      if constexpr (MODE == MODE_G) {
+        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_UNITY)
+          m = row_f32(pre[u].v, cg, gc);   // also pre-rendered rows, silent and padding records
+        else
+          m = row_stride(pre[u], cg, gc);  // KIND_STRIDE and KIND_WINDOW rows
+      } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
           m = row_window(std::integral_constant<bool, MODE == MODE_WN>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
-      } else if (MODE == MODE_I16) {
+      } else if constexpr (MODE == MODE_I16) {
         m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
-      } else if (MODE == MODE_I32) {
+      } else if constexpr (MODE == MODE_I32) {
         m = row_i32(pre[u].v, r.format, cg, gc);
       } else {
         m = row_f32(pre[u].v, cg, gc);
@@ -590,20 +632,22 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   };
 
-  // two-stage software pipeline over batches of U tracks (trip count is uniform: padded with null records);
-  // one iteration covers kIter = lcm(2U, 4) tracks so that the peaks can be reduced four tracks at a time
+  // two-stage software pipeline over batches of D tracks (trip count is uniform: padded with null records);
+  // one iteration covers kIter = lcm(2D, 4) tracks so that the peaks can be reduced four tracks at a time.
+  // D = U except for the per-frame-tap mode, whose rows hold 12 registers each: depth 1 keeps it out of scratch
   auto pipeline = [&](auto mode, uint32_t cn) {
-    constexpr int kIter = (2 * U) % 4 == 0 ? 2 * U : 4;
-    Pre pa[U], pb[U];
+    constexpr int D = decltype(mode)::value == MODE_G ? 1 : U;
+    constexpr int kIter = (2 * D) % 4 == 0 ? 2 * D : 4;
+    std::conditional_t<decltype(mode)::value == MODE_G, PreG, Pre> pa[D], pb[D];
     issue(mode, 0, pa);
     for (uint32_t u0 = 0; u0 < cn; u0 += kIter) {
       float pk[kIter];
 #pragma unroll
-      for (int h = 0; h < kIter; h += 2 * U) {
-        issue(mode, u0 + h + U, pb);
+      for (int h = 0; h < kIter; h += 2 * D) {
+        issue(mode, u0 + h + D, pb);
         render(mode, u0 + h, pa, pk + h);
-        issue(mode, u0 + h + 2 * U, pa);
-        render(mode, u0 + h + U, pb, pk + h + U);
+        issue(mode, u0 + h + 2 * D, pa);
+        render(mode, u0 + h + D, pb, pk + h + D);
       }
       if (FULL) {
 #pragma unroll
@@ -631,6 +675,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         Pre p;
         load_window(r.src[c], r.pos, r.speed, p);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
+      } else if (G && k == KIND_STRIDE) {
+        if constexpr (G) {
+          PreG p;
+          load_stride(r.src[c], r.pos, r.speed, p);
+          m = row_stride(p, cg, gc);
+        }
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
         i2u w = {0, 0};
@@ -675,13 +725,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     int shape = 0;
     for (uint32_t i = tid; i < cn; i += 256u) {
       const int k = s_tb[i].kind;
-      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : 0;
+      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : k == KIND_STRIDE ? 64 : 0;
       if (k == KIND_WINDOW && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
-    const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
+    const int has_f32 = __syncthreads_or(shape & (3 | 64)), has_win = __syncthreads_or(shape & 2);
+    const int has_stride = G ? __syncthreads_or(shape & 64) : 0;   // !G: the session holds no such clip (launch_mix)
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
     const int has_wide = __syncthreads_or(shape & 16);
-    const int mode = (!has_i16 && !has_i32) ? (has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
+    const int mode = (!has_i16 && !has_i32) ? (has_stride ? MODE_G : has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
                      : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
@@ -706,6 +757,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn); break;
       case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn); break;
       case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn); break;
+      case MODE_G:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn);
+        break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
       case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
       default: mixed(cn); break;
@@ -903,24 +957,30 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
-void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s) {
+void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s) {
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;
   const bool full = ((a.channels * S4) % 256u == 0u) && (S4 % 64u == 0u);
   if (!full) {
-    hipLaunchKernelGGL((mix_kernel<2, false, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((mix_kernel<2, false, 1, true>), grid, block, 0, s, a);
+    return;
+  }
+  // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
+  // per-frame-tap mode; every other session keeps the leaner code
+  if (stride_rows) {
+    hipLaunchKernelGGL((mix_kernel<2, true, 4, true>), grid, block, 0, s, a);
     return;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
-#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W>), grid, block, 0, s, a); break;
+#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W, false>), grid, block, 0, s, a); break;
     WBX_V(1, 6) WBX_V(1, 8)
     WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6) WBX_V(2, 8)
     WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
     WBX_V(8, 2)
 #undef WBX_V
-    default: hipLaunchKernelGGL((mix_kernel<2, true, 4>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((mix_kernel<2, true, 4, false>), grid, block, 0, s, a); break;
   }
 }
 

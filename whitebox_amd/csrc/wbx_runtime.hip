@@ -27,7 +27,7 @@
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
-void launch_mix(const MixArgs& a, uint32_t n_blocks, int unroll, hipStream_t s);
+void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
@@ -162,6 +162,7 @@ struct wbx_ctx {
                                       // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;
   bool has_integer_clips = false;
+  bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
 };
 
 namespace {
@@ -393,7 +394,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
-    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43), c->stream);
+    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
+               c->has_stride_clips, c->stream);
     if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
@@ -1134,8 +1136,9 @@ struct wbx_engine {
   double playhead = 0.0, playhead_start = 0.0, sample_position = 0.0, beat_duration = 0.5;
   bool playing = false;
   bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
-  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (integer PCM, speed > 0.999, != 1)
+  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (resampled integer PCM, speed > 4096)
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
+  bool any_stride_clip = false;         // a clip played faster than recorded (speed > 0.999, != 1): per-frame taps
   size_t total_clips = 0;
   uint32_t next_clip_uid = 0;
   // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
@@ -1429,8 +1432,9 @@ void note_clip(wbx_engine* e, const DClip& c) {
   const DSample& smp = e->ctx->clips[c.sample].d;
   const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * c.speed;   // sampler.h:24
   // every block of such a clip goes through the pre-render pass: resampled integer PCM, fast-forward
-  if ((smp.format != FMT_F32 && ps != 1.0) || !(ps == 1.0 || (ps > 0.0 && ps <= 0.999))) e->any_slow_clip = true;
+  if ((smp.format != FMT_F32 && ps != 1.0) || !(ps > 0.0 && ps <= 4096.0)) e->any_slow_clip = true;
   if (ps != 1.0) e->any_window_clip = true;
+  if (ps > 0.999 && ps != 1.0) e->any_stride_clip = true;
 }
 
 void finish_edit(wbx_engine* e, HostTrack& t) {
@@ -1855,6 +1859,7 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = e->any_window_clip;
+  c->has_stride_clips = e->any_stride_clip;
   const int mix_parity = (int)(c->render_seq % kRing);
   st = launch_mix_sum(c, K, N);
   if (st != WBX_OK) return st;

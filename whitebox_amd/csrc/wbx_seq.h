@@ -338,6 +338,7 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
       // taps of 4 consecutive frames fit a 5-sample window only while floor(x_e) - floor(x_0) <= e: keep a
       // margin below 1.0 so fp64 rounding of j*speed can never push it over
       if (s.speed > 0.0 && s.speed <= 0.999) return KIND_WINDOW;
+      if (s.speed > 0.999 && s.speed <= 4096.0) return KIND_STRIDE;   // downsampling / fast-forward: per-frame taps
     }
   }
   return KIND_GENERIC;
