@@ -42,8 +42,10 @@ WORKLOADS = {
     "i16": ("next-2 (SURVEY 8f): 4096 stereo 16-bit PCM tracks, gain+pan, unity rate, 512-frame blocks", 48000, 0, "i16"),
     "d96": ("4096 stereo 96 kHz tracks played in the 48 kHz session (playback speed 2, per-frame taps), 512-frame blocks",
             96000, 0, "f32"),
+    "i16r": ("4096 stereo 16-bit 44.1 kHz tracks resampled into the 48 kHz session (per-frame taps), 512-frame blocks",
+             44100, 0, "i16"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7}
 FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4}
 
 

@@ -286,6 +286,22 @@ def test_downsampled_clips_hot_loop(src_rate, sample_rate):
     check_against_oracle(spec, 5, group_size=12, expect_exact=False)
 
 
+@pytest.mark.parametrize("fmt", ["i16", "i24", "i32"])
+@pytest.mark.parametrize("src_rate", [44100, 96000])
+def test_resampled_integer_pcm_hot_loop(fmt, src_rate):
+    """Integer PCM clips at a rate other than the session's (the usual 16-bit 44.1 kHz file in a 48 kHz
+    session): whole-block rows are read by the mix kernel with per-frame taps and the linear path's
+    normalisers (sampler.cpp:9-14,34-59); also next to unity rows of the same format."""
+    spec = synth.make_session("pcmr_" + fmt, 192, fmt=fmt, seek=True, n_blocks=5, seed=0xA26, src_rate=src_rate)
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -40.0 + (t % 5)
+    for i, smp in enumerate(spec.samples):
+        if i % 3 == 2:
+            smp.rate = 48000
+    check_against_oracle(spec, 5)
+    check_against_oracle(spec, 5, group_size=192, expect_exact=True)
+
+
 def test_clamp_and_unclamped_partial():
     spec = synth.make_session("hot", 16, n_blocks=2, amp=0.5, seed=0x5EED0007)
     om, _, _, _, _ = run_oracle(spec, 2)

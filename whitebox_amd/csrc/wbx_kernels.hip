@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
       u.speed = 1.0;
       u.gain = 1.0f;
       u.kind = KIND_UNITY;
+      u.format = FMT_F32;   // the row is fp32 whatever the clip's storage format (MODE_G reads by format)
       a.tmpl[idx] = u;
     }
   }
@@ -489,35 +490,90 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
     p.fx0 = (float)__builtin_amdgcn_fract(x0);
   };
-  // per-frame taps for any playback speed (sampler.cpp:50-52 for each of the lane's 4 frames): four unaligned 8-B
-  // loads {src[ix], src[ix+1]}; also valid for unity rows (fx = 0, first tap = the sample itself)
+  // per-frame taps for any playback speed and storage format (sampler.cpp:50-52 for each of the lane's 4 frames):
+  // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v); also valid
+  // for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-  auto load_stride = [&](const void* src_c, double pos, double speed, PreG& p) {
-    const float WBX_GLOBAL* base = as_global<float>(src_c);
+  typedef int i1u __attribute__((aligned(2)));
+  auto load_stride = [&](const void* src_c, double pos, double speed, uint32_t fmt, PreG& p) {
     const double jd[4] = {j0d, jd1, jd2, jd3};
     float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, f4x[4];
+    int ix[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const double x = __dadd_rn(pos, __dmul_rn(jd[k], speed));                           // :50
-      const int ix = (int)x;                                                              // :51
+      ix[k] = (int)x;                                                                     // :51
       f4x[k] = (float)__builtin_amdgcn_fract(x);                                          // :52
-      if (active) {
-        const f2u t = *reinterpret_cast<const f2u WBX_GLOBAL*>(base + ix);
-        a4[k] = t.x;
-        b4[k] = t.y;
+    }
+    if (fmt == FMT_I16) {
+      const short WBX_GLOBAL* base = as_global<short>(src_c);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (active) a4[k] = __int_as_float(*reinterpret_cast<const i1u WBX_GLOBAL*>(base + ix[k]));
+    } else {   // fp32 and 24/32-bit PCM: 4-byte containers
+      const float WBX_GLOBAL* base = as_global<float>(src_c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (active) {
+          const f2u t = *reinterpret_cast<const f2u WBX_GLOBAL*>(base + ix[k]);
+          a4[k] = t.x;
+          b4[k] = t.y;
+        }
       }
     }
     p.v = f4{a4[0], a4[1], a4[2], a4[3]};
     p.b = f4{b4[0], b4[1], b4[2], b4[3]};
     p.fx = f4{f4x[0], f4x[1], f4x[2], f4x[3]};
   };
-  auto row_stride = [&](const PreG& p, float cg, float gc) {
-    f4 m;
-    m.x = __fmul_rn(__fmul_rn(__fadd_rn(p.v.x, __fmul_rn(p.fx.x, __fsub_rn(p.b.x, p.v.x))), cg), gc);   // :55-56, track.cpp:731
-    m.y = __fmul_rn(__fmul_rn(__fadd_rn(p.v.y, __fmul_rn(p.fx.y, __fsub_rn(p.b.y, p.v.y))), cg), gc);
-    m.z = __fmul_rn(__fmul_rn(__fadd_rn(p.v.z, __fmul_rn(p.fx.z, __fsub_rn(p.b.z, p.v.z))), cg), gc);
-    m.w = __fmul_rn(__fmul_rn(__fadd_rn(p.v.w, __fmul_rn(p.fx.w, __fsub_rn(p.b.w, p.v.w))), cg), gc);
-    return m;
+  // the row of a per-frame-tap record; kind and fmt are wave-uniform
+  auto row_stride = [&](const PreG& p, uint32_t kind, uint32_t fmt, float cg, float gc) {
+    const float va[4] = {p.v.x, p.v.y, p.v.z, p.v.w}, vb[4] = {p.b.x, p.b.y, p.b.z, p.b.w};
+    const float fx[4] = {p.fx.x, p.fx.y, p.fx.z, p.fx.w};
+    float m[4];
+    if (kind == KIND_UNITY) {                     // fp32 at unity speed, pre-rendered rows, silent and padding records
+#pragma unroll
+      for (int k = 0; k < 4; k++) m[k] = __fmul_rn(__fmul_rn(va[k], cg), gc);                // sampler.cpp:151-152
+    } else if (kind == KIND_UNITY_I16) {          // sampler.cpp:109-120
+      const float norm = 1.0f / 32767.0f;                                                    // :95
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float d = (float)(short)(__float_as_int(va[k]) & 0xFFFF);
+        m[k] = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d, norm), -1.0f, 1.0f), cg), gc);
+      }
+    } else if (kind == KIND_UNITY_I32) {          // sampler.cpp:121-144
+      const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;             // :96-97
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        m[k] = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(va[k]), norm), -1.0, 1.0), cg), gc);
+    } else {                                      // linear interpolation, sampler.cpp:34-59
+      float ta[4], tb[4];
+      if (fmt == FMT_F32) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          ta[k] = va[k];
+          tb[k] = vb[k];
+        }
+      } else if (fmt == FMT_I16) {
+        const float norm = (float)(1.0 / 32767.0);                                           // :9-10
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int w = __float_as_int(va[k]);
+          ta[k] = __fmul_rn(norm, (float)(short)(w & 0xFFFF));
+          tb[k] = __fmul_rn(norm, (float)(short)((unsigned)w >> 16));
+        }
+      } else {
+        const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;           // :11-14
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          ta[k] = (float)__dmul_rn(norm, (double)__float_as_int(va[k]));
+          tb[k] = (float)__dmul_rn(norm, (double)__float_as_int(vb[k]));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)                                                            // :55-56, track.cpp:731
+        m[k] = __fmul_rn(__fmul_rn(__fadd_rn(ta[k], __fmul_rn(fx[k], __fsub_rn(tb[k], ta[k]))), cg), gc);
+    }
+    return f4{m[0], m[1], m[2], m[3]};
   };
   auto add_row = [&](const f4& m0) {
     f4 m = m0;
@@ -567,9 +623,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.src = t.src[c];
         r.pos = t.pos;
         r.speed = t.speed;
+        r.format = t.format;
       }
       if constexpr (MODE == MODE_G) {
-        load_stride(r.src, r.pos, r.speed, pre[u]);
+        load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
         load_window(r.src, r.pos, r.speed, pre[u]);
       } else {
@@ -612,10 +669,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const float gc = r.gc;
       f4 m;
       if constexpr (MODE == MODE_G) {
-        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_UNITY)
-          m = row_f32(pre[u].v, cg, gc);   // also pre-rendered rows, silent and padding records
-        else
-          m = row_stride(pre[u], cg, gc);  // KIND_STRIDE and KIND_WINDOW rows
+        m = row_stride(pre[u], (uint32_t)__builtin_amdgcn_readfirstlane((int)r.kind),
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
           m = row_window(std::integral_constant<bool, MODE == MODE_WN>{}, pre[u], r.pos, r.speed, cg, gc);
@@ -675,12 +730,6 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         Pre p;
         load_window(r.src[c], r.pos, r.speed, p);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
-      } else if (G && k == KIND_STRIDE) {
-        if constexpr (G) {
-          PreG p;
-          load_stride(r.src[c], r.pos, r.speed, p);
-          m = row_stride(p, cg, gc);
-        }
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
         i2u w = {0, 0};
@@ -732,7 +781,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     const int has_stride = G ? __syncthreads_or(shape & 64) : 0;   // !G: the session holds no such clip (launch_mix)
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
     const int has_wide = __syncthreads_or(shape & 16);
-    const int mode = (!has_i16 && !has_i32) ? (has_stride ? MODE_G : has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
+    // a chunk with per-frame-tap rows runs in MODE_G whatever else it holds (that mode reads every kind and format)
+    const int mode = has_stride ? MODE_G
+                     : (!has_i16 && !has_i32) ? (has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
                      : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows

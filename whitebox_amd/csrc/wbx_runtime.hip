@@ -1136,9 +1136,9 @@ struct wbx_engine {
   double playhead = 0.0, playhead_start = 0.0, sample_position = 0.0, beat_duration = 0.5;
   bool playing = false;
   bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
-  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (resampled integer PCM, speed > 4096)
+  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (speed > 4096)
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
-  bool any_stride_clip = false;         // a clip played faster than recorded (speed > 0.999, != 1): per-frame taps
+  bool any_stride_clip = false;         // a clip read with per-frame taps: fp32 played faster than recorded (speed > 0.999, != 1), resampled integer PCM
   size_t total_clips = 0;
   uint32_t next_clip_uid = 0;
   // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
@@ -1431,10 +1431,10 @@ namespace {
 void note_clip(wbx_engine* e, const DClip& c) {
   const DSample& smp = e->ctx->clips[c.sample].d;
   const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * c.speed;   // sampler.h:24
-  // every block of such a clip goes through the pre-render pass: resampled integer PCM, fast-forward
-  if ((smp.format != FMT_F32 && ps != 1.0) || !(ps > 0.0 && ps <= 4096.0)) e->any_slow_clip = true;
+  // every block of such a clip goes through the pre-render pass (the hot loop takes playback speeds up to 4096)
+  if (!(ps > 0.0 && ps <= 4096.0)) e->any_slow_clip = true;
   if (ps != 1.0) e->any_window_clip = true;
-  if (ps > 0.999 && ps != 1.0) e->any_stride_clip = true;
+  if ((ps > 0.999 || smp.format != FMT_F32) && ps != 1.0) e->any_stride_clip = true;
 }
 
 void finish_edit(wbx_engine* e, HostTrack& t) {
