@@ -300,6 +300,16 @@ def test_resampled_integer_pcm_hot_loop(fmt, src_rate):
             smp.rate = 48000
     check_against_oracle(spec, 5)
     check_against_oracle(spec, 5, group_size=192, expect_exact=True)
+    # time-stretched on top (speeds below 0.75 take the general tap selection of the windowed 16-bit read,
+    # speeds above 0.999 the per-frame taps)
+    stretch = [0.5, 0.31, 0.76, 0.999, 1.0, 0.9990001, 0.05, 1.3]
+    for c in spec.clips:   # groups of 8 in the first half of the tracks hold no per-frame-tap row
+        k = stretch[c.track % 8]
+        c.speed = 0.6 if (k > 0.999 and c.track < 96) else k
+    for smp in spec.samples:
+        smp.frames = int(smp.frames * 1.5) + 64
+    check_against_oracle(spec, 5, group_size=8, expect_exact=False)
+    check_against_oracle(spec, 5, group_size=192, expect_exact=True)
 
 
 def test_clamp_and_unclamped_partial():

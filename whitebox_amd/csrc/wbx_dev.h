@@ -31,8 +31,11 @@ enum : uint8_t {
   KIND_GENERIC = 3,  // anything else: several segments, partial coverage, resampled integer PCM, speed > 0.999
   KIND_UNITY_I16 = 4,  // one 16-bit PCM segment covering the whole block at playback_speed == 1.0 (sampler.cpp:109-120)
   KIND_UNITY_I32 = 5,  // the same for 24-bit (in 32-bit containers) and 32-bit PCM (sampler.cpp:121-144)
-  KIND_STRIDE = 6      // one fp32 segment covering the whole block, playback_speed > 0.999 and != 1 (linear, sampler.cpp:34-59):
-                       // the taps of a lane's 4 frames no longer fit one 5-sample window, each frame loads its own pair
+  KIND_STRIDE = 6,     // one fp32 segment covering the whole block, playback_speed > 0.999 and != 1 (linear, sampler.cpp:34-59):
+                       // the taps of a lane's 4 frames no longer fit one 5-sample window, each frame loads its own pair;
+                       // also resampled 24/32-bit PCM at any speed and 16-bit PCM above 0.999
+  KIND_WINDOW_I16 = 7  // one 16-bit PCM segment covering the whole block, 0 < playback_speed <= 0.999 (linear): the 5-sample
+                       // window of a lane's 4 frames is one 8-B and one 4-B load
 };
 
 enum : uint8_t {

@@ -328,7 +328,7 @@ __device__ __forceinline__ uint32_t wave_max_quad(uint32_t p0, uint32_t p1, uint
   return v;
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6 };   // row shapes of a staged chunk
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -490,6 +490,37 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // delivers exactly (the subtraction is exact in fp64), one instruction instead of trunc + sub
     p.fx0 = (float)__builtin_amdgcn_fract(x0);
   };
+  // the same window for a 16-bit PCM row: samples ix0..ix0+3 in one 8-B load (2-byte aligned), ix0+4 in the low half
+  // of a 4-B load; the halves stay packed until the render phase
+  auto load_window16 = [&](const void* src_c, double pos, double speed, Pre& p) {
+    typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
+    typedef int i1w __attribute__((aligned(2)));
+    const double x0 = __dadd_rn(pos, __dmul_rn(j0d, speed));                              // sampler.cpp:50, frame j0
+    const int ix0 = (int)x0;                                                              // :51
+    const short WBX_GLOBAL* src = as_global<short>(src_c) + ix0;
+    if (active) {
+      const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(src));
+      p.v.x = __int_as_float(w.x);
+      p.v.y = __int_as_float(w.y);
+      p.w4 = __int_as_float(*reinterpret_cast<const i1w WBX_GLOBAL*>(src + 4));
+    }
+    p.ix0 = ix0;
+    p.fx0 = (float)__builtin_amdgcn_fract(x0);                                            // :52
+  };
+  // 16-bit PCM row, linear resample: taps a = norm * (float)src[ix] (sampler.cpp:9-10,53-54), then as fp32
+  auto row_window16 = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+    const float norm = (float)(1.0 / 32767.0);
+    const int lo = __float_as_int(p.v.x), hi = __float_as_int(p.v.y), tl = __float_as_int(p.w4);
+    Pre f;
+    f.v.x = __fmul_rn(norm, (float)(short)(lo & 0xFFFF));
+    f.v.y = __fmul_rn(norm, (float)(short)((unsigned)lo >> 16));
+    f.v.z = __fmul_rn(norm, (float)(short)(hi & 0xFFFF));
+    f.v.w = __fmul_rn(norm, (float)(short)((unsigned)hi >> 16));
+    f.w4 = __fmul_rn(norm, (float)(short)(tl & 0xFFFF));
+    f.ix0 = p.ix0;
+    f.fx0 = p.fx0;
+    return row_window(narrow, f, pos, speed, cg, gc);
+  };
   // per-frame taps for any playback speed and storage format (sampler.cpp:50-52 for each of the lane's 4 frames):
   // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v); also valid
   // for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
@@ -629,6 +660,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
         load_window(r.src, r.pos, r.speed, pre[u]);
+      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
+        load_window16(r.src, r.pos, r.speed, pre[u]);
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
         if (MODE == MODE_I16) {
@@ -676,6 +709,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
           m = row_window(std::integral_constant<bool, MODE == MODE_WN>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
+      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
+        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
+          m = row_window16(std::integral_constant<bool, MODE == MODE_WIN>{}, pre[u], r.pos, r.speed, cg, gc);
+        else
+          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);   // unity, silent, padding
       } else if constexpr (MODE == MODE_I16) {
         m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
       } else if constexpr (MODE == MODE_I32) {
@@ -774,15 +812,17 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     int shape = 0;
     for (uint32_t i = tid; i < cn; i += 256u) {
       const int k = s_tb[i].kind;
-      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : k == KIND_STRIDE ? 64 : 0;
-      if (k == KIND_WINDOW && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
+      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
+      if ((k == KIND_WINDOW || k == KIND_WINDOW_I16) && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
     const int has_f32 = __syncthreads_or(shape & (3 | 64)), has_win = __syncthreads_or(shape & 2);
     const int has_stride = G ? __syncthreads_or(shape & 64) : 0;   // !G: the session holds no such clip (launch_mix)
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
     const int has_wide = __syncthreads_or(shape & 16);
+    const int has_win16 = G ? __syncthreads_or(shape & 32) : 0;
     // a chunk with per-frame-tap rows runs in MODE_G whatever else it holds (that mode reads every kind and format)
     const int mode = has_stride ? MODE_G
+                     : has_win16 ? ((!has_f32 && !has_i32) ? (has_wide ? MODE_WI : MODE_WIN) : MODE_G)
                      : (!has_i16 && !has_i32) ? (has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
                      : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
@@ -798,8 +838,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.gain = 0.0f;
         r.g[0] = 0.0f;
         r.g[1] = 0.0f;
-        r.format = mode == MODE_I16 ? FMT_I16 : mode == MODE_I32 ? FMT_I32 : FMT_F32;
-        r.kind = mode == MODE_I16 ? KIND_UNITY_I16 : mode == MODE_I32 ? KIND_UNITY_I32 : KIND_UNITY;
+        const bool m16 = mode == MODE_I16 || mode == MODE_WI || mode == MODE_WIN;
+        r.format = m16 ? FMT_I16 : mode == MODE_I32 ? FMT_I32 : FMT_F32;
+        r.kind = m16 ? KIND_UNITY_I16 : mode == MODE_I32 ? KIND_UNITY_I32 : KIND_UNITY;
       }
     }
     __syncthreads();
@@ -810,6 +851,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn); break;
       case MODE_G:
         if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn);
+        break;
+      case MODE_WI:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_WI>{}, cn);
+        break;
+      case MODE_WIN:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn);
         break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
       case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
