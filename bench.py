@@ -210,10 +210,14 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
-def mix_kernel_name(resampled_or_integer):
-    """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides)."""
-    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if resampled_or_integer else 43)
-    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}>"
+def mix_kernel_name(src_rate, fmt):
+    """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides).
+    Sessions with per-frame-tap / resampled integer rows (fp32 played faster than recorded, integer PCM at another
+    rate) take the G instance."""
+    if (src_rate > SR and fmt == "f32") or (src_rate != SR and fmt != "f32"):
+        return "wbx::mix_kernel<2, true, 4, true>"
+    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if (src_rate != SR or fmt != "f32") else 43)
+    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}, false>"
 
 
 def main():
@@ -425,7 +429,7 @@ def main():
             "realtime_factor": master_frames / dt / SR,
             "host_enqueue_ms_max": 1e3 * enq_max,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate != SR or fmt != "f32"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate, fmt),
                          "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n), "sum_tail_ms_avg": tail_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
