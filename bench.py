@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
     ap.add_argument("--blocks", type=int, default=256, help="512-frame blocks per step (one device pass)")
     ap.add_argument("--group-size", type=int, default=0)
+    ap.add_argument("--block-frames", type=int, default=512, help="frames per block (BASELINE.json: 512; other sizes "
+                    "are side measurements)")
     ap.add_argument("--session-blocks", type=int, default=0, help="length of the resident session in blocks "
                     "(0 = as long as the run needs, capped by memory); the transport rewinds at its end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,6 +242,8 @@ def main():
     ap.add_argument("--force-dist-path", action="store_true",
                     help="run the multi-GPU code path (RCCL reduce + clamp on root) even with one rank")
     args = ap.parse_args()
+    global F
+    F = args.block_frames
 
     import torch
     import torch.distributed as dist

@@ -240,11 +240,33 @@ def test_parameter_changes_are_block_rate():
     eng.close()
 
 
-@pytest.mark.parametrize("block,channels", [(128, 2), (256, 2), (1024, 2), (2048, 2), (512, 1), (96, 2)])
+@pytest.mark.parametrize("block,channels", [(128, 2), (256, 2), (1024, 2), (2048, 2), (512, 1), (96, 2), (256, 1), (64, 2)])
 def test_other_block_sizes_and_mono_out(block, channels):
     spec = synth.make_session("blk", 40, n_blocks=3, block=block, seed=0x42, src_rate=44100)
     spec.channels = channels
     check_against_oracle(spec, 3, group_size=8)
+
+
+@pytest.mark.parametrize("block,channels,n_blocks", [(256, 2, 7), (256, 2, 8), (512, 1, 5), (256, 1, 6), (256, 1, 9)])
+@pytest.mark.parametrize("kind", ["resampled", "buses_i16", "downsampled"])
+def test_short_blocks_several_per_workgroup(block, channels, n_blocks, kind):
+    """256-frame blocks (and mono 512 / 256): the mix kernel renders 2 or 4 consecutive blocks per workgroup;
+    odd block counts leave the last workgroup with an empty sub-block.  Clip boundaries inside blocks, bus
+    routing, 16-bit clips and per-frame-tap rows go through the same instances."""
+    if kind == "resampled":
+        spec = synth.make_session("sb", 300, seek=True, n_blocks=n_blocks, block=block, seed=0x5B0, src_rate=44100)
+    elif kind == "buses_i16":
+        spec = synth.make_session("sb", 192, seek=True, n_blocks=n_blocks, block=block, seed=0x5B1, n_buses=6, fmt="i16")
+        for i, smp in enumerate(spec.samples):
+            if i % 3 == 0:
+                smp.rate = 44100
+        for t in range(spec.n_tracks):
+            spec.volumes_db[t] = -40.0
+    else:
+        spec = synth.make_session("sb", 150, seek=True, n_blocks=n_blocks, block=block, seed=0x5B2, src_rate=96000)
+    spec.channels = channels
+    check_against_oracle(spec, n_blocks)
+    check_against_oracle(spec, n_blocks, group_size=512, expect_exact=(kind != "buses_i16"))
 
 
 def test_speed_variants_and_formats():

@@ -183,6 +183,7 @@ struct MixArgs {
   uint32_t* levels;             // [N][C] running maxima (VUMeter::level) as uint images, or null
   uint32_t n_tracks, n_groups, block_frames, channels;
   uint32_t tiles;               // ceil(C*F/4 / 256)
+  uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
 };
 
 struct SumArgs {

@@ -358,24 +358,31 @@ struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = f
 //   FULL  every lane owns a slot and every wave is channel-uniform (C*F/4 % 256 == 0, F/4 % 64 == 0):
 //         no lane predicate, the channel index is a scalar
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, bool G>
+template <int U, bool FULL, int W, bool G, int SB>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
+  static_assert(SB == 1 || FULL, "sub-blocks need channel-uniform waves");
   constexpr uint32_t kRecs = kStage + 2 * U + 4;   // staged records + null padding for the last batches
-  __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[kRecs];
-  __shared__ uint32_t s_pk[kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
-  __shared__ uint32_t s_wc[4];           // FULL: the channel each wave works on
+  __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
+  __shared__ uint32_t s_pk[SB * kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
+  __shared__ uint32_t s_wc[4];           // FULL: sub-block * C + channel each wave works on
 
   // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
   // of a group read adjacent pieces of the same clip rows (they share the cache line at the seam), so give every
   // XCD a contiguous run of blocks: id x -> block (x % 8) * K/8 + x / 8.
-  uint32_t b = blockIdx.x;
-  if ((gridDim.x & 7u) == 0u) b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  uint32_t bx = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint32_t g = blockIdx.y, tile = blockIdx.z;
   const uint32_t tid = threadIdx.x;
   const DGroup grp = a.groups[g];
   const uint32_t F = a.block_frames, C = a.channels, N = a.n_tracks;
   const uint32_t S4 = F >> 2;
-  const uint32_t slot = tile * 256u + tid;
+  // SB > 1 (blocks shorter than a workgroup: C*F/4 * SB == 256): the workgroup renders SB consecutive blocks, every
+  // wave stays inside one (sub-block, channel) and reads its own sub-block's records
+  const uint32_t sub = SB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / (C * S4))) : 0u;
+  const uint32_t rb = sub * kRecs;                 // this wave's records in s_tb
+  const uint32_t b = bx * SB + sub;
+  const bool bvalid = SB == 1 || b < a.n_blocks;   // the last workgroup of an odd render has an empty sub-block
+  const uint32_t slot = SB > 1 ? tid - sub * (C * S4) : tile * 256u + tid;
   const bool active = FULL ? true : (slot < C * S4);
   uint32_t c = active ? slot / S4 : 0u;
   if (FULL) c = __builtin_amdgcn_readfirstlane(c);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     uint32_t kind, format;
   };
   auto load_urec = [&](uint32_t rec) {
-    const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rec])[lane & 15u];
+    const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rb + rec])[lane & 15u];
     auto rl = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(w, (int)i); };
     URec r;
     const uint32_t cs = FULL ? c : 0u;   // (only used when FULL: the channel is wave-uniform)
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   auto post_peak = [&](float pk, uint32_t tl) {
     if (FULL) {
       pk = wave_max_lane63(pk);
-      if (lane == 63u) s_pk[tl * 4u + (tid >> 6)] = __float_as_uint(pk);   // this wave's own slot: no atomic
+      if (lane == 63u) s_pk[(rb + tl) * 4u + (tid >> 6)] = __float_as_uint(pk);   // this wave's own slot: no atomic
     } else {
       for (uint32_t off = 1; off < span; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
       if ((lane & (span - 1u)) == 0u && active) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   const bool quad_writer = (lane & 15u) == 0u;
   auto post_peak4 = [&](const float (&pk)[4], uint32_t tl) {
     const uint32_t v = wave_max_quad(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]));
-    if (quad_writer) s_pk[tl * 4u + quad_slot] = v;
+    if (quad_writer) s_pk[(rb + tl) * 4u + quad_slot] = v;
   };
 
   // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line per mode) ----
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   // a time with a wave-uniform dispatch on the row kind — correct for any combination, not software-pipelined
   auto mixed = [&](uint32_t cn) {
     for (uint32_t tl = 0; tl < cn; tl++) {
-      const DTrackBlock& r = s_tb[tl];
+      const DTrackBlock& r = s_tb[rb + tl];
       const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
       const float cg = r.gain, gc = r.g[c];
       const uint32_t off = (uint32_t)r.pos + j0;
@@ -788,12 +795,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
     // A record = the template its 16-B plan row points at, with the row's position patched in when the template
     // is shared by a run of blocks; silent rows become all-zero records (kind 0).
-    for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
-      const uint32_t rec = i >> 2, q = i & 3u;
+    for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) {
+      const uint32_t sb = SB > 1 ? i / (kRecs * 4u) : 0u;
+      const uint32_t rec = (i - sb * kRecs * 4u) >> 2, q = i & 3u;
+      const uint32_t bb = bx * SB + sb;
       uint4 w = {0u, 0u, 0u, 0u};
-      if (rec < cn) {
+      if (rec < cn && (SB == 1 || bb < a.n_blocks)) {
         const uint32_t track = a.order[grp.first + chunk0 + rec];
-        const DRow row = a.rows[(size_t)b * N + track];
+        const DRow row = a.rows[(size_t)bb * N + track];
         if (!(row.flags & ROW_SILENT)) {
           w = reinterpret_cast<const uint4*>(a.tmpl + row.tmpl)[q];
           if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
@@ -805,12 +814,13 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }
-    for (uint32_t i = tid; i < kRecs * 4u; i += 256u) s_pk[i] = 0u;
-    if (FULL && lane == 0u) s_wc[tid >> 6] = c;
+    for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) s_pk[i] = 0u;
+    if (FULL && lane == 0u) s_wc[tid >> 6] = sub * C + c;
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
-    for (uint32_t i = tid; i < cn; i += 256u) {
+    for (uint32_t i0 = tid; i0 < SB * cn; i0 += 256u) {
+      const uint32_t i = SB > 1 ? (i0 / cn) * kRecs + i0 % cn : i0;
       const int k = s_tb[i].kind;
       shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
       if ((k == KIND_WINDOW || k == KIND_WINDOW_I16) && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
@@ -828,9 +838,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
                      : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
     // of the chunk's own shape, so that the load phase stays straight-line
-    for (uint32_t i = tid; i < kRecs; i += 256u) {
+    for (uint32_t i = tid; i < SB * kRecs; i += 256u) {
       DTrackBlock& r = s_tb[i];
-      if (i >= cn || r.kind == KIND_SILENT) {
+      if ((SB > 1 ? i % kRecs : i) >= cn || r.kind == KIND_SILENT) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -864,15 +874,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
 
     __syncthreads();
-    for (uint32_t i = tid; i < cn * C; i += 256u) {
+    for (uint32_t i0 = tid; i0 < SB * cn * C; i0 += 256u) {
+      const uint32_t sb = SB > 1 ? i0 / (cn * C) : 0u;
+      const uint32_t i = i0 - sb * cn * C;
       const uint32_t rec = i / C, ch = i - rec * C;
+      const uint32_t bb = bx * SB + sb;
+      if (SB > 1 && bb >= a.n_blocks) continue;
       const uint32_t track = a.order[grp.first + chunk0 + rec];
-      uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)b * N + track) * C + ch;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)bb * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
       if (FULL) {
+        const uint32_t* slots = &s_pk[(sb * kRecs + rec) * 4u];
 #pragma unroll
         for (uint32_t w = 0; w < 4u; w++)
-          if (s_wc[w] == ch) pk = pk > s_pk[rec * 4u + w] ? pk : s_pk[rec * 4u + w];
+          if (s_wc[w] == sb * C + ch) pk = pk > slots[w] ? pk : slots[w];
       } else {
         pk = s_pk[rec * 2u + ch];
       }
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   }
 
-  if (active) {
+  if (active && bvalid) {
     float* out = a.partial + (((size_t)b * a.n_groups + g) * C + c) * F + j0;
     *reinterpret_cast<f4*>(out) = acc;
   }
@@ -1058,27 +1073,46 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
 void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s) {
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;
-  const bool full = ((a.channels * S4) % 256u == 0u) && (S4 % 64u == 0u);
+  const uint32_t lanes = a.channels * S4;   // lanes one block needs
+  const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (!full) {
-    hipLaunchKernelGGL((mix_kernel<2, false, 1, true>), grid, block, 0, s, a);
+    // blocks shorter than a workgroup whose waves are still channel-uniform (256 frames; 512 mono): 2 or 4
+    // consecutive blocks per workgroup, same code as the full instances
+    if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) {
+      const uint32_t sb = 256u / lanes;
+      const dim3 g2((n_blocks + sb - 1u) / sb, a.n_groups, 1);
+      if (sb == 2u) {
+        if (stride_rows)
+          hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 2>), g2, block, 0, s, a);
+        else
+          hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 2>), g2, block, 0, s, a);
+      } else {
+        if (stride_rows)
+          hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 4>), g2, block, 0, s, a);
+        else
+          hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 4>), g2, block, 0, s, a);
+      }
+      return;
+    }
+    hipLaunchKernelGGL((mix_kernel<2, false, 1, true, 1>), grid, block, 0, s, a);
     return;
   }
   // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
   // per-frame-tap mode; every other session keeps the leaner code
   if (stride_rows) {
-    hipLaunchKernelGGL((mix_kernel<2, true, 4, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 1>), grid, block, 0, s, a);
     return;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
-#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W, false>), grid, block, 0, s, a); break;
+#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W, false, 1>), grid, block, 0, s, a); break;
     WBX_V(1, 6) WBX_V(1, 8)
     WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6) WBX_V(2, 8)
     WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
     WBX_V(8, 2)
 #undef WBX_V
-    default: hipLaunchKernelGGL((mix_kernel<2, true, 4, false>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 1>), grid, block, 0, s, a); break;
   }
 }
 
