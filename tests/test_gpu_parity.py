@@ -247,11 +247,13 @@ def test_other_block_sizes_and_mono_out(block, channels):
     check_against_oracle(spec, 3, group_size=8)
 
 
-@pytest.mark.parametrize("block,channels,n_blocks", [(256, 2, 7), (256, 2, 8), (512, 1, 5), (256, 1, 6), (256, 1, 9)])
+@pytest.mark.parametrize("block,channels,n_blocks", [(256, 2, 7), (256, 2, 8), (512, 1, 5), (256, 1, 6), (256, 1, 9),
+                                                     (128, 2, 5), (128, 2, 8), (128, 2, 11)])
 @pytest.mark.parametrize("kind", ["resampled", "buses_i16", "downsampled"])
 def test_short_blocks_several_per_workgroup(block, channels, n_blocks, kind):
     """256-frame blocks (and mono 512 / 256): the mix kernel renders 2 or 4 consecutive blocks per workgroup;
-    odd block counts leave the last workgroup with an empty sub-block.  Clip boundaries inside blocks, bus
+    128-frame stereo blocks: one block per wave with a channel in each half-wave.  Block counts that are not
+    a multiple leave the last workgroup with empty sub-blocks.  Clip boundaries inside blocks, bus
     routing, 16-bit clips and per-frame-tap rows go through the same instances."""
     if kind == "resampled":
         spec = synth.make_session("sb", 300, seek=True, n_blocks=n_blocks, block=block, seed=0x5B0, src_rate=44100)

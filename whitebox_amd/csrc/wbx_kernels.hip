@@ -328,6 +328,29 @@ __device__ __forceinline__ uint32_t wave_max_quad(uint32_t p0, uint32_t p1, uint
   return v;
 }
 
+// The same when the two 32-lane halves of the wave hold different channels (128-frame stereo blocks): the maxima
+// of four tracks per half.  The first swap level then separates the channels instead of folding them: x keeps
+// channel 0 of tracks {0 | 1}, y channel 1; rows end up holding tracks 0, 2, 1, 3 as above, once per channel.
+__device__ __forceinline__ void wave_max_quad_halves(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t& ch0,
+                                                     uint32_t& ch1) {
+  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+  const u2v a = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);   // x = {p0.lo | p1.lo}, y = {p0.hi | p1.hi}
+  const u2v b = __builtin_amdgcn_permlane32_swap(p2, p3, false, false);
+  const u2v c0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  const u2v c1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  uint32_t v = c0.x > c0.y ? c0.x : c0.y, w = c1.x > c1.y ? c1.x : c1.y;
+#define WBX_DPP_MAX(x, ctrl)                                                                      \
+  {                                                                                               \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true); \
+    (x) = (x) > o ? (x) : o;                                                                      \
+  }
+  WBX_DPP_MAX(v, 0xB1) WBX_DPP_MAX(v, 0x4E) WBX_DPP_MAX(v, 0x141) WBX_DPP_MAX(v, 0x140)
+  WBX_DPP_MAX(w, 0xB1) WBX_DPP_MAX(w, 0x4E) WBX_DPP_MAX(w, 0x141) WBX_DPP_MAX(w, 0x140)
+#undef WBX_DPP_MAX
+  ch0 = v;
+  ch1 = w;
+}
+
 enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
@@ -358,9 +381,10 @@ struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = f
 //   FULL  every lane owns a slot and every wave is channel-uniform (C*F/4 % 256 == 0, F/4 % 64 == 0):
 //         no lane predicate, the channel index is a scalar
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, bool G, int SB>
+template <int U, bool FULL, int W, bool G, int SB, int CW = 1>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
-  static_assert(SB == 1 || FULL, "sub-blocks need channel-uniform waves");
+  static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
+  static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
   constexpr uint32_t kRecs = kStage + 2 * U + 4;   // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
   __shared__ uint32_t s_pk[SB * kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   const uint32_t slot = SB > 1 ? tid - sub * (C * S4) : tile * 256u + tid;
   const bool active = FULL ? true : (slot < C * S4);
   uint32_t c = active ? slot / S4 : 0u;
-  if (FULL) c = __builtin_amdgcn_readfirstlane(c);
+  if (FULL && CW == 1) c = __builtin_amdgcn_readfirstlane(c);   // CW == 2: lanes 0-31 channel 0, lanes 32-63 channel 1
   const uint32_t j0 = active ? (slot - c * S4) * 4u : 0u;
   // lanes of an aligned `span`-lane group share a channel (span = largest power of two dividing F/4, <= 64)
   uint32_t span = 64u;
@@ -415,6 +439,17 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rb + rec])[lane & 15u];
     auto rl = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(w, (int)i); };
     URec r;
+    if (CW == 2) {   // both channels' pointer and gain as scalars, a per-lane select between them
+      const uint64_t s0 = ((uint64_t)rl(1) << 32) | rl(0), s1 = ((uint64_t)rl(3) << 32) | rl(2);
+      r.src = (const void*)(c ? s1 : s0);
+      r.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
+      r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
+      r.gain = __uint_as_float(rl(8));
+      r.gc = __uint_as_float(c ? rl(10) : rl(9));
+      r.kind = (rl(11) >> 8) & 0xFFu;
+      r.format = rl(13) & 0xFFu;
+      return r;
+    }
     const uint32_t cs = FULL ? c : 0u;   // (only used when FULL: the channel is wave-uniform)
     r.src = (const void*)(((uint64_t)rl(2u * cs + 1u) << 32) | rl(2u * cs));
     r.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
@@ -625,7 +660,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes that
   // share a channel otherwise; then one LDS atomic per wave / lane group
   auto post_peak = [&](float pk, uint32_t tl) {
-    if (FULL) {
+    if (FULL && CW == 2) {
+      for (uint32_t off = 1; off < 32u; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
+      if ((lane & 31u) == 0u) s_pk[(rb + tl) * 4u + c] = __float_as_uint(pk);      // slot = channel: one wave per sub-block
+    } else if (FULL) {
       pk = wave_max_lane63(pk);
       if (lane == 63u) s_pk[(rb + tl) * 4u + (tid >> 6)] = __float_as_uint(pk);   // this wave's own slot: no atomic
     } else {
@@ -639,6 +677,16 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   const uint32_t quad_slot = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * 4u + (tid >> 6);   // rows hold tracks 0,2,1,3
   const bool quad_writer = (lane & 15u) == 0u;
   auto post_peak4 = [&](const float (&pk)[4], uint32_t tl) {
+    if (CW == 2) {
+      uint32_t v0, v1;
+      wave_max_quad_halves(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]), v0, v1);
+      if (quad_writer) {
+        uint32_t* slots = &s_pk[(rb + tl + (((lane >> 4) & 1u) * 2u + (lane >> 5))) * 4u];
+        slots[0] = v0;
+        slots[1] = v1;
+      }
+      return;
+    }
     const uint32_t v = wave_max_quad(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]));
     if (quad_writer) s_pk[(rb + tl) * 4u + quad_slot] = v;
   };
@@ -883,7 +931,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       const uint32_t track = a.order[grp.first + chunk0 + rec];
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)bb * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
-      if (FULL) {
+      if (FULL && CW == 2) {
+        pk = s_pk[(sb * kRecs + rec) * 4u + ch];
+      } else if (FULL) {
         const uint32_t* slots = &s_pk[(sb * kRecs + rec) * 4u];
 #pragma unroll
         for (uint32_t w = 0; w < 4u; w++)
@@ -1078,6 +1128,14 @@ void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_ro
   if (!full) {
     // blocks shorter than a workgroup whose waves are still channel-uniform (256 frames; 512 mono): 2 or 4
     // consecutive blocks per workgroup, same code as the full instances
+    if (S4 == 32u && a.channels == 2u) {   // 128-frame stereo blocks: one block per wave, a channel per half-wave
+      const dim3 g4((n_blocks + 3u) / 4u, a.n_groups, 1);
+      if (stride_rows)
+        hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 4, 2>), g4, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 4, 2>), g4, block, 0, s, a);
+      return;
+    }
     if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) {
       const uint32_t sb = 256u / lanes;
       const dim3 g2((n_blocks + sb - 1u) / sb, a.n_groups, 1);
