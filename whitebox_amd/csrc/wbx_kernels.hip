@@ -385,7 +385,8 @@ template <int U, bool FULL, int W, bool G, int SB, int CW = 1>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
   static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
-  constexpr uint32_t kRecs = kStage + 2 * U + 4;   // staged records + null padding for the last batches
+  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kStage;   // records staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS)
+  constexpr uint32_t kRecs = kSt + 2 * U + 4;      // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
   __shared__ uint32_t s_pk[SB * kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[4];           // FULL: sub-block * C + channel each wave works on
@@ -837,8 +838,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
   };
 
-  for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kStage) {
-    const uint32_t cn = (grp.count - chunk0) < kStage ? (grp.count - chunk0) : kStage;
+  for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kSt) {
+    const uint32_t cn = (grp.count - chunk0) < kSt ? (grp.count - chunk0) : kSt;
     __syncthreads();
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
     // A record = the template its 16-B plan row points at, with the row's position patched in when the template
