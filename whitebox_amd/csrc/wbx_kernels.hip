@@ -8,7 +8,9 @@
 //                    records (gain / pan / resample parameters) are staged in LDS, each lane owns 4
 //                    consecutive output frames of one channel, clip audio is streamed with 16-B loads
 //                    through a software pipeline, rendered, scaled and accumulated in registers IN TRACK
-//                    ORDER; per-track peaks via permlane-swap / DPP wave maxima, four tracks at a time
+//                    ORDER; per-track peaks via permlane-swap / DPP wave maxima, four tracks at a time.
+//                    Resampled rows: 5-sample window (fp32, 16-bit PCM) or per-frame tap pairs (speed > 1,
+//                    24/32-bit PCM); blocks shorter than 512 frames: several blocks per workgroup
 //   sum_kernel       group sums -> bus sums -> master (fixed order), master clamp
 //   clamp / clamp_into / convert / synth: small helpers
 //
@@ -378,8 +380,13 @@ struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = f
 //
 //   U     tracks per batch; two batches are in flight (software pipeline: the loads of batch i+1 are
 //         issued before batch i is rendered), so 2*U clip rows per wave are outstanding
-//   FULL  every lane owns a slot and every wave is channel-uniform (C*F/4 % 256 == 0, F/4 % 64 == 0):
-//         no lane predicate, the channel index is a scalar
+//   FULL  every lane owns a slot and every wave stays inside one block, so that a staged record is wave-uniform:
+//         no lane predicate, record fields in scalar registers
+//   W     waves per SIMD the register budget is capped for
+//   G     the instance carries the per-frame-tap and 16-bit window modes (MODE_G, MODE_WI, MODE_WIN); sessions
+//         without such clips run the instance without them
+//   SB    consecutive blocks per workgroup (1: C*F/4 is a multiple of 256; 2 / 4: blocks of 128 / 64 lanes)
+//   CW    channels per wave (1: the channel is a scalar; 2: 128-frame stereo, a channel per 32-lane half)
 // ------------------------------------------------------------------------------------------------
 template <int U, bool FULL, int W, bool G, int SB, int CW = 1>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
