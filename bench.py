@@ -44,8 +44,10 @@ WORKLOADS = {
             96000, 0, "f32"),
     "i16r": ("4096 stereo 16-bit 44.1 kHz tracks resampled into the 48 kHz session (per-frame taps), 512-frame blocks",
              44100, 0, "i16"),
+    "i24r": ("4096 stereo 24-bit 44.1 kHz tracks (32-bit containers) resampled into the 48 kHz session, 512-frame blocks",
+             44100, 0, "i24"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8}
 FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4}
 
 

@@ -27,13 +27,14 @@ enum : uint32_t { FMT_I16 = 3, FMT_I24 = 5, FMT_I32 = 7, FMT_F32 = 9 };  // refe
 enum : uint8_t {
   KIND_SILENT = 0,   // nothing to render
   KIND_UNITY = 1,    // one fp32 segment covering the whole block at playback_speed == 1.0 (sampler.cpp:145-156)
-  KIND_WINDOW = 2,   // one fp32 segment covering the whole block, 0 < playback_speed <= 1 (linear, sampler.cpp:34-59)
-  KIND_GENERIC = 3,  // anything else: several segments, partial coverage, resampled integer PCM, speed > 0.999
+  KIND_WINDOW = 2,   // one fp32 (or 24/32-bit PCM: `format`) segment covering the whole block, 0 < playback_speed <= 0.999
+                     // (linear, sampler.cpp:34-59)
+  KIND_GENERIC = 3,  // anything else: several segments, partial coverage, playback speed above 4096
   KIND_UNITY_I16 = 4,  // one 16-bit PCM segment covering the whole block at playback_speed == 1.0 (sampler.cpp:109-120)
   KIND_UNITY_I32 = 5,  // the same for 24-bit (in 32-bit containers) and 32-bit PCM (sampler.cpp:121-144)
   KIND_STRIDE = 6,     // one fp32 segment covering the whole block, playback_speed > 0.999 and != 1 (linear, sampler.cpp:34-59):
                        // the taps of a lane's 4 frames no longer fit one 5-sample window, each frame loads its own pair;
-                       // also resampled 24/32-bit PCM at any speed and 16-bit PCM above 0.999
+                       // also resampled integer PCM above 0.999
   KIND_WINDOW_I16 = 7  // one 16-bit PCM segment covering the whole block, 0 < playback_speed <= 0.999 (linear): the 5-sample
                        // window of a lane's 4 frames is one 8-B and one 4-B load
 };

@@ -571,6 +571,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     f.fx0 = p.fx0;
     return row_window(narrow, f, pos, speed, cg, gc);
   };
+  // 24/32-bit PCM row (4-byte containers: the fp32 window loads), linear resample: taps a = (float)(norm * (double)src[ix])
+  // (sampler.cpp:11-14,53-54), then as fp32
+  auto row_window32 = [&](auto narrow, const Pre& p, uint32_t fmt, double pos, double speed, float cg, float gc) {
+    const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;
+    Pre f;
+    f.v.x = (float)__dmul_rn(norm, (double)__float_as_int(p.v.x));
+    f.v.y = (float)__dmul_rn(norm, (double)__float_as_int(p.v.y));
+    f.v.z = (float)__dmul_rn(norm, (double)__float_as_int(p.v.z));
+    f.v.w = (float)__dmul_rn(norm, (double)__float_as_int(p.v.w));
+    f.w4 = (float)__dmul_rn(norm, (double)__float_as_int(p.w4));
+    f.ix0 = p.ix0;
+    f.fx0 = p.fx0;
+    return row_window(narrow, f, pos, speed, cg, gc);
+  };
   // per-frame taps for any playback speed and storage format (sampler.cpp:50-52 for each of the lane's 4 frames):
   // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v); also valid
   // for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
@@ -768,10 +782,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         m = row_stride(pre[u], (uint32_t)__builtin_amdgcn_readfirstlane((int)r.kind),
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
-        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
-          m = row_window(std::integral_constant<bool, MODE == MODE_WN>{}, pre[u], r.pos, r.speed, cg, gc);
-        else
+        const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+        const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
+        constexpr std::integral_constant<bool, MODE == MODE_WN> narrow{};
+        if (k == KIND_WINDOW) {
+          if (G && fmt != FMT_F32) {   // 24/32-bit PCM through the same window loads (G instances only)
+            if constexpr (G) m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
+          } else {
+            m = row_window(narrow, pre[u], r.pos, r.speed, cg, gc);
+          }
+        } else if (G && k == KIND_UNITY_I32) {
+          if constexpr (G) m = row_i32(pre[u].v, fmt, cg, gc);
+        } else {
           m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
+        }
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
           m = row_window16(std::integral_constant<bool, MODE == MODE_WIN>{}, pre[u], r.pos, r.speed, cg, gc);
@@ -878,20 +902,30 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     for (uint32_t i0 = tid; i0 < SB * cn; i0 += 256u) {
       const uint32_t i = SB > 1 ? (i0 / cn) * kRecs + i0 % cn : i0;
       const int k = s_tb[i].kind;
-      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? 2 : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8 : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
+      shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? (s_tb[i].format == FMT_F32 ? 2 : 128) : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8
+               : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
       if ((k == KIND_WINDOW || k == KIND_WINDOW_I16) && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
-    const int has_f32 = __syncthreads_or(shape & (3 | 64)), has_win = __syncthreads_or(shape & 2);
-    const int has_stride = G ? __syncthreads_or(shape & 64) : 0;   // !G: the session holds no such clip (launch_mix)
+    const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
     const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
     const int has_wide = __syncthreads_or(shape & 16);
-    const int has_win16 = G ? __syncthreads_or(shape & 32) : 0;
-    // a chunk with per-frame-tap rows runs in MODE_G whatever else it holds (that mode reads every kind and format)
-    const int mode = has_stride ? MODE_G
-                     : has_win16 ? ((!has_f32 && !has_i32) ? (has_wide ? MODE_WI : MODE_WIN) : MODE_G)
-                     : (!has_i16 && !has_i32) ? (has_win ? (has_wide ? MODE_W : MODE_WN) : MODE_U)
-                     : (has_i16 && !has_i32 && !has_f32) ? MODE_I16
-                     : (has_i32 && !has_i16 && !has_f32) ? MODE_I32 : MODE_MIXED;
+    // (G instances only: sessions without such clips run the instance that does not carry these modes)
+    const int has_stride = G ? __syncthreads_or(shape & 64) : 0;    // per-frame taps
+    const int has_win16 = G ? __syncthreads_or(shape & 32) : 0;     // 16-bit PCM window rows
+    const int has_win32 = G ? __syncthreads_or(shape & 128) : 0;    // 24/32-bit PCM window rows
+    int mode;
+    if (has_stride) {
+      mode = MODE_G;             // reads every kind and format, whatever else the chunk holds
+    } else if (has_win16) {
+      mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : MODE_WIN) : MODE_G;
+    } else if (has_i16) {
+      mode = (has_win32 || (G && has_win)) ? MODE_G : (!has_i32 && !has_f32) ? MODE_I16 : MODE_MIXED;
+    } else if (has_win || has_win32) {
+      // fp32 unity + window rows; in G instances also 24/32-bit PCM unity + window rows (all 4-byte containers)
+      mode = (G || !has_i32) ? (has_wide ? MODE_W : MODE_WN) : MODE_MIXED;
+    } else {
+      mode = !has_i32 ? MODE_U : !has_f32 ? MODE_I32 : MODE_MIXED;
+    }
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
     // of the chunk's own shape, so that the load phase stays straight-line
     for (uint32_t i = tid; i < SB * kRecs; i += 256u) {

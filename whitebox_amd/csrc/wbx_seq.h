@@ -343,7 +343,7 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
     // resampled integer PCM (sampler.cpp:159-207): per-frame taps at any speed
     if (s.format != FMT_F32 && s.dst_start == 0 && s.len == block_frames && s.pos >= 0.0 && s.pos < 2147483000.0 &&
         s.speed > 0.0 && s.speed <= 4096.0)
-      return (s.format == FMT_I16 && s.speed <= 0.999) ? KIND_WINDOW_I16 : KIND_STRIDE;
+      return s.speed > 0.999 ? KIND_STRIDE : s.format == FMT_I16 ? KIND_WINDOW_I16 : KIND_WINDOW;   // 24/32-bit: 4-byte containers, the fp32 window loads
   }
   return KIND_GENERIC;
 }
