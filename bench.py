@@ -59,7 +59,8 @@ def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2,
     return F * (n_tracks * channels * FMT_BYTES[fmt] * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
 
 
-def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, stream_ptr, group_size):
+def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, stream_ptr, group_size,
+                         clip_blocks=0.0):
     from whitebox_amd.engine import Engine
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
     eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank),
@@ -84,7 +85,18 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
         tr.set_pan(float(p))
         if n_buses:
             tr.set_bus(min(t // per_bus, n_buses - 1))
-        eng.add_audio_clip(tr, "clip", 0.0, (session_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
+        if clip_blocks <= 0.0:
+            eng.add_audio_clip(tr, "clip", 0.0, (session_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
+        else:
+            # side measurement: the track is cut into back-to-back clips of clip_blocks blocks (each reading on from
+            # where the previous one stopped), staggered per track: a clip boundary inside a block sends that
+            # track-block through the pre-render pass
+            L = clip_blocks * F
+            pos = -((t * 37) % 512) / 512.0 * L
+            while pos < (session_blocks + 1) * F:
+                a, b = max(pos, 0.0), pos + L
+                eng.add_audio_clip(tr, "clip", a / beat_frames, b / beat_frames, a * (src_rate / SR), sid, 1.0, 1.0)
+                pos = b
     return eng, seed, amp
 
 
@@ -234,6 +246,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
     ap.add_argument("--blocks", type=int, default=256, help="512-frame blocks per step (one device pass)")
     ap.add_argument("--group-size", type=int, default=0)
+    ap.add_argument("--clip-blocks", type=float, default=0.0, help="side measurement: cut every track into back-to-back "
+                    "clips of this many blocks (0: one clip per track, the BASELINE.json configs)")
     ap.add_argument("--block-frames", type=int, default=512, help="frames per block (BASELINE.json: 512; other sizes "
                     "are side measurements)")
     ap.add_argument("--session-blocks", type=int, default=0, help="length of the resident session in blocks "
@@ -293,10 +307,13 @@ def main():
     # root: clamp of a reduced master into host memory, beside the next renders.  Highest priority: at normal
     # priority its workgroups only get CU slots as the concurrent mix drains, and the step that reuses the buffer waits
     fin_stream = torch.cuda.Stream(priority=-1)
+    t_setup = time.perf_counter()
     with torch.cuda.stream(stream):
         eng, seed, amp = build_device_session(W, synth, args.workload, n_tracks, K, session_blocks, rank,
-                                              stream.cuda_stream, args.group_size)
+                                              stream.cuda_stream, args.group_size, args.clip_blocks)
         host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
+        if os.environ.get("WBX_BENCH_VERBOSE"):
+            print(f"[bench] session built in {time.perf_counter() - t_setup:.2f} s", file=sys.stderr, flush=True)
         if use_dist:
             from whitebox_amd.dist import MasterReducer
             NS = 3                                             # master buffers in flight (render / reduce / finalize)

@@ -154,7 +154,9 @@ inline bool query_clip_by_range(const std::vector<HostClip>& c, double min, doub
 // Track::update_clip_ordering, track.cpp:159-180
 inline void update_clip_ordering(std::vector<HostClip>& c) {
   c.erase(std::remove_if(c.begin(), c.end(), [](const HostClip& x) { return x.deleted; }), c.end());
-  std::sort(c.begin(), c.end(), [](const HostClip& a, const HostClip& b) { return a.d.min_time < b.d.min_time; });
+  const auto by_start = [](const HostClip& a, const HostClip& b) { return a.d.min_time < b.d.min_time; };
+  // appending in timeline order is the common edit: a linear check instead of a sort of thousands of clips
+  if (!std::is_sorted(c.begin(), c.end(), by_start)) std::sort(c.begin(), c.end(), by_start);
 }
 
 // Engine::reserve_track_region, engine.cpp:478-569.  `rate_of(sample)` gives the asset's sample rate;

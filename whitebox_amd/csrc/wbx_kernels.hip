@@ -114,7 +114,7 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {
 // One source sample of Sampler::stream for destination frame jj of segment sg, channel c:
 // unity path sampler.cpp:106-158, linear path sampler.cpp:34-59 (normalisers :7-18 and :95-97).
 __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t jj) {
-  const void* base = sg.src[c];
+  const void* base = c ? sg.src[1] : sg.src[0];   // (no dynamic index: keeps the descriptor in registers)
   const float WBX_GLOBAL* bf = as_global<float>(base);
   const int16_t WBX_GLOBAL* b16 = as_global<int16_t>(base);
   const int32_t WBX_GLOBAL* b32 = as_global<int32_t>(base);
@@ -172,11 +172,48 @@ __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t 
 // at engine.cpp:1602 and Sampler::stream accumulates into, sampler.cpp:56,152).
 // One lane's 4 frames of a generic track-block: the mixing-buffer values BEFORE the track gain.
 __device__ __forceinline__ f4 render_generic(const DTrackBlock& tb, const DSeg* pool, uint32_t c, uint32_t j0) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const uint32_t nseg = tb.nseg;
   for (uint32_t s = 0; s < nseg; s++) {
     const DSeg sg = (s == 0) ? get_seg0(tb) : pool[(size_t)tb.extra * kChunk + (s - 1)];
     const uint32_t d0 = sg.dst_start, n = sg.len;
+    if (j0 + 4u <= d0 || j0 >= d0 + n) continue;   // none of the lane's frames lies in this segment
+    // fp32 segments whose source positions stay below 2^31 (all but multi-hour clips): 32-bit index math, and one
+    // 16-B load for a lane whose four frames all lie inside a unity-speed segment
+    const bool small = sg.pos >= 0.0 && sg.pos + (double)n * (sg.speed > 1.0 ? sg.speed : 1.0) < 2147483000.0;
+    if (sg.format == FMT_F32 && small) {
+      const float WBX_GLOBAL* bf = as_global<float>(c ? sg.src[1] : sg.src[0]);
+      if (sg.speed == 1.0) {
+        const uint32_t base = (uint32_t)sg.pos;                                            // sampler.cpp:107
+        if (j0 >= d0 && j0 + 4u <= d0 + n) {
+          const f4u v = *reinterpret_cast<const f4u WBX_GLOBAL*>(bf + base + (j0 - d0));
+          acc[0] = __fadd_rn(acc[0], __fmul_rn(v.x, sg.gain));                             // :151-152
+          acc[1] = __fadd_rn(acc[1], __fmul_rn(v.y, sg.gain));
+          acc[2] = __fadd_rn(acc[2], __fmul_rn(v.z, sg.gain));
+          acc[3] = __fadd_rn(acc[3], __fmul_rn(v.w, sg.gain));
+        } else {
+#pragma unroll
+          for (uint32_t e = 0; e < 4; e++) {
+            const uint32_t j = j0 + e;
+            if (j >= d0 && j < d0 + n) acc[e] = __fadd_rn(acc[e], __fmul_rn(bf[base + (j - d0)], sg.gain));
+          }
+        }
+      } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+          const uint32_t j = j0 + e;
+          if (j >= d0 && j < d0 + n) {
+            const double x = __dadd_rn(sg.pos, __dmul_rn((double)(int32_t)(j - d0), sg.speed));   // :50
+            const int ix = (int)x;                                                                // :51
+            const float fx = (float)__builtin_amdgcn_fract(x);                                    // :52 (x >= 0: exact)
+            const float a = bf[ix], b = bf[ix + 1];
+            acc[e] = __fadd_rn(acc[e], __fmul_rn(__fadd_rn(a, __fmul_rn(fx, __fsub_rn(b, a))), sg.gain));   // :55-56
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (uint32_t e = 0; e < 4; e++) {
       const uint32_t j = j0 + e;
@@ -187,35 +224,141 @@ __device__ __forceinline__ f4 render_generic(const DTrackBlock& tb, const DSeg* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// gen: pre-render of the KIND_GENERIC track-blocks (clip boundaries inside a block, integer PCM,
-// speed > 0.999 ...).  One workgroup per queued record: render the track's mixing buffer (all segments,
-// sampler.cpp:88-210) into a scratch row, then rewrite the record as a KIND_UNITY read of that row with
-// clip gain 1, so the mix kernel's hot loop only ever sees two shapes.  grid-stride over the queue.
+// gen: pre-render of the KIND_GENERIC track-blocks (clip boundaries inside a block, several segments ...).
+// One WAVE per queued record, no LDS and no barriers: the 64-B record is read one dword per lane and broadcast
+// into scalar registers, so the segment loop and its format / speed branches are wave-uniform; the wave renders
+// the track's mixing buffer (all segments, sampler.cpp:88-210) into a scratch row and rewrites the record as a
+// KIND_UNITY read of that row with clip gain 1, so the mix kernel's hot loop never sees partial rows.  The rows
+// are independent latency chains (queue entry -> record -> segments -> samples): a full complement of waves
+// per CU, each on its own row, hides them.  Grid-stride over the queue.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gen_kernel(GenArgs a) {
-  __shared__ DTrackBlock s_rec;
+__global__ __launch_bounds__(256, 6) void gen_kernel(GenArgs a) {
   const uint32_t count = min(*a.gen_count, a.gen_cap);
   const uint32_t F = a.block_frames, C = a.channels, S4 = F >> 2;
   const size_t row_floats = (size_t)C * (F + 8);
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const uint32_t idx = a.gen_list[i];
-    __syncthreads();
-    if (threadIdx.x < 4) reinterpret_cast<uint4*>(&s_rec)[threadIdx.x] = reinterpret_cast<const uint4*>(a.tmpl + idx)[threadIdx.x];
-    __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  // the queue entry and the record of the wave's NEXT row are fetched while the current one is rendered (queued
+  // templates are distinct, so the rewrite at the end of a row cannot touch the one in flight)
+  uint32_t idx_n = 0u, w_n = 0u;
+  if (wave < count) {
+    idx_n = a.gen_list[wave];
+    w_n = reinterpret_cast<const uint32_t*>(a.tmpl + idx_n)[lane & 15u];
+  }
+  for (uint32_t i = wave; i < count; i += n_waves) {
+    const uint32_t idx = idx_n, w = w_n;
+    if (i + n_waves < count) {
+      idx_n = a.gen_list[i + n_waves];
+      w_n = reinterpret_cast<const uint32_t*>(a.tmpl + idx_n)[lane & 15u];
+    }
+    DTrackBlock rec;   // assembled field by field from the broadcast dwords (wave-uniform, scalar registers)
+    {
+      auto rl = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)w, k); };
+      rec.src[0] = (const void*)(((uint64_t)rl(1) << 32) | rl(0));
+      rec.src[1] = (const void*)(((uint64_t)rl(3) << 32) | rl(2));
+      rec.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
+      rec.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
+      rec.gain = __uint_as_float(rl(8));
+      rec.g[0] = __uint_as_float(rl(9));
+      rec.g[1] = __uint_as_float(rl(10));
+      const uint32_t q = rl(11), h = rl(12), m = rl(13);
+      rec.nseg = (uint8_t)(q & 0xFFu);
+      rec.kind = (uint8_t)((q >> 8) & 0xFFu);
+      rec.dst_start = (uint16_t)(q >> 16);
+      rec.len = (uint16_t)(h & 0xFFFFu);
+      rec.req_len = (uint16_t)(h >> 16);
+      rec.format = (uint8_t)(m & 0xFFu);
+      rec.flags = (uint8_t)((m >> 8) & 0xFFu);
+      rec._pad = (uint16_t)(m >> 16);
+      rec.sample = rl(14);
+      rec.extra = rl(15);
+    }
     float* row = a.rows + (size_t)i * row_floats;
-    for (uint32_t slot = threadIdx.x; slot < C * S4; slot += 256u) {
-      const uint32_t c = slot / S4, j0 = (slot - c * S4) * 4u;
-      const f4 r = render_generic(s_rec, a.pool, c, j0);
-      *reinterpret_cast<f4*>(row + (size_t)c * (F + 8) + j0) = r;
+    // The usual boundary row: one or two fp32 segments that do not overlap (a clip ends and/or the next one starts
+    // inside the block), source positions below 2^31.  Every frame then belongs to at most one segment: pick the
+    // segment per frame and read its tap pair with ONE unconditional 8-B load (clamped index), eight frames of a
+    // lane in flight together — straight-line code, so the row costs a few memory round trips instead of one per
+    // segment and slot.  Anything else takes the general renderer.
+    const DSeg s0 = get_seg0(rec);
+    bool fast = (rec.nseg == 1u || rec.nseg == 2u) && s0.format == FMT_F32 && s0.len != 0u && s0.pos >= 0.0 &&
+                s0.speed > 0.0 && s0.pos + (double)s0.len * (s0.speed > 1.0 ? s0.speed : 1.0) < 2147483000.0;
+    DSeg s1 = s0;
+    s1.dst_start = 0xFFFFu;   // (no second segment: never selected)
+    s1.len = 0u;
+    if (fast && rec.nseg == 2u) {
+      s1 = a.pool[(size_t)rec.extra * kChunk];
+      fast = s1.format == FMT_F32 && s1.len != 0u && s1.pos >= 0.0 && s1.speed > 0.0 &&
+             s1.pos + (double)s1.len * (s1.speed > 1.0 ? s1.speed : 1.0) < 2147483000.0 &&
+             (uint32_t)s0.dst_start + s0.len <= s1.dst_start;
     }
-    if (threadIdx.x < 8u * C) {   // the 8 floats behind each channel row that a 5-sample window load may touch
-      const uint32_t c = threadIdx.x >> 3;
-      row[(size_t)c * (F + 8) + F + (threadIdx.x & 7u)] = 0.0f;
+    if (fast) {
+      typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+      const uint32_t d0 = s0.dst_start, n0 = s0.len, d1 = s1.dst_start, n1 = s1.len;
+      const bool unity0 = s0.speed == 1.0, unity1 = s1.speed == 1.0;
+      struct Taps {
+        f2u t0, t1, t2, t3;
+        float f0, f1, f2, f3;
+        uint32_t meta;   // per frame e, bits 4e..4e+2: inside a segment / that segment plays at unity speed / second segment
+      };
+      auto load_slot = [&](uint32_t slot) {
+        Taps t;
+        const bool valid = slot < C * S4;
+        const uint32_t c = valid ? slot / S4 : 0u, j0 = valid ? (slot - c * S4) * 4u : 0u;
+        const float WBX_GLOBAL* p0 = as_global<float>(c ? s0.src[1] : s0.src[0]);
+        const float WBX_GLOBAL* p1 = as_global<float>(c ? s1.src[1] : s1.src[0]);
+        t.meta = 0u;
+        auto one = [&](uint32_t e, f2u& tap, float& fx) {
+          const uint32_t j = j0 + e;
+          const bool second = j >= d1;
+          const uint32_t d = second ? d1 : d0, n = second ? n1 : n0;
+          const bool in = valid && j >= d && j < d + n;
+          const uint32_t jj = in ? j - d : 0u;
+          const double pos = second ? s1.pos : s0.pos, sp = second ? s1.speed : s0.speed;
+          const bool unity = second ? unity1 : unity0;
+          const double x = __dadd_rn(pos, __dmul_rn((double)(int32_t)jj, sp));                  // sampler.cpp:50
+          const int ix = unity ? (int)((uint32_t)pos + jj) : (int)x;                           // :107 / :51
+          fx = (float)__builtin_amdgcn_fract(x);                                                // :52 (x >= 0: exact)
+          tap = *reinterpret_cast<const f2u WBX_GLOBAL*>((second ? p1 : p0) + ix);
+          t.meta |= ((in ? 1u : 0u) | (unity ? 2u : 0u) | (second ? 4u : 0u)) << (4u * e);
+        };
+        one(0u, t.t0, t.f0);
+        one(1u, t.t1, t.f1);
+        one(2u, t.t2, t.f2);
+        one(3u, t.t3, t.f3);
+        return t;
+      };
+      auto store_slot = [&](uint32_t slot, const Taps& t) {
+        if (slot >= C * S4) return;
+        const uint32_t c = slot / S4, j0 = (slot - c * S4) * 4u;
+        auto one = [&](uint32_t e, const f2u& tap, float fx) {
+          const uint32_t m = t.meta >> (4u * e);
+          const float lin = __fadd_rn(tap.x, __fmul_rn(fx, __fsub_rn(tap.y, tap.x)));           // :55
+          const float smp = (m & 2u) ? tap.x : lin;                                             // :151
+          const float g = (m & 4u) ? s1.gain : s0.gain;
+          return (m & 1u) ? __fadd_rn(0.0f, __fmul_rn(smp, g)) : 0.0f;                          // :56 / :152 into the cleared buffer
+        };
+        const f4 r = {one(0u, t.t0, t.f0), one(1u, t.t1, t.f1), one(2u, t.t2, t.f2), one(3u, t.t3, t.f3)};
+        *reinterpret_cast<f4*>(row + (size_t)c * (F + 8) + j0) = r;
+      };
+      for (uint32_t slot0 = lane; slot0 < C * S4; slot0 += 128u) {
+        const Taps ta = load_slot(slot0), tb = load_slot(slot0 + 64u);
+        store_slot(slot0, ta);
+        store_slot(slot0 + 64u, tb);
+      }
+    } else {
+      for (uint32_t slot = lane; slot < C * S4; slot += 64u) {
+        const uint32_t c = slot / S4, j0 = (slot - c * S4) * 4u;
+        const f4 r = render_generic(rec, a.pool, c, j0);
+        *reinterpret_cast<f4*>(row + (size_t)c * (F + 8) + j0) = r;
+      }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      a.saved[i] = s_rec;
-      DTrackBlock u = s_rec;
+    if (lane < 8u * C) {   // the 8 floats behind each channel row that a 5-sample window load may touch
+      const uint32_t c = lane >> 3;
+      row[(size_t)c * (F + 8) + F + (lane & 7u)] = 0.0f;
+    }
+    if (lane < 16u) reinterpret_cast<uint32_t*>(a.saved + i)[lane] = w;
+    if (lane == 0u) {
+      DTrackBlock u = rec;
       u.src[0] = row;
       u.src[1] = row + (C > 1 ? (F + 8) : 0);
       u.pos = 0.0;
@@ -1158,7 +1301,8 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
 
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   // grid-stride over the queue: the grid only bounds the parallelism (a short render cannot queue many rows)
-  const uint32_t grid = a.gen_cap < max_grid ? (a.gen_cap ? a.gen_cap : 1u) : max_grid;
+  const uint32_t wgs = (a.gen_cap + 3u) / 4u;   // one wave per queued record
+  const uint32_t grid = wgs < max_grid ? (wgs ? wgs : 1u) : max_grid;
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 

@@ -355,7 +355,9 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   ga.gen_cap = PB(c).gen_cap;
   ga.block_frames = F;
   ga.channels = C;
-  launch_gen(ga, K < kOverlapMinBlocks ? 64u * K : 2048u, on);
+  // one wave per queued row, grid-stride: no more workgroups than the device holds at once (256 CUs x 6 workgroups at
+  // the kernel's register budget), or the surplus would start when the first ones have finished their whole share
+  launch_gen(ga, K < kOverlapMinBlocks ? 64u * K : 1536u, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
 }
