@@ -336,6 +336,40 @@ def test_resampled_integer_pcm_hot_loop(fmt, src_rate):
     check_against_oracle(spec, 5, group_size=192, expect_exact=True)
 
 
+@pytest.mark.parametrize("clip_blocks,block", [(1.3, 512), (0.7, 512), (2.45, 256), (0.4, 128), (3.1, 96)])
+def test_sessions_cut_into_many_clips(clip_blocks, block):
+    """Every track is a chain of back-to-back clips a fraction of a block to a few blocks long, staggered per
+    track, alternating samples (rates 48 k / 44.1 k / 96 k), stretch factors, gains and fractional start
+    offsets: most track-blocks hold one or two clip boundaries and go through the pre-render pass (two-segment
+    fast path, three and more segments, unity reads at fractional positions)."""
+    n_tracks, n_blocks = 96, 9
+    beat_frames = 48000 * 60.0 / 120.0
+    total = (n_blocks + 1) * block
+    samples, clips, vols, pans = [], [], [], []
+    rates = [48000, 44100, 96000]
+    for t in range(n_tracks):
+        for r in range(3):
+            samples.append(synth.SampleSpec(seed_track=3 * t + r, channels=1 + (t + r) % 2, rate=rates[(t + r) % 3],
+                                            frames=int(total * 2.2) + 400, fmt="f32", amp=0.02))
+        v, p = synth.track_params(0xC11, t)
+        vols.append(float(v))
+        pans.append(float(p))
+        L = clip_blocks * block
+        pos = -((t * 37) % 101) / 101.0 * L
+        k = 0
+        while pos < total:
+            a, b = max(pos, 0.0), pos + L
+            stretch = [1.0, 1.0, 0.5, 1.25][(t + k) % 4]
+            clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.8 + 0.37 * (k % 3),
+                                        speed=stretch, gain=[1.0, 0.5, 1.7][k % 3], sample=3 * t + k % 3))
+            pos = b
+            k += 1
+    spec = synth.SessionSpec(name="cut", n_tracks=n_tracks, seed=0xC11, samples=samples, clips=clips, volumes_db=vols,
+                             pans=pans, mutes=[False] * n_tracks, block=block)
+    check_against_oracle(spec, n_blocks, group_size=n_tracks, expect_exact=True)
+    check_against_oracle(spec, n_blocks, group_size=16)
+
+
 def test_clamp_and_unclamped_partial():
     spec = synth.make_session("hot", 16, n_blocks=2, amp=0.5, seed=0x5EED0007)
     om, _, _, _, _ = run_oracle(spec, 2)
