@@ -225,13 +225,19 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
 
 
 def mix_kernel_name(src_rate, fmt):
-    """Template instance libwbx launches for the workload (wbx_runtime.hip: WBX_MIX_VARIANT=10*U+W overrides).
-    Sessions with per-frame-tap / resampled integer rows (fp32 played faster than recorded, integer PCM at another
-    rate) take the G instance."""
+    """Template instance libwbx launches for the workload: mix_kernel<U, FULL, W, G, SB, CW> (wbx_kernels.hip;
+    WBX_MIX_VARIANT=10*U+W overrides U and W).  Sessions with per-frame-tap / resampled integer rows (fp32 played
+    faster than recorded, integer PCM at another rate) take the G instance; 256- and 128-frame stereo blocks the
+    instances with 2 / 4 blocks per workgroup."""
+    sb, cw = {512: (1, 1), 256: (2, 1), 128: (4, 2)}.get(F, (1, 1))
+    if F % 512 and F not in (256, 128):
+        return "wbx::mix_kernel<2, false, 1, true, 1, 1>"
     if (src_rate > SR and fmt == "f32") or (src_rate != SR and fmt != "f32"):
-        return "wbx::mix_kernel<2, true, 4, true>"
+        return f"wbx::mix_kernel<2, true, 4, true, {sb}, {cw}>"
+    if sb > 1:
+        return f"wbx::mix_kernel<2, true, 4, false, {sb}, {cw}>"
     v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if (src_rate != SR or fmt != "f32") else 43)
-    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}, false>"
+    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}, false, 1, 1>"
 
 
 def main():

@@ -31,7 +31,7 @@ def one(trace, bench, title):
     for k in sorted(per, key=lambda k: ["plan", "gen_", "mix_", "sum_"].index(k[:4])):
         v = per[k]
         last = v[-timed:]
-        print(f"{k:<28}{len(v):>6}{sum(v) / len(v):>11.1f}{sum(last) / len(last):>11.1f}{min(v):>11.1f}{max(v):>11.1f}")
+        print(f"{k:<34}{len(v):>6}{sum(v) / len(v):>11.1f}{sum(last) / len(last):>11.1f}{min(v):>11.1f}{max(v):>11.1f}")
     print()
 
 
