@@ -336,6 +336,27 @@ def test_resampled_integer_pcm_hot_loop(fmt, src_rate):
     check_against_oracle(spec, 5, group_size=192, expect_exact=True)
 
 
+@pytest.mark.parametrize("block,channels", [(256, 2), (128, 2), (256, 1), (512, 1)])
+def test_callback_mode_short_blocks(block, channels):
+    """Engine::process one block per call (the audio callback) at the block sizes that pack several blocks into
+    a workgroup in batch mode: here every workgroup has one valid sub-block and empty ones beside it."""
+    n_blocks = 7
+    spec = synth.make_session("cb", 150, seek=True, n_blocks=n_blocks, block=block, seed=0xCB0 + block, src_rate=44100)
+    spec.channels = channels
+    om, opk, _, orows, otr = run_oracle(spec, n_blocks)
+    eng = build_engine(spec, max_blocks=1, group_size=150)
+    eng.play()
+    out = W.AudioBuffer(block, channels)
+    for b in range(n_blocks):
+        eng.process(None, out, float(spec.sample_rate))
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om[b])), b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0], opk[b][..., :channels]), b
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(otr[0]), O.f64_bits(otr[1]))
+    eng.close()
+
+
 @pytest.mark.parametrize("clip_blocks,block", [(1.3, 512), (0.7, 512), (2.45, 256), (0.4, 128), (3.1, 96)])
 def test_sessions_cut_into_many_clips(clip_blocks, block):
     """Every track is a chain of back-to-back clips a fraction of a block to a few blocks long, staggered per
