@@ -46,9 +46,11 @@ WORKLOADS = {
              44100, 0, "i16"),
     "i24r": ("4096 stereo 24-bit 44.1 kHz tracks (32-bit containers) resampled into the 48 kHz session, 512-frame blocks",
              44100, 0, "i24"),
+    "mixfmt": ("4096 stereo tracks at the session rate, storage format cycling fp32 / 16-bit / 24-bit per track, 512-frame blocks",
+               48000, 0, "mix3"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8}
-FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8, "mixfmt": 9}
+FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4, "mix3": 10.0 / 3.0}
 
 
 def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2, fmt: str = "f32") -> float:
@@ -76,10 +78,11 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
     per_bus = max(1, n_tracks // n_buses) if n_buses else 0
     for t in range(n_tracks):
         gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
-        sid = eng.add_sample_synth(fmt, 2, src_rate, frames, seed, gt, amp)
+        tfmt = ("f32", "i16", "i24")[gt % 3] if fmt == "mix3" else fmt
+        sid = eng.add_sample_synth(tfmt, 2, src_rate, frames, seed, gt, amp)
         tr = eng.add_track(f"t{gt}")
         v, p = synth.track_params(seed, gt)
-        if fmt != "f32":
+        if tfmt != "f32":
             v = v - 20.0 * math.log10(0.25 / amp)     # integer clips are full scale: the session level goes into the faders
         tr.set_volume(float(v))
         tr.set_pan(float(p))

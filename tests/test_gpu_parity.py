@@ -627,6 +627,24 @@ def test_mixed_storage_formats_in_one_group():
     check_against_oracle(spec, 6, expect_exact=True)
 
 
+@pytest.mark.parametrize("block", [512, 256, 128])
+def test_mixed_unity_formats_pipelined(block):
+    """fp32, 16-bit, 24-bit and 32-bit clips, all at the session rate, interleaved in every group: the chunk runs
+    pipelined with one 16-B load per row whatever its format (odd sample positions: 2-byte aligned 16-bit rows;
+    clip boundaries inside blocks add pre-rendered fp32 rows)."""
+    spec = synth.make_session("mu", 200, seek=True, n_blocks=6, block=block, seed=0xA18)
+    fmts = ["f32", "i16", "i24", "i32", "i16"]
+    for i, smp in enumerate(spec.samples):
+        smp.fmt = fmts[i % 5]
+        smp.amp = 0.02 if smp.fmt == "f32" else 1.0
+    for i, c in enumerate(spec.clips):
+        c.start_offset = float(i % 7)          # odd and even first samples
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -44.0
+    check_against_oracle(spec, 6)
+    check_against_oracle(spec, 6, group_size=200, expect_exact=True)
+
+
 def test_long_batches_and_ragged_track_counts():
     """K up to the configured maximum, track counts that do not fill the last 64-lane plan workgroup, and
     batches of odd length."""

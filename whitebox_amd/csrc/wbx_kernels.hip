@@ -496,7 +496,7 @@ __device__ __forceinline__ void wave_max_quad_halves(uint32_t p0, uint32_t p1, u
   ch1 = w;
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8 };   // row shapes of a staged chunk
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -882,6 +882,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         load_window(r.src, r.pos, r.speed, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
         load_window16(r.src, r.pos, r.speed, pre[u]);
+      } else if constexpr (MODE == MODE_MU) {
+        // unity rows of several storage formats: one 16-B load per row whatever the format (a 16-bit row uses its
+        // low half; the rest is its neighbour's samples or the clip's padding), so the loads stay straight-line
+        typedef float f4a2 __attribute__((ext_vector_type(4), aligned(2)));
+        const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
+        const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
+        const char WBX_GLOBAL* p = as_global<char>(r.src) + ((size_t)off << sh);
+        if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
       } else {
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
         if (MODE == MODE_I16) {
@@ -944,6 +952,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
           m = row_window16(std::integral_constant<bool, MODE == MODE_WIN>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);   // unity, silent, padding
+      } else if constexpr (MODE == MODE_MU) {
+        const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+        if (k == KIND_UNITY_I16)
+          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+        else if (k == KIND_UNITY_I32)
+          m = row_i32(pre[u].v, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
+        else
+          m = row_f32(pre[u].v, cg, gc);
       } else if constexpr (MODE == MODE_I16) {
         m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
       } else if constexpr (MODE == MODE_I32) {
@@ -1062,12 +1078,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     } else if (has_win16) {
       mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : MODE_WIN) : MODE_G;
     } else if (has_i16) {
-      mode = (has_win32 || (G && has_win)) ? MODE_G : (!has_i32 && !has_f32) ? MODE_I16 : MODE_MIXED;
+      mode = (has_win32 || (G && has_win)) ? MODE_G : (!has_i32 && !has_f32) ? MODE_I16 : has_win ? MODE_MIXED : MODE_MU;
     } else if (has_win || has_win32) {
       // fp32 unity + window rows; in G instances also 24/32-bit PCM unity + window rows (all 4-byte containers)
       mode = (G || !has_i32) ? (has_wide ? MODE_W : MODE_WN) : MODE_MIXED;
     } else {
-      mode = !has_i32 ? MODE_U : !has_f32 ? MODE_I32 : MODE_MIXED;
+      mode = !has_i32 ? MODE_U : !has_f32 ? MODE_I32 : MODE_MU;   // unity rows of several formats
     }
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
     // of the chunk's own shape, so that the load phase stays straight-line
@@ -1101,6 +1117,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       case MODE_WIN:
         if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn);
         break;
+      case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn); break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
       case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
       default: mixed(cn); break;
