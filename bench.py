@@ -48,9 +48,12 @@ WORKLOADS = {
              44100, 0, "i24"),
     "mixfmt": ("4096 stereo tracks at the session rate, storage format cycling fp32 / 16-bit / 24-bit per track, 512-frame blocks",
                48000, 0, "mix3"),
+    "mixr": ("4096 stereo tracks, alternating 16-bit 44.1 kHz clips (resampled) and 24-bit 48 kHz clips, 512-frame blocks",
+             48000, 0, "mixr"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8, "mixfmt": 9}
-FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4, "mix3": 10.0 / 3.0}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8, "mixfmt": 9, "mixr": 10}
+# bytes per stored sample (the mixed workloads: mean over their tracks, rate ratio folded in for mixr)
+FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4, "mix3": 10.0 / 3.0, "mixr": (2 * 0.91875 + 4) / 2}
 
 
 def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2, fmt: str = "f32") -> float:
@@ -78,8 +81,9 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
     per_bus = max(1, n_tracks // n_buses) if n_buses else 0
     for t in range(n_tracks):
         gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
-        tfmt = ("f32", "i16", "i24")[gt % 3] if fmt == "mix3" else fmt
-        sid = eng.add_sample_synth(tfmt, 2, src_rate, frames, seed, gt, amp)
+        tfmt = ("f32", "i16", "i24")[gt % 3] if fmt == "mix3" else ("i16", "i24")[gt % 2] if fmt == "mixr" else fmt
+        trate = 44100 if (fmt == "mixr" and gt % 2 == 0) else src_rate
+        sid = eng.add_sample_synth(tfmt, 2, trate, frames, seed, gt, amp)
         tr = eng.add_track(f"t{gt}")
         v, p = synth.track_params(seed, gt)
         if tfmt != "f32":
@@ -235,7 +239,7 @@ def mix_kernel_name(src_rate, fmt):
     sb, cw = {512: (1, 1), 256: (2, 1), 128: (4, 2)}.get(F, (1, 1))
     if F % 512 and F not in (256, 128):
         return "wbx::mix_kernel<2, false, 1, true, 1, 1>"
-    if (src_rate > SR and fmt == "f32") or (src_rate != SR and fmt != "f32"):
+    if (src_rate > SR and fmt == "f32") or (src_rate != SR and fmt != "f32") or fmt == "mixr":
         return f"wbx::mix_kernel<2, true, 4, true, {sb}, {cw}>"
     if sb > 1:
         return f"wbx::mix_kernel<2, true, 4, false, {sb}, {cw}>"

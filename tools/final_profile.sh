@@ -17,6 +17,7 @@ timeout 300 python bench.py --workload d96 --no-cpu-baseline > $O/bench_d96.json
 timeout 300 python bench.py --workload i16r --no-cpu-baseline > $O/bench_i16r.json 2>> $O/bench_default.err
 timeout 300 python bench.py --workload i24r --no-cpu-baseline > $O/bench_i24r.json 2>> $O/bench_default.err
 timeout 300 python bench.py --workload mixfmt --no-cpu-baseline > $O/bench_mixfmt.json 2>> $O/bench_default.err
+timeout 300 python bench.py --workload mixr --no-cpu-baseline > $O/bench_mixr.json 2>> $O/bench_default.err
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o c3 -- python $R/bench.py --no-cpu-baseline --latency-blocks 0 > $O/kt_bench.json 2> $O/kt.err
 WBX_OVERLAP=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_noov -o c3 -- python $R/bench.py --no-cpu-baseline --latency-blocks 0 > $O/kt_noov_bench.json 2> $O/kt_noov.err

@@ -496,7 +496,7 @@ __device__ __forceinline__ void wave_max_quad_halves(uint32_t p0, uint32_t p1, u
   ch1 = w;
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9 };   // row shapes of a staged chunk
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9, MODE_MW = 10, MODE_MWN = 11 };   // row shapes of a staged chunk
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -875,6 +875,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.pos = t.pos;
         r.speed = t.speed;
         r.format = t.format;
+        r.kind = t.kind;
       }
       if constexpr (MODE == MODE_G) {
         load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
@@ -882,6 +883,24 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         load_window(r.src, r.pos, r.speed, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
         load_window16(r.src, r.pos, r.speed, pre[u]);
+      } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
+        // unity and window rows of several storage formats (16-bit loops at another rate next to 24-bit stems ...):
+        // every row reads 16 B + 4 B at its first sample — the five window samples of a 4-byte format, the low
+        // 10 B for a 16-bit window, the four (8 B or 16 B) samples of a unity row — so the loads stay straight-line
+        typedef float f4a2 __attribute__((ext_vector_type(4), aligned(2)));
+        typedef float f1a2 __attribute__((aligned(2)));
+        const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+        const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
+        const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                      // sampler.cpp:50, frame j0
+        const bool win = k == KIND_WINDOW || k == KIND_WINDOW_I16;
+        const int ix0 = win ? (int)x0 : (int)((uint32_t)r.pos + j0);                      // :51 / :107
+        const char WBX_GLOBAL* p = as_global<char>(r.src) + ((size_t)(uint32_t)ix0 << sh);
+        if (active) {
+          pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
+          pre[u].w4 = *reinterpret_cast<const f1a2 WBX_GLOBAL*>(p + 16);
+        }
+        pre[u].ix0 = ix0;
+        pre[u].fx0 = (float)__builtin_amdgcn_fract(x0);                                   // :52
       } else if constexpr (MODE == MODE_MU) {
         // unity rows of several storage formats: one 16-B load per row whatever the format (a 16-bit row uses its
         // low half; the rest is its neighbour's samples or the clip's padding), so the loads stay straight-line
@@ -952,6 +971,24 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
           m = row_window16(std::integral_constant<bool, MODE == MODE_WIN>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);   // unity, silent, padding
+      } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
+        const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+        const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
+        constexpr std::integral_constant<bool, MODE == MODE_MWN> narrow{};
+        if (k == KIND_WINDOW_I16) {
+          Pre q = pre[u];
+          q.w4 = pre[u].v.z;   // the fifth sample of a 16-bit window is the low half of the load's third dword
+          m = row_window16(narrow, q, r.pos, r.speed, cg, gc);
+        } else if (k == KIND_WINDOW) {
+          m = fmt == FMT_F32 ? row_window(narrow, pre[u], r.pos, r.speed, cg, gc)
+                             : row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
+        } else if (k == KIND_UNITY_I16) {
+          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+        } else if (k == KIND_UNITY_I32) {
+          m = row_i32(pre[u].v, fmt, cg, gc);
+        } else {
+          m = row_f32(pre[u].v, cg, gc);
+        }
       } else if constexpr (MODE == MODE_MU) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         if (k == KIND_UNITY_I16)
@@ -1076,9 +1113,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     if (has_stride) {
       mode = MODE_G;             // reads every kind and format, whatever else the chunk holds
     } else if (has_win16) {
-      mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : MODE_WIN) : MODE_G;
+      mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : MODE_WIN) : (has_wide ? MODE_MW : MODE_MWN);
     } else if (has_i16) {
-      mode = (has_win32 || (G && has_win)) ? MODE_G : (!has_i32 && !has_f32) ? MODE_I16 : has_win ? MODE_MIXED : MODE_MU;
+      mode = (has_win32 || (G && has_win)) ? (has_wide ? MODE_MW : MODE_MWN)
+             : (!has_i32 && !has_f32) ? MODE_I16 : has_win ? MODE_MIXED : MODE_MU;
     } else if (has_win || has_win32) {
       // fp32 unity + window rows; in G instances also 24/32-bit PCM unity + window rows (all 4-byte containers)
       mode = (G || !has_i32) ? (has_wide ? MODE_W : MODE_WN) : MODE_MIXED;
@@ -1118,6 +1156,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn);
         break;
       case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn); break;
+      case MODE_MW:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_MW>{}, cn);
+        break;
+      case MODE_MWN:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_MWN>{}, cn);
+        break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
       case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
       default: mixed(cn); break;
