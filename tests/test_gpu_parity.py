@@ -645,6 +645,21 @@ def test_mixed_unity_formats_pipelined(block):
     check_against_oracle(spec, 6, group_size=200, expect_exact=True)
 
 
+def test_resampled_fp32_next_to_integer_unity():
+    """fp32 clips at another rate (window rows) in the same groups as 16/24-bit clips at the session rate."""
+    spec = synth.make_session("mwf", 160, seek=True, n_blocks=5, seed=0xA19)
+    for i, smp in enumerate(spec.samples):
+        if i % 3 == 0:
+            smp.rate = 44100
+        else:
+            smp.fmt = "i16" if i % 3 == 1 else "i24"
+            smp.amp = 1.0
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = -40.0 if t % 3 else 0.0
+    check_against_oracle(spec, 5)
+    check_against_oracle(spec, 5, group_size=160, expect_exact=True)
+
+
 def test_long_batches_and_ragged_track_counts():
     """K up to the configured maximum, track counts that do not fill the last 64-lane plan workgroup, and
     batches of odd length."""

@@ -398,7 +398,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
     }
     launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
-               c->has_stride_clips, c->stream);
+               // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
+               c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), c->stream);
     if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
