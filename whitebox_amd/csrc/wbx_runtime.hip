@@ -162,6 +162,7 @@ struct wbx_ctx {
                                       // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;
   bool has_integer_clips = false;
+  bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
 };
 
@@ -399,7 +400,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     }
     launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
-               c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), c->stream);
+               c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), c->stream);
     if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
     }
@@ -506,6 +507,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   c->cfg = *cfg;
   if (c->cfg.group_size == 0) c->cfg.group_size = kStage;   // 128: one staging round per workgroup
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
+  if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {
