@@ -9,6 +9,8 @@ sample-index math bit-exact.  What is actually asserted is tighter wherever the 
   * the device sequencer's plan (buffer offsets, lengths, sample offsets as bit patterns) is EQUAL
     to the oracle's Sampler::stream call log.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -791,7 +793,8 @@ def random_session(seed):
                              playhead_start=float(rng.choice([0.0, 0.0, total_beats * 0.1]))), n_blocks
 
 
-@pytest.mark.parametrize("seed", range(160))
+# WBX_FUZZ_FROM / WBX_FUZZ_TO widen the seed range for a soak run (default: seeds 0..159)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ_FROM", "0")), int(os.environ.get("WBX_FUZZ_TO", "160"))))
 def test_random_sessions_match_oracle(seed):
     spec, n_blocks = random_session(seed)
     # fewer tracks than one group and the oracle's bus order: everything bit-equal, including the stream-call log
