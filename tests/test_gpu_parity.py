@@ -465,12 +465,17 @@ def test_interleaved_output_formats():
 # ---------------------------------------------------------------------------------------------------
 # layer 1: host-sequenced segments (the reference keeps Track::process_event, the device mixes)
 # ---------------------------------------------------------------------------------------------------
-def test_layer1_submit_host_sequenced():
-    spec = synth.make_session("l1", 96, seek=True, src_rate=44100, n_blocks=5, seed=0x81)
+@pytest.mark.parametrize("src_rate,fmt,block", [(44100, "f32", 512), (96000, "f32", 512), (44100, "i16", 256),
+                                                (44100, "i24", 128), (48000, "i16", 512)])
+def test_layer1_submit_host_sequenced(src_rate, fmt, block):
+    spec = synth.make_session("l1", 96, seek=True, src_rate=src_rate, n_blocks=5, seed=0x81, fmt=fmt, block=block)
+    if fmt != "f32":
+        for t in range(spec.n_tracks):
+            spec.volumes_db[t] = -40.0
     e = O.build_oracle_engine(spec)
     e.enable_seglog()
     e.play()
-    ctx = W.MixContext(spec.n_tracks, max_blocks=5, group_size=32)
+    ctx = W.MixContext(spec.n_tracks, max_blocks=5, block=block, group_size=32)
     for i, s in enumerate(spec.samples):
         ctx.clip_upload(i, s.fmt, s.rate, [np.ascontiguousarray(a[:s.frames]) for a in spec.sample_data(i)])
     segs, offs, gains, masters, peaks = [], [0], [], [], []
