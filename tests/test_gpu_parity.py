@@ -393,6 +393,28 @@ def test_sessions_cut_into_many_clips(clip_blocks, block):
     check_against_oracle(spec, n_blocks, group_size=16)
 
 
+def test_extreme_playback_speeds():
+    """Stretch factors at and beyond the bounds of the hot loop's row kinds: 0.001 (window, general tap selection),
+    0.999 / 0.9990001 (window / per-frame taps), 4096 (per-frame taps) and 5000, 20000 (pre-render pass)."""
+    block, n_blocks = 64, 4
+    speeds = [0.001, 0.999, 0.9990001, 1.0, 4096.0, 4096.5, 5000.0, 20000.0, 37.25, 0.75, 0.7499999]
+    beat_frames = 48000 * 60.0 / 120.0
+    samples, clips = [], []
+    for t, sp in enumerate(speeds):
+        frames = int(block * (n_blocks + 2) * max(sp, 1.0)) + 64
+        samples.append(synth.SampleSpec(seed_track=t, channels=2, rate=48000, frames=frames, fmt="f32" if t % 2 == 0 else "i16",
+                                        amp=0.05 if t % 2 == 0 else 1.0))
+        clips.append(synth.ClipSpec(t, 0.0, (n_blocks + 1) * block / beat_frames, start_offset=3.0, speed=sp, gain=0.5))
+    n = len(speeds)
+    spec = synth.SessionSpec(name="xs", n_tracks=n, seed=0xE5, samples=samples, clips=clips, volumes_db=[-30.0] * n,
+                             pans=[0.1 * (i - 5) for i in range(n)], mutes=[False] * n, block=block)
+    check_against_oracle(spec, n_blocks, expect_exact=True)
+    spec.block = 512
+    for smp, sp in zip(samples, speeds):
+        smp.frames = int(512 * (n_blocks + 2) * max(sp, 1.0)) + 64
+    check_against_oracle(spec, n_blocks, expect_exact=True)
+
+
 def test_clamp_and_unclamped_partial():
     spec = synth.make_session("hot", 16, n_blocks=2, amp=0.5, seed=0x5EED0007)
     om, _, _, _, _ = run_oracle(spec, 2)
