@@ -393,6 +393,13 @@ def test_sessions_cut_into_many_clips(clip_blocks, block):
     check_against_oracle(spec, n_blocks, group_size=16)
 
 
+def test_one_engine_20000_tracks():
+    """More tracks on one device than any BASELINE single-GPU config: 20000 tracks (157 groups, the last one
+    ragged) in one engine, clips generated on the device."""
+    spec = synth.make_session("big", 20000, n_blocks=2, seed=0xB16, src_rate=44100)
+    check_against_oracle(spec, 2, device_synth=True)
+
+
 def test_extreme_playback_speeds():
     """Stretch factors at and beyond the bounds of the hot loop's row kinds: 0.001 (window, general tap selection),
     0.999 / 0.9990001 (window / per-frame taps), 4096 (per-frame taps) and 5000, 20000 (pre-render pass)."""
