@@ -835,6 +835,30 @@ def test_random_sessions_match_oracle(seed):
     check_against_oracle(spec, n_blocks, expect_exact=True)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ2_FROM", "0")), int(os.environ.get("WBX_FUZZ2_TO", "40"))))
+def test_random_sessions_grouped_and_callback(seed):
+    """The same random sessions with small track groups (several chunks of records, ragged last group: plan rows,
+    transport and per-track peaks bit-equal, master inside the RMS budget) and rendered one block per call
+    (Engine::process) against the batch render of the same engine configuration: bit-identical."""
+    spec, n_blocks = random_session(seed + 100000)
+    gs = [1, 2, 3, 5, 8][seed % 5]
+    check_against_oracle(spec, n_blocks, group_size=gs)
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=gs)
+    eng.play()
+    eng.render(n_blocks)
+    batch, pk_b, _ = eng.ctx.fetch(peaks=True)
+    eng.close()
+    eng = build_engine(spec, max_blocks=1, group_size=gs)
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    for b in range(n_blocks):
+        eng.process(None, out, float(spec.sample_rate))
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(batch[b])), b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0], pk_b[b]), b
+    eng.close()
+
+
 def test_track_management_while_playing():
     """Engine::move_track / delete_track / solo_track (engine.cpp:210-262) between blocks of a running transport:
     tracks keep their sequencer and sampler state, only their slots (= the summation order) change; solo goes
