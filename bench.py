@@ -314,7 +314,10 @@ def main():
     if args.force_dist_path and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True          # the same options as the multi-rank path
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank),
+                                pg_options=opts)
 
     stream = torch.cuda.Stream()
     # root: clamp of a reduced master into host memory, beside the next renders.  Highest priority: at normal
