@@ -398,7 +398,7 @@ def main():
         for _ in range(args.warmup + args.ramp_steps):
             step()
         drain()
-        eng.ctx.kernel_time(reset=True)
+        pre_ms, pre_n = eng.ctx.kernel_time(reset=True)     # warm-up + ramp launches (for the rocprofv3 cross-check)
         nstep = 0
         if world > 1:
             dist.barrier()
@@ -470,6 +470,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate, fmt),
                          "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n), "sum_tail_ms_avg": tail_ms,
+                         # mean over EVERY launch of the run incl. warm-up and ramp: what `rocprofv3 --stats` averages
+                         "kernel_ms_avg_all_launches": (pre_ms * pre_n + mix_ms * mix_n) / max(1, pre_n + mix_n),
+                         "kernel_launches_all": int(pre_n + mix_n),
                          "algorithmic_bytes_per_launch": alg},
         }
         if lat is not None:

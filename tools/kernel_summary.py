@@ -26,7 +26,9 @@ def one(trace, bench, title):
     print(f"# rocprofv3 --kernel-trace of `{title}` ({d['config']['workload'].split(' ')[0]}, K={d['config']['blocks_per_step']}): "
           f"{d['warmup']} warm-up + {d['ramp_steps']} ramp + {timed} timed steps")
     print(f"# the same run's bench line: ms_per_step {d['ms_per_step']:.3f}, roofline.kernel_ms_avg (HIP events, timed steps) "
-          f"{1e3 * d['roofline']['kernel_ms_avg']:.1f} us")
+          f"{1e3 * d['roofline']['kernel_ms_avg']:.1f} us"
+          + (f", over all {d['roofline']['kernel_launches_all']} launches {1e3 * d['roofline']['kernel_ms_avg_all_launches']:.1f} us"
+             if "kernel_ms_avg_all_launches" in d["roofline"] else ""))
     print("# kernel, launches, mean us (all), mean us (last %d = the timed steps), min us, max us" % timed)
     for k in sorted(per, key=lambda k: ["plan", "gen_", "mix_", "sum_"].index(k[:4])):
         v = per[k]
