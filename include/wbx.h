@@ -190,7 +190,8 @@ wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot);
 wbx_status wbx_engine_clear_all(wbx_engine* e);                       /* Engine::clear_all, engine.cpp:59-66 */
 wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot);
 wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot);
-wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);      /* extension A13 */
+/* extension A13: bus < 0 or >= the configured number of buses routes the track straight into the master */
+wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);
 /* Sample assets (SampleAsset, engine/assets_table.h:22-35): upload once, reference by id from clips. */
 wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
                                  const void* const* planar, uint32_t* sample_out);

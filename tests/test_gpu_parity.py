@@ -393,6 +393,54 @@ def test_sessions_cut_into_many_clips(clip_blocks, block):
     check_against_oracle(spec, n_blocks, group_size=16)
 
 
+def test_empty_and_tiny_samples():
+    """Clips on samples of 0, 1 and 3 frames (shorter than a lane's four frames), at unity and resampled rates:
+    the sampler's tail arithmetic (sampler.cpp:100-104) leaves nothing or a few frames to render."""
+    spec = synth.make_session("tiny", 12, n_blocks=3, seed=0x717)
+    for i, smp in enumerate(spec.samples):
+        smp.frames = [0, 1, 3, 700][i % 4]
+        smp.rate = [48000, 44100, 96000][i % 3]
+    check_against_oracle(spec, 3, expect_exact=True)
+
+
+def test_api_errors_leave_the_engine_usable():
+    """Where the reference asserts (audio_buffer.h:35,50,74; track.cpp:687-688) the C ABI returns a status: invalid
+    arguments are refused with WBX_ERR_INVALID and the engine keeps rendering the same bits afterwards."""
+    spec = synth.make_session("err", 6, n_blocks=3, seed=0xE77)
+    om, _, _, _, _ = run_oracle(spec, 3)
+    eng = build_engine(spec, max_blocks=2)
+    eng.play()
+    with pytest.raises(W.WbxError):
+        eng.render(3)                                   # more blocks than wbx_config.max_blocks
+    with pytest.raises(W.WbxError):
+        eng.render(0)
+    with pytest.raises(W.WbxError):
+        eng.add_audio_clip(eng.tracks[0], "x", 1.0, 2.0, 0.0, 999)          # unknown sample
+    with pytest.raises(W.WbxError):
+        eng.add_audio_clip(eng.tracks[0], "x", 3.0, 2.0, 0.0, 0)            # min_time > max_time
+    with pytest.raises(W.WbxError):
+        eng.delete_track(17)
+    with pytest.raises(W.WbxError):
+        eng.move_track(0, 17)
+    with pytest.raises(W.WbxError):
+        eng.move_clip(eng.tracks[0], 5, 0.25)                               # no such clip
+    eng.tracks[0].set_bus(3)                 # defined, not an error: without such a bus the track feeds the master
+    eng.render(2)
+    m, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m), bits(om[:2]))
+    eng.render(1)
+    m, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m[0]), bits(om[2]))
+    eng.close()
+    # a track more than the configured maximum
+    eng = W.Engine(2)
+    eng.add_track()
+    eng.add_track()
+    with pytest.raises(W.WbxError):
+        eng.add_track()
+    eng.close()
+
+
 def test_one_engine_20000_tracks():
     """More tracks on one device than any BASELINE single-GPU config: 20000 tracks (157 groups, the last one
     ragged) in one engine, clips generated on the device."""
