@@ -242,7 +242,8 @@ def test_parameter_changes_are_block_rate():
     eng.close()
 
 
-@pytest.mark.parametrize("block,channels", [(128, 2), (256, 2), (1024, 2), (2048, 2), (512, 1), (96, 2), (256, 1), (64, 2)])
+@pytest.mark.parametrize("block,channels", [(128, 2), (256, 2), (1024, 2), (2048, 2), (512, 1), (96, 2), (256, 1), (64, 2), (4096, 2),
+                                            (32768, 2), (4, 2)])
 def test_other_block_sizes_and_mono_out(block, channels):
     spec = synth.make_session("blk", 40, n_blocks=3, block=block, seed=0x42, src_rate=44100)
     spec.channels = channels
