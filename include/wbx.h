@@ -142,7 +142,8 @@ wbx_status wbx_submit(wbx_ctx* ctx, uint32_t n_blocks, uint32_t n_tracks, const 
 
 /* Results of the last submit (blocks until done).  Any pointer may be NULL.
  *  master_planar[c] : K*F floats, block after block (the AudioBuffer the audio thread hands to process)
- *  peaks            : [K][N][C]  max|x| per track/channel/block (VUMeter::push_samples, vu_meter.h:20-25)
+ *  peaks            : [K][N][C]  max|x| per track/channel/block (VUMeter::push_samples, vu_meter.h:20-25); NaN samples
+ *                     are ignored (the reference's running maximum restarts after a NaN, an order-dependent result)
  *  buses            : [K][n_buses][C][F] bus sums */
 wbx_status wbx_fetch(wbx_ctx* ctx, float* const* master_planar, float* peaks, float* buses);
 wbx_status wbx_fetch_interleaved(wbx_ctx* ctx, int out_format, void* dst);  /* K*F*C interleaved samples */

@@ -9,6 +9,7 @@ sample-index math bit-exact.  What is actually asserted is tighter wherever the 
   * the device sequencer's plan (buffer offsets, lengths, sample offsets as bit patterns) is EQUAL
     to the oracle's Sampler::stream call log.
 """
+import dataclasses
 import os
 
 import numpy as np
@@ -392,6 +393,55 @@ def test_sessions_cut_into_many_clips(clip_blocks, block):
                              pans=pans, mutes=[False] * n_tracks, block=block)
     check_against_oracle(spec, n_blocks, group_size=n_tracks, expect_exact=True)
     check_against_oracle(spec, n_blocks, group_size=16)
+
+
+class _SpecialValuesSpec(synth.SessionSpec):
+    """fp32 clips salted with denormals, signed zeros, huge values, infinities and NaNs."""
+    SALTS = {"denormals_and_zeros": [1e-40, -1e-45, -0.0, 0.0, 1.17549435e-38, -1e-39],
+             "huge": [3e38, -3e38, 1e-40, -0.0, 2.5e37],
+             "nonfinite": [np.inf, -np.inf, np.nan, 3e38, -0.0, 1e-40]}
+
+    def sample_data(self, i):
+        out = super().sample_data(i)
+        if self.samples[i].fmt != "f32":
+            return out
+        specials = np.array(self.SALTS[self.salt], np.float32)
+        for c, a in enumerate(out):
+            n = len(a) - 16
+            idx = (np.arange(0, n, 37) + 5 * i + c) % max(n, 1)
+            a[idx] = specials[(np.arange(len(idx)) + i) % len(specials)]
+        return out
+
+
+@pytest.mark.parametrize("salt", ["denormals_and_zeros", "huge", "nonfinite"])
+@pytest.mark.parametrize("src_rate", [48000, 44100, 96000])
+def test_special_float_values(salt, src_rate):
+    """Denormal samples and products are kept (the reference build does not flush them), signed zeros follow the
+    reference's additions, values near FLT_MAX overflow where the reference's do: master and peaks bit-equal.
+    With infinities and NaNs in the clips the master still matches sample for sample (NaN where the reference has
+    NaN — the clamp of engine.cpp:1627-1636 lets it through —, the same bits everywhere else).  The peak of a
+    track-block that CONTAINS a NaN is the one documented deviation: the reference's math::max restarts after every
+    NaN (its result depends on where the NaN sits in the block), the wave-parallel maximum ignores NaN."""
+    base = synth.make_session("spv", 24, seek=True, n_blocks=4, seed=0x5F0 + src_rate // 100, src_rate=src_rate, amp=1e-3)
+    spec = _SpecialValuesSpec(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)})
+    spec.salt = salt
+    for t in range(spec.n_tracks):
+        spec.volumes_db[t] = [-60.0, 0.0, -20.0][t % 3]
+    om, opk, _, orows, _ = run_oracle(spec, 4)
+    eng = build_engine(spec, max_blocks=4, group_size=24)
+    eng.play()
+    eng.render(4)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert plan_rows(eng.fetch_plan()) == orows
+    if salt != "nonfinite":
+        assert np.array_equal(bits(pk), bits(opk[..., :spec.channels]))
+        assert np.array_equal(bits(m), bits(om))
+    else:
+        assert np.array_equal(np.isnan(m), np.isnan(om))
+        ok = ~np.isnan(om)
+        assert np.array_equal(bits(m)[ok], bits(om)[ok])
+        assert not np.isnan(pk).any()
+    eng.close()
 
 
 def test_empty_and_tiny_samples():
