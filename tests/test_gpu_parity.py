@@ -663,15 +663,27 @@ def _clip_rows(clips):
     return [(O.f64_bits(a), O.f64_bits(b), O.f64_bits(c), O.f64_bits(d), O.f32_bits(g), s) for (a, b, c, d, g, s) in clips]
 
 
-def test_clip_edits_match_oracle_lists_and_audio():
+# WBX_FUZZ3_FROM / WBX_FUZZ3_TO widen the seed range for a soak run (default: seeds 2024..2029; 2024 is the original
+# all-fp32 512-frame script, the others also draw the block size, the storage formats and the sample rates)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ3_FROM", "2024")), int(os.environ.get("WBX_FUZZ3_TO", "2030"))))
+def test_clip_edits_match_oracle_lists_and_audio(seed):
     """Random edit scripts applied to both engines through their reference-shaped APIs, between rendered
     blocks: the sorted clip lists (fp64 bit patterns), the sequencer's plan and the audio must stay equal."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     n_tracks, beat = 6, 24000.0
-    spec = synth.make_session("edits", n_tracks, n_blocks=40, seed=0xED17, amp=0.05)
+    block = 512 if seed == 2024 else int(np.random.default_rng(seed + 7).choice([512, 256, 128, 64]))
+    spec = synth.make_session("edits", n_tracks, n_blocks=40, seed=0xED17, amp=0.05, block=block)
     spec.clips = []
-    for s in spec.samples:
+    for i, s in enumerate(spec.samples):
         s.frames = 40000
+        if seed != 2024:
+            r2 = np.random.default_rng(seed * 31 + i)
+            s.fmt = str(r2.choice(["f32", "f32", "i16", "i24"]))
+            s.rate = int(r2.choice([48000, 48000, 44100, 96000]))
+            s.amp = 0.05 if s.fmt == "f32" else 1.0
+    if seed != 2024:
+        for t in range(n_tracks):
+            spec.volumes_db[t] = -30.0
     e = O.build_oracle_engine(spec)
     eng = build_engine(spec, max_blocks=2)
     e.enable_seglog()
@@ -728,8 +740,8 @@ def test_clip_edits_match_oracle_lists_and_audio():
             assert _clip_rows(eng.clips(eng.tracks[tt])) == _clip_rows(e.clips(tt)), (step, op, tt)
         om, _ = e.process()
         eng.process(None, out, 48000.0)
-        assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), (step, op)
-        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), (step, op)
+        assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), (seed, step, op)
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), (seed, step, op)
     e.close()
     eng.close()
 
