@@ -108,3 +108,75 @@ def test_shard_ranges_cover_all_tracks():
                 f, c = shard_tracks(n, w, r)
                 seen += list(range(f, f + c))
             assert seen == list(range(n))
+
+
+def _worker_pipelined(rank, world, port, n_tracks, q):
+    """bench.py's N>1 loop shape: one render per step into a ring of three master buffers, the reduce of step i
+    enqueued asynchronously, the finalize (root clamp) of step i-1 issued afterwards, the last one drained."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_ffi as O
+    from whitebox_amd.dist import MasterReducer, shard_tracks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = _session(n_tracks, 0.6)
+    for s in spec.samples:
+        s.frames *= 4                      # 10 blocks are rendered here
+    first, count = shard_tracks(n_tracks, world, rank)
+    e = O.build_oracle_engine(_shard_spec(spec, first, count))
+    e.play()
+    NS, K, steps = 3, 2, 5
+    masters = [torch.zeros(K, 2, 512) for _ in range(NS)]
+    results = []
+
+    def finalize(buf):
+        a = buf.numpy()
+        for b in range(a.shape[0]):
+            chans = [a[b, c] for c in range(a.shape[1])]
+            O.lib().wbo_master_clamp(O.planar_ptrs(chans), a.shape[1], a.shape[2])
+        results.append(a.copy())
+
+    red = MasterReducer(finalize, root=0)
+    for i in range(steps):
+        slot = i % NS
+        masters[slot].copy_(torch.from_numpy(np.stack([e.process(clamp=False)[0] for _ in range(K)])))   # "render"
+        red.reduce(masters[slot], slot=slot)
+        if i >= 1:
+            red.finish(masters[(i - 1) % NS], slot=(i - 1) % NS)
+    red.finish(masters[(steps - 1) % NS], slot=(steps - 1) % NS)
+    e.close()
+    if rank == 0:
+        q.put(np.concatenate(results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tracks", [(2, 23), (3, 20)])
+def test_pipelined_reduce_ring_of_three(world, n_tracks):
+    import oracle_ffi as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, n_tracks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from whitebox_amd import synth
+    spec = synth.make_session("dist", n_tracks, n_blocks=N_BLOCKS, src_rate=44100, seed=0xD157, amp=0.6)
+    for s in spec.samples:
+        s.frames *= 4                      # 10 blocks are rendered here
+    e = O.build_oracle_engine(spec)
+    e.play()
+    want = np.stack([e.process()[0] for _ in range(10)])
+    e.close()
+    assert got.shape == want.shape
+    d = got.astype(np.float64) - want.astype(np.float64)
+    assert np.sqrt(np.mean(d * d)) <= 1e-6
+    assert np.abs(got).max() <= 1.0
