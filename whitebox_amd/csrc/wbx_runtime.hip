@@ -505,7 +505,9 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   wbx_ctx* c = new (std::nothrow) wbx_ctx();
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
-  if (c->cfg.group_size == 0) c->cfg.group_size = kStage;   // 128: one staging round per workgroup
+  // default 128: one staging round per workgroup; a context that can only render one block per call (the audio
+  // callback) takes 64 — twice the workgroups for the one block, ≈15 % less latency at 4096 tracks
+  if (c->cfg.group_size == 0) c->cfg.group_size = c->cfg.max_blocks == 1 ? kStage / 2 : kStage;
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
   if (cfg->stream) {
