@@ -47,3 +47,24 @@ def test_clip_edit_arithmetic_matches_oracle_random(oracle):
                  O.f64_bits(Lo.wbo_calc_clip_shift(vals[2], vals[6], vals[10], vals[4])),
                  O.f64_bits(Lo.wbo_shift_clip_content(vals[2], vals[3], vals[4], vals[6], vals[10]))]
         assert _product(vals, flags) == want
+
+
+def test_bench_algorithmic_bytes_match_survey_figures():
+    """SURVEY §8(d): 16.78 MB per 4096-track block at unity rate, 15.41 MB at 44.1 -> 48 kHz (clip reads only;
+    bench.py adds the master write, the peaks and the 32 B of tables per track)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    extra = 512 * 2 * 4 + 4096 * 2 * 4 + 4096 * 32
+    assert abs(b.algorithmic_bytes_per_block(4096, 48000) - (512 * 32768 + extra)) < 1e-6
+    assert abs(b.algorithmic_bytes_per_block(4096, 44100) - (512 * 32768 * 0.91875 + extra)) < 1e-3
+    assert abs(b.algorithmic_bytes_per_block(4096, 48000, fmt="i16") - (512 * 16384 + extra)) < 1e-6
+    assert abs(512 * 32768 / 1e6 - 16.78) < 0.01 and abs(512 * 32768 * 0.91875 / 1e6 - 15.41) < 0.01
+    # the kernel instance named in the bench line follows the launch rules of wbx_kernels.hip:launch_mix
+    assert b.mix_kernel_name(44100, "f32") == "wbx::mix_kernel<2, true, 4, false, 1, 1>"
+    assert b.mix_kernel_name(48000, "f32") == "wbx::mix_kernel<4, true, 3, false, 1, 1>"
+    assert b.mix_kernel_name(44100, "i16") == "wbx::mix_kernel<2, true, 4, true, 1, 1>"
+    assert b.mix_kernel_name(96000, "f32") == "wbx::mix_kernel<2, true, 4, true, 1, 1>"
