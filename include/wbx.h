@@ -52,9 +52,14 @@ enum {
 enum { WBX_FMT_I16 = 3, WBX_FMT_I24 = 5, WBX_FMT_I32 = 7, WBX_FMT_F32 = 9 };
 
 /* Interleaved device-output formats for wbx_*_fetch_interleaved — reference converters
- * src/core/audio_format_conv.cpp:5-91 (I24 packed is WBX_ERR_UNSUPPORTED: the reference writer
- * ignores the channel, audio_format_conv.cpp:22-43). */
-enum { WBX_OUT_I16 = 3, WBX_OUT_I24_X8 = 6, WBX_OUT_I32 = 7, WBX_OUT_F32 = 9 };
+ * src/core/audio_format_conv.cpp:5-91 (values of the reference's AudioFormat enum).
+ * WBX_OUT_I24 (packed 3-byte samples, audio_format_conv.cpp:22-43) mirrors the reference's bytes, quirk included:
+ * its writer's destination index ignores the channel and the channel count, so every channel overwrites bytes
+ * [0, 3*F) of a block's output and the LAST channel is what remains; the other 3*F*(C-1) bytes of the block's
+ * 3*F*C-byte region are never written (wbx leaves them as the caller passed them).
+ * Float -> integer conversions give the x86 results the reference build produces, also out of range (master
+ * left un-clamped, NaN): cvttss2si / cvttsd2si return 0x80000000, the i16 / i24 paths then truncate. */
+enum { WBX_OUT_I16 = 3, WBX_OUT_I24 = 5, WBX_OUT_I24_X8 = 6, WBX_OUT_I32 = 7, WBX_OUT_F32 = 9 };
 
 typedef struct wbx_config {
   int32_t device;          /* HIP device ordinal */
@@ -149,6 +154,12 @@ wbx_status wbx_submit(wbx_ctx* ctx, uint32_t n_blocks, uint32_t n_tracks, const 
 wbx_status wbx_fetch(wbx_ctx* ctx, float* const* master_planar, float* peaks, float* buses);
 wbx_status wbx_fetch_interleaved(wbx_ctx* ctx, int out_format, void* dst);  /* K*F*C interleaved samples */
 wbx_status wbx_sync(wbx_ctx* ctx);
+/* Order `stream` (a hipStream_t; NULL = the ctx stream) after every kernel that writes the results of the last
+ * submit / render (master, bus sums, peaks).  The sum of a render runs on a stream of its own beside the next mix:
+ * work the CALLER enqueues that reads a caller-owned master target (wbx_set_master_target) — a collective, a copy,
+ * an own kernel — must be ordered with this call first; wbx_fetch*, wbx_sync, wbx_partial_master, wbx_finalize_master*
+ * and the wbx_dist_* calls do it themselves.  Device-side ordering only: the host does not block. */
+wbx_status wbx_master_ready(wbx_ctx* ctx, void* stream);
 
 /* Multi-GPU: the un-clamped partial master of the last submit, on the device, [K][C][F] fp32 ... */
 wbx_status wbx_partial_master(wbx_ctx* ctx, void** device_ptr, size_t* n_floats);
@@ -175,6 +186,11 @@ wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
  * reference; all seek / sample-index math is done in the reference's order in fp64/int64. */
 wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out);  /* + set_audio_channel_config, engine.cpp:43-57 */
 void wbx_engine_destroy(wbx_engine* e);
+/* Engine::set_audio_channel_config (engine.cpp:43-57) on a live engine — a new block size, channel count or device
+ * rate (the audio backend was reconfigured).  Tracks, clips, samples and the transport stay. */
+wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_t output_channels, uint32_t buffer_size,
+                                               uint32_t sample_rate);
+/* message of the last failed wbx_engine_* / wbx_track_* call made by the CALLING thread */
 const char* wbx_engine_last_error(const wbx_engine* e);
 wbx_ctx* wbx_engine_ctx(wbx_engine* e);
 
@@ -194,6 +210,35 @@ wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_
 wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot);
 /* extension A13: bus < 0 or >= the configured number of buses routes the track straight into the master */
 wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t track, int32_t bus);
+
+/* Effect slot of a track (Track::plugin_instance, track.h:124; call site track.cpp:645-662; attach / detach
+ * Engine::add_plugin_to_track / delete_plugin_from_track, engine.h:227-229).  The reference's effects are third-party
+ * VST3 binaries whose arithmetic is not part of this path: the slot is kept in the boundary so that a host can
+ * describe such a session, but nothing is processed through it — attaching a plugin returns WBX_ERR_UNIMPLEMENTED
+ * (PluginResult::Unimplemented) and leaves the slot empty; detaching and querying always succeed.
+ * wbx_plugin_process_info has the fields of PluginProcessInfo (plughost/plugin_interface.h:77-90) with the
+ * AudioBuffer<float>* members flattened to planar channel arrays. */
+typedef struct wbx_plugin_process_info {
+  uint32_t sample_count;
+  uint32_t input_buffer_count;
+  uint32_t output_buffer_count;
+  uint32_t n_channels;
+  float* const* input_buffer;       /* [n_channels][sample_count] */
+  float* const* output_buffer;
+  void* input_event_list;           /* MidiEventList*, unused (MIDI is out of scope) */
+  double sample_rate;
+  double tempo;
+  double project_time_in_ppq;
+  int64_t project_time_in_samples;
+  int32_t playing;
+} wbx_plugin_process_info;
+typedef struct wbx_plugin {
+  void* userdata;
+  int (*process)(void* userdata, wbx_plugin_process_info* info);   /* PluginInterface::process, :146; returns a status */
+} wbx_plugin;
+wbx_status wbx_engine_add_plugin_to_track(wbx_engine* e, uint32_t track, const wbx_plugin* plugin);
+wbx_status wbx_engine_delete_plugin_from_track(wbx_engine* e, uint32_t track);
+wbx_status wbx_track_get_plugin(wbx_engine* e, uint32_t track, const wbx_plugin** plugin_out);   /* always NULL today */
 /* Sample assets (SampleAsset, engine/assets_table.h:22-35): upload once, reference by id from clips. */
 wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
                                  const void* const* planar, uint32_t* sample_out);
@@ -248,6 +293,15 @@ wbx_status wbx_engine_render(wbx_engine* e, uint32_t n_blocks);
 wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing);
 /* VUMeter::level per track/channel: max since the last call (vu_meter.h:20-40). levels: [n_tracks][C]. */
 wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks);
+
+/* What the last process / render took from the state it shares with the UI thread (the threading contract is the
+ * reference's: one audio thread in process / render holding the editor lock — Engine::editor_lock, engine.cpp:1587-1651
+ * — one UI thread whose edits take the same lock while Track::set_volume / set_pan / set_mute go through a per-track
+ * single-producer ring of 64 messages, track.cpp:47-79, core/queue.h:142-196):
+ *   edits_seen  number of locked edit calls (clip / track / transport edits, play, stop) completed before it
+ *   drained     [n_tracks] cumulative parameter messages the audio thread has taken from each track's ring
+ * Together with the UI thread's own log this reconstructs the exact state every block was rendered from. */
+wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_seen, uint64_t* drained, uint32_t n_tracks);
 
 /* The plan the device sequencer produced for the last process/render: one record per Sampler::stream
  * call, ordered by (block, track, call).  For seek-math parity checks (bit patterns, not tolerances). */

@@ -9,7 +9,9 @@
 //   wb::Track::set_volume/set_pan/set_mute          src/engine/track.h:137-139
 // Compiles with any C++17 compiler (no HIP headers needed); link against libwbx.so.
 #pragma once
+#include <atomic>
 #include <cassert>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -107,10 +109,36 @@ struct Error : std::runtime_error {
 
 struct Engine;
 
-struct Track {   // track.h:137-139
+// engine/vu_meter.h:16-46 — the UI-side half is the reference's code shape (level is exchanged with 0 by update());
+// the audio-side push_samples runs on the GPU (running per-track maxima), Engine::fetch_levels() moves them in here.
+struct VUMeter {
+  std::atomic<float> level{0.0f};
+  float current_level = 0.0f;
+  void push_level(float new_level) {   // the CAS-max tail of VUMeter::push_samples, vu_meter.h:26-29
+    float old_level = level.load(std::memory_order_relaxed);
+    while (old_level < new_level &&
+           !level.compare_exchange_weak(old_level, new_level, std::memory_order_release, std::memory_order_relaxed))
+      ;
+  }
+  void update(float frame_rate, float speed) {   // vu_meter.h:32-40
+    float new_level = level.exchange(0.0f, std::memory_order_release);
+    if (new_level > current_level) {
+      current_level = new_level;
+    } else {
+      float update_rate = 1.0f - std::exp(-1.0f / (frame_rate * speed));
+      current_level += (new_level - current_level) * update_rate;
+    }
+  }
+  float get_value() const { return current_level; }
+};
+
+struct Track {   // track.h:110-139
   Engine* engine{};
   uint32_t index{};
   std::string name;
+  VUMeter level_meter[2]{};             // track.h:121
+  const wbx_plugin* plugin_instance{};  // track.h:124: the effect slot, always empty in this path
+  Track(Engine* e, uint32_t i, std::string n) : engine(e), index(i), name(std::move(n)) {}
   void set_volume(float db);
   void set_pan(float pan);
   void set_mute(bool mute);
@@ -126,20 +154,30 @@ struct Engine {
   wbx_engine* h{};
   uint32_t num_output_channels = 0, audio_buffer_size = 0, audio_sample_rate = 0;
   std::vector<std::unique_ptr<Track>> tracks;
+  // device-side limits, fixed when the engine is first configured (not part of the reference's surface)
+  uint32_t max_tracks = 4096, max_blocks = 1;
+  int device = 0;
+  // The audio path has no exceptions in the reference (Engine::process returns void, failures are asserts): process()
+  // never throws — a failed block leaves silence in the output buffer and latches its status here.
+  std::atomic<wbx_status> process_status{WBX_OK};
+  std::string process_error;   // written by the audio thread only
 
-  // set_audio_channel_config(in, out, buffer_size, sample_rate), engine.cpp:43-57 (sizes the device context)
-  void set_audio_channel_config(uint32_t /*input_channels*/, uint32_t output_channels, uint32_t buffer_size,
-                                uint32_t sample_rate, uint32_t max_tracks = 4096, uint32_t max_blocks = 1, int device = 0) {
-    if (h) wbx_engine_destroy(h);
-    h = nullptr;
-    wbx_config cfg{};
-    cfg.device = device;
-    cfg.max_tracks = max_tracks;
-    cfg.max_blocks = max_blocks;
-    cfg.block_frames = buffer_size;
-    cfg.channels = output_channels;
-    cfg.sample_rate = sample_rate;
-    check(wbx_engine_create(&cfg, &h), "wbx_engine_create");
+  // set_audio_channel_config(in, out, buffer_size, sample_rate), engine.cpp:43-57.  The first call creates the device
+  // context; later calls (the audio backend was reconfigured) resize it in place — tracks and clips stay, as in the
+  // reference.
+  void set_audio_channel_config(uint32_t /*input_channels*/, uint32_t output_channels, uint32_t buffer_size, uint32_t sample_rate) {
+    if (!h) {
+      wbx_config cfg{};
+      cfg.device = device;
+      cfg.max_tracks = max_tracks;
+      cfg.max_blocks = max_blocks;
+      cfg.block_frames = buffer_size;
+      cfg.channels = output_channels;
+      cfg.sample_rate = sample_rate;
+      check(wbx_engine_create(&cfg, &h), "wbx_engine_create");
+    } else {
+      check(wbx_engine_set_audio_channel_config(h, output_channels, buffer_size, sample_rate), "set_audio_channel_config");
+    }
     num_output_channels = output_channels;
     audio_buffer_size = buffer_size;
     audio_sample_rate = sample_rate;
@@ -152,7 +190,7 @@ struct Engine {
   Track* add_track(const std::string& name) {
     uint32_t idx = 0;
     check(wbx_engine_add_track(h, &idx), "add_track");
-    tracks.emplace_back(new Track{this, idx, name});
+    tracks.emplace_back(new Track(this, idx, name));
     return tracks.back().get();
   }
   // engine.cpp:210-262
@@ -196,11 +234,37 @@ struct Engine {
   void play() { check(wbx_engine_play(h), "play"); }
   void stop() { check(wbx_engine_stop(h), "stop"); }
   // void Engine::process(const AudioBuffer<float>&, AudioBuffer<float>&, double), engine.h:235-239
-  void process(const AudioBuffer<float>& /*input_buffer*/, AudioBuffer<float>& output_buffer, double sample_rate) {
+  // Audio thread.  Never throws: on a failure the block is silence and process_status / process_error say why.
+  void process(const AudioBuffer<float>& /*input_buffer*/, AudioBuffer<float>& output_buffer, double sample_rate) noexcept {
     assert(output_buffer.n_samples == audio_buffer_size && output_buffer.n_channels == num_output_channels);
     assert(sample_rate == (double)audio_sample_rate);
     (void)sample_rate;
-    check(wbx_engine_process(h, output_buffer.channel_buffers.data()), "process");
+    const wbx_status st = wbx_engine_process(h, output_buffer.channel_buffers.data());
+    if (st != WBX_OK) {
+      output_buffer.clear();
+      process_error = wbx_engine_last_error(h);
+      process_status.store(st, std::memory_order_release);
+    }
+  }
+  // UI thread, once per frame before Track::level_meter[c].update(): the running per-track maxima the GPU kept since
+  // the last call (VUMeter::push_samples, vu_meter.h:20-30) go into the tracks' meters
+  void fetch_levels() {
+    if (tracks.empty()) return;
+    std::vector<float> lv(tracks.size() * num_output_channels);
+    check(wbx_engine_levels(h, lv.data(), (uint32_t)tracks.size()), "fetch_levels");
+    for (size_t t = 0; t < tracks.size(); t++)
+      for (uint32_t c = 0; c < num_output_channels && c < 2; c++) tracks[t]->level_meter[c].push_level(lv[t * num_output_channels + c]);
+  }
+  // Engine::add_plugin_to_track / delete_plugin_from_track (engine.h:227-229): the slot exists, processing through it
+  // is PluginResult::Unimplemented — returns nullptr like the reference does when a plugin cannot be opened
+  const wbx_plugin* add_plugin_to_track(Track* track, const wbx_plugin* plugin) {
+    if (wbx_engine_add_plugin_to_track(h, track->index, plugin) != WBX_OK) return nullptr;
+    track->plugin_instance = nullptr;
+    return nullptr;
+  }
+  void delete_plugin_from_track(Track* track) {
+    check(wbx_engine_delete_plugin_from_track(h, track->index), "delete_plugin_from_track");
+    track->plugin_instance = nullptr;
   }
   void check(wbx_status s, const char* where) const {
     if (s != WBX_OK) throw Error(s, std::string(where) + ": " + (h ? wbx_engine_last_error(h) : wbx_status_string(s)));

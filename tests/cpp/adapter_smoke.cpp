@@ -21,7 +21,9 @@ int main() {
 
   // ---- product, through the adapter -------------------------------------------------------------
   wbx::Engine g_engine;
-  g_engine.set_audio_channel_config(0, C, F, SR, /*max_tracks*/ 8);
+  g_engine.max_tracks = 8;
+  g_engine.set_audio_channel_config(0, C, 128, 44100);   // as a host does at start-up, before the device is known ...
+  g_engine.set_audio_channel_config(0, C, F, SR);          // ... and again when the backend settles: same engine
   g_engine.set_bpm(120.0);
   const uint32_t s48 = g_engine.add_sample(WBX_FMT_F32, 2, 48000, cnt, planar);
   const uint32_t s44 = g_engine.add_sample(WBX_FMT_F32, 2, 44100, cnt, planar);
@@ -63,7 +65,49 @@ int main() {
       }
   }
   if (out.n_samples != F || out.n_channels != C) return 2;
+  if (g_engine.process_status.load() != WBX_OK) return 3;
   wbo_engine_destroy(o);
-  std::printf("adapter ok: %u blocks bit-identical to the oracle\n", NB);
+
+  // meters: Track::level_meter[c] as the UI reads them (vu_meter.h:32-46)
+  g_engine.fetch_levels();
+  for (auto& t : g_engine.tracks)
+    for (uint32_t c = 0; c < C; c++) t->level_meter[c].update(60.0f, 0.1f);
+  if (!(g_engine.tracks[0]->level_meter[0].get_value() > 0.0f) || !(g_engine.tracks[1]->level_meter[1].get_value() > 0.0f)) return 4;
+  // the effect slot exists and stays empty
+  wbx_plugin fx{nullptr, nullptr};
+  if (g_engine.add_plugin_to_track(t0, &fx) != nullptr || t0->plugin_instance != nullptr) return 5;
+
+  // the audio backend is reconfigured (engine.cpp:43-57): half the buffer size — tracks, clips and samples stay.
+  // Checked against a fresh oracle built at the new size from the same session.
+  const uint32_t F2 = 256;
+  g_engine.stop();
+  g_engine.set_audio_channel_config(0, C, F2, SR);
+  g_engine.play();
+  wbo_engine* o2 = wbo_engine_create(C, F2, SR);
+  wbo_engine_set_bpm(o2, 120.0);
+  const int p48 = wbo_engine_add_sample(o2, WBO_FMT_F32, 2, 48000, cnt, planar);
+  const int p44 = wbo_engine_add_sample(o2, WBO_FMT_F32, 2, 44100, cnt, planar);
+  wbo_engine_add_track(o2);
+  wbo_engine_add_track(o2);
+  wbo_track_set_volume(o2, 0, 0.0f);
+  wbo_track_set_volume(o2, 1, -6.0f);
+  wbo_track_set_pan(o2, 1, 0.3f);
+  wbo_engine_add_audio_clip(o2, 0, 100.0 / 24000, 700.0 / 24000, 10.0, p48, 1.0, 0.5f);
+  wbo_engine_add_audio_clip(o2, 0, 812.0 / 24000, 2000.0 / 24000, 0.0, p48, 1.0, 1.0f);
+  wbo_engine_add_audio_clip(o2, 1, 40.0 / 24000, 2500.0 / 24000, 3.0, p44, 1.0, 0.8f);
+  wbo_engine_play(o2);
+  wbx::AudioBuffer<float> in2(F2, C), out2(F2, C);
+  for (uint32_t b = 0; b < 2 * NB; b++) {
+    g_engine.process(in2, out2, (double)SR);
+    wbo_engine_process(o2, optr, nullptr);
+    for (uint32_t c = 0; c < C; c++)
+      if (std::memcmp(out2.channel_buffers[c], optr[c], F2 * sizeof(float)) != 0) {
+        std::printf("MISMATCH after set_audio_channel_config: block %u channel %u\n", b, c);
+        return 6;
+      }
+  }
+  wbo_engine_destroy(o2);
+  if (g_engine.process_status.load() != WBX_OK) return 7;
+  std::printf("adapter ok: %u + %u blocks bit-identical to the oracle\n", NB, 2 * NB);
   return 0;
 }

@@ -1,0 +1,125 @@
+"""Seeded random sessions and clip-edit scripts shared by the GPU parity tests (product engine vs oracle) and the
+CPU-side host tests (the product's host code + sequencer source vs oracle)."""
+import numpy as np
+
+import oracle_ffi as O
+from whitebox_amd import synth
+
+
+def random_session(seed):
+    """A small session with everything the sequencer and the sampler can meet at once: several clips per track at
+    random beat positions (touching, short, starting/ending mid-block, beyond the sample's end), random start
+    offsets, stretch speeds on both sides of 1, 44.1/48/96 kHz sources, all PCM formats, mono and stereo, mutes,
+    random gains, sub-buses, odd block sizes."""
+    rng = np.random.default_rng(seed)
+    n_tracks = int(rng.integers(1, 28))
+    block = int(rng.choice([64, 128, 256, 512]))
+    n_blocks = int(rng.integers(2, 7))
+    sr = 48000
+    bpm = float(rng.choice([120.0, 97.0, 140.5]))
+    beat_frames = sr * 60.0 / bpm
+    total_beats = n_blocks * block / beat_frames
+    samples, clips = [], []
+    for t in range(n_tracks):
+        fmt = str(rng.choice(["f32", "f32", "i16", "i24", "i32"]))
+        samples.append(synth.SampleSpec(seed_track=t, channels=int(rng.integers(1, 3)), rate=int(rng.choice([44100, 48000, 96000])),
+                                        frames=int(rng.integers(300, 5000)), fmt=fmt, amp=0.2 if fmt == "f32" else 1.0))
+        pos = -0.2 * total_beats * rng.random() if rng.random() < 0.3 else total_beats * rng.random() * 0.3
+        for _ in range(int(rng.integers(0, 4))):
+            length = total_beats * (0.02 + 0.5 * rng.random())
+            speed = float(rng.choice([1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 1.0625, 1.9, 0.3]))
+            clips.append(synth.ClipSpec(track=t, min_beat=float(pos), max_beat=float(pos + length),
+                                        start_offset=float(rng.integers(0, 400)), speed=speed, gain=float(rng.choice([1.0, 0.5, 1.3]))))
+            pos += length + (0.0 if rng.random() < 0.3 else total_beats * 0.1 * rng.random())   # touching or a gap
+    n_buses = int(rng.choice([0, 0, 3]))
+    return synth.SessionSpec(name=f"fuzz{seed}", n_tracks=n_tracks, seed=0xF0220000 + seed, samples=samples, clips=clips,
+                             volumes_db=[float(rng.uniform(-30, 3)) for _ in range(n_tracks)],
+                             pans=[float(rng.uniform(-1, 1)) for _ in range(n_tracks)],
+                             mutes=[bool(rng.random() < 0.1) for _ in range(n_tracks)],
+                             n_buses=n_buses, track_bus=[int(rng.integers(-1, n_buses)) for _ in range(n_tracks)] if n_buses else None,
+                             bpm=bpm, sample_rate=sr, block=block, channels=int(rng.choice([1, 2, 2])),
+                             playhead_start=float(rng.choice([0.0, 0.0, total_beats * 0.1]))), n_blocks
+
+
+
+def clip_rows(clips):
+    return [(O.f64_bits(a), O.f64_bits(b), O.f64_bits(c), O.f64_bits(d), O.f32_bits(g), s) for (a, b, c, d, g, s) in clips]
+
+
+def edit_session_spec(seed):
+    """6 tracks, no clips yet; seed 2024 is the original all-fp32 512-frame script, the others also draw the block
+    size, the storage formats and the sample rates."""
+    n_tracks = 6
+    block = 512 if seed == 2024 else int(np.random.default_rng(seed + 7).choice([512, 256, 128, 64]))
+    spec = synth.make_session("edits", n_tracks, n_blocks=40, seed=0xED17, amp=0.05, block=block)
+    spec.clips = []
+    for i, s in enumerate(spec.samples):
+        s.frames = 40000
+        if seed != 2024:
+            r2 = np.random.default_rng(seed * 31 + i)
+            s.fmt = str(r2.choice(["f32", "f32", "i16", "i24"]))
+            s.rate = int(r2.choice([48000, 48000, 44100, 96000]))
+            s.amp = 0.05 if s.fmt == "f32" else 1.0
+    if seed != 2024:
+        for t in range(n_tracks):
+            spec.volumes_db[t] = -30.0
+    return spec
+
+
+def run_edit_script(seed, spec, e, eng, on_block, steps=24):
+    """The same random edits through the oracle `e` and an engine `eng` with the reference-shaped method names
+    (whitebox_amd.engine.Engine or tests/host_sim.HostSimEngine); after every edit the sorted clip lists must agree
+    bit for bit, then on_block(step, op) renders one block on both and compares what it can."""
+    rng = np.random.default_rng(seed)
+    n_tracks, beat = spec.n_tracks, 24000.0
+
+    def both(fn_o, fn_p):
+        ro = fn_o()
+        fn_p()
+        return ro
+
+    # overlapping adds: the new clip trims / splits / deletes what it covers (reserve_track_region)
+    for t in range(n_tracks):
+        for _ in range(6):
+            mn = float(rng.uniform(0, 8000)) / beat
+            mx = mn + float(rng.uniform(300, 5000)) / beat
+            so = float(rng.integers(0, 500))
+            sp = float(rng.choice([1.0, 1.0, 0.5, 1.5]))
+            g = float(np.float32(rng.choice([1.0, 0.5, 0.25])))
+            smp = int(rng.integers(0, n_tracks))
+            both(lambda: e.add_audio_clip(t, mn, mx, so, smp, sp, g),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, so, smp, sp, g))
+        assert clip_rows(eng.clips(eng.tracks[t])) == clip_rows(e.clips(t)), t
+    e.play()
+    eng.play()
+    for step in range(steps):
+        # one edit per step on a random track, then one block
+        t = int(rng.integers(0, n_tracks))
+        n = len(e.clips(t))
+        op = int(rng.integers(0, 6))
+        if n and op == 0:
+            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 1500)) / beat
+            both(lambda: e.move_clip(t, i, rel), lambda: eng.move_clip(eng.tracks[t], i, rel))
+        elif n and op == 1:
+            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 800)) / beat
+            left, shift, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            both(lambda: e.resize_clip(t, i, rel, 0.0, 1.0 / 96.0, left, shift, stretch),
+                 lambda: eng.resize_clip(eng.tracks[t], i, rel, 0.0, 1.0 / 96.0, left, shift, stretch))
+        elif n and op == 2:
+            i = int(rng.integers(0, n))
+            both(lambda: e.delete_clip(t, i), lambda: eng.delete_clip(eng.tracks[t], i))
+        elif n and op == 3:
+            i, g = int(rng.integers(0, n)), float(np.float32(rng.uniform(0.1, 1.5)))
+            both(lambda: e.set_clip_gain(t, i, g), lambda: eng.set_clip_gain(eng.tracks[t], i, g))
+        elif op == 4:
+            mn = float(rng.uniform(0, 12000)) / beat
+            mx = mn + float(rng.uniform(100, 3000)) / beat
+            both(lambda: e.delete_region(t, mn, mx), lambda: eng.delete_region(eng.tracks[t], mn, mx))
+        else:
+            mn = float(rng.uniform(0, 14000)) / beat
+            mx = mn + float(rng.uniform(200, 4000)) / beat
+            both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, 1.0),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, 1.0))
+        for tt in range(n_tracks):
+            assert clip_rows(eng.clips(eng.tracks[tt])) == clip_rows(e.clips(tt)), (step, op, tt)
+        on_block(step, op)

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 
+import fuzz_util as FZ
 import golden_util as G
 import oracle_ffi as O
 import whitebox_amd as W
@@ -578,16 +579,136 @@ def test_interleaved_output_formats():
     eng.play()
     eng.render(2)
     L = O.lib()
-    for fmt, dt in (("i16", np.int16), ("i24_x8", np.int32), ("i32", np.int32), ("f32", np.float32)):
+    for fmt, dt in (("i16", np.int16), ("i24", np.uint8), ("i24_x8", np.int32), ("i32", np.int32), ("f32", np.float32)):
         got = eng.ctx.fetch_interleaved(fmt)
         exp = []
         for b in range(2):
-            a = np.zeros(512 * 2, dt)
+            # packed 24-bit: 3 bytes per sample; the reference's writer leaves all but the first 3*F bytes of a block
+            # untouched (its destination index has no channel term, audio_format_conv.cpp:22-43) — zero on both sides
+            a = np.zeros(512 * 2 * (3 if fmt == "i24" else 1), dt)
             src = [np.ascontiguousarray(om[b][c]) for c in range(2)]
             getattr(L, "wbo_f32_to_interleaved_" + fmt)(a.ctypes.data, O.planar_ptrs(src), 0, 512, 2)
             exp.append(a)
         assert np.array_equal(got.view(np.uint8), np.concatenate(exp).view(np.uint8)), fmt
     eng.close()
+
+
+def test_interleaved_output_of_an_unclamped_master():
+    """wbx_set_clamp(0) (shard mode) or NaN in the master: the float -> integer conversions must give what the
+    reference's x86 build gives — cvttss2si / cvttsd2si return 0x80000000 out of range, the 16- and 24-bit paths then
+    truncate — not the GPU's saturating conversion."""
+    spec = synth.make_session("hotconv", 16, n_blocks=2, amp=60000.0, seed=0x72)     # far above full scale
+    spec.volumes_db = [12.0] * 16
+    e = O.build_oracle_engine(spec)
+    e.play()
+    om = np.stack([e.process(clamp=False)[0] for _ in range(2)])
+    e.close()
+    assert np.abs(om).max() > 40000.0        # 32767 * |v| leaves the int32 range for part of the block
+    eng = build_engine(spec, max_blocks=2)
+    eng.ctx.set_clamp(False)
+    eng.play()
+    eng.render(2)
+    m, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m), bits(om))
+    L = O.lib()
+    for fmt, dt in (("i16", np.int16), ("i24", np.uint8), ("i24_x8", np.int32), ("i32", np.int32)):
+        got = eng.ctx.fetch_interleaved(fmt)
+        exp = []
+        for b in range(2):
+            a = np.zeros(512 * 2 * (3 if fmt == "i24" else 1), dt)
+            src = [np.ascontiguousarray(om[b][c]) for c in range(2)]
+            getattr(L, "wbo_f32_to_interleaved_" + fmt)(a.ctypes.data, O.planar_ptrs(src), 0, 512, 2)
+            exp.append(a)
+        assert np.array_equal(got.view(np.uint8), np.concatenate(exp).view(np.uint8)), fmt
+    eng.close()
+
+
+def test_effect_slot_is_kept_but_unimplemented():
+    """SURVEY A14: the boundary keeps Track::plugin_instance / Engine::add_plugin_to_track; attaching a plugin is
+    PluginResult::Unimplemented (-2) and leaves the slot empty, detaching and rendering work as before."""
+    from whitebox_amd import _ffi
+    spec = synth.make_session("fx", 4, n_blocks=2, seed=0x73)
+    om, opk, _, _, _ = run_oracle(spec, 2)
+    eng = build_engine(spec, max_blocks=2)
+    assert eng.tracks[1].plugin_instance is None
+    eng.add_plugin_to_track(eng.tracks[1], None)             # NULL: clears the (empty) slot
+    with pytest.raises(W.WbxError) as ei:
+        eng.add_plugin_to_track(eng.tracks[1], _ffi.Plugin(None, None))
+    assert ei.value.status == -2
+    assert eng.tracks[1].plugin_instance is None
+    eng.delete_plugin_from_track(eng.tracks[1])
+    eng.play()
+    eng.render(2)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert np.array_equal(bits(m), bits(om)) and np.array_equal(pk, opk[..., :spec.channels])
+    eng.close()
+
+
+def test_abi_rejects_what_would_fault_the_device():
+    """the C ABI is the trust boundary: segments with a negative / NaN position or a non-positive / NaN speed, and
+    freeing a sample a clip list still names, are refused instead of reaching the kernels"""
+    spec = synth.make_session("trust", 2, n_blocks=2, seed=0x74)
+    eng = build_engine(spec, max_blocks=1)
+    so, g = np.array([0, 1, 1], np.uint32), np.ones(4, np.float32)
+    for bad in ((-1.0, 1.0), (float("nan"), 1.0), (0.0, 0.0), (0.0, -1.0), (0.0, float("nan")), (0.0, 1e300)):
+        with pytest.raises(W.WbxError) as ei:
+            eng.ctx.submit(1, 2, [(bad[0], bad[1], 0, 0, 512, 1.0)], so, g)
+        assert ei.value.status == -4, bad
+    with pytest.raises(W.WbxError) as ei:
+        _check_free(eng, 0)
+    assert ei.value.status == -4
+    eng.delete_clip(eng.tracks[0], 0)
+    _check_free(eng, 0)                                      # no clip names it any more
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    eng.process(None, out, float(spec.sample_rate))          # still usable
+    eng.close()
+
+
+def _check_free(eng, clip):
+    st = eng.L.wbx_clip_free(eng.ctx.h, clip)
+    if st != 0:
+        raise W.WbxError(st, "wbx_clip_free", eng.L.wbx_last_error(eng.ctx.h).decode())
+
+
+def test_master_ready_orders_a_foreign_stream():
+    """the sum of a render runs on its own stream; a caller that reads a caller-owned master target
+    on ANOTHER stream must be ordered after it with wbx_master_ready — without any host synchronisation."""
+    import torch
+    K = 16
+    spec = synth.make_session("ready", 96, src_rate=44100, n_blocks=K, seed=0x75)
+    om, _, _, _, _ = run_oracle(spec, K)
+    eng = build_engine(spec, max_blocks=K)
+    target = torch.zeros(K * 2 * 512, dtype=torch.float32, device="cuda")
+    copy = torch.zeros_like(target)
+    side = torch.cuda.Stream()
+    eng.ctx.set_master_target(target.data_ptr())
+    eng.play()
+    for rep in range(3):                                     # also across renders in flight
+        if rep:
+            eng.stop()
+            eng.play()
+        eng.render(K)
+        eng.ctx.master_ready(side.cuda_stream)
+        with torch.cuda.stream(side):
+            copy.copy_(target, non_blocking=True)
+        side.synchronize()
+        got = copy.cpu().numpy().reshape(K, 2, 512)
+        assert np.array_equal(bits(got), bits(om)), rep
+    eng.ctx.set_master_target(None)
+    eng.close()
+
+
+def test_batch_render_of_clips_that_outlast_their_audio():
+    """a clip region much longer than its sample used to take one plan template per block and
+    overflow the template array in long batches; the finished stream calls now share one template."""
+    K = 256
+    spec = synth.make_session("outlast", 3, n_blocks=4, seed=0x0A71)
+    for s in spec.samples:
+        s.frames = 700
+    for c in spec.clips:
+        c.max_beat = c.min_beat + (K + 8) * 512 / 24000.0
+    check_against_oracle(spec, K, expect_exact=True)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -659,89 +780,25 @@ def test_cpp_host_through_the_adapter(tmp_path):
 # ---------------------------------------------------------------------------------------------------
 # clip edits: add with overlap / move / resize / delete / gain, while playing
 # ---------------------------------------------------------------------------------------------------
-def _clip_rows(clips):
-    return [(O.f64_bits(a), O.f64_bits(b), O.f64_bits(c), O.f64_bits(d), O.f32_bits(g), s) for (a, b, c, d, g, s) in clips]
-
-
 # WBX_FUZZ3_FROM / WBX_FUZZ3_TO widen the seed range for a soak run (default: seeds 2024..2029; 2024 is the original
 # all-fp32 512-frame script, the others also draw the block size, the storage formats and the sample rates)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ3_FROM", "2024")), int(os.environ.get("WBX_FUZZ3_TO", "2030"))))
 def test_clip_edits_match_oracle_lists_and_audio(seed):
     """Random edit scripts applied to both engines through their reference-shaped APIs, between rendered
     blocks: the sorted clip lists (fp64 bit patterns), the sequencer's plan and the audio must stay equal."""
-    rng = np.random.default_rng(seed)
-    n_tracks, beat = 6, 24000.0
-    block = 512 if seed == 2024 else int(np.random.default_rng(seed + 7).choice([512, 256, 128, 64]))
-    spec = synth.make_session("edits", n_tracks, n_blocks=40, seed=0xED17, amp=0.05, block=block)
-    spec.clips = []
-    for i, s in enumerate(spec.samples):
-        s.frames = 40000
-        if seed != 2024:
-            r2 = np.random.default_rng(seed * 31 + i)
-            s.fmt = str(r2.choice(["f32", "f32", "i16", "i24"]))
-            s.rate = int(r2.choice([48000, 48000, 44100, 96000]))
-            s.amp = 0.05 if s.fmt == "f32" else 1.0
-    if seed != 2024:
-        for t in range(n_tracks):
-            spec.volumes_db[t] = -30.0
+    spec = FZ.edit_session_spec(seed)
     e = O.build_oracle_engine(spec)
     eng = build_engine(spec, max_blocks=2)
     e.enable_seglog()
     out = W.AudioBuffer(spec.block, spec.channels)
 
-    def both(fn_o, fn_p):
-        ro = fn_o()
-        fn_p()
-        return ro
-
-    # overlapping adds: the new clip trims / splits / deletes what it covers (reserve_track_region)
-    for t in range(n_tracks):
-        for _ in range(6):
-            mn = float(rng.uniform(0, 8000)) / beat
-            mx = mn + float(rng.uniform(300, 5000)) / beat
-            so = float(rng.integers(0, 500))
-            sp = float(rng.choice([1.0, 1.0, 0.5, 1.5]))
-            g = float(np.float32(rng.choice([1.0, 0.5, 0.25])))
-            smp = int(rng.integers(0, n_tracks))
-            both(lambda: e.add_audio_clip(t, mn, mx, so, smp, sp, g),
-                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, so, smp, sp, g))
-        assert _clip_rows(eng.clips(eng.tracks[t])) == _clip_rows(e.clips(t)), t
-    e.play()
-    eng.play()
-    for step in range(24):
-        # one edit per step on a random track, then one block
-        t = int(rng.integers(0, n_tracks))
-        n = len(e.clips(t))
-        op = int(rng.integers(0, 6))
-        if n and op == 0:
-            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 1500)) / beat
-            both(lambda: e.move_clip(t, i, rel), lambda: eng.move_clip(eng.tracks[t], i, rel))
-        elif n and op == 1:
-            i, rel = int(rng.integers(0, n)), float(rng.normal(0, 800)) / beat
-            left, shift, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-            both(lambda: e.resize_clip(t, i, rel, 0.0, 1.0 / 96.0, left, shift, stretch),
-                 lambda: eng.resize_clip(eng.tracks[t], i, rel, 0.0, 1.0 / 96.0, left, shift, stretch))
-        elif n and op == 2:
-            i = int(rng.integers(0, n))
-            both(lambda: e.delete_clip(t, i), lambda: eng.delete_clip(eng.tracks[t], i))
-        elif n and op == 3:
-            i, g = int(rng.integers(0, n)), float(np.float32(rng.uniform(0.1, 1.5)))
-            both(lambda: e.set_clip_gain(t, i, g), lambda: eng.set_clip_gain(eng.tracks[t], i, g))
-        elif op == 4:
-            mn = float(rng.uniform(0, 12000)) / beat
-            mx = mn + float(rng.uniform(100, 3000)) / beat
-            both(lambda: e.delete_region(t, mn, mx), lambda: eng.delete_region(eng.tracks[t], mn, mx))
-        else:
-            mn = float(rng.uniform(0, 14000)) / beat
-            mx = mn + float(rng.uniform(200, 4000)) / beat
-            both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, 1.0),
-                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, 1.0))
-        for tt in range(n_tracks):
-            assert _clip_rows(eng.clips(eng.tracks[tt])) == _clip_rows(e.clips(tt)), (step, op, tt)
+    def on_block(step, op):
         om, _ = e.process()
         eng.process(None, out, 48000.0)
         assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), (seed, step, op)
         assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), (seed, step, op)
+
+    FZ.run_edit_script(seed, spec, e, eng, on_block)
     e.close()
     eng.close()
 
@@ -903,45 +960,10 @@ def test_tempo_change_and_playhead_jump_while_playing():
     eng.close()
 
 
-def random_session(seed):
-    """A small session with everything the sequencer and the sampler can meet at once: several clips per track at
-    random beat positions (touching, short, starting/ending mid-block, beyond the sample's end), random start
-    offsets, stretch speeds on both sides of 1, 44.1/48/96 kHz sources, all PCM formats, mono and stereo, mutes,
-    random gains, sub-buses, odd block sizes."""
-    rng = np.random.default_rng(seed)
-    n_tracks = int(rng.integers(1, 28))
-    block = int(rng.choice([64, 128, 256, 512]))
-    n_blocks = int(rng.integers(2, 7))
-    sr = 48000
-    bpm = float(rng.choice([120.0, 97.0, 140.5]))
-    beat_frames = sr * 60.0 / bpm
-    total_beats = n_blocks * block / beat_frames
-    samples, clips = [], []
-    for t in range(n_tracks):
-        fmt = str(rng.choice(["f32", "f32", "i16", "i24", "i32"]))
-        samples.append(synth.SampleSpec(seed_track=t, channels=int(rng.integers(1, 3)), rate=int(rng.choice([44100, 48000, 96000])),
-                                        frames=int(rng.integers(300, 5000)), fmt=fmt, amp=0.2 if fmt == "f32" else 1.0))
-        pos = -0.2 * total_beats * rng.random() if rng.random() < 0.3 else total_beats * rng.random() * 0.3
-        for _ in range(int(rng.integers(0, 4))):
-            length = total_beats * (0.02 + 0.5 * rng.random())
-            speed = float(rng.choice([1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 1.0625, 1.9, 0.3]))
-            clips.append(synth.ClipSpec(track=t, min_beat=float(pos), max_beat=float(pos + length),
-                                        start_offset=float(rng.integers(0, 400)), speed=speed, gain=float(rng.choice([1.0, 0.5, 1.3]))))
-            pos += length + (0.0 if rng.random() < 0.3 else total_beats * 0.1 * rng.random())   # touching or a gap
-    n_buses = int(rng.choice([0, 0, 3]))
-    return synth.SessionSpec(name=f"fuzz{seed}", n_tracks=n_tracks, seed=0xF0220000 + seed, samples=samples, clips=clips,
-                             volumes_db=[float(rng.uniform(-30, 3)) for _ in range(n_tracks)],
-                             pans=[float(rng.uniform(-1, 1)) for _ in range(n_tracks)],
-                             mutes=[bool(rng.random() < 0.1) for _ in range(n_tracks)],
-                             n_buses=n_buses, track_bus=[int(rng.integers(-1, n_buses)) for _ in range(n_tracks)] if n_buses else None,
-                             bpm=bpm, sample_rate=sr, block=block, channels=int(rng.choice([1, 2, 2])),
-                             playhead_start=float(rng.choice([0.0, 0.0, total_beats * 0.1]))), n_blocks
-
-
 # WBX_FUZZ_FROM / WBX_FUZZ_TO widen the seed range for a soak run (default: seeds 0..159)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ_FROM", "0")), int(os.environ.get("WBX_FUZZ_TO", "160"))))
 def test_random_sessions_match_oracle(seed):
-    spec, n_blocks = random_session(seed)
+    spec, n_blocks = FZ.random_session(seed)
     # fewer tracks than one group and the oracle's bus order: everything bit-equal, including the stream-call log
     check_against_oracle(spec, n_blocks, expect_exact=True)
 
@@ -951,7 +973,7 @@ def test_random_sessions_grouped_and_callback(seed):
     """The same random sessions with small track groups (several chunks of records, ragged last group: plan rows,
     transport and per-track peaks bit-equal, master inside the RMS budget) and rendered one block per call
     (Engine::process) against the batch render of the same engine configuration: bit-identical."""
-    spec, n_blocks = random_session(seed + 100000)
+    spec, n_blocks = FZ.random_session(seed + 100000)
     gs = [1, 2, 3, 5, 8][seed % 5]
     check_against_oracle(spec, n_blocks, group_size=gs)
     eng = build_engine(spec, max_blocks=n_blocks, group_size=gs)

@@ -1,0 +1,191 @@
+"""CPU-side coverage of the product's layer-2 HOST code and of the sequencer source the plan kernel runs
+(whitebox_amd/csrc/wbx_host.h, wbx_seq.h, wbx_clip_edit.h compiled with g++ into tests/cpp/host_sim.cpp): seek /
+sample-index math, transport, block-rate gains and clip edits bit-equal to the oracle on the fuzz seeds of the GPU
+suite, the plan-template budget, and a ThreadSanitizer run of the UI-thread / audio-thread contract.
+No device, no audio samples: per-sample work exists only in the HIP kernels."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fuzz_util as FZ
+import host_sim as HS
+import oracle_ffi as O
+from whitebox_amd import synth
+
+
+def plan_rows(plan):
+    return [(b, t, bo, ns, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (b, t, bo, ns, na, smp, off, spd, g, fl) in plan]
+
+
+def oracle_rows(e, block):
+    return [(block, t, ds, min(ln, 0xFFFF), O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (t, ds, ln, off, spd, g, smp) in e.seglog()]
+
+
+def check_session(spec, n_blocks, batch):
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    rows = []
+    for b in range(n_blocks):
+        e.process()
+        rows += oracle_rows(e, b)
+    sim = HS.build_sim_engine(spec, max_blocks=n_blocks)
+    sim.play()
+    if batch:
+        sim.render(n_blocks)
+        got = plan_rows(sim.fetch_plan())
+    else:
+        got = []
+        for b in range(n_blocks):
+            sim.render(1)
+            got += [(b,) + r[1:] for r in plan_rows(sim.fetch_plan())]
+    assert got == rows
+    ph, sp, _ = sim.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
+    # fl(volume * pan_c) per track (track.cpp:728-731), as bit patterns
+    assert np.array_equal(sim.gains().view(np.uint32), e.gains().view(np.uint32))
+    e.close()
+    sim.close()
+
+
+@pytest.mark.parametrize("seed", range(0, 160))
+def test_host_sequencer_random_sessions_batched(seed):
+    """the 160 fuzz sessions of the GPU suite, all blocks in one plan (steady runs, templates, overflow pool)"""
+    spec, n_blocks = FZ.random_session(seed)
+    check_session(spec, n_blocks, batch=True)
+
+
+@pytest.mark.parametrize("seed", range(0, 40))
+def test_host_sequencer_random_sessions_block_by_block(seed):
+    """the second generator's sessions one block per plan (the audio-callback shape)"""
+    spec, n_blocks = FZ.random_session(seed + 100000)
+    check_session(spec, n_blocks, batch=False)
+
+
+@pytest.mark.parametrize("name,kw", [("c1", dict(n_tracks=8, channels_src=1)), ("seek", dict(n_tracks=24, seek=True)),
+                                     ("seek441", dict(n_tracks=24, seek=True, src_rate=44100)),
+                                     ("d96", dict(n_tracks=8, src_rate=96000)), ("long", dict(n_tracks=5, src_rate=44100))])
+def test_host_sequencer_baseline_shapes(name, kw):
+    kw = dict(kw)
+    kw.pop("channels_src", None)
+    n_blocks = 300 if name == "long" else 8
+    spec = synth.make_session(name, n_blocks=n_blocks, seed=0x5EED0000 + len(name), **kw)
+    check_session(spec, n_blocks, batch=True)
+
+
+@pytest.mark.parametrize("seed", range(2024, 2064))
+def test_host_clip_edits_match_oracle(seed):
+    """random edit scripts (add with overlap / move / resize / delete / region delete / gain) between blocks: the clip
+    lists and the plan of the following block stay bit-equal to the oracle's"""
+    spec = FZ.edit_session_spec(seed)
+    e = O.build_oracle_engine(spec)
+    sim = HS.build_sim_engine(spec, max_blocks=2)
+    e.enable_seglog()
+
+    def on_block(step, op):
+        e.process()
+        sim.render(1)
+        assert plan_rows(sim.fetch_plan()) == oracle_rows(e, 0), (seed, step, op)
+
+    FZ.run_edit_script(seed, spec, e, sim, on_block)
+    ph, sp, _ = sim.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
+    e.close()
+    sim.close()
+
+
+def test_clip_outlasting_its_audio_shares_one_template():
+    """A clip whose timeline region is far longer than its sample makes one zero-length 'finished' stream call per
+    block (sampler.cpp:99-100) for the rest of the region.  Those calls share ONE plan template: a 256-block render of
+    such tracks stays inside the template budget (it used to take one template per block and overflow)."""
+    n_tracks, K = 3, 256
+    spec = synth.make_session("outlast", n_tracks, n_blocks=4, seed=0x0A71)
+    for s in spec.samples:
+        s.frames = 700                    # ~1.4 blocks of audio
+    for c in spec.clips:
+        c.max_beat = c.min_beat + (K + 8) * 512 / 24000.0
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    rows = []
+    for b in range(K):
+        e.process()
+        rows += oracle_rows(e, b)
+    e.close()
+    sim = HS.build_sim_engine(spec, max_blocks=K)
+    sim.play()
+    sim.render(K)
+    assert plan_rows(sim.fetch_plan()) == rows          # every finished call is still in the plan
+    pc = sim.plan_counters()
+    assert pc[1] == 0, f"plan status bits {pc[1]}"
+    assert pc[3] <= 4 * n_tracks, f"{pc[3]} templates for {n_tracks} tracks"
+    assert sim.template_capacity() < K * n_tracks       # the budget really is smaller than one template per block
+    sim.close()
+
+
+def test_crawling_clip_gets_a_template_per_block():
+    """(count - offset) / speed >= 2^32 (a clip slowed down a million-fold) leaves the shared-template path: the host
+    sizes the template array for one template per block instead of reporting an overflow"""
+    K = 64
+    spec = synth.make_session("crawl", 2, n_blocks=4, seed=0x0A72)
+    for c in spec.clips:
+        c.speed = 1e-7
+        c.max_beat = c.min_beat + (K + 8) * 512 / 24000.0
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    rows = []
+    for b in range(K):
+        e.process()
+        rows += oracle_rows(e, b)
+    e.close()
+    sim = HS.build_sim_engine(spec, max_blocks=K)
+    sim.play()
+    sim.render(K)
+    assert sim.plan_counters()[1] == 0
+    assert plan_rows(sim.fetch_plan()) == rows
+    sim.close()
+
+
+def test_parameter_ring_is_block_rate_and_ordered():
+    """Track::set_volume / set_pan / set_mute reach the audio side at the next block, in order (the last value wins),
+    and the drain counters say how many messages each block took"""
+    spec = synth.make_session("ring", 4, n_blocks=4, seed=0x0A73)
+    e = O.build_oracle_engine(spec)
+    sim = HS.build_sim_engine(spec, max_blocks=1)
+    e.play()
+    sim.play()
+    e.process()
+    sim.render(1)
+    _, d0 = sim.thread_stats()
+    assert all(x in (5, 6) for x in d0)   # 3 from Track::Track + set_volume + set_pan (+ set_mute)
+    for k in range(20):
+        for t in range(4):
+            e.set_volume(t, -float(k + t))
+            sim.tracks[t].set_volume(-float(k + t))
+        e.set_pan(1, 0.01 * k)
+        sim.tracks[1].set_pan(0.01 * k)
+    e.set_mute(2, True)
+    sim.tracks[2].set_mute(True)
+    e.process()
+    sim.render(1)
+    assert np.array_equal(sim.gains().view(np.uint32), e.gains().view(np.uint32))
+    _, d1 = sim.thread_stats()
+    assert [b - a for a, b in zip(d0, d1)] == [20, 40, 21, 20]
+    e.close()
+    sim.close()
+
+
+def test_two_thread_contract_under_thread_sanitizer():
+    """UI thread (lock-free parameter rings + locked clip edits + tempo stores) against the audio thread's render,
+    3000 blocks, built with -fsanitize=thread: no data race, every message drained, the last value of each fader wins."""
+    exe = HS.build_tsan()
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host_tsan ok" in r.stdout
+    assert "WARNING: ThreadSanitizer" not in r.stderr

@@ -30,6 +30,18 @@ class ClipInfo(C.Structure):
                 ("gain", C.c_float), ("sample", C.c_uint32)]
 
 
+class PluginProcessInfo(C.Structure):
+    _fields_ = [("sample_count", C.c_uint32), ("input_buffer_count", C.c_uint32), ("output_buffer_count", C.c_uint32),
+                ("n_channels", C.c_uint32), ("input_buffer", C.POINTER(C.POINTER(C.c_float))),
+                ("output_buffer", C.POINTER(C.POINTER(C.c_float))), ("input_event_list", C.c_void_p),
+                ("sample_rate", C.c_double), ("tempo", C.c_double), ("project_time_in_ppq", C.c_double),
+                ("project_time_in_samples", C.c_int64), ("playing", C.c_int32)]
+
+
+class Plugin(C.Structure):
+    _fields_ = [("userdata", C.c_void_p), ("process", C.c_void_p)]
+
+
 class PlanRecord(C.Structure):
     _fields_ = [("block", C.c_uint32), ("track", C.c_uint32), ("buffer_offset", C.c_uint32),
                 ("num_samples", C.c_uint32), ("num_actual", C.c_uint32), ("sample", C.c_uint32),
@@ -38,7 +50,7 @@ class PlanRecord(C.Structure):
 
 
 FMT = {"i16": 3, "i24": 5, "i32": 7, "f32": 9}
-OUT_FMT = {"i16": 3, "i24_x8": 6, "i32": 7, "f32": 9}
+OUT_FMT = {"i16": 3, "i24": 5, "i24_x8": 6, "i32": 7, "f32": 9}
 
 # every symbol include/wbx.h declares: name -> (restype, argtypes)
 _vp, _u32, _i32, _f, _d, _sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_double, C.c_size_t
@@ -67,6 +79,7 @@ SYMBOLS = {
     "wbx_fetch": (C.c_int, [_vp, _fpp, C.POINTER(_f), C.POINTER(_f)]),
     "wbx_fetch_interleaved": (C.c_int, [_vp, C.c_int, _vp]),
     "wbx_sync": (C.c_int, [_vp]),
+    "wbx_master_ready": (C.c_int, [_vp, _vp]),
     "wbx_partial_master": (C.c_int, [_vp, _pp, C.POINTER(_sz)]),
     "wbx_finalize_master": (C.c_int, [_vp, _vp, _u32, C.c_int, _vp]),
     "wbx_finalize_master_into": (C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp]),
@@ -76,6 +89,7 @@ SYMBOLS = {
     "wbx_tail_time": (C.c_int, [_vp, C.POINTER(_d)]),
     "wbx_engine_create": (C.c_int, [C.POINTER(Config), _pp]),
     "wbx_engine_destroy": (None, [_vp]),
+    "wbx_engine_set_audio_channel_config": (C.c_int, [_vp, _u32, _u32, _u32]),
     "wbx_engine_last_error": (C.c_char_p, [_vp]),
     "wbx_engine_ctx": (_vp, [_vp]),
     "wbx_engine_set_bpm": (C.c_int, [_vp, _d]),
@@ -86,6 +100,9 @@ SYMBOLS = {
     "wbx_track_set_pan": (C.c_int, [_vp, _u32, _f]),
     "wbx_track_set_mute": (C.c_int, [_vp, _u32, C.c_int]),
     "wbx_track_set_bus": (C.c_int, [_vp, _u32, _i32]),
+    "wbx_engine_add_plugin_to_track": (C.c_int, [_vp, _u32, _vp]),
+    "wbx_engine_delete_plugin_from_track": (C.c_int, [_vp, _u32]),
+    "wbx_track_get_plugin": (C.c_int, [_vp, _u32, _pp]),
     "wbx_engine_delete_track": (C.c_int, [_vp, _u32]),
     "wbx_engine_clear_all": (C.c_int, [_vp]),
     "wbx_engine_move_track": (C.c_int, [_vp, _u32, _u32]),
@@ -112,6 +129,7 @@ SYMBOLS = {
     "wbx_engine_render": (C.c_int, [_vp, _u32]),
     "wbx_engine_transport": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int)]),
     "wbx_engine_levels": (C.c_int, [_vp, C.POINTER(_f), _u32]),
+    "wbx_engine_thread_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u32]),
     "wbx_engine_fetch_plan": (C.c_int, [_vp, C.POINTER(PlanRecord), _sz, C.POINTER(_sz)]),
 }
 

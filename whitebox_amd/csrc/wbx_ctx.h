@@ -1,0 +1,227 @@
+// wbx_ctx.h — internals shared by the translation units of libwbx.so's host side (wbx_runtime.hip: layer 1,
+// wbx_engine.hip: layer 2, wbx_dist.hip: multi-GPU).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wbx.h"
+#include "wbx_dev.h"
+
+namespace wbx {
+void launch_plan(const PlanArgs& a, hipStream_t s);
+void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
+void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);
+void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
+void launch_clamp(float* buf, size_t n, hipStream_t s);
+void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
+void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
+void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
+void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
+                         hipStream_t s);
+void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s);
+}  // namespace wbx
+
+namespace wbx {
+
+constexpr int kEventRing = 64;
+// Plan buffers, partial-sum buffers and their events form a ring of three: the plan of render i may start as soon as
+// the mix of render i-3 and the sum of render i-3 are over, i.e. a full render before its own mix — the one-wave-per-
+// track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
+constexpr int kRing = 3;
+constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
+
+struct ClipSlot {
+  void* base = nullptr;     // one allocation holding all channels
+  size_t stride = 0;        // bytes between channel rows
+  DSample d{};
+  bool used = false;
+  // waveform mip-maps (built on request): one allocation, level l at mip_off[l], [channels][mip_count[l]] elements
+  void* mip = nullptr;
+  int mip_bits = 0;
+  std::vector<size_t> mip_off;
+  std::vector<uint64_t> mip_count;
+};
+
+template <class T>
+struct DevBuf {             // grow-only device array
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct DistState;   // wbx_dist.hip
+
+}  // namespace wbx
+
+using namespace wbx;   // (internal header: only the host-side translation units of the library include it)
+
+struct wbx_ctx {
+  wbx_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  std::vector<ClipSlot> clips;
+  DevBuf<DSample> d_samples;
+  bool samples_dirty = true;
+
+  // routing
+  uint32_t routing_tracks = 0, n_buses = 0;
+  std::vector<int32_t> track_bus;
+  std::vector<uint32_t> order;
+  std::vector<DGroup> groups;
+  DevBuf<uint32_t> d_order;
+  DevBuf<DGroup> d_groups;
+  bool routing_dirty = true;
+
+  // The plan of a render (track-block records, overflow pool, pre-render queue + rows) is double-buffered:
+  // the sequencer of step i+1 runs on `plan_stream` while the mix of step i runs on `stream`.
+  struct PlanBuf {
+    DevBuf<DRow> prows;               // [K][N] 16-B plan rows
+    DevBuf<DTrackBlock> tmpl;         // templates the rows point at (one per steady run / per block with events)
+    uint32_t tmpl_cap = 0;
+    DevBuf<DSeg> pool;
+    uint32_t pool_chunks = 0;
+    uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued,
+                                      // [3] templates allocated
+    DevBuf<uint32_t> gen_list;        // pre-render queue of KIND_GENERIC records
+    DevBuf<float> rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
+    DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
+    uint32_t gen_cap = 0;
+    hipEvent_t planned = nullptr;     // recorded on plan_stream when plan + pre-render are done
+    hipEvent_t consumed = nullptr;    // (not owned) ctx->mix_done[] of the render whose mix read this buffer
+    bool consumed_valid = false;
+  } pb[kRing];
+  int cur = 0;
+  hipStream_t plan_stream = nullptr;
+  bool overlap = true;
+  DevBuf<float> d_zero;               // zero page (F+8 floats)
+  uint32_t* levels_target = nullptr;  // [N][C] running per-track maxima (VUMeter::level), or null
+  DevBuf<float> d_partial2[kRing];    // group partials, one per render in flight (a sum may still read an older one)
+  DevBuf<float> d_master, d_buses, d_peaks, d_gains;
+  // The sum of render i runs on its own stream beside the mix of render i+1 (it is PCIe-bound when the master goes to
+  // host memory and needs few CUs).  sum_pending: a sum has been issued that the main stream has not waited for yet.
+  hipStream_t sum_stream = nullptr;
+  hipEvent_t mix_done[kRing] = {}, sum_done[kRing] = {};
+  bool sum_valid[kRing] = {};
+  int sum_pending = -1;
+  uint32_t render_seq = 0;
+  bool partial_wait_done = false;     // the caller already ordered this render after the sum of two renders ago
+  bool sum_overlap = true;            // WBX_SUM_OVERLAP=0: sum on the main stream
+  DevBuf<uint8_t> d_conv;
+  std::vector<DTrackBlock> h_tb;      // layer-1 staging
+  std::vector<DRow> h_rows;
+  std::vector<DSeg> h_pool;
+
+  uint32_t last_K = 0, last_N = 0;
+  uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
+  bool buses_alias_partials = false;  // see build_routing
+  const float* last_buses = nullptr;  // where the last render's bus sums are: d_buses or the partial buffer
+  bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation
+  float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
+  bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
+  bool clamp = true;
+  float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
+
+  // kernel timing (mix kernel)
+  hipEvent_t ev[kEventRing][3]{};       // before the mix, after the mix, after the sum
+  int ev_pending = 0;
+  double mix_ms_total = 0.0;
+  double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
+  uint64_t mix_launches = 0;
+  bool profiling = true;
+  int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
+                                      // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
+  bool has_window_clips = true;
+  bool has_integer_clips = false;
+  bool force_g = false;
+  bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
+
+  hipStream_t upload_stream = nullptr; // clip uploads of layer 2 run here, outside the engine's editor lock
+  hipEvent_t ready_ev = nullptr;       // wbx_master_ready: results of an in-stream sum, for a foreign stream
+  // layer 2 back pointer: asks whether a clip list still names a sample (wbx_clip_free), null for a bare ctx
+  bool (*sample_in_use)(void* owner, uint32_t sample) = nullptr;
+  void* owner = nullptr;
+  wbx::DistState* dist = nullptr;      // multi-GPU exchange (wbx_dist.hip), null on a single GPU
+};
+
+namespace wbx {
+
+inline wbx_ctx::PlanBuf& PB(wbx_ctx* c) { return c->pb[c->cur]; }
+
+inline wbx_status fail(wbx_ctx* c, wbx_status s, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return s;
+}
+
+#define WBX_HIP(ctx, call)                                                       \
+  do {                                                                           \
+    hipError_t _e = (call);                                                      \
+    if (_e != hipSuccess) return ::wbx::fail((ctx), WBX_ERR_DEVICE, #call, _e);  \
+  } while (0)
+
+inline size_t fmt_bytes(int fmt) {
+  switch (fmt) {
+    case WBX_FMT_I16: return 2;
+    case WBX_FMT_I24:
+    case WBX_FMT_I32:
+    case WBX_FMT_F32: return 4;
+    default: return 0;
+  }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+enum : int { CLIP_SRC_PLANAR = 0, CLIP_SRC_INTERLEAVED_HOST = 1, CLIP_SRC_INTERLEAVED_DEVICE = 2, CLIP_SRC_SYNTH = 3 };
+struct ClipFill {           // where a new clip's audio comes from
+  int kind;
+  const void* const* planar;   // CLIP_SRC_PLANAR: host channel arrays
+  const void* interleaved;     // CLIP_SRC_INTERLEAVED_*: [frames][channels]
+  uint64_t seed;               // CLIP_SRC_SYNTH
+  uint32_t key_track;
+  float amp;
+};
+
+// wbx_runtime.hip
+wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
+                      const ClipFill& f, hipStream_t on);
+wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s);
+void clip_release(ClipSlot& s);
+hipError_t join_sum(wbx_ctx* c);
+void drain_events(wbx_ctx* c);
+wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks);
+wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N);
+wbx_status ensure_template_capacity(wbx_ctx* c, size_t n);
+wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows);
+wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
+wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
+wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
+
+}  // namespace wbx

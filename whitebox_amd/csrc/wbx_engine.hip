@@ -1,0 +1,869 @@
+// wbx_engine.hip — layer 2 of libwbx.so (wbx_engine): the reference's Engine / Track surface.
+//
+// The host keeps what the UI thread edits (clip lists, parameters, transport: wbx_host.h, plain C++ shared with the
+// CPU-only test harness), the device keeps what the audio thread mutates per block (sequencer + sampler state) and does
+// all per-block work.  Threading is the reference's (wbx_host.h): one audio thread in wbx_engine_process / _render
+// holding the editor lock for its host side, one UI thread whose edits take the same lock and whose
+// wbx_track_set_volume / _pan / _mute go through the per-track SPSC ring without it.
+#include "wbx_ctx.h"
+#include "wbx_host.h"
+#include "wbx_seq.h"
+
+using namespace wbx;
+
+struct wbx_engine {
+  wbx_ctx* ctx = nullptr;
+  HostSession hs;
+  // pinned host buffers the plan kernel reads in place (one 16-B / 8-B read per lane): state patches and per-track
+  // gains reach the device without a copy and, above all, without a stream synchronisation that would drain the
+  // renders the audio thread has run ahead by.  Rings of three; a buffer is refilled only after the plan kernel that
+  // last read it has finished.
+  DPatch* h_patch[kRing] = {};
+  uint32_t patch_cap[kRing] = {};
+  hipEvent_t patch_done[kRing] = {};
+  bool patch_valid[kRing] = {};
+  uint32_t patch_seq = 0;
+  float* h_gains[kRing] = {};           // [N][2] fl(volume * pan_coeffs[c])
+  uint32_t gains_cap = 0;
+  hipEvent_t gains_done[kRing] = {};
+  bool gains_valid[kRing] = {};
+  int gains_slot = -1;                  // the buffer plans currently read
+  std::vector<float> gains_tmp;
+  // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
+  // and the plan status lands in — the callback path then needs no copy-engine transfer at all
+  float* h_block = nullptr;             // [C][F]
+  uint32_t* h_status = nullptr;         // plan counters [4]
+  size_t d_clips_count = 0;
+  bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
+  uint32_t state_tracks = 0;            // tracks that have device state
+  std::vector<DClip> flat;              // staging of the clip table upload
+  std::vector<uint32_t> first;
+
+  DevBuf<DClip> d_clips;
+  DevBuf<uint32_t> d_clip_first;
+  DevBuf<DTrackState> d_state;
+  DevBuf<float> d_levels;
+};
+
+namespace {
+
+// The message of the last failed engine call made by the CALLING thread: the UI thread and the audio thread fail
+// independently, one shared string would be a data race.
+thread_local std::string tls_err;
+
+wbx_status efail(wbx_engine*, wbx_status s, const char* what) {
+  tls_err = what;
+  return s;
+}
+
+// a failed layer-1 call made under the lock: take its message along
+wbx_status cfail(wbx_engine* e, wbx_status s) {
+  if (s != WBX_OK) tls_err = e->ctx->err;
+  return s;
+}
+
+#define WBX_EHIP(e, call)                                           \
+  do {                                                              \
+    hipError_t _e = (call);                                         \
+    if (_e != hipSuccess) {                                         \
+      tls_err = std::string(#call) + ": " + hipGetErrorString(_e);  \
+      return WBX_ERR_DEVICE;                                        \
+    }                                                               \
+  } while (0)
+
+bool sample_in_use_cb(void* owner, uint32_t sample) { return static_cast<wbx_engine*>(owner)->hs.sample_referenced(sample); }
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out) {
+  if (!cfg || !out) return WBX_ERR_INVALID;
+  *out = nullptr;
+  wbx_ctx* c = nullptr;
+  wbx_status st = wbx_create(cfg, &c);
+  if (st != WBX_OK) return st;
+  wbx_engine* e = new (std::nothrow) wbx_engine();
+  if (!e) {
+    wbx_destroy(c);
+    return WBX_ERR_OOM;
+  }
+  e->ctx = c;
+  e->hs.max_tracks = cfg->max_tracks;
+  e->hs.dst_rate = cfg->sample_rate;
+  c->owner = e;
+  c->sample_in_use = sample_in_use_cb;
+  *out = e;
+  return WBX_OK;
+}
+
+extern "C" void wbx_engine_destroy(wbx_engine* e) {
+  if (!e) return;
+  if (e->ctx) {
+    (void)hipSetDevice(e->ctx->cfg.device);
+    (void)hipStreamSynchronize(e->ctx->plan_stream);
+    (void)hipStreamSynchronize(e->ctx->stream);
+  }
+  e->d_clips.release();
+  e->d_clip_first.release();
+  e->d_state.release();
+  e->d_levels.release();
+  for (int i = 0; i < kRing; i++) {
+    if (e->h_patch[i]) (void)hipHostFree(e->h_patch[i]);
+    if (e->patch_done[i]) (void)hipEventDestroy(e->patch_done[i]);
+    if (e->h_gains[i]) (void)hipHostFree(e->h_gains[i]);
+    if (e->gains_done[i]) (void)hipEventDestroy(e->gains_done[i]);
+  }
+  if (e->h_block) (void)hipHostFree(e->h_block);
+  if (e->h_status) (void)hipHostFree(e->h_status);
+  wbx_destroy(e->ctx);
+  delete e;
+}
+
+// Engine::set_audio_channel_config (engine.cpp:43-57) on a live engine: new block size / channel count / device rate,
+// tracks, clips, samples and the transport stay — like the reference, which only resizes its mixing buffers.  Sampler
+// state of clips that are playing keeps the playback speed it was started with (Sampler::reset_state ran with the
+// old rate), as in the reference.
+extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_t output_channels, uint32_t buffer_size,
+                                                          uint32_t sample_rate) {
+  if (!e) return WBX_ERR_INVALID;
+  if (output_channels < 1 || output_channels > 2 || buffer_size < 4 || (buffer_size & 3u) || buffer_size > 32768 || sample_rate == 0)
+    return efail(e, WBX_ERR_INVALID, "set_audio_channel_config: channels 1-2, buffer size a multiple of 4 up to 32768");
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  wbx_ctx* c = e->ctx;
+  if (c->cfg.channels == output_channels && c->cfg.block_frames == buffer_size && c->cfg.sample_rate == sample_rate) return WBX_OK;
+  (void)hipSetDevice(c->cfg.device);
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, join_sum(c));
+  WBX_EHIP(e, hipStreamSynchronize(c->sum_stream));
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  c->cfg.channels = output_channels;
+  c->cfg.block_frames = buffer_size;
+  c->cfg.sample_rate = sample_rate;
+  // everything whose size or row pitch depends on C or F is dropped and re-grown by the next render
+  for (auto& B : c->pb) {
+    B.rows.release();
+    B.gen_list.release();
+    B.saved.release();
+    B.gen_cap = 0;
+    B.consumed_valid = false;
+  }
+  for (auto& P : c->d_partial2) P.release();
+  for (auto& v : c->sum_valid) v = false;
+  c->sum_pending = -1;
+  c->d_master.release();
+  c->d_buses.release();
+  c->d_peaks.release();
+  c->buses_clean = false;
+  c->d_zero.release();
+  WBX_EHIP(e, c->d_zero.ensure(buffer_size + 8));
+  WBX_EHIP(e, hipMemset(c->d_zero.p, 0, (buffer_size + 8) * sizeof(float)));
+  c->last_K = 0;
+  if (e->h_block) {
+    WBX_EHIP(e, hipHostFree(e->h_block));
+    e->h_block = nullptr;
+  }
+  if (e->d_levels.p) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+  // the destination rate enters every clip's playback speed: which clips the hot loop streams directly is re-derived
+  e->hs.dst_rate = sample_rate;
+  e->hs.any_slow_clip = e->hs.any_window_clip = e->hs.any_stride_clip = e->hs.any_crawl_clip = false;
+  for (auto& t : e->hs.tracks)
+    for (auto& hc : t->clips) e->hs.note_clip(hc.d);
+  return WBX_OK;
+}
+
+extern "C" const char* wbx_engine_last_error(const wbx_engine* e) {
+  if (!e) return "null engine";
+  return tls_err.c_str();
+}
+
+extern "C" wbx_ctx* wbx_engine_ctx(wbx_engine* e) { return e ? e->ctx : nullptr; }
+
+extern "C" wbx_status wbx_engine_set_bpm(wbx_engine* e, double bpm) {   // engine.cpp:24-30: an atomic store, no lock
+  if (!e || !(bpm > 0.0)) return WBX_ERR_INVALID;
+  e->hs.set_bpm(bpm);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_set_playhead_position(wbx_engine* e, double beat) {   // engine.cpp:32-41
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.set_playhead_position_locked(beat);
+  e->hs.note_edit_locked();
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_add_track(wbx_engine* e, uint32_t* track_out) {   // engine.cpp:200-208
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (e->hs.n_tracks() >= e->ctx->cfg.max_tracks) return efail(e, WBX_ERR_INVALID, "max_tracks reached");
+  const uint32_t t = e->hs.add_track_locked();
+  if (track_out) *track_out = t;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_set_buses(wbx_engine* e, uint32_t n_buses) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.n_buses = n_buses;
+  e->hs.routing_dirty = true;
+  e->hs.note_edit_locked();
+  return WBX_OK;
+}
+
+// Track::set_volume / set_pan / set_mute (track.cpp:47-79): UI thread, no lock — a message into the track's ring,
+// applied by the audio thread at the start of its next block.  Like the reference's, the producer yields while the
+// ring (63 usable entries) is full: it needs a running audio thread to make progress then.
+extern "C" wbx_status wbx_track_set_volume(wbx_engine* e, uint32_t t, float db) {
+  if (!e || !e->hs.valid_track(t)) return WBX_ERR_INVALID;
+  e->hs.set_volume(t, db);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t t, float pan) {
+  if (!e || !e->hs.valid_track(t)) return WBX_ERR_INVALID;
+  e->hs.set_pan(t, pan);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t t, int mute) {
+  if (!e || !e->hs.valid_track(t)) return WBX_ERR_INVALID;
+  e->hs.set_mute(t, mute != 0);
+  return WBX_OK;
+}
+
+namespace {
+
+// new track i = old track order[i] (order.size() = new track count): the per-track device state (sequencer,
+// sampler, running levels) follows its Track object, as the pointers in the reference's vector do
+wbx_status permute_tracks_locked(wbx_engine* e, const std::vector<uint32_t>& order) {
+  wbx_ctx* c = e->ctx;
+  (void)hipSetDevice(c->cfg.device);
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, join_sum(c));
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  const uint32_t new_n = (uint32_t)order.size();
+  if (e->state_tracks) {
+    const uint32_t C = c->cfg.channels;
+    std::vector<DTrackState> st(e->state_tracks), st2(std::max<size_t>(new_n, 1));
+    std::vector<float> lv((size_t)e->state_tracks * C), lv2((size_t)std::max<uint32_t>(new_n, 1) * C, 0.0f);
+    WBX_EHIP(e, hipMemcpy(st.data(), e->d_state.p, st.size() * sizeof(DTrackState), hipMemcpyDeviceToHost));
+    WBX_EHIP(e, hipMemcpy(lv.data(), e->d_levels.p, lv.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < new_n; i++) {
+      if (order[i] < e->state_tracks) {
+        st2[i] = st[order[i]];
+        for (uint32_t ch = 0; ch < C; ch++) lv2[(size_t)i * C + ch] = lv[(size_t)order[i] * C + ch];
+      } else {
+        st2[i] = DTrackState{};   // a track added since the last render
+      }
+    }
+    WBX_EHIP(e, hipMemset(e->d_state.p, 0, e->d_state.cap * sizeof(DTrackState)));
+    WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    if (new_n) {
+      WBX_EHIP(e, hipMemcpy(e->d_state.p, st2.data(), (size_t)new_n * sizeof(DTrackState), hipMemcpyHostToDevice));
+      WBX_EHIP(e, hipMemcpy(e->d_levels.p, lv2.data(), (size_t)new_n * C * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->state_tracks = new_n;
+  }
+  e->hs.permute_tracks_locked(order);
+  return WBX_OK;
+}
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:210-218
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(slot)) return WBX_ERR_INVALID;
+  std::vector<uint32_t> order;
+  for (uint32_t i = 0; i < e->hs.n_tracks(); i++)
+    if (i != slot) order.push_back(i);
+  return permute_tracks_locked(e, order);
+}
+
+extern "C" wbx_status wbx_engine_clear_all(wbx_engine* e) {   // engine.cpp:59-66: every track goes
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  return permute_tracks_locked(e, std::vector<uint32_t>{});
+}
+
+extern "C" wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot) {   // engine.cpp:228-243
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(from_slot) || !e->hs.valid_track(to_slot)) return WBX_ERR_INVALID;
+  if (from_slot == to_slot) return WBX_OK;
+  std::vector<uint32_t> order(e->hs.n_tracks());
+  for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+  order.erase(order.begin() + from_slot);
+  order.insert(order.begin() + to_slot, from_slot);
+  return permute_tracks_locked(e, order);
+}
+
+extern "C" wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:245-262 (no lock: messages only)
+  if (!e || !e->hs.valid_track(slot)) return WBX_ERR_INVALID;
+  e->hs.solo_track(slot);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t t, int32_t bus) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(t)) return WBX_ERR_INVALID;
+  e->hs.tracks[t]->bus = bus;
+  e->hs.routing_dirty = true;
+  return WBX_OK;
+}
+
+// ---- effect slot: kept in the boundary, nothing processed through it ----
+extern "C" wbx_status wbx_engine_add_plugin_to_track(wbx_engine* e, uint32_t track, const wbx_plugin* plugin) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track)) return WBX_ERR_INVALID;
+  if (plugin)
+    return efail(e, WBX_ERR_UNIMPLEMENTED, "effect processing is not part of this path (third-party VST3 arithmetic): the slot stays empty");
+  e->hs.tracks[track]->plugin = nullptr;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_delete_plugin_from_track(wbx_engine* e, uint32_t track) {   // engine.h:229
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track)) return WBX_ERR_INVALID;
+  e->hs.tracks[track]->plugin = nullptr;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_track_get_plugin(wbx_engine* e, uint32_t track, const wbx_plugin** plugin_out) {
+  if (!e || !plugin_out) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (!e->hs.valid_track(track)) return WBX_ERR_INVALID;
+  *plugin_out = static_cast<const wbx_plugin*>(e->hs.tracks[track]->plugin);
+  return WBX_OK;
+}
+
+namespace {
+
+// Sample assets (SampleAsset, engine/assets_table.h:22-35).  The reference decodes a file outside the editor lock and
+// only links the finished asset in; here the id is reserved under the lock, the audio goes to HBM on the upload
+// stream without it, and the finished slot is published under the lock again — the audio thread never waits for a
+// transfer.
+wbx_status add_sample_common(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
+                             const ClipFill& f, uint32_t* sample_out) {
+  if (!e || !sample_out) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  uint32_t id;
+  {
+    LockGuard g(e->hs.editor_lock);
+    id = (uint32_t)c->clips.size();
+    c->clips.emplace_back();            // reserved, unused until published
+    e->hs.samples.resize(c->clips.size());
+  }
+  ClipSlot s;
+  wbx_status st = clip_build(c, s, format, channels, sample_rate, frames, f, c->upload_stream);
+  if (st == WBX_OK && hipStreamSynchronize(c->upload_stream) != hipSuccess) {
+    clip_release(s);
+    st = WBX_ERR_DEVICE;
+  }
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (st != WBX_OK) return cfail(e, st);
+  st = clip_publish(c, id, s);
+  if (st != WBX_OK) return cfail(e, st);
+  SampleMeta& m = e->hs.samples[id];
+  m.format = (uint32_t)format;
+  m.channels = channels;
+  m.sample_rate = sample_rate;
+  m.count = frames;
+  m.used = true;
+  *sample_out = id;
+  return WBX_OK;
+}
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                            uint64_t frames, const void* const* planar, uint32_t* sample_out) {
+  ClipFill f{};
+  f.kind = CLIP_SRC_PLANAR;
+  f.planar = planar;
+  return add_sample_common(e, format, channels, sample_rate, frames, f, sample_out);
+}
+
+extern "C" wbx_status wbx_engine_add_sample_interleaved(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                                        uint64_t frames, const void* interleaved, uint32_t* sample_out) {
+  ClipFill f{};
+  f.kind = CLIP_SRC_INTERLEAVED_HOST;
+  f.interleaved = interleaved;
+  return add_sample_common(e, format, channels, sample_rate, frames, f, sample_out);
+}
+
+extern "C" wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
+                                                  uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
+                                                  uint32_t* sample_out) {
+  ClipFill f{};
+  f.kind = CLIP_SRC_SYNTH;
+  f.seed = seed;
+  f.key_track = key_track;
+  f.amp = amp;
+  return add_sample_common(e, format, channels, sample_rate, frames, f, sample_out);
+}
+
+// Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461
+extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
+                                                double start_offset, uint32_t sample, double speed, float gain) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track)) return WBX_ERR_INVALID;
+  if (!e->hs.valid_sample(sample) && sample < e->ctx->clips.size() && e->ctx->clips[sample].used) {
+    // a clip the host put into the engine's pool through layer 1 (wbx_clip_upload on wbx_engine_ctx): adopt it
+    const DSample& d = e->ctx->clips[sample].d;
+    if (e->hs.samples.size() <= sample) e->hs.samples.resize(sample + 1);
+    e->hs.samples[sample] = SampleMeta{d.format, d.channels, d.sample_rate, d.count, true};
+  }
+  if (!e->hs.valid_sample(sample)) return efail(e, WBX_ERR_INVALID, "unknown sample");
+  if (!(min_time <= max_time)) return efail(e, WBX_ERR_INVALID, "min_time > max_time");
+  e->hs.add_audio_clip_locked(track, min_time, max_time, start_offset, sample, speed, gain);
+  return WBX_OK;
+}
+
+// Engine::move_clip, engine.cpp:346-363
+extern "C" wbx_status wbx_engine_move_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track) || clip >= e->hs.tracks[track]->clips.size()) return WBX_ERR_INVALID;
+  e->hs.move_clip_locked(track, clip, relative_pos);
+  return WBX_OK;
+}
+
+// Engine::resize_clip, engine.cpp:365-398
+extern "C" wbx_status wbx_engine_resize_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos,
+                                             double resize_limit, double min_length, int left_side, int shift,
+                                             int stretch) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track) || clip >= e->hs.tracks[track]->clips.size()) return WBX_ERR_INVALID;
+  e->hs.resize_clip_locked(track, clip, relative_pos, resize_limit, min_length, left_side != 0, shift != 0, stretch != 0);
+  return WBX_OK;
+}
+
+// Engine::delete_clip, engine.cpp:400-407
+extern "C" wbx_status wbx_engine_delete_clip(wbx_engine* e, uint32_t track, uint32_t clip) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track) || clip >= e->hs.tracks[track]->clips.size()) return WBX_ERR_INVALID;
+  e->hs.delete_clip_locked(track, clip);
+  return WBX_OK;
+}
+
+// Engine::delete_region, engine.cpp:463-475
+extern "C" wbx_status wbx_engine_delete_region(wbx_engine* e, uint32_t track, double min, double max) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track) || !(min <= max)) return WBX_ERR_INVALID;
+  e->hs.delete_region_locked(track, min, max);
+  return WBX_OK;
+}
+
+// Engine::set_clip_gain, engine.cpp:1460-1464
+extern "C" wbx_status wbx_engine_set_clip_gain(wbx_engine* e, uint32_t track, uint32_t clip, float gain) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_track(track) || clip >= e->hs.tracks[track]->clips.size()) return WBX_ERR_INVALID;
+  e->hs.set_clip_gain_locked(track, clip, gain);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_clip_count(wbx_engine* e, uint32_t track, uint32_t* count) {
+  if (!e || !count) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (!e->hs.valid_track(track)) return WBX_ERR_INVALID;
+  *count = (uint32_t)e->hs.tracks[track]->clips.size();
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_get_clip(wbx_engine* e, uint32_t track, uint32_t clip, wbx_clip_info* out) {
+  if (!e || !out) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (!e->hs.valid_track(track) || clip >= e->hs.tracks[track]->clips.size()) return WBX_ERR_INVALID;
+  const DClip& d = e->hs.tracks[track]->clips[clip].d;
+  out->min_time = d.min_time;
+  out->max_time = d.max_time;
+  out->start_offset = d.start_offset;
+  out->speed = d.speed;
+  out->gain = d.gain;
+  out->sample = d.sample;
+  return WBX_OK;
+}
+
+// the clip placement arithmetic on its own (engine/clip_edit.h:10-150), for hosts that preview an edit
+extern "C" void wbx_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
+                                   double* new_max) {
+  edit::calc_move_clip(clip_min, clip_max, relative_pos, min_move, new_min, new_max);
+}
+
+extern "C" void wbx_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
+                                     double sample_rate, double sample_count, double relative_pos, double resize_limit,
+                                     double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
+                                     int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
+                                     double* out_start_offset, double* out_speed) {
+  const edit::ResizeResult r = edit::calc_resize_clip(clip_min, clip_max, clip_start_offset, clip_speed, sample_rate,
+                                                      sample_count, relative_pos, resize_limit, min_length, min_resize_pos,
+                                                      beat_duration, is_min != 0, shift != 0, stretch != 0,
+                                                      clamp_at_resize_pos != 0);
+  *out_min = r.min;
+  *out_max = r.max;
+  *out_start_offset = r.start_offset;
+  *out_speed = r.speed;
+}
+
+extern "C" double wbx_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
+  return edit::calc_clip_shift(start_offset, relative_pos, beat_duration, sample_rate);
+}
+
+extern "C" double wbx_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
+                                         double beat_duration) {
+  return edit::shift_clip_content(start_offset, speed, sample_rate, relative_pos, beat_duration);
+}
+
+extern "C" wbx_status wbx_engine_play(wbx_engine* e) {   // engine.cpp:68-80
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.play_locked();
+  e->hs.note_edit_locked();
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_stop(wbx_engine* e) {   // engine.cpp:82-93, Track::stop track.cpp:249-256
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.stop_locked();
+  e->hs.note_edit_locked();
+  return WBX_OK;
+}
+
+namespace {
+
+// (re)allocate the three pinned patch and gain buffers at once — pinning memory synchronises the device, so it must
+// not happen in mid-run
+wbx_status ensure_pinned_tables(wbx_engine* e, uint32_t N) {
+  wbx_ctx* c = e->ctx;
+  if (e->gains_cap >= N && e->patch_cap[0] >= N) return WBX_OK;
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  const uint32_t cap = std::max<uint32_t>(N, c->cfg.max_tracks);
+  for (int i = 0; i < kRing; i++) {
+    if (e->h_patch[i]) WBX_EHIP(e, hipHostFree(e->h_patch[i]));
+    if (e->h_gains[i]) WBX_EHIP(e, hipHostFree(e->h_gains[i]));
+    e->h_patch[i] = nullptr;
+    e->h_gains[i] = nullptr;
+    WBX_EHIP(e, hipHostMalloc((void**)&e->h_patch[i], (size_t)cap * sizeof(DPatch), hipHostMallocDefault));
+    WBX_EHIP(e, hipHostMalloc((void**)&e->h_gains[i], (size_t)cap * 2 * sizeof(float), hipHostMallocDefault));
+    e->patch_cap[i] = cap;
+    e->patch_valid[i] = false;
+    e->gains_valid[i] = false;
+    if (!e->patch_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->patch_done[i], hipEventDisableTiming));
+    if (!e->gains_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->gains_done[i], hipEventDisableTiming));
+  }
+  e->gains_cap = cap;
+  e->gains_slot = -1;
+  e->hs.gains_dirty = true;   // the buffers are new: fill one
+  return WBX_OK;
+}
+
+// the audio thread's render, editor lock held by the caller
+wbx_status render_locked(wbx_engine* e, uint32_t K) {
+  wbx_ctx* c = e->ctx;
+  HostSession& hs = e->hs;
+  tls_err.clear();
+  if (K > c->cfg.max_blocks) return efail(e, WBX_ERR_INVALID, "n_blocks above wbx_config.max_blocks");
+  const uint32_t N = hs.n_tracks();
+  (void)hipSetDevice(c->cfg.device);
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  hipStream_t s = c->stream;
+  hs.render_edit_seq = hs.edit_seq;
+  // engine.cpp:1579,1585: the tempo and the play state are read once per block
+  const double beat_duration = hs.beat_duration.load(std::memory_order_relaxed);
+  const bool playing = hs.playing.load(std::memory_order_relaxed);
+  if (N == 0) {
+    // Engine::process with an empty track list: output_buffer.clear() and the transport advance (engine.cpp:1598,
+    // :1619-1623) — silence
+    WBX_EHIP(e, join_sum(c));
+    WBX_EHIP(e, c->d_master.ensure((size_t)K * C * F));
+    float* master = c->master_target ? c->master_target : c->d_master.p;
+    WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * sizeof(float), s));
+    c->last_master = master;
+    c->last_master_on_host = false;
+    c->last_K = K;
+    c->last_N = 0;
+    hs.advance_transport_locked(K, F, beat_duration);
+    return WBX_OK;
+  }
+
+  wbx_status st = ensure_pinned_tables(e, N);
+  if (st != WBX_OK) return st;
+
+  // -- parameters: drain the message rings (process_track_messages track.cpp:773-779) and apply them
+  //    (track.cpp:618-643); the factor used per sample is fl(volume * pan_coeffs[c]) (track.cpp:728-731)
+  if (hs.drain_params_locked()) {
+    const int slot = (e->gains_slot + 1) % kRing;
+    if (e->gains_valid[slot]) WBX_EHIP(e, hipEventSynchronize(e->gains_done[slot]));   // its last reader, >= 2 changes ago
+    hs.build_gains_locked(e->gains_tmp);
+    std::memcpy(e->h_gains[slot], e->gains_tmp.data(), e->gains_tmp.size() * sizeof(float));
+    e->gains_slot = slot;
+  }
+
+  // -- clip lists
+  if (hs.clips_dirty) {
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    // Clip::internal_state_changed is cleared by the sequencer on the device (track.cpp:373,392,418): before
+    // the table is replaced, take the live flags back for every clip no edit has touched since the last upload
+    if (e->clips_uploaded && e->d_clips_count) {
+      std::vector<DClip> live(e->d_clips_count);
+      WBX_EHIP(e, hipMemcpy(live.data(), e->d_clips.p, live.size() * sizeof(DClip), hipMemcpyDeviceToHost));
+      hs.merge_live_flags_locked(live.data(), live.size());
+    }
+    hs.flatten_clips_locked(e->flat, e->first);
+    WBX_EHIP(e, e->d_clips.ensure(std::max<size_t>(1, e->flat.size())));
+    WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
+    e->d_clips_count = e->flat.size();
+    e->clips_uploaded = true;
+    if (!e->flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, e->flat.data(), e->flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
+    WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, e->first.data(), e->first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+
+  // -- per-track device state for tracks added since the last render
+  if (e->state_tracks < N) {
+    DevBuf<DTrackState> grown;
+    WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
+    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
+    if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
+    e->d_state.release();
+    e->d_state = grown;
+    WBX_EHIP(e, e->d_levels.ensure((size_t)c->cfg.max_tracks * 2));
+    if (e->state_tracks == 0) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    e->state_tracks = N;
+  }
+
+  // -- pending state edits (play / stop / clip-list changes)
+  const DPatch* d_patch = nullptr;
+  int patch_slot = -1;
+  if (hs.patches_pending) {
+    patch_slot = (int)(e->patch_seq++ % kRing);
+    if (e->patch_valid[patch_slot]) WBX_EHIP(e, hipEventSynchronize(e->patch_done[patch_slot]));
+    hs.take_patches_locked(e->h_patch[patch_slot]);
+    d_patch = e->h_patch[patch_slot];
+  }
+
+  // -- routing
+  if (hs.routing_dirty || c->routing_tracks != N) {
+    std::vector<int32_t> tb(N);
+    for (uint32_t t = 0; t < N; t++) tb[t] = hs.tracks[t]->bus;
+    st = wbx_set_routing(c, N, hs.n_buses ? tb.data() : nullptr, hs.n_buses);
+    if (st != WBX_OK) return cfail(e, st);
+    hs.routing_dirty = false;
+  }
+  st = upload_tables(c, N);
+  if (st != WBX_OK) return cfail(e, st);
+  st = ensure_result_buffers(c, K, N);
+  if (st != WBX_OK) return cfail(e, st);
+
+  // -- rows for the track-blocks the hot loop cannot stream directly, and the plan's templates
+  st = ensure_gen_capacity(c, hs.gen_rows_hint(K));
+  if (st != WBX_OK) return cfail(e, st);
+  st = ensure_template_capacity(c, hs.template_hint(K));
+  if (st != WBX_OK) return cfail(e, st);
+
+  // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
+  //    while the mix of the previous render is still busy on the main stream
+  c->cur = (c->cur + 1) % kRing;
+  wbx_ctx::PlanBuf& B = PB(c);
+  const bool plan_beside = c->overlap && K >= kOverlapMinBlocks;
+  hipStream_t ps = plan_beside ? c->plan_stream : s;
+  if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
+  {
+    const int pp = (int)(c->render_seq % kRing);
+    if (plan_beside && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
+      WBX_EHIP(e, hipStreamWaitEvent(ps, c->sum_done[pp], 0));
+      c->partial_wait_done = true;
+    }
+  }
+  WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
+  const double sample_rate = (double)c->cfg.sample_rate;
+  PlanArgs a{};
+  a.clips = e->d_clips.p;
+  a.clip_first = e->d_clip_first.p;
+  a.samples = c->d_samples.p;
+  a.state = e->d_state.p;
+  a.patch = d_patch;
+  a.gains = e->h_gains[e->gains_slot];
+  a.rows = B.prows.p;
+  a.tmpl = B.tmpl.p;
+  a.tmpl_count = B.counters + 3;
+  a.tmpl_cap = B.tmpl_cap;
+  a.pool = B.pool.p;
+  a.pool_count = B.counters;
+  a.status = B.counters + 1;
+  a.gen_list = B.gen_list.p;
+  a.gen_count = B.counters + 2;
+  a.gen_cap = B.gen_cap;
+  a.pool_chunks = B.pool_chunks;
+  a.n_tracks = N;
+  a.n_blocks = K;
+  a.block_frames = F;
+  a.channels = C;
+  a.sample_rate = sample_rate;
+  a.playing = playing ? 1u : 0u;
+  a.clips_changed = hs.clips_edited ? 1u : 0u;
+  hs.clips_edited = false;
+  a.playhead = hs.playhead;
+  a.sample_position = hs.sample_position;
+  a.beat_duration = beat_duration;
+  launch_plan(a, ps);
+  if (patch_slot >= 0) {
+    WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
+    e->patch_valid[patch_slot] = true;
+  }
+  WBX_EHIP(e, hipEventRecord(e->gains_done[e->gains_slot], ps));   // (re-recorded by every plan that reads the buffer)
+  e->gains_valid[e->gains_slot] = true;
+  st = launch_pre_render(c, K, ps);
+  if (st != WBX_OK) return cfail(e, st);
+  if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
+
+  // -- mix + sum on the main stream, after the plan
+  if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
+  c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
+  c->has_window_clips = hs.any_window_clip;
+  c->has_stride_clips = hs.any_stride_clip;
+  const int mix_parity = (int)(c->render_seq % kRing);
+  st = launch_mix_sum(c, K, N);
+  if (st != WBX_OK) return cfail(e, st);
+  B.consumed = c->mix_done[mix_parity];   // recorded right after the mix: the plan buffer is free before the sum runs
+  B.consumed_valid = true;
+
+  // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
+  //    the plan kernel performs for its K blocks, so both sides hold the same playhead / sample_position bits
+  hs.advance_transport_locked(K, F, beat_duration);
+  return WBX_OK;
+}
+
+}  // namespace
+
+extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
+  if (!e || K == 0) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  return render_locked(e, K);
+}
+
+extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar) {   // engine.cpp:1576-1654
+  if (!e || !out_planar) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  LockGuard g(e->hs.editor_lock);   // held for the whole block, like editor_lock in Engine::process (engine.cpp:1587-1651)
+  if (c->master_target || c->dist) {   // the caller redirected the master: leave it there and fetch the ordinary way
+    wbx_status st = render_locked(e, 1);
+    if (st != WBX_OK) return st;
+    return cfail(e, wbx_fetch(c, out_planar, nullptr, nullptr));
+  }
+  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
+  if (!e->h_block) WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
+  if (!e->h_status) WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
+  c->status_dst = e->h_status;            // and it drops the plan status next to it
+  wbx_status st = render_locked(e, 1);
+  c->master_target = nullptr;
+  c->status_dst = nullptr;
+  if (st != WBX_OK) return st;
+  WBX_EHIP(e, join_sum(c));
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
+  c->last_master_on_host = true;   // set after launch_mix_sum cleared it: the master of this block is e->h_block
+  if (e->hs.n_tracks() == 0) return WBX_OK;
+  return cfail(e, plan_status_to_error(c, e->h_status[1]));
+}
+
+extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (playhead) *playhead = e->hs.playhead;
+  if (sample_position) *sample_position = e->hs.sample_position;
+  if (playing) *playing = e->hs.playing.load(std::memory_order_relaxed) ? 1 : 0;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks) {
+  if (!e || !levels) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (n_tracks > e->state_tracks) return WBX_ERR_INVALID;
+  wbx_ctx* c = e->ctx;
+  const size_t n = (size_t)n_tracks * c->cfg.channels;
+  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  return WBX_OK;
+}
+
+// What the last process / render took from the shared state: the number of locked edits that had completed when it
+// took the editor lock, and per track the cumulative count of parameter messages it (and its predecessors) drained.
+// With the UI thread's own log of what it issued this reconstructs, block by block, the exact state the audio thread
+// rendered from (tests/test_gpu_threads.py).
+extern "C" wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_seen, uint64_t* drained, uint32_t n_tracks) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  if (edits_seen) *edits_seen = e->hs.render_edit_seq;
+  if (drained) {
+    if (n_tracks > e->hs.n_tracks()) return WBX_ERR_INVALID;
+    for (uint32_t t = 0; t < n_tracks; t++) drained[t] = e->hs.tracks[t]->drained;
+  }
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out, size_t cap, size_t* n_out) {
+  if (!e || !n_out) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  wbx_ctx* c = e->ctx;
+  if (c->last_K == 0) return efail(e, WBX_ERR_FAILED, "nothing rendered");
+  const uint32_t K = c->last_K, N = c->last_N;
+  uint32_t pc[4] = {0, 0, 0, 0};
+  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
+  std::vector<DRow> rows((size_t)K * N);
+  const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);
+  std::vector<DTrackBlock> tmpl(nt);
+  if (!rows.empty()) WBX_EHIP(e, hipMemcpy(rows.data(), PB(c).prows.p, rows.size() * sizeof(DRow), hipMemcpyDeviceToHost));
+  if (nt) WBX_EHIP(e, hipMemcpy(tmpl.data(), PB(c).tmpl.p, nt * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+  // templates the pre-render pass rewrote: put the sequencer's originals back
+  const uint32_t ng = std::min(pc[2], PB(c).gen_cap);
+  if (ng) {
+    std::vector<uint32_t> idx(ng);
+    std::vector<DTrackBlock> saved(ng);
+    WBX_EHIP(e, hipMemcpy(idx.data(), PB(c).gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    WBX_EHIP(e, hipMemcpy(saved.data(), PB(c).saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < ng; i++)
+      if (idx[i] < tmpl.size()) tmpl[idx[i]] = saved[i];
+  }
+  const uint32_t used = std::min(pc[0], PB(c).pool_chunks);
+  std::vector<DSeg> pool((size_t)used * kChunk);
+  if (used) WBX_EHIP(e, hipMemcpy(pool.data(), PB(c).pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
+  const size_t n = plan_records(K, N, rows.data(), tmpl.data(), tmpl.size(), pool.data(), used, out, cap);
+  *n_out = n;
+  if (pc[1] & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow");
+  if (pc[1] & 16u) return efail(e, WBX_ERR_OVERFLOW, "plan template array full");
+  return WBX_OK;
+}

@@ -46,55 +46,11 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
   // exactly the arithmetic of Engine::process (engine.cpp:1578-1585 per block, :1619-1623 between blocks).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   DBlockTime* s_times = reinterpret_cast<DBlockTime*>(s_raw);
-  if (threadIdx.x == 0) {
-    double playhead = a.playhead, sample_position = a.sample_position;
-    for (uint32_t i = 0; i < a.n_blocks; i++) {
-      const double buffer_duration = (double)a.block_frames / a.sample_rate;            // :1578
-      const double buffer_duration_in_beats = buffer_duration / a.beat_duration;       // :1581
-      const double next_playhead_pos = playhead + buffer_duration_in_beats;            // :1582
-      s_times[i] = DBlockTime{playhead, next_playhead_pos, sample_position, a.beat_duration};
-      if (a.playing) {
-        sample_position += beat_to_samples(buffer_duration_in_beats, a.sample_rate, a.beat_duration);   // :1620
-        playhead = next_playhead_pos;                                                                   // :1621
-      }
-    }
-  }
+  if (threadIdx.x == 0) block_times(a, s_times);
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.n_tracks) return;
-  DTrackState st = a.state[t];
-  if (a.patch) {
-    const DPatch p = a.patch[t];
-    if (p.flags & PATCH_CLIPIDX) {   // Track::reset_playback_state(time, false), track.cpp:220-232
-      st.has_clip_idx = p.has_clip_idx;
-      st.clip_idx = p.clip_idx;
-      st.partially_ended = 0;
-    }
-    if (p.flags & PATCH_REFRESH) st.refresh_voice = p.refresh_voice;
-    if (p.flags & PATCH_STOP) st.cur_type = EV_NONE;   // Track::stop, track.cpp:249-256
-  }
-  const uint32_t c0 = a.clip_first[t];
-  const uint32_t nc = a.clip_first[t + 1] - c0;
-  DClip* clips = const_cast<DClip*>(a.clips) + c0;
-  if (a.clips_changed && st.cur_type == EV_PLAY) {
-    // the reference reads current_audio_event.clip->audio.gain at every stream call (track.cpp:676,716):
-    // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity
-    for (uint32_t i = 0; i < nc; i++)
-      if (clips[i].uid == st.cur_clip_uid) st.cur_gain = clips[i].gain;
-  }
-  TrackCache cache;
-  cache.clip_idx = 0xFFFFFFFFu;
-  cache.smp_idx = 0xFFFFFFFFu;
-  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
-  uint32_t b = 0;
-  while (b < a.n_blocks) {
-    b += plan_steady_run(a, t, b, &st, nc, &cache, s_times, gl, gr);   // tight loop over the common case
-    if (b < a.n_blocks) {
-      plan_track_block(a, t, b, &st, clips, nc, &cache, s_times[b], gl, gr);
-      b++;
-    }
-  }
-  a.state[t] = st;
+  plan_track(a, t, s_times);   // wbx_seq.h: the same source runs on the host in the CPU-side tests
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1302,11 +1258,30 @@ __global__ __launch_bounds__(256) void clamp_into_kernel(const float* __restrict
   }
 }
 
+// float -> int32 as the reference's x86 build converts (cvttss2si / cvttsd2si): truncation toward zero, and the
+// "integer indefinite" 0x80000000 for NaN and for anything outside [-2^31, 2^31) — the GPU's own conversion saturates
+// and maps NaN to 0, which differs whenever the master is left un-clamped or holds NaN.
+__device__ __forceinline__ int x86_cvtt_f32(float t) { return (t >= -2147483648.0f && t < 2147483648.0f) ? (int)t : (int)0x80000000; }
+__device__ __forceinline__ int x86_cvtt_f64(double t) { return (t >= -2147483648.0 && t < 2147483648.0) ? (int)t : (int)0x80000000; }
+
 // planar fp32 master [K][C][F] -> interleaved device-format samples [K*F][C]; reference
-// core/audio_format_conv.cpp:5-20 (i16), :45-60 (i24 in 32-bit containers), :62-77 (i32), :79-91 (f32)
+// core/audio_format_conv.cpp:5-20 (i16), :45-60 (i24 in 32-bit containers), :62-77 (i32), :79-91 (f32).
+// Packed 24-bit (:22-43): the reference's writer has no channel term in its destination index, so what a block's
+// conversion leaves is the LAST channel, 3 bytes per frame at byte 3*frame — dst is [K][F][3] here.
 __global__ __launch_bounds__(256) void convert_kernel(const float* master, void* dst, uint32_t n_blocks, uint32_t F,
                                                       uint32_t C, int fmt) {
-  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;   // index into [K*F][C]
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;   // index into [K*F][C]  (packed 24-bit: [K*F])
+  if (fmt == 5) {
+    if (i >= (size_t)n_blocks * F) return;
+    const uint32_t b = (uint32_t)(i / F), j = (uint32_t)(i % F);
+    const float v = master[((size_t)b * C + (C - 1u)) * F + j];
+    const int q = v > 0.0f ? x86_cvtt_f32(__fmul_rn(v, 8388607.0f)) : x86_cvtt_f32(__fmul_rn(v, 8388608.0f));
+    uint8_t* o = (uint8_t*)dst + i * 3u;
+    o[0] = (uint8_t)q;
+    o[1] = (uint8_t)(q >> 8);
+    o[2] = (uint8_t)(q >> 16);
+    return;
+  }
   const size_t total = (size_t)n_blocks * F * C;
   if (i >= total) return;
   const uint32_t c = (uint32_t)(i % C);
@@ -1314,14 +1289,14 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* master, void*
   const uint32_t b = (uint32_t)(frame / F), j = (uint32_t)(frame % F);
   const float v = master[((size_t)b * C + c) * F + j];
   switch (fmt) {
-    case 3: ((int16_t*)dst)[i] = (int16_t)(int)(v > 0.0f ? __fmul_rn(v, 32767.0f) : __fmul_rn(v, 32768.0f)); break;
+    case 3: ((int16_t*)dst)[i] = (int16_t)x86_cvtt_f32(v > 0.0f ? __fmul_rn(v, 32767.0f) : __fmul_rn(v, 32768.0f)); break;
     case 6: {
-      const int q = v > 0.0f ? (int)__fmul_rn(v, 8388607.0f) : (int)__fmul_rn(v, 8388608.0f);
+      const int q = v > 0.0f ? x86_cvtt_f32(__fmul_rn(v, 8388607.0f)) : x86_cvtt_f32(__fmul_rn(v, 8388608.0f));
       ((int32_t*)dst)[i] = q & 0xFFFFFF;
       break;
     }
     case 7:
-      ((int32_t*)dst)[i] = (int32_t)(v > 0.0f ? __dmul_rn((double)v, 2147483647.0) : __dmul_rn((double)v, 2147483648.0));
+      ((int32_t*)dst)[i] = x86_cvtt_f64(v > 0.0f ? __dmul_rn((double)v, 2147483647.0) : __dmul_rn((double)v, 2147483648.0));
       break;
     default: ((float*)dst)[i] = v; break;
   }

@@ -1,203 +1,14 @@
-// wbx_runtime.hip — host side of libwbx.so: the C ABI of include/wbx.h over the gfx950 kernels.
-//
-//   layer 1 (wbx_ctx)     clip pool in HBM, routing, plan upload, launches, result fetch
-//   layer 2 (wbx_engine)  the reference's Engine/Track surface: host keeps what the UI thread edits
-//                         (clip lists, parameters, transport), the device keeps what the audio thread
-//                         mutates per block (sequencer + sampler state) and does all per-block work
+// wbx_runtime.hip — layer 1 of libwbx.so (wbx_ctx): clip pool in HBM, routing, plan upload, launches, result fetch.
+// Layer 2 (the engine surface) lives in wbx_engine.hip, the multi-GPU exchange in wbx_dist.hip.
 //
 // There is no CPU implementation of the mix in this library: without a gfx950 device the create calls
 // fail with WBX_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <numbers>
-#include <string>
-#include <vector>
-
-#include "../../include/wbx.h"
-#include "wbx_clip_edit.h"
-#include "wbx_dev.h"
+#include "wbx_ctx.h"
 #include "wbx_seq.h"
-
-namespace wbx {
-void launch_plan(const PlanArgs& a, hipStream_t s);
-void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
-void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);
-void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
-void launch_clamp(float* buf, size_t n, hipStream_t s);
-void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
-void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
-void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
-void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
-                         hipStream_t s);
-void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s);
-}  // namespace wbx
 
 using namespace wbx;
 
-namespace {
-
-constexpr int kEventRing = 64;
-// Plan buffers, partial-sum buffers and their events form a ring of three: the plan of render i may start as soon as
-// the mix of render i-3 and the sum of render i-3 are over, i.e. a full render before its own mix — the one-wave-per-
-// track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
-constexpr int kRing = 3;
-constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
-
-struct ClipSlot {
-  void* base = nullptr;     // one allocation holding all channels
-  size_t stride = 0;        // bytes between channel rows
-  DSample d{};
-  bool used = false;
-  // waveform mip-maps (built on request): one allocation, level l at mip_off[l], [channels][mip_count[l]] elements
-  void* mip = nullptr;
-  int mip_bits = 0;
-  std::vector<size_t> mip_off;
-  std::vector<uint64_t> mip_count;
-};
-
-template <class T>
-struct DevBuf {             // grow-only device array
-  T* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t n) {
-    if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
-    if (e == hipSuccess) cap = n;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-}  // namespace
-
-struct wbx_ctx {
-  wbx_config cfg{};
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  std::string err;
-
-  std::vector<ClipSlot> clips;
-  DevBuf<DSample> d_samples;
-  bool samples_dirty = true;
-
-  // routing
-  uint32_t routing_tracks = 0, n_buses = 0;
-  std::vector<int32_t> track_bus;
-  std::vector<uint32_t> order;
-  std::vector<DGroup> groups;
-  DevBuf<uint32_t> d_order;
-  DevBuf<DGroup> d_groups;
-  bool routing_dirty = true;
-
-  // The plan of a render (track-block records, overflow pool, pre-render queue + rows) is double-buffered:
-  // the sequencer of step i+1 runs on `plan_stream` while the mix of step i runs on `stream`.
-  struct PlanBuf {
-    DevBuf<DRow> prows;               // [K][N] 16-B plan rows
-    DevBuf<DTrackBlock> tmpl;         // templates the rows point at (one per steady run / per block with events)
-    uint32_t tmpl_cap = 0;
-    DevBuf<DSeg> pool;
-    uint32_t pool_chunks = 0;
-    uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued,
-                                      // [3] templates allocated
-    DevBuf<uint32_t> gen_list;        // pre-render queue of KIND_GENERIC records
-    DevBuf<float> rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
-    DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
-    uint32_t gen_cap = 0;
-    hipEvent_t planned = nullptr;     // recorded on plan_stream when plan + pre-render are done
-    hipEvent_t consumed = nullptr;    // (not owned) ctx->mix_done[] of the render whose mix read this buffer
-    bool consumed_valid = false;
-  } pb[kRing];
-  int cur = 0;
-  hipStream_t plan_stream = nullptr;
-  bool overlap = true;
-  DevBuf<float> d_zero;               // zero page (F+8 floats)
-  uint32_t* levels_target = nullptr;  // [N][C] running per-track maxima (VUMeter::level), or null
-  DevBuf<float> d_partial2[kRing];    // group partials, one per render in flight (a sum may still read an older one)
-  DevBuf<float> d_master, d_buses, d_peaks, d_gains;
-  // The sum of render i runs on its own stream beside the mix of render i+1 (it is PCIe-bound when the master goes to
-  // host memory and needs few CUs).  sum_pending: a sum has been issued that the main stream has not waited for yet.
-  hipStream_t sum_stream = nullptr;
-  hipEvent_t mix_done[kRing] = {}, sum_done[kRing] = {};
-  bool sum_valid[kRing] = {};
-  int sum_pending = -1;
-  uint32_t render_seq = 0;
-  bool partial_wait_done = false;     // the caller already ordered this render after the sum of two renders ago
-  bool sum_overlap = true;            // WBX_SUM_OVERLAP=0: sum on the main stream
-  DevBuf<uint8_t> d_conv;
-  std::vector<DTrackBlock> h_tb;      // layer-1 staging
-  std::vector<DRow> h_rows;
-  std::vector<DSeg> h_pool;
-
-  uint32_t last_K = 0, last_N = 0;
-  uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
-  bool buses_alias_partials = false;  // see build_routing
-  const float* last_buses = nullptr;  // where the last render's bus sums are: d_buses or the partial buffer
-  bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation
-  float* last_master = nullptr;       // where the last render / submit put its master (d_master, the caller's target, or
-  bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
-  bool clamp = true;
-  float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
-
-  // kernel timing (mix kernel)
-  hipEvent_t ev[kEventRing][3]{};       // before the mix, after the mix, after the sum
-  int ev_pending = 0;
-  double mix_ms_total = 0.0;
-  double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
-  uint64_t mix_launches = 0;
-  bool profiling = true;
-  int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
-                                      // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
-  bool has_window_clips = true;
-  bool has_integer_clips = false;
-  bool force_g = false;
-  bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
-};
-
-namespace {
-
-inline wbx_ctx::PlanBuf& PB(wbx_ctx* c) { return c->pb[c->cur]; }
-
-wbx_status fail(wbx_ctx* c, wbx_status s, const char* what, hipError_t e = hipSuccess) {
-  if (c) {
-    c->err = what;
-    if (e != hipSuccess) {
-      c->err += ": ";
-      c->err += hipGetErrorString(e);
-    }
-  }
-  return s;
-}
-
-#define WBX_HIP(ctx, call)                                                  \
-  do {                                                                      \
-    hipError_t _e = (call);                                                 \
-    if (_e != hipSuccess) return fail((ctx), WBX_ERR_DEVICE, #call, _e);    \
-  } while (0)
-
-size_t fmt_bytes(int fmt) {
-  switch (fmt) {
-    case WBX_FMT_I16: return 2;
-    case WBX_FMT_I24:
-    case WBX_FMT_I32:
-    case WBX_FMT_F32: return 4;
-    default: return 0;
-  }
-}
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+namespace wbx {
 
 // make the main stream wait for the sum that is still running beside it (device-side; a following
 // hipStreamSynchronize(c->stream) then covers it)
@@ -452,7 +263,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   return WBX_OK;
 }
 
-}  // namespace
+}  // namespace wbx
 
 // =================================================================================================
 // library
@@ -551,6 +362,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     for (int i = 0; i < kRing && ok; i++)
       ok = hipEventCreateWithFlags(&c->mix_done[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
@@ -601,6 +413,8 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   }
   if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
   if (c->sum_stream) (void)hipStreamDestroy(c->sum_stream);
+  if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+  if (c->ready_ev) (void)hipEventDestroy(c->ready_ev);
   for (int i = 0; i < kRing; i++) {
     if (c->mix_done[i]) (void)hipEventDestroy(c->mix_done[i]);
     if (c->sum_done[i]) (void)hipEventDestroy(c->sum_done[i]);
@@ -623,23 +437,29 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
 
 extern "C" const char* wbx_last_error(const wbx_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
-static wbx_status clip_alloc(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
-                             uint64_t frames, size_t* stride_out) {
-  if (!c) return WBX_ERR_INVALID;
+namespace wbx {
+
+void clip_release(ClipSlot& s) {
+  if (s.base) (void)hipFree(s.base);
+  if (s.mip) (void)hipFree(s.mip);
+  s = ClipSlot{};
+}
+
+// Clip audio -> a fresh slot `s` (not yet visible to any render): allocation, the 16 zero frames of tail padding
+// (Sample::sample_padding, sample.cpp:127,140) and the fill, all enqueued on `on`.  Touches nothing of the ctx but
+// its error string, so layer 2 can run it outside the editor lock on the upload stream.
+wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
+                      const ClipFill& f, hipStream_t on) {
   const size_t eb = fmt_bytes(format);
   if (!eb) return fail(c, WBX_ERR_UNSUPPORTED, "clip format");
   if (channels < 1 || channels > 2) return fail(c, WBX_ERR_UNSUPPORTED, "clip channel count (1 or 2)");
   if (frames >= 2147483632ull) return fail(c, WBX_ERR_UNSUPPORTED, "clip longer than 2^31-16 frames");
-  if (clip >= (1u << 24)) return fail(c, WBX_ERR_INVALID, "clip id");
+  if (f.kind == CLIP_SRC_PLANAR && !f.planar) return WBX_ERR_INVALID;
+  if ((f.kind == CLIP_SRC_INTERLEAVED_HOST || f.kind == CLIP_SRC_INTERLEAVED_DEVICE) && !f.interleaved && frames) return WBX_ERR_INVALID;
+  if (f.kind == CLIP_SRC_INTERLEAVED_DEVICE && ((uintptr_t)f.interleaved & 15u))
+    return fail(c, WBX_ERR_INVALID, "interleaved device buffer must be 16-byte aligned");
   (void)hipSetDevice(c->cfg.device);
-  if (clip >= c->clips.size()) c->clips.resize(clip + 1);
-  ClipSlot& s = c->clips[clip];
-  if (s.base) {
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(s.base);
-    if (s.mip) (void)hipFree(s.mip);
-    s = ClipSlot{};
-  }
+  s = ClipSlot{};
   const size_t stride = align_up((frames + kPad) * eb, 256);
   WBX_HIP(c, hipMalloc(&s.base, stride * channels));
   s.d.ch[0] = s.base;
@@ -650,105 +470,143 @@ static wbx_status clip_alloc(wbx_ctx* c, uint32_t clip, int format, uint32_t cha
   s.d.sample_rate = sample_rate;
   s.used = true;
   s.stride = stride;
-  c->samples_dirty = true;
-  *stride_out = stride;
+  hipError_t err = hipSuccess;
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t freed[2] = {nullptr, nullptr};
+  auto pad_tails = [&]() {   // the padding frames (and the alignment slack) read as zero
+    for (uint32_t ch = 0; ch < channels && err == hipSuccess; ch++)
+      err = hipMemsetAsync((char*)s.base + stride * ch + frames * eb, 0, stride - frames * eb, on);
+  };
+  switch (f.kind) {
+    case CLIP_SRC_PLANAR:
+      pad_tails();
+      for (uint32_t ch = 0; ch < channels && err == hipSuccess; ch++)
+        err = hipMemcpyAsync((char*)s.base + stride * ch, f.planar[ch], frames * eb, hipMemcpyHostToDevice, on);
+      if (err == hipSuccess) err = hipStreamSynchronize(on);   // the caller's arrays may go away
+      break;
+    case CLIP_SRC_SYNTH:
+      for (uint32_t ch = 0; ch < channels; ch++) {
+        const uint64_t key = f.seed ^ ((uint64_t)f.key_track << 40) ^ ((uint64_t)ch << 32);
+        launch_synth((char*)s.base + stride * ch, frames, key, f.amp, format, on);   // writes the padding as well
+      }
+      err = hipGetLastError();
+      break;
+    case CLIP_SRC_INTERLEAVED_DEVICE:
+      pad_tails();
+      if (err == hipSuccess) {
+        launch_deinterleave(f.interleaved, s.base, (char*)s.base + (channels > 1 ? stride : 0), frames, channels, (uint32_t)eb, on);
+        err = hipGetLastError();
+      }
+      break;
+    default: {   // CLIP_SRC_INTERLEAVED_HOST
+      pad_tails();
+      // chunks of the decoder's interleaved output go host -> device staging -> transposed into the channel rows;
+      // two staging buffers so the copy of chunk i+1 overlaps the transposition of chunk i
+      const uint64_t chunk_frames = (uint64_t)4 << 20;   // a multiple of 4 frames: lane groups never straddle chunks
+      const size_t chunk_bytes = (size_t)chunk_frames * channels * eb;
+      const int nstage = frames > chunk_frames ? 2 : 1;
+      for (int i = 0; i < nstage && err == hipSuccess; i++) {
+        err = hipMalloc(&stage[i], std::min<size_t>(chunk_bytes, std::max<size_t>(16, (size_t)frames * channels * eb)));
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&freed[i], hipEventDisableTiming);
+      }
+      uint64_t done = 0;
+      for (int i = 0; done < frames && err == hipSuccess; i++) {
+        const uint64_t n = std::min<uint64_t>(chunk_frames, frames - done);
+        const int b = i % nstage;
+        if (i >= nstage) err = hipEventSynchronize(freed[b]);
+        if (err == hipSuccess)
+          err = hipMemcpyAsync(stage[b], (const char*)f.interleaved + (size_t)done * channels * eb, (size_t)n * channels * eb,
+                               hipMemcpyHostToDevice, on);
+        if (err == hipSuccess) {
+          launch_deinterleave(stage[b], (char*)s.base + (size_t)done * eb,
+                              (char*)s.base + (channels > 1 ? stride : 0) + (size_t)done * eb, n, channels, (uint32_t)eb, on);
+          err = hipEventRecord(freed[b], on);
+        }
+        done += n;
+      }
+      if (err == hipSuccess) err = hipStreamSynchronize(on);
+      else (void)hipStreamSynchronize(on);   // nothing may still read the staging buffers freed below
+      for (int i = 0; i < 2; i++) {
+        if (stage[i]) (void)hipFree(stage[i]);
+        if (freed[i]) (void)hipEventDestroy(freed[i]);
+      }
+      break;
+    }
+  }
+  if (err != hipSuccess) {
+    (void)hipStreamSynchronize(on);
+    clip_release(s);
+    return fail(c, WBX_ERR_DEVICE, "clip upload", err);
+  }
   return WBX_OK;
+}
+
+// make slot `clip` of the pool hold `s` (an earlier clip of that id is freed once the device is done with it)
+wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s) {
+  if (clip >= (1u << 24)) {
+    clip_release(s);
+    return fail(c, WBX_ERR_INVALID, "clip id");
+  }
+  if (clip >= c->clips.size()) c->clips.resize(clip + 1);
+  ClipSlot& dst = c->clips[clip];
+  if (dst.base) {
+    (void)hipStreamSynchronize(c->plan_stream);
+    (void)join_sum(c);
+    (void)hipStreamSynchronize(c->stream);
+    clip_release(dst);
+  }
+  dst = std::move(s);
+  s = ClipSlot{};
+  c->samples_dirty = true;
+  return WBX_OK;
+}
+
+}  // namespace wbx
+
+static wbx_status clip_create(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
+                              const ClipFill& f) {
+  if (!c) return WBX_ERR_INVALID;
+  if (clip >= (1u << 24)) return fail(c, WBX_ERR_INVALID, "clip id");
+  ClipSlot s;
+  wbx_status st = clip_build(c, s, format, channels, sample_rate, frames, f, c->stream);
+  if (st != WBX_OK) return st;
+  return clip_publish(c, clip, s);
 }
 
 extern "C" wbx_status wbx_clip_upload(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
                                       uint64_t frames, const void* const* planar) {
   if (!c || !planar) return WBX_ERR_INVALID;
-  size_t stride = 0;
-  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
-  if (st != WBX_OK) return st;
-  const size_t eb = fmt_bytes(format);
-  ClipSlot& s = c->clips[clip];
-  WBX_HIP(c, hipMemsetAsync(s.base, 0, stride * channels, c->stream));   // the 16 padding frames read as zero
-  for (uint32_t ch = 0; ch < channels; ch++)
-    WBX_HIP(c, hipMemcpyAsync((char*)s.base + stride * ch, planar[ch], frames * eb, hipMemcpyHostToDevice, c->stream));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
-  return WBX_OK;
+  ClipFill f{};
+  f.kind = CLIP_SRC_PLANAR;
+  f.planar = planar;
+  return clip_create(c, clip, format, channels, sample_rate, frames, f);
 }
 
 extern "C" wbx_status wbx_clip_synth(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
                                      uint64_t frames, uint64_t seed, uint32_t key_track, float amp) {
-  if (!c) return WBX_ERR_INVALID;
-  size_t stride = 0;
-  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
-  if (st != WBX_OK) return st;
-  ClipSlot& s = c->clips[clip];
-  for (uint32_t ch = 0; ch < channels; ch++) {
-    const uint64_t key = seed ^ ((uint64_t)key_track << 40) ^ ((uint64_t)ch << 32);
-    launch_synth((char*)s.base + stride * ch, frames, key, amp, format, c->stream);
-  }
-  WBX_HIP(c, hipGetLastError());
-  return WBX_OK;
+  ClipFill f{};
+  f.kind = CLIP_SRC_SYNTH;
+  f.seed = seed;
+  f.key_track = key_track;
+  f.amp = amp;
+  return clip_create(c, clip, format, channels, sample_rate, frames, f);
 }
-
 
 // ---- clip ingest (dsp/sample.cpp:29-43, :112-197) ------------------------------------------------
 extern "C" wbx_status wbx_clip_ingest_device(wbx_ctx* c, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
                                              uint64_t frames, const void* device_interleaved) {
-  if (!c || (!device_interleaved && frames)) return WBX_ERR_INVALID;
-  if ((uintptr_t)device_interleaved & 15u) return fail(c, WBX_ERR_INVALID, "interleaved device buffer must be 16-byte aligned");
-  size_t stride = 0;
-  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
-  if (st != WBX_OK) return st;
-  const size_t eb = fmt_bytes(format);
-  ClipSlot& s = c->clips[clip];
-  // the 16 padding frames (and the alignment slack) read as zero: sample.cpp:127,140
-  for (uint32_t ch = 0; ch < channels; ch++)
-    WBX_HIP(c, hipMemsetAsync((char*)s.base + stride * ch + frames * eb, 0, stride - frames * eb, c->stream));
-  launch_deinterleave(device_interleaved, s.base, (char*)s.base + (channels > 1 ? stride : 0), frames, channels, (uint32_t)eb,
-                      c->stream);
-  WBX_HIP(c, hipGetLastError());
-  return WBX_OK;
+  ClipFill f{};
+  f.kind = CLIP_SRC_INTERLEAVED_DEVICE;
+  f.interleaved = device_interleaved;
+  return clip_create(c, clip, format, channels, sample_rate, frames, f);
 }
 
 extern "C" wbx_status wbx_clip_upload_interleaved(wbx_ctx* c, uint32_t clip, int format, uint32_t channels,
                                                   uint32_t sample_rate, uint64_t frames, const void* interleaved) {
-  if (!c || (!interleaved && frames)) return WBX_ERR_INVALID;
-  size_t stride = 0;
-  wbx_status st = clip_alloc(c, clip, format, channels, sample_rate, frames, &stride);
-  if (st != WBX_OK) return st;
-  const size_t eb = fmt_bytes(format);
-  ClipSlot& s = c->clips[clip];
-  for (uint32_t ch = 0; ch < channels; ch++)
-    WBX_HIP(c, hipMemsetAsync((char*)s.base + stride * ch + frames * eb, 0, stride - frames * eb, c->stream));
-  // chunks of the decoder's interleaved output go host -> device staging -> transposed into the channel rows;
-  // two staging buffers so the copy of chunk i+1 overlaps the transposition of chunk i
-  const uint64_t chunk_frames = (uint64_t)4 << 20;   // a multiple of 4 frames: lane groups never straddle chunks
-  const size_t chunk_bytes = (size_t)chunk_frames * channels * eb;
-  void* stage[2] = {nullptr, nullptr};
-  hipEvent_t freed[2] = {nullptr, nullptr};
-  const int nstage = frames > chunk_frames ? 2 : 1;
-  for (int i = 0; i < nstage; i++) {
-    WBX_HIP(c, hipMalloc(&stage[i], std::min<size_t>(chunk_bytes, std::max<size_t>(16, (size_t)frames * channels * eb))));
-    WBX_HIP(c, hipEventCreateWithFlags(&freed[i], hipEventDisableTiming));
-  }
-  hipError_t err = hipSuccess;
-  uint64_t done = 0;
-  for (int i = 0; done < frames && err == hipSuccess; i++) {
-    const uint64_t n = std::min<uint64_t>(chunk_frames, frames - done);
-    const int b = i % nstage;
-    if (i >= nstage) err = hipEventSynchronize(freed[b]);
-    if (err == hipSuccess)
-      err = hipMemcpyAsync(stage[b], (const char*)interleaved + (size_t)done * channels * eb, (size_t)n * channels * eb,
-                           hipMemcpyHostToDevice, c->stream);
-    if (err == hipSuccess) {
-      launch_deinterleave(stage[b], (char*)s.base + (size_t)done * eb, (char*)s.base + (channels > 1 ? stride : 0) + (size_t)done * eb,
-                          n, channels, (uint32_t)eb, c->stream);
-      err = hipEventRecord(freed[b], c->stream);
-    }
-    done += n;
-  }
-  if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
-  for (int i = 0; i < nstage; i++) {
-    (void)hipFree(stage[i]);
-    (void)hipEventDestroy(freed[i]);
-  }
-  if (err != hipSuccess) return fail(c, WBX_ERR_DEVICE, "clip ingest", err);
-  return WBX_OK;
+  ClipFill f{};
+  f.kind = CLIP_SRC_INTERLEAVED_HOST;
+  f.interleaved = interleaved;
+  return clip_create(c, clip, format, channels, sample_rate, frames, f);
 }
 
 extern "C" wbx_status wbx_clip_download(wbx_ctx* c, uint32_t clip, uint32_t channel, void* dst) {
@@ -845,10 +703,14 @@ extern "C" wbx_status wbx_clip_fetch_mipmap(wbx_ctx* c, uint32_t clip, uint32_t 
 
 extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
   if (!c || clip >= c->clips.size() || !c->clips[clip].base) return WBX_ERR_INVALID;
+  // layer 2: a clip list that still names the sample would make the sequencer hand the mix a dangling pointer
+  if (c->sample_in_use && c->sample_in_use(c->owner, clip))
+    return fail(c, WBX_ERR_INVALID, "sample is still referenced by a clip (delete the clips first)");
+  (void)hipSetDevice(c->cfg.device);
+  WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
+  WBX_HIP(c, join_sum(c));
   WBX_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(c->clips[clip].base);
-  if (c->clips[clip].mip) (void)hipFree(c->clips[clip].mip);
-  c->clips[clip] = ClipSlot{};
+  clip_release(c->clips[clip]);
   c->samples_dirty = true;
   return WBX_OK;
 }
@@ -907,6 +769,9 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     for (uint32_t i = s0; i < s1; i++) {
       const wbx_segment& sg = segs[i];
       if (sg.clip >= c->clips.size() || !c->clips[sg.clip].used) return fail(c, WBX_ERR_INVALID, "segment names an unknown clip");
+      // the ABI is the trust boundary: a negative / NaN position or a non-positive / NaN speed would index outside the clip
+      if (!(sg.sample_offset >= 0.0) || !(sg.playback_speed > 0.0) || !(sg.playback_speed < 1e12))
+        return fail(c, WBX_ERR_INVALID, "segment needs sample_offset >= 0 and 0 < playback_speed < 1e12");
       // the prologue of Sampler::stream (sampler.cpp:99-104) through the shared walker
       DTrackState ts{};
       ts.cur_type = EV_PLAY;
@@ -918,7 +783,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
       BlockWalker w{};
       DTrackBlock scratch{};
       TrackCache tc{};
-      tc.clip_idx = tc.smp_idx = 0xFFFFFFFFu;
+      tc.clip_idx = tc.smp_idx = tc.fin_tmpl = 0xFFFFFFFFu;
       uint32_t pc = 0, stbits = 0;
       w.st = &ts;
       w.cache = &tc;
@@ -989,6 +854,30 @@ extern "C" wbx_status wbx_sync(wbx_ctx* c) {
   return WBX_OK;
 }
 
+extern "C" wbx_status wbx_master_ready(wbx_ctx* c, void* stream) {
+  if (!c) return WBX_ERR_INVALID;
+  hipStream_t on = stream ? (hipStream_t)stream : c->stream;
+  if (on == c->stream) {
+    WBX_HIP(c, join_sum(c));
+    return WBX_OK;
+  }
+  if (c->sum_pending >= 0) {   // the sum runs on its own stream: its event orders any stream
+    WBX_HIP(c, hipStreamWaitEvent(on, c->sum_done[c->sum_pending], 0));
+  } else {                     // everything is on the main stream: mark where it stands now
+    if (!c->ready_ev) WBX_HIP(c, hipEventCreateWithFlags(&c->ready_ev, hipEventDisableTiming));
+    WBX_HIP(c, hipEventRecord(c->ready_ev, c->stream));
+    WBX_HIP(c, hipStreamWaitEvent(on, c->ready_ev, 0));
+  }
+  return WBX_OK;
+}
+
+wbx_status wbx::plan_status_to_error(wbx_ctx* c, uint32_t bits) {
+  if (bits & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
+  if (bits & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
+  if (bits & 16u) return fail(c, WBX_ERR_OVERFLOW, "plan template array full");
+  return WBX_OK;
+}
+
 extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* peaks, float* buses) {
   if (!c) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
@@ -1015,10 +904,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   drain_events(c);
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_HIP(c, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
-  if (pc[1] & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
-  if (pc[1] & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
-  if (pc[1] & 16u) return fail(c, WBX_ERR_OVERFLOW, "plan template array full");
-  return WBX_OK;
+  return plan_status_to_error(c, pc[1]);
 }
 
 extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* dst) {
@@ -1028,12 +914,23 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
   size_t eb;
   switch (out_format) {
     case WBX_OUT_I16: eb = 2; break;
+    case WBX_OUT_I24: eb = 3; break;
     case WBX_OUT_I24_X8:
     case WBX_OUT_I32:
     case WBX_OUT_F32: eb = 4; break;
     default: return fail(c, WBX_ERR_UNSUPPORTED, "interleaved output format");
   }
   const uint32_t K = c->last_K, C = c->cfg.channels, F = c->cfg.block_frames;
+  if (out_format == WBX_OUT_I24) {
+    // convert_f32_to_interleaved_i24 (audio_format_conv.cpp:22-43) writes byte 3*i.. of EVERY channel's sample i — the
+    // destination index has no channel term — so per converted block the last channel's packed samples fill bytes
+    // [0, 3F) and the remaining 3F(C-1) bytes of the block's region are never touched: reproduced as written
+    WBX_HIP(c, c->d_conv.ensure((size_t)K * F * 3));
+    launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);
+    WBX_HIP(c, hipMemcpy2DAsync(dst, (size_t)F * C * 3, c->d_conv.p, (size_t)F * 3, (size_t)F * 3, K, hipMemcpyDeviceToHost, c->stream));
+    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    return WBX_OK;
+  }
   const size_t bytes = (size_t)K * F * C * eb;
   WBX_HIP(c, c->d_conv.ensure(bytes));
   launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);   // pinned staging is device-readable too
@@ -1092,917 +989,5 @@ extern "C" wbx_status wbx_tail_time(wbx_ctx* c, double* tail_ms_avg) {
   WBX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   *tail_ms_avg = c->mix_launches ? c->tail_ms_total / (double)c->mix_launches : 0.0;
-  return WBX_OK;
-}
-
-// =================================================================================================
-// layer 2: the engine surface
-// =================================================================================================
-namespace {
-
-enum : uint32_t { PARAM_VOLUME = 0, PARAM_PAN = 1, PARAM_MUTE = 2 };   // reference TrackParameter, track.h:29-34
-
-struct ParamMsg {
-  uint32_t id;
-  double value;
-};
-
-struct HostTrack {
-  std::vector<HostClip> clips;         // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
-  float volume = 0.0f, pan = 0.0f, pan_coeffs[2] = {0.0f, 0.0f};
-  bool mute = false;
-  bool ui_solo = false;                 // ui_parameter_state.solo (track.h:52)
-  std::vector<ParamMsg> msgs;          // TrackMessage::ParamChange ring (track.h:131), drained at the next block
-  int32_t bus = -1;
-  DPatch patch{};
-};
-
-// math::db_to_linear<float>, reference core/core_math.h:83-89
-float db_to_linear(float x) {
-  if (x <= -72.0f) return 0.0f;
-  return std::pow(10.0f, (float)((double)x * 0.05));
-}
-
-// calculate_panning_coefs(p, ConstantPower_3db), reference core/panning_law.cpp:9-32
-void pan_constant_power_3db(float p, float* l, float* r) {
-  double x = 0.5 * ((double)p + 1.0);
-  double left = std::sin(0.5 * std::numbers::pi * (1.0 - x));
-  double right = std::sin(0.5 * std::numbers::pi * x);
-  double boost = std::sqrt(2.0);
-  *l = (float)(left * boost);
-  *r = (float)(right * boost);
-}
-
-}  // namespace
-
-struct wbx_engine {
-  wbx_ctx* ctx = nullptr;
-  std::string err;
-  std::vector<HostTrack> tracks;
-  uint32_t n_buses = 0;
-  double ppq = 96.0;                    // engine.h:43
-  double playhead = 0.0, playhead_start = 0.0, sample_position = 0.0, beat_duration = 0.5;
-  bool playing = false;
-  bool clips_dirty = true, gains_dirty = true, routing_dirty = true, patches_pending = false;
-  bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (speed > 4096)
-  bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
-  bool any_stride_clip = false;         // a clip read with per-frame taps: fp32 played faster than recorded (speed > 0.999, != 1), resampled integer PCM
-  size_t total_clips = 0;
-  uint32_t next_clip_uid = 0;
-  // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
-  // and the plan status lands in — the callback path then needs no copy-engine transfer at all
-  DPatch* h_patch[kRing] = {};          // pinned patch buffers the plan kernel reads in place
-  uint32_t patch_cap[kRing] = {};
-  hipEvent_t patch_done[kRing] = {};    // the plan kernel that read the buffer
-  bool patch_valid[kRing] = {};
-  uint32_t patch_seq = 0;
-  float* h_block = nullptr;             // [C][F]
-  uint32_t* h_status = nullptr;         // plan counters [4]
-  size_t d_clips_count = 0;
-  bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
-  bool clips_edited = false;            // a clip list changed since the previous plan (PlanArgs::clips_changed)
-  uint32_t state_tracks = 0;            // tracks that have device state
-
-  DevBuf<DClip> d_clips;
-  DevBuf<uint32_t> d_clip_first;
-  DevBuf<DTrackState> d_state;
-  DevBuf<DPatch> d_patch;
-  DevBuf<float> d_gains, d_levels;
-};
-
-namespace {
-
-wbx_status efail(wbx_engine* e, wbx_status s, const char* what) {
-  if (e) e->err = what;
-  return s;
-}
-
-#define WBX_EHIP(e, call)                                      \
-  do {                                                         \
-    hipError_t _e = (call);                                    \
-    if (_e != hipSuccess) {                                    \
-      (e)->err = std::string(#call) + ": " + hipGetErrorString(_e); \
-      return WBX_ERR_DEVICE;                                   \
-    }                                                          \
-  } while (0)
-
-// Track::find_next_clip over the host copy (track.cpp:182-213)
-bool host_find_next_clip(const HostTrack& t, double time_pos, uint32_t* idx) {
-  if (t.clips.empty()) return false;
-  if (t.clips.back().d.max_time < time_pos) return false;
-  *idx = edit::lower_bound_max(t.clips, time_pos);
-  return true;
-}
-
-// Track::reset_playback_state, track.cpp:220-232
-void reset_playback_state(wbx_engine* e, HostTrack& t, double time_pos, bool refresh_voices) {
-  if (!refresh_voices) {
-    uint32_t idx = 0;
-    bool has = host_find_next_clip(t, time_pos, &idx);
-    t.patch.flags |= PATCH_CLIPIDX;
-    t.patch.has_clip_idx = has ? 1u : 0u;
-    t.patch.clip_idx = idx;
-  }
-  t.patch.flags |= PATCH_REFRESH;
-  t.patch.refresh_voice = refresh_voices ? 1u : 0u;
-  e->patches_pending = true;
-}
-
-// bookkeeping shared by every clip-list edit: which clips the hot loop can stream directly
-void note_clip(wbx_engine* e, const DClip& c);
-
-// after a clip-list edit: Track::update_clip_ordering + reset_playback_state(playhead, true)
-void finish_edit(wbx_engine* e, HostTrack& t);
-
-}  // namespace
-
-extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out) {
-  if (!cfg || !out) return WBX_ERR_INVALID;
-  *out = nullptr;
-  wbx_ctx* c = nullptr;
-  wbx_status st = wbx_create(cfg, &c);
-  if (st != WBX_OK) return st;
-  wbx_engine* e = new (std::nothrow) wbx_engine();
-  if (!e) {
-    wbx_destroy(c);
-    return WBX_ERR_OOM;
-  }
-  e->ctx = c;
-  *out = e;
-  return WBX_OK;
-}
-
-extern "C" void wbx_engine_destroy(wbx_engine* e) {
-  if (!e) return;
-  if (e->ctx) {
-    (void)hipSetDevice(e->ctx->cfg.device);
-    (void)hipStreamSynchronize(e->ctx->stream);
-  }
-  e->d_clips.release();
-  e->d_clip_first.release();
-  e->d_state.release();
-  e->d_patch.release();
-  e->d_gains.release();
-  e->d_levels.release();
-  for (int i = 0; i < kRing; i++) {
-    if (e->h_patch[i]) (void)hipHostFree(e->h_patch[i]);
-    if (e->patch_done[i]) (void)hipEventDestroy(e->patch_done[i]);
-  }
-  if (e->h_block) (void)hipHostFree(e->h_block);
-  if (e->h_status) (void)hipHostFree(e->h_status);
-  wbx_destroy(e->ctx);
-  delete e;
-}
-
-extern "C" const char* wbx_engine_last_error(const wbx_engine* e) {
-  if (!e) return "null engine";
-  if (!e->err.empty()) return e->err.c_str();
-  return wbx_last_error(e->ctx);
-}
-
-extern "C" wbx_ctx* wbx_engine_ctx(wbx_engine* e) { return e ? e->ctx : nullptr; }
-
-extern "C" wbx_status wbx_engine_set_bpm(wbx_engine* e, double bpm) {   // engine.cpp:24-30
-  if (!e || !(bpm > 0.0)) return WBX_ERR_INVALID;
-  e->beat_duration = 60.0 / bpm;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_set_playhead_position(wbx_engine* e, double beat) {   // engine.cpp:32-41
-  if (!e) return WBX_ERR_INVALID;
-  e->playhead_start = beat;
-  e->playhead = beat;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_add_track(wbx_engine* e, uint32_t* track_out) {   // engine.cpp:200-208, Track::Track track.cpp:22-27
-  if (!e) return WBX_ERR_INVALID;
-  if (e->tracks.size() >= e->ctx->cfg.max_tracks) return efail(e, WBX_ERR_INVALID, "max_tracks reached");
-  e->tracks.emplace_back();
-  const uint32_t t = (uint32_t)e->tracks.size() - 1;
-  wbx_track_set_volume(e, t, 0.0f);
-  wbx_track_set_pan(e, t, 0.0f);
-  wbx_track_set_mute(e, t, 0);
-  e->clips_dirty = e->routing_dirty = e->gains_dirty = true;
-  if (track_out) *track_out = t;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_set_buses(wbx_engine* e, uint32_t n_buses) {
-  if (!e) return WBX_ERR_INVALID;
-  e->n_buses = n_buses;
-  e->routing_dirty = true;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_track_set_volume(wbx_engine* e, uint32_t t, float db) {   // track.cpp:47-57
-  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
-  e->tracks[t].msgs.push_back({PARAM_VOLUME, (double)db_to_linear(db)});
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_track_set_pan(wbx_engine* e, uint32_t t, float pan) {   // track.cpp:59-68
-  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
-  e->tracks[t].msgs.push_back({PARAM_PAN, (double)pan});
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_track_set_mute(wbx_engine* e, uint32_t t, int mute) {   // track.cpp:70-79
-  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
-  e->tracks[t].msgs.push_back({PARAM_MUTE, (double)(mute ? 1 : 0)});
-  return WBX_OK;
-}
-
-namespace {
-
-// new track i = old track order[i] (order.size() = new track count): the per-track device state (sequencer,
-// sampler, running levels) follows its Track object, as the pointers in the reference's vector do
-wbx_status permute_tracks(wbx_engine* e, const std::vector<uint32_t>& order) {
-  wbx_ctx* c = e->ctx;
-  (void)hipSetDevice(c->cfg.device);
-  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-  WBX_EHIP(e, join_sum(c));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  const uint32_t old_n = (uint32_t)e->tracks.size(), new_n = (uint32_t)order.size();
-  if (e->state_tracks) {
-    const uint32_t C = c->cfg.channels;
-    std::vector<DTrackState> st(e->state_tracks), st2(std::max<size_t>(new_n, 1));
-    std::vector<float> lv((size_t)e->state_tracks * C), lv2((size_t)std::max<uint32_t>(new_n, 1) * C, 0.0f);
-    WBX_EHIP(e, hipMemcpy(st.data(), e->d_state.p, st.size() * sizeof(DTrackState), hipMemcpyDeviceToHost));
-    WBX_EHIP(e, hipMemcpy(lv.data(), e->d_levels.p, lv.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < new_n; i++) {
-      if (order[i] < e->state_tracks) {
-        st2[i] = st[order[i]];
-        for (uint32_t ch = 0; ch < C; ch++) lv2[(size_t)i * C + ch] = lv[(size_t)order[i] * C + ch];
-      } else {
-        st2[i] = DTrackState{};   // a track added since the last render
-      }
-    }
-    WBX_EHIP(e, hipMemset(e->d_state.p, 0, e->d_state.cap * sizeof(DTrackState)));
-    WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
-    if (new_n) {
-      WBX_EHIP(e, hipMemcpy(e->d_state.p, st2.data(), (size_t)new_n * sizeof(DTrackState), hipMemcpyHostToDevice));
-      WBX_EHIP(e, hipMemcpy(e->d_levels.p, lv2.data(), (size_t)new_n * C * sizeof(float), hipMemcpyHostToDevice));
-    }
-    e->state_tracks = new_n;
-  }
-  std::vector<HostTrack> moved(new_n);
-  for (uint32_t i = 0; i < new_n; i++) moved[i] = std::move(e->tracks[order[i]]);
-  e->tracks = std::move(moved);
-  (void)old_n;
-  e->clips_dirty = e->gains_dirty = e->routing_dirty = true;
-  e->total_clips = 0;
-  for (auto& tr : e->tracks) e->total_clips += tr.clips.size();
-  return WBX_OK;
-}
-
-}  // namespace
-
-extern "C" wbx_status wbx_engine_delete_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:210-218
-  if (!e || slot >= e->tracks.size()) return WBX_ERR_INVALID;
-  std::vector<uint32_t> order;
-  for (uint32_t i = 0; i < e->tracks.size(); i++)
-    if (i != slot) order.push_back(i);
-  return permute_tracks(e, order);
-}
-
-extern "C" wbx_status wbx_engine_clear_all(wbx_engine* e) {   // engine.cpp:59-66: every track goes
-  if (!e) return WBX_ERR_INVALID;
-  return permute_tracks(e, std::vector<uint32_t>{});
-}
-
-extern "C" wbx_status wbx_engine_move_track(wbx_engine* e, uint32_t from_slot, uint32_t to_slot) {   // engine.cpp:228-243
-  if (!e || from_slot >= e->tracks.size() || to_slot >= e->tracks.size()) return WBX_ERR_INVALID;
-  if (from_slot == to_slot) return WBX_OK;
-  std::vector<uint32_t> order(e->tracks.size());
-  for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-  order.erase(order.begin() + from_slot);
-  order.insert(order.begin() + to_slot, from_slot);
-  return permute_tracks(e, order);
-}
-
-extern "C" wbx_status wbx_engine_solo_track(wbx_engine* e, uint32_t slot) {   // engine.cpp:245-262
-  if (!e || slot >= e->tracks.size()) return WBX_ERR_INVALID;
-  bool mute = false;
-  if (e->tracks[slot].ui_solo) {
-    e->tracks[slot].ui_solo = false;
-  } else {
-    e->tracks[slot].ui_solo = true;
-    wbx_track_set_mute(e, slot, 0);
-    mute = true;
-  }
-  for (uint32_t i = 0; i < e->tracks.size(); i++) {
-    if (i == slot) continue;
-    e->tracks[i].ui_solo = false;
-    wbx_track_set_mute(e, i, mute ? 1 : 0);
-  }
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_track_set_bus(wbx_engine* e, uint32_t t, int32_t bus) {
-  if (!e || t >= e->tracks.size()) return WBX_ERR_INVALID;
-  e->tracks[t].bus = bus;
-  e->routing_dirty = true;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_add_sample(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
-                                            uint64_t frames, const void* const* planar, uint32_t* sample_out) {
-  if (!e || !sample_out) return WBX_ERR_INVALID;
-  const uint32_t id = (uint32_t)e->ctx->clips.size();
-  wbx_status st = wbx_clip_upload(e->ctx, id, format, channels, sample_rate, frames, planar);
-  if (st == WBX_OK) *sample_out = id;
-  return st;
-}
-
-extern "C" wbx_status wbx_engine_add_sample_interleaved(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
-                                                        uint64_t frames, const void* interleaved, uint32_t* sample_out) {
-  if (!e || !sample_out) return WBX_ERR_INVALID;
-  const uint32_t id = (uint32_t)e->ctx->clips.size();
-  wbx_status st = wbx_clip_upload_interleaved(e->ctx, id, format, channels, sample_rate, frames, interleaved);
-  if (st == WBX_OK) *sample_out = id;
-  return st;
-}
-
-extern "C" wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
-                                                  uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
-                                                  uint32_t* sample_out) {
-  if (!e || !sample_out) return WBX_ERR_INVALID;
-  const uint32_t id = (uint32_t)e->ctx->clips.size();
-  wbx_status st = wbx_clip_synth(e->ctx, id, format, channels, sample_rate, frames, seed, key_track, amp);
-  if (st == WBX_OK) *sample_out = id;
-  return st;
-}
-
-namespace {
-
-void note_clip(wbx_engine* e, const DClip& c) {
-  const DSample& smp = e->ctx->clips[c.sample].d;
-  const double ps = ((double)smp.sample_rate / (double)e->ctx->cfg.sample_rate) * c.speed;   // sampler.h:24
-  // every block of such a clip goes through the pre-render pass (the hot loop takes playback speeds up to 4096)
-  if (!(ps > 0.0 && ps <= 4096.0)) e->any_slow_clip = true;
-  if (ps != 1.0) e->any_window_clip = true;
-  if ((ps > 0.999 || smp.format != FMT_F32) && ps != 1.0) e->any_stride_clip = true;
-}
-
-void finish_edit(wbx_engine* e, HostTrack& t) {
-  edit::update_clip_ordering(t.clips);
-  reset_playback_state(e, t, e->playhead, true);   // engine.cpp:360,395,405,416,426,437,449,459,473
-  e->clips_dirty = true;
-  e->clips_edited = true;
-  e->total_clips = 0;
-  for (auto& tr : e->tracks) e->total_clips += tr.clips.size();
-}
-
-double rate_of_sample(const wbx_engine* e, uint32_t sample) { return (double)e->ctx->clips[sample].d.sample_rate; }
-
-}  // namespace
-
-// Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461.  A clip that overlaps existing ones
-// trims, splits or deletes them through reserve_track_region (engine.cpp:478-569), as the reference does.
-extern "C" wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,
-                                                double start_offset, uint32_t sample, double speed, float gain) {
-  if (!e || track >= e->tracks.size()) return WBX_ERR_INVALID;
-  if (sample >= e->ctx->clips.size() || !e->ctx->clips[sample].used) return efail(e, WBX_ERR_INVALID, "unknown sample");
-  if (!(min_time <= max_time)) return efail(e, WBX_ERR_INVALID, "min_time > max_time");
-  HostTrack& t = e->tracks[track];
-  const bool empty = t.clips.empty();
-  const bool back = !empty && t.clips.back().d.max_time < min_time;
-  const bool front = !empty && !back && t.clips.front().d.min_time > max_time;
-  ClipQuery q{};
-  if (!empty && !back && !front && edit::query_clip_by_range(t.clips, min_time, max_time, &q))
-    edit::reserve_track_region(t.clips, q.first, q.last, min_time, max_time, 0u, e->beat_duration,
-                               [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
-  HostClip c{};
-  c.d.min_time = min_time;
-  c.d.max_time = max_time;
-  c.d.start_offset = start_offset;
-  c.d.speed = speed;
-  c.d.gain = gain;
-  c.d.sample = sample;
-  c.d.internal_state_changed = 0;
-  c.d.uid = ++e->next_clip_uid;
-  t.clips.push_back(c);
-  note_clip(e, c.d);
-  finish_edit(e, t);
-  return WBX_OK;
-}
-
-// Engine::move_clip, engine.cpp:346-363
-extern "C" wbx_status wbx_engine_move_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos) {
-  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
-  if (relative_pos == 0.0) return WBX_OK;
-  HostTrack& t = e->tracks[track];
-  const uint32_t uid = t.clips[clip].d.uid;
-  double mn, mx;
-  edit::calc_move_clip(t.clips[clip].d.min_time, t.clips[clip].d.max_time, relative_pos, 0.0, &mn, &mx);
-  ClipQuery q{};
-  if (edit::query_clip_by_range(t.clips, mn, mx, &q))
-    edit::reserve_track_region(t.clips, q.first, q.last, mn, mx, uid, e->beat_duration,
-                               [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
-  for (auto& c : t.clips)
-    if (c.d.uid == uid) {
-      c.d.min_time = mn;
-      c.d.max_time = mx;
-      c.d.internal_state_changed = 1;
-      c.flag_dirty = true;
-    }
-  finish_edit(e, t);
-  return WBX_OK;
-}
-
-// Engine::resize_clip, engine.cpp:365-398
-extern "C" wbx_status wbx_engine_resize_clip(wbx_engine* e, uint32_t track, uint32_t clip, double relative_pos,
-                                             double resize_limit, double min_length, int left_side, int shift,
-                                             int stretch) {
-  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
-  if (relative_pos == 0.0) return WBX_OK;
-  HostTrack& t = e->tracks[track];
-  const DClip c0 = t.clips[clip].d;
-  const DSample& smp = e->ctx->clips[c0.sample].d;
-  const edit::ResizeResult r =
-      edit::calc_resize_clip(c0.min_time, c0.max_time, c0.start_offset, c0.speed, (double)smp.sample_rate, (double)smp.count,
-                             relative_pos, resize_limit, min_length, c0.min_time, e->beat_duration, left_side != 0,
-                             shift != 0, stretch != 0, false);
-  ClipQuery q{};
-  if (edit::query_clip_by_range(t.clips, r.min, r.max, &q))
-    edit::reserve_track_region(t.clips, q.first, q.last, r.min, r.max, c0.uid, e->beat_duration,
-                               [&](uint32_t s2) { return rate_of_sample(e, s2); }, &e->next_clip_uid);
-  for (auto& c : t.clips)
-    if (c.d.uid == c0.uid) {
-      if (left_side)
-        c.d.min_time = r.min;
-      else
-        c.d.max_time = r.max;
-      c.d.start_offset = r.start_offset;
-      if (stretch) c.d.speed = r.speed;
-      c.d.internal_state_changed = (shift || stretch) ? 1u : 0u;
-      c.flag_dirty = true;
-      note_clip(e, c.d);
-    }
-  finish_edit(e, t);
-  return WBX_OK;
-}
-
-// Engine::delete_clip, engine.cpp:400-407
-extern "C" wbx_status wbx_engine_delete_clip(wbx_engine* e, uint32_t track, uint32_t clip) {
-  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
-  HostTrack& t = e->tracks[track];
-  t.clips[clip].deleted = true;
-  finish_edit(e, t);
-  return WBX_OK;
-}
-
-// Engine::delete_region, engine.cpp:463-475
-extern "C" wbx_status wbx_engine_delete_region(wbx_engine* e, uint32_t track, double min, double max) {
-  if (!e || track >= e->tracks.size() || !(min <= max)) return WBX_ERR_INVALID;
-  HostTrack& t = e->tracks[track];
-  ClipQuery q{};
-  if (!edit::query_clip_by_range(t.clips, min, max, &q)) return WBX_OK;
-  edit::reserve_track_region(t.clips, q.first, q.last, min, max, 0u, e->beat_duration,
-                             [&](uint32_t smp) { return rate_of_sample(e, smp); }, &e->next_clip_uid);
-  finish_edit(e, t);
-  return WBX_OK;
-}
-
-// Engine::set_clip_gain, engine.cpp:1460-1464
-extern "C" wbx_status wbx_engine_set_clip_gain(wbx_engine* e, uint32_t track, uint32_t clip, float gain) {
-  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size()) return WBX_ERR_INVALID;
-  e->tracks[track].clips[clip].d.gain = gain;
-  e->clips_dirty = true;
-  e->clips_edited = true;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_clip_count(wbx_engine* e, uint32_t track, uint32_t* count) {
-  if (!e || track >= e->tracks.size() || !count) return WBX_ERR_INVALID;
-  *count = (uint32_t)e->tracks[track].clips.size();
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_get_clip(wbx_engine* e, uint32_t track, uint32_t clip, wbx_clip_info* out) {
-  if (!e || track >= e->tracks.size() || clip >= e->tracks[track].clips.size() || !out) return WBX_ERR_INVALID;
-  const DClip& d = e->tracks[track].clips[clip].d;
-  out->min_time = d.min_time;
-  out->max_time = d.max_time;
-  out->start_offset = d.start_offset;
-  out->speed = d.speed;
-  out->gain = d.gain;
-  out->sample = d.sample;
-  return WBX_OK;
-}
-
-// the clip placement arithmetic on its own (engine/clip_edit.h:10-150), for hosts that preview an edit
-extern "C" void wbx_calc_move_clip(double clip_min, double clip_max, double relative_pos, double min_move, double* new_min,
-                                   double* new_max) {
-  edit::calc_move_clip(clip_min, clip_max, relative_pos, min_move, new_min, new_max);
-}
-
-extern "C" void wbx_calc_resize_clip(double clip_min, double clip_max, double clip_start_offset, double clip_speed,
-                                     double sample_rate, double sample_count, double relative_pos, double resize_limit,
-                                     double min_length, double min_resize_pos, double beat_duration, int is_min, int shift,
-                                     int stretch, int clamp_at_resize_pos, double* out_min, double* out_max,
-                                     double* out_start_offset, double* out_speed) {
-  const edit::ResizeResult r = edit::calc_resize_clip(clip_min, clip_max, clip_start_offset, clip_speed, sample_rate,
-                                                      sample_count, relative_pos, resize_limit, min_length, min_resize_pos,
-                                                      beat_duration, is_min != 0, shift != 0, stretch != 0,
-                                                      clamp_at_resize_pos != 0);
-  *out_min = r.min;
-  *out_max = r.max;
-  *out_start_offset = r.start_offset;
-  *out_speed = r.speed;
-}
-
-extern "C" double wbx_calc_clip_shift(double start_offset, double relative_pos, double beat_duration, double sample_rate) {
-  return edit::calc_clip_shift(start_offset, relative_pos, beat_duration, sample_rate);
-}
-
-extern "C" double wbx_shift_clip_content(double start_offset, double speed, double sample_rate, double relative_pos,
-                                         double beat_duration) {
-  return edit::shift_clip_content(start_offset, speed, sample_rate, relative_pos, beat_duration);
-}
-
-extern "C" wbx_status wbx_engine_play(wbx_engine* e) {   // engine.cpp:68-80
-  if (!e) return WBX_ERR_INVALID;
-  for (auto& t : e->tracks) reset_playback_state(e, t, e->playhead_start, false);
-  e->sample_position = 0;
-  e->playing = true;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_stop(wbx_engine* e) {   // engine.cpp:82-93, Track::stop track.cpp:249-256
-  if (!e) return WBX_ERR_INVALID;
-  e->playing = false;
-  e->playhead = e->playhead_start;
-  for (auto& t : e->tracks) t.patch.flags |= PATCH_STOP;
-  e->patches_pending = true;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
-  if (!e || K == 0) return WBX_ERR_INVALID;
-  wbx_ctx* c = e->ctx;
-  e->err.clear();
-  if (K > c->cfg.max_blocks) return efail(e, WBX_ERR_INVALID, "n_blocks above wbx_config.max_blocks");
-  const uint32_t N = (uint32_t)e->tracks.size();
-  (void)hipSetDevice(c->cfg.device);
-  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
-  hipStream_t s = c->stream;
-  if (N == 0) {
-    // Engine::process with an empty track list: output_buffer.clear() and the transport advance (engine.cpp:1598,
-    // :1619-1623) — silence
-    WBX_EHIP(e, join_sum(c));
-    WBX_EHIP(e, c->d_master.ensure((size_t)K * C * F));
-    float* master = c->master_target ? c->master_target : c->d_master.p;
-    WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * sizeof(float), s));
-    c->last_master = master;
-    c->last_master_on_host = false;
-    c->last_K = K;
-    c->last_N = 0;
-    const double sample_rate = (double)c->cfg.sample_rate;
-    for (uint32_t b = 0; b < K; b++) {
-      const double buffer_duration_in_beats = ((double)F / sample_rate) / e->beat_duration;
-      if (e->playing) {
-        e->sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, e->beat_duration);
-        e->playhead = e->playhead + buffer_duration_in_beats;
-      }
-    }
-    return WBX_OK;
-  }
-
-  // -- parameters: drain the message rings (process_track_messages track.cpp:773-779) and apply them
-  //    (track.cpp:618-643); the factor used per sample is fl(volume * pan_coeffs[c]) (track.cpp:728-731)
-  for (auto& t : e->tracks) {
-    if (t.msgs.empty()) continue;
-    for (const ParamMsg& m : t.msgs) {
-      switch (m.id) {
-        case PARAM_VOLUME: t.volume = (float)m.value; break;
-        case PARAM_PAN:
-          t.pan = (float)m.value;
-          pan_constant_power_3db(t.pan, &t.pan_coeffs[0], &t.pan_coeffs[1]);
-          break;
-        case PARAM_MUTE: t.mute = m.value > 0.0; break;
-        default: break;
-      }
-    }
-    t.msgs.clear();
-    e->gains_dirty = true;
-  }
-  if (e->gains_dirty) {
-    std::vector<float> g((size_t)N * 2);
-    for (uint32_t t = 0; t < N; t++) {
-      const HostTrack& tr = e->tracks[t];
-      float volume = tr.mute ? 0.0f : tr.volume;
-      g[2 * t + 0] = volume * tr.pan_coeffs[0];
-      g[2 * t + 1] = volume * tr.pan_coeffs[1];
-    }
-    WBX_EHIP(e, e->d_gains.ensure(g.size()));
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
-    WBX_EHIP(e, hipMemcpy(e->d_gains.p, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
-    e->gains_dirty = false;
-  }
-
-  // -- clip lists
-  if (e->clips_dirty) {
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
-    // Clip::internal_state_changed is cleared by the sequencer on the device (track.cpp:373,392,418): before
-    // the table is replaced, take the live flags back for every clip no edit has touched since the last upload
-    if (e->clips_uploaded && e->d_clips_count) {
-      std::vector<DClip> live(e->d_clips_count);
-      WBX_EHIP(e, hipMemcpy(live.data(), e->d_clips.p, live.size() * sizeof(DClip), hipMemcpyDeviceToHost));
-      std::vector<uint32_t> flag(e->next_clip_uid + 1, 2u);
-      for (const DClip& d : live)
-        if (d.uid < flag.size()) flag[d.uid] = d.internal_state_changed;
-      for (auto& tr : e->tracks)
-        for (auto& hc : tr.clips)
-          if (!hc.flag_dirty && hc.d.uid < flag.size() && flag[hc.d.uid] != 2u) hc.d.internal_state_changed = flag[hc.d.uid];
-    }
-    std::vector<uint32_t> first(N + 1, 0);
-    std::vector<DClip> flat;
-    for (uint32_t t = 0; t < N; t++) {
-      first[t] = (uint32_t)flat.size();
-      for (auto& hc : e->tracks[t].clips) {
-        flat.push_back(hc.d);
-        hc.flag_dirty = false;
-      }
-    }
-    first[N] = (uint32_t)flat.size();
-    WBX_EHIP(e, e->d_clips.ensure(std::max<size_t>(1, flat.size())));
-    WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
-    e->d_clips_count = flat.size();
-    e->clips_uploaded = true;
-    if (!flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, flat.data(), flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
-    WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    e->clips_dirty = false;
-  }
-
-  // -- per-track device state for tracks added since the last render
-  if (e->state_tracks < N) {
-    DevBuf<DTrackState> grown;
-    WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
-    WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
-    if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
-    e->d_state.release();
-    e->d_state = grown;
-    WBX_EHIP(e, e->d_levels.ensure((size_t)c->cfg.max_tracks * 2));
-    if (e->state_tracks == 0) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
-    e->state_tracks = N;
-  }
-
-  // -- pending state edits (play / stop / clip-list changes)
-  // The patches sit in pinned host memory that the plan kernel reads directly (one 16-B read per lane): no copy, and
-  // above all no stream synchronisation — a drain here would empty the queue of renders the host has run ahead by.
-  // Three buffers in rotation; a buffer is refilled only after the plan kernel that last read it has finished.
-  const DPatch* d_patch = nullptr;
-  int patch_slot = -1;
-  if (e->patches_pending) {
-    patch_slot = (int)(e->patch_seq++ % kRing);
-    if (e->patch_cap[patch_slot] < N) {
-      // (re)allocate all three at once — pinning memory synchronises the device, so it must not happen in mid-run
-      WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-      WBX_EHIP(e, hipStreamSynchronize(s));
-      const uint32_t cap = std::max<uint32_t>(N, c->cfg.max_tracks);
-      for (int i = 0; i < kRing; i++) {
-        if (e->h_patch[i]) WBX_EHIP(e, hipHostFree(e->h_patch[i]));
-        e->h_patch[i] = nullptr;
-        WBX_EHIP(e, hipHostMalloc((void**)&e->h_patch[i], (size_t)cap * sizeof(DPatch), hipHostMallocDefault));
-        e->patch_cap[i] = cap;
-        e->patch_valid[i] = false;
-        if (!e->patch_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->patch_done[i], hipEventDisableTiming));
-      }
-    }
-    if (e->patch_valid[patch_slot]) WBX_EHIP(e, hipEventSynchronize(e->patch_done[patch_slot]));
-    for (uint32_t t = 0; t < N; t++) {
-      e->h_patch[patch_slot][t] = e->tracks[t].patch;
-      e->tracks[t].patch = DPatch{};
-    }
-    d_patch = e->h_patch[patch_slot];
-    e->patches_pending = false;
-  }
-
-  // -- routing
-  if (e->routing_dirty || c->routing_tracks != N) {
-    std::vector<int32_t> tb(N);
-    for (uint32_t t = 0; t < N; t++) tb[t] = e->tracks[t].bus;
-    wbx_status st = wbx_set_routing(c, N, e->n_buses ? tb.data() : nullptr, e->n_buses);
-    if (st != WBX_OK) return st;
-    e->routing_dirty = false;
-  }
-  wbx_status st = upload_tables(c, N);
-  if (st != WBX_OK) return st;
-  st = ensure_result_buffers(c, K, N);
-  if (st != WBX_OK) return st;
-
-  // -- rows for the track-blocks the hot loop cannot stream directly: every clip start / end inside a block,
-  //    and all blocks of integer-PCM or fast-forward clips
-  {
-    const size_t all = (size_t)K * N;
-    const size_t rows = e->any_slow_clip ? all : std::min(all, 4 * e->total_clips + 2 * (size_t)N + 64);
-    st = ensure_gen_capacity(c, rows);
-    if (st != WBX_OK) return st;
-    // templates: one per block with events (same bound as above) + one per steady run (a run ends at every event)
-    st = ensure_template_capacity(c, std::min(all, rows + 2 * (size_t)N + 64) + (size_t)N);
-    if (st != WBX_OK) return st;
-  }
-
-  // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
-  //    while the mix of the previous render is still busy on the main stream
-  c->cur = (c->cur + 1) % kRing;
-  wbx_ctx::PlanBuf& B = PB(c);
-  const bool plan_beside = c->overlap && K >= kOverlapMinBlocks;
-  hipStream_t ps = plan_beside ? c->plan_stream : s;
-  if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
-  {
-    const int pp = (int)(c->render_seq % kRing);
-    if (plan_beside && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
-      WBX_EHIP(e, hipStreamWaitEvent(ps, c->sum_done[pp], 0));
-      c->partial_wait_done = true;
-    }
-  }
-  WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
-  const double sample_rate = (double)c->cfg.sample_rate;
-  PlanArgs a{};
-  a.clips = e->d_clips.p;
-  a.clip_first = e->d_clip_first.p;
-  a.samples = c->d_samples.p;
-  a.state = e->d_state.p;
-  a.patch = d_patch;
-  a.gains = e->d_gains.p;
-  a.rows = B.prows.p;
-  a.tmpl = B.tmpl.p;
-  a.tmpl_count = B.counters + 3;
-  a.tmpl_cap = B.tmpl_cap;
-  a.pool = B.pool.p;
-  a.pool_count = B.counters;
-  a.status = B.counters + 1;
-  a.gen_list = B.gen_list.p;
-  a.gen_count = B.counters + 2;
-  a.gen_cap = B.gen_cap;
-  a.pool_chunks = B.pool_chunks;
-  a.n_tracks = N;
-  a.n_blocks = K;
-  a.block_frames = F;
-  a.channels = C;
-  a.sample_rate = sample_rate;
-  a.playing = e->playing ? 1u : 0u;
-  a.clips_changed = e->clips_edited ? 1u : 0u;
-  e->clips_edited = false;
-  a.playhead = e->playhead;
-  a.sample_position = e->sample_position;
-  a.beat_duration = e->beat_duration;
-  launch_plan(a, ps);
-  if (patch_slot >= 0) {
-    WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
-    e->patch_valid[patch_slot] = true;
-  }
-  st = launch_pre_render(c, K, ps);
-  if (st != WBX_OK) return st;
-  if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
-
-  // -- mix + sum on the main stream, after the plan
-  if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
-  c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
-  c->has_window_clips = e->any_window_clip;
-  c->has_stride_clips = e->any_stride_clip;
-  const int mix_parity = (int)(c->render_seq % kRing);
-  st = launch_mix_sum(c, K, N);
-  if (st != WBX_OK) return st;
-  B.consumed = c->mix_done[mix_parity];   // recorded right after the mix: the plan buffer is free before the sum runs
-  B.consumed_valid = true;
-
-  // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
-  //    the plan kernel performs for its K blocks, so both sides hold the same playhead / sample_position bits
-  double playhead = e->playhead, sample_position = e->sample_position;
-  for (uint32_t b = 0; b < K; b++) {
-    double buffer_duration = (double)F / sample_rate;
-    double current_beat_duration = e->beat_duration;
-    double buffer_duration_in_beats = buffer_duration / current_beat_duration;
-    double next_playhead_pos = playhead + buffer_duration_in_beats;
-    if (e->playing) {
-      sample_position += beat_to_samples(buffer_duration_in_beats, sample_rate, current_beat_duration);
-      playhead = next_playhead_pos;
-    }
-  }
-  e->playhead = playhead;
-  e->sample_position = sample_position;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar) {   // engine.cpp:1576-1654
-  if (!e || !out_planar) return WBX_ERR_INVALID;
-  wbx_ctx* c = e->ctx;
-  if (c->master_target) {   // the caller redirected the master: leave it there and fetch the ordinary way
-    wbx_status st = wbx_engine_render(e, 1);
-    if (st != WBX_OK) return st;
-    return wbx_fetch(c, out_planar, nullptr, nullptr);
-  }
-  const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
-  if (!e->h_block) {
-    WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
-    WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
-  }
-  c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
-  c->status_dst = e->h_status;            // and it drops the plan status next to it
-  wbx_status st = wbx_engine_render(e, 1);
-  c->master_target = nullptr;
-  c->status_dst = nullptr;
-  if (st != WBX_OK) return st;
-  WBX_EHIP(e, join_sum(c));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  drain_events(c);
-  for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
-  c->last_master_on_host = true;   // set after launch_mix_sum cleared it: the master of this block is e->h_block
-  const uint32_t flags = e->h_status[1];
-  if (flags & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
-  if (flags & 8u) return efail(e, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
-  if (flags & 16u) return efail(e, WBX_ERR_OVERFLOW, "plan template array full");
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing) {
-  if (!e) return WBX_ERR_INVALID;
-  if (playhead) *playhead = e->playhead;
-  if (sample_position) *sample_position = e->sample_position;
-  if (playing) *playing = e->playing ? 1 : 0;
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks) {
-  if (!e || !levels || n_tracks > e->state_tracks) return WBX_ERR_INVALID;
-  wbx_ctx* c = e->ctx;
-  const size_t n = (size_t)n_tracks * c->cfg.channels;
-  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-  WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  return WBX_OK;
-}
-
-extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out, size_t cap, size_t* n_out) {
-  if (!e || !n_out) return WBX_ERR_INVALID;
-  wbx_ctx* c = e->ctx;
-  if (c->last_K == 0) return efail(e, WBX_ERR_FAILED, "nothing rendered");
-  const uint32_t K = c->last_K, N = c->last_N;
-  std::vector<DTrackBlock> tb((size_t)K * N);
-  uint32_t pc[4] = {0, 0, 0, 0};
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
-  WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
-  {
-    // rebuild the per-(block, track) records from the 16-B rows and the templates they point at
-    std::vector<DRow> rows((size_t)K * N);
-    const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);
-    std::vector<DTrackBlock> tmpl(nt);
-    WBX_EHIP(e, hipMemcpy(rows.data(), PB(c).prows.p, rows.size() * sizeof(DRow), hipMemcpyDeviceToHost));
-    if (nt) WBX_EHIP(e, hipMemcpy(tmpl.data(), PB(c).tmpl.p, nt * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
-    // templates the pre-render pass rewrote: put the sequencer's originals back
-    const uint32_t ng = std::min(pc[2], PB(c).gen_cap);
-    if (ng) {
-      std::vector<uint32_t> idx(ng);
-      std::vector<DTrackBlock> saved(ng);
-      WBX_EHIP(e, hipMemcpy(idx.data(), PB(c).gen_list.p, ng * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      WBX_EHIP(e, hipMemcpy(saved.data(), PB(c).saved.p, ng * sizeof(DTrackBlock), hipMemcpyDeviceToHost));
-      for (uint32_t i = 0; i < ng; i++)
-        if (idx[i] < tmpl.size()) tmpl[idx[i]] = saved[i];
-    }
-    for (size_t i = 0; i < rows.size(); i++) {
-      tb[i] = DTrackBlock{};
-      if (rows[i].tmpl >= tmpl.size()) continue;   // no stream call at all in this track-block
-      tb[i] = tmpl[rows[i].tmpl];
-      if (rows[i].flags & ROW_POS) tb[i].pos = rows[i].pos;
-    }
-  }
-  const uint32_t used = std::min(pc[0], PB(c).pool_chunks);
-  std::vector<DSeg> pool((size_t)used * kChunk);
-  if (used) WBX_EHIP(e, hipMemcpy(pool.data(), PB(c).pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
-  size_t n = 0;
-  for (uint32_t b = 0; b < K; b++)
-    for (uint32_t t = 0; t < N; t++) {
-      const DTrackBlock& r = tb[(size_t)b * N + t];
-      for (uint32_t i = 0; i < r.nseg; i++) {
-        const DSeg s0 = get_seg0(r);
-        const DSeg* sg = (i == 0) ? &s0 : (r.extra < used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
-        if (!sg) continue;
-        if (out && n < cap) {
-          wbx_plan_record& o = out[n];
-          o.block = b;
-          o.track = t;
-          o.buffer_offset = sg->dst_start;
-          o.num_samples = sg->req_len;
-          o.num_actual = sg->len;
-          o.sample = sg->sample;
-          o.sample_offset = sg->pos;
-          o.playback_speed = sg->speed;
-          o.gain = sg->gain;
-          o._pad = sg->flags;
-        }
-        n++;
-      }
-    }
-  *n_out = n;
-  if (pc[1] & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow");
   return WBX_OK;
 }

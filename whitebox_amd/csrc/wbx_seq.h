@@ -11,7 +11,15 @@
 //
 // Build with -ffp-contract=off: a fused multiply-add anywhere in here changes results.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else   // host-only build of the sequencer (tests/cpp/host_sim.cpp, plain g++): the qualifiers mean nothing there
+#define __host__
+#define __device__
+struct uint4 {   // (no over-alignment: the records it views live in ordinary host containers)
+  unsigned int x, y, z, w;
+};
+#endif
 #include <math.h>
 
 #include "wbx_dev.h"
@@ -97,6 +105,10 @@ struct TrackCache {
   DSample smp;
   uint32_t clip_idx;   // index within the track's clip list, 0xFFFFFFFF = empty
   uint32_t smp_idx;    // sample id, 0xFFFFFFFF = empty
+  // A clip whose timeline region outlasts its audio makes one zero-length "finished" stream call per block
+  // (sampler.cpp:99-100) for the rest of the region, every one with the same record: they share one template.
+  DTrackBlock fin;     // the record of the last such block
+  uint32_t fin_tmpl;   // its template index, 0xFFFFFFFF = none yet
 };
 
 struct BlockWalker {
@@ -424,15 +436,28 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
     row.tmpl = 0xFFFFFFFFu;
     row.flags = ROW_SILENT;
     if (rec.nseg != 0) {   // also for calls that render nothing (finished clip): the plan keeps every stream call
-      const uint32_t ti = alloc_template(a);
-      if (ti != 0xFFFFFFFFu) {
-        uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
-        dstq[0] = srcq[0];
-        dstq[1] = srcq[1];
-        dstq[2] = srcq[2];
-        dstq[3] = srcq[3];
-        row.tmpl = ti;
-        row.flags = rec.kind == KIND_SILENT ? ROW_SILENT : 0u;
+      const bool finished = rec.nseg == 1 && rec.len == 0 && (rec.flags & SEG_FINISHED);
+      const uint4* fq = reinterpret_cast<const uint4*>(&cache->fin);
+      bool same = finished && cache->fin_tmpl != 0xFFFFFFFFu;
+      for (int q = 0; q < 4 && same; q++)
+        same = srcq[q].x == fq[q].x && srcq[q].y == fq[q].y && srcq[q].z == fq[q].z && srcq[q].w == fq[q].w;
+      if (same) {          // the same finished call as in the block before: no new template
+        row.tmpl = cache->fin_tmpl;
+      } else {
+        const uint32_t ti = alloc_template(a);
+        if (ti != 0xFFFFFFFFu) {
+          uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
+          dstq[0] = srcq[0];
+          dstq[1] = srcq[1];
+          dstq[2] = srcq[2];
+          dstq[3] = srcq[3];
+          row.tmpl = ti;
+          row.flags = rec.kind == KIND_SILENT ? ROW_SILENT : 0u;
+          if (finished) {
+            cache->fin = rec;
+            cache->fin_tmpl = ti;
+          }
+        }
       }
     }
     *reinterpret_cast<uint4*>(&a.rows[(size_t)b * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
@@ -555,6 +580,96 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     n++;
   }
   st->sample_offset = off;
+  return n;
+}
+
+// The transport of K consecutive blocks, exactly the arithmetic of Engine::process (engine.cpp:1578-1585 per block,
+// :1619-1623 between blocks).
+__host__ __device__ inline void block_times(const PlanArgs& a, DBlockTime* times) {
+  double playhead = a.playhead, sample_position = a.sample_position;
+  for (uint32_t i = 0; i < a.n_blocks; i++) {
+    const double buffer_duration = (double)a.block_frames / a.sample_rate;            // :1578
+    const double buffer_duration_in_beats = buffer_duration / a.beat_duration;       // :1581
+    const double next_playhead_pos = playhead + buffer_duration_in_beats;            // :1582
+    times[i] = DBlockTime{playhead, next_playhead_pos, sample_position, a.beat_duration};
+    if (a.playing) {
+      sample_position += beat_to_samples(buffer_duration_in_beats, a.sample_rate, a.beat_duration);   // :1620
+      playhead = next_playhead_pos;                                                                   // :1621
+    }
+  }
+}
+
+// One track through the K blocks of a render: what a lane of plan_kernel does (and the host harness of the tests,
+// track by track).  Applies the pending state patch, then alternates steady runs and general blocks.
+__host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const DBlockTime* times) {
+  DTrackState st = a.state[t];
+  if (a.patch) {
+    const DPatch p = a.patch[t];
+    if (p.flags & PATCH_CLIPIDX) {   // Track::reset_playback_state(time, false), track.cpp:220-232
+      st.has_clip_idx = p.has_clip_idx;
+      st.clip_idx = p.clip_idx;
+      st.partially_ended = 0;
+    }
+    if (p.flags & PATCH_REFRESH) st.refresh_voice = p.refresh_voice;
+    if (p.flags & PATCH_STOP) st.cur_type = EV_NONE;   // Track::stop, track.cpp:249-256
+  }
+  const uint32_t c0 = a.clip_first[t];
+  const uint32_t nc = a.clip_first[t + 1] - c0;
+  DClip* clips = const_cast<DClip*>(a.clips) + c0;
+  if (a.clips_changed && st.cur_type == EV_PLAY) {
+    // the reference reads current_audio_event.clip->audio.gain at every stream call (track.cpp:676,716):
+    // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity
+    for (uint32_t i = 0; i < nc; i++)
+      if (clips[i].uid == st.cur_clip_uid) st.cur_gain = clips[i].gain;
+  }
+  TrackCache cache;
+  cache.clip_idx = 0xFFFFFFFFu;
+  cache.smp_idx = 0xFFFFFFFFu;
+  cache.fin_tmpl = 0xFFFFFFFFu;
+  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
+  uint32_t b = 0;
+  while (b < a.n_blocks) {
+    b += plan_steady_run(a, t, b, &st, nc, &cache, times, gl, gr);   // tight loop over the common case
+    if (b < a.n_blocks) {
+      plan_track_block(a, t, b, &st, clips, nc, &cache, times[b], gl, gr);
+      b++;
+    }
+  }
+  a.state[t] = st;
+}
+
+// Host side: the per-(block, track) stream-call records of a finished plan, rebuilt from the 16-B rows, the templates
+// they point at and the overflow pool, ordered by (block, track, call).  Rec has the fields of wbx_plan_record.
+template <class Rec>
+inline size_t plan_records(uint32_t K, uint32_t N, const DRow* rows, const DTrackBlock* tmpl, size_t n_tmpl, const DSeg* pool,
+                           uint32_t pool_used, Rec* out, size_t cap) {
+  size_t n = 0;
+  for (uint32_t b = 0; b < K; b++)
+    for (uint32_t t = 0; t < N; t++) {
+      const DRow& row = rows[(size_t)b * N + t];
+      if (row.tmpl >= n_tmpl) continue;   // no stream call at all in this track-block
+      DTrackBlock r = tmpl[row.tmpl];
+      if (row.flags & ROW_POS) r.pos = row.pos;
+      for (uint32_t i = 0; i < r.nseg; i++) {
+        const DSeg s0 = get_seg0(r);
+        const DSeg* sg = (i == 0) ? &s0 : (r.extra < pool_used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
+        if (!sg) continue;
+        if (out && n < cap) {
+          Rec& o = out[n];
+          o.block = b;
+          o.track = t;
+          o.buffer_offset = sg->dst_start;
+          o.num_samples = sg->req_len;
+          o.num_actual = sg->len;
+          o.sample = sg->sample;
+          o.sample_offset = sg->pos;
+          o.playback_speed = sg->speed;
+          o.gain = sg->gain;
+          o._pad = sg->flags;
+        }
+        n++;
+      }
+    }
   return n;
 }
 

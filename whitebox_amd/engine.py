@@ -177,13 +177,17 @@ class MixContext:
 
     def fetch_interleaved(self, fmt: str) -> np.ndarray:
         K, _ = self.last
-        dt = {"i16": np.int16, "i24_x8": np.int32, "i32": np.int32, "f32": np.float32}[fmt]
-        out = np.zeros(K * self.block * self.channels, dtype=dt)
+        dt = {"i16": np.int16, "i24": np.uint8, "i24_x8": np.int32, "i32": np.int32, "f32": np.float32}[fmt]
+        out = np.zeros(K * self.block * self.channels * (3 if fmt == "i24" else 1), dtype=dt)
         _check(self.L.wbx_fetch_interleaved(self.h, _ffi.OUT_FMT[fmt], out.ctypes.data), "wbx_fetch_interleaved", self.h)
         return out
 
     def sync(self):
         _check(self.L.wbx_sync(self.h), "wbx_sync", self.h)
+
+    def master_ready(self, stream: Optional[int] = None):
+        """Order `stream` (None: the ctx stream) after the kernels that write the last render's results."""
+        _check(self.L.wbx_master_ready(self.h, stream), "wbx_master_ready", self.h)
 
     def set_master_target(self, device_ptr: Optional[int]):
         _check(self.L.wbx_set_master_target(self.h, device_ptr), "wbx_set_master_target", self.h)
@@ -231,6 +235,14 @@ class Track:
     def set_bus(self, bus: int):
         _check(self.engine.L.wbx_track_set_bus(self.engine.h, self.index, bus), "Track::set_bus", self.engine.h, True)
 
+    @property
+    def plugin_instance(self):
+        """Track::plugin_instance (track.h:124): the effect slot — always empty (None) in this path."""
+        p = C.c_void_p()
+        _check(self.engine.L.wbx_track_get_plugin(self.engine.h, self.index, C.byref(p)), "wbx_track_get_plugin",
+               self.engine.h, True)
+        return p.value
+
 
 class Engine:
     """wb::Engine surface (engine.h:29-273) for the mix path."""
@@ -262,6 +274,13 @@ class Engine:
             pass
 
     # ---- reference-shaped surface ----
+    def set_audio_channel_config(self, input_channels: int, output_channels: int, buffer_size: int, sample_rate: int):
+        """Engine::set_audio_channel_config (engine.cpp:43-57) on the live engine: tracks and clips stay."""
+        _check(self.L.wbx_engine_set_audio_channel_config(self.h, output_channels, buffer_size, sample_rate),
+               "Engine::set_audio_channel_config", self.h, True)
+        self.audio_buffer_size, self.audio_sample_rate, self.num_output_channels = buffer_size, sample_rate, output_channels
+        self.ctx.block, self.ctx.channels, self.ctx.sample_rate = buffer_size, output_channels, sample_rate
+
     def set_bpm(self, bpm: float):
         _check(self.L.wbx_engine_set_bpm(self.h, bpm), "Engine::set_bpm", self.h, True)
 
@@ -302,6 +321,22 @@ class Engine:
 
     def solo_track(self, slot: int):
         _check(self.L.wbx_engine_solo_track(self.h, slot), "Engine::solo_track", self.h, True)
+
+    def add_plugin_to_track(self, track: Track, plugin=None):
+        """Engine::add_plugin_to_track (engine.h:227): the slot is kept, processing through it is Unimplemented."""
+        _check(self.L.wbx_engine_add_plugin_to_track(self.h, track.index, C.byref(plugin) if plugin is not None else None),
+               "Engine::add_plugin_to_track", self.h, True)
+
+    def delete_plugin_from_track(self, track: Track):
+        _check(self.L.wbx_engine_delete_plugin_from_track(self.h, track.index), "Engine::delete_plugin_from_track", self.h, True)
+
+    def thread_stats(self):
+        """(locked edits the last process / render had seen, per-track cumulative drained parameter messages)"""
+        n = len(self.tracks)
+        seen = C.c_uint64()
+        dr = (C.c_uint64 * max(1, n))()
+        _check(self.L.wbx_engine_thread_stats(self.h, C.byref(seen), dr, n), "wbx_engine_thread_stats", self.h, True)
+        return seen.value, list(dr[:n])
 
     def add_sample(self, fmt: str, rate: int, data: Sequence[np.ndarray], frames: Optional[int] = None) -> int:
         """Sample asset -> HBM.  `data` planar channel arrays (padding is added by the library)."""
