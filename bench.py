@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the whitebox mix path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N>1: either launched one rank per GPU by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+      environment), or run plainly — bench.py then starts the N ranks itself.
 
 A "step" is one device pass of the hot path (clip sequencer + per-track render/gain/pan/resample +
 peaks + group/bus/master sum + clamp) over one batch of `--blocks` consecutive 512-frame blocks of a
@@ -9,7 +11,7 @@ synthetic session that is already resident in HBM.  The default workload is BASE
 ("4096 stereo tracks, gain+pan + linear clip resample (44.1->48 kHz), 1 MI355X") — the configuration the
 metric "…4096 tracks @ 512-frame blocks" is quoted on.  With N GPUs every rank mixes its own 4096 tracks
 (weak scaling = configs[4]: 32768 tracks sharded 8-way) and the un-clamped partial masters are reduced
-to rank 0 with one RCCL reduce per step, then clamped there.
+to rank 0 with one RCCL reduce per step, then clamped there — all of it inside libwbx.so (wbx_dist_*), no torch.
 
 Prints ONE JSON line on rank 0.  `value` = 4096-track-equivalent stereo frames mixed per second over the
 whole job = (total tracks / 4096) x master frames / wall time; at N=1 it is exactly master frames/s.
@@ -64,17 +66,15 @@ def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2,
     return F * (n_tracks * channels * FMT_BYTES[fmt] * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
 
 
-def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, stream_ptr, group_size,
-                         clip_blocks=0.0):
+def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, world, group_size, clip_blocks=0.0):
     from whitebox_amd.engine import Engine
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
-    eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank),
-                 stream=stream_ptr)
+    eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank))
     eng.set_bpm(120.0)
     if n_buses:
         eng.set_buses(n_buses)
     seed = 0x5EED0000 + SEEDS[workload]
-    total_tracks = n_tracks * max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    total_tracks = n_tracks * world
     amp = synth.default_amp(total_tracks)
     frames = int(math.ceil((session_blocks + 2) * F * (src_rate / SR))) + 64
     beat_frames = SR * 60.0 / 120.0
@@ -108,11 +108,7 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
 
 
 def rank_device(rank):
-    dev = int(os.environ.get("LOCAL_RANK", rank))
-    if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":     # debugging aid: several ranks on one device
-        import torch
-        dev %= torch.cuda.device_count()
-    return dev
+    return int(os.environ.get("LOCAL_RANK", rank))
 
 
 def cpu_baseline(workload, n_tracks, budget_s=12.0):
@@ -247,6 +243,162 @@ def mix_kernel_name(src_rate, fmt):
     return f"wbx::mix_kernel<{v // 10}, true, {v % 10}, false, 1, 1>"
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` run plainly: start the N ranks (one process per GPU) and pass rank 0's line through."""
+    import subprocess
+    import whitebox_amd as W
+    have = W.lib().wbx_device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n} needs {n} gfx950 devices on this node, {have} visible "
+                         "(one process per GPU; --force-dist-path runs the multi-GPU code path on one)")
+    port = free_port()
+    rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wbx_rdzv_{port}_{os.getpid()}")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), WBX_RDZV=rdzv)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes here
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    try:
+        os.remove(rdzv)
+    except OSError:
+        pass
+    raise SystemExit(rc)
+
+
+def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, warmup, ramp, clip_blocks=0.0,
+                 use_dist=False, dist_mode=0, mem_budget=96e9, latency_blocks=0):
+    """Build the session in HBM, run warmup + ramp untimed steps straight into `steps` timed ones, return the measurements."""
+    from whitebox_amd.dist import Dist, PinnedBuffer
+    desc, src_rate, n_buses, fmt = WORKLOADS[workload]
+    total_blocks = (warmup + ramp + steps) * K
+    bytes_per_block_src = n_tracks * 2 * FMT_BYTES[fmt] * F * src_rate / SR
+    session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
+    if args.session_blocks:
+        session_blocks = max(K, min(session_blocks, args.session_blocks))
+    session_blocks = (session_blocks // K) * K
+
+    t_setup = time.perf_counter()
+    eng, seed, amp = build_device_session(W, synth, workload, n_tracks, K, session_blocks, rank, world, args.group_size,
+                                          clip_blocks)
+    host_master = PinnedBuffer(K * 2 * F)             # the final (clamped) master lands here every step
+    dist = None
+    if use_dist:
+        # wbx_dist_*: partial masters in a ring of three device buffers, RCCL reduce (or gather + ordered add) on its own
+        # high-priority stream, the root's clamp straight into pinned host memory
+        dist = Dist(eng.ctx, rank, world, dist_mode)
+    else:
+        # single GPU: the sum kernel stores the clamped master straight into pinned host memory
+        eng.ctx.set_master_target(host_master.ptr)
+    if os.environ.get("WBX_BENCH_VERBOSE"):
+        print(f"[bench] {workload}: session built in {time.perf_counter() - t_setup:.2f} s", file=sys.stderr, flush=True)
+
+    L = W.lib()
+    state = {"done": 0}
+
+    def step():
+        if state["done"] + K > session_blocks:     # end of the resident session: rewind (Engine::stop + play)
+            eng.stop()
+            eng.play()
+            state["done"] = 0
+        eng.render(K)
+        if dist is not None:
+            dist.exchange(host_master.ptr if rank == 0 else None)   # asynchronous, beside the next renders
+        # keep the submitting thread at most 12 steps ahead of the device: far deeper, the HIP runtime stalls a
+        # launch until its queue has drained (tens of ms) and the device then idles
+        L.wbx_pace(eng.ctx.h, 12)
+        state["done"] += K
+
+    def drain():
+        if dist is not None:
+            dist.sync()
+        else:
+            eng.ctx.sync()
+
+    # the submitting thread must not stall inside the timed region: a cyclic-GC pass over the session's Python
+    # objects (thousands of tracks / clips) costs milliseconds — several steps' worth of GPU time.  Done BEFORE the
+    # warm-up so that no idle gap separates the warm-up from the timed steps (the clocks would drop again).
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    eng.play()
+    for _ in range(warmup + ramp):
+        step()
+    drain()
+    pre_ms, pre_n = eng.ctx.kernel_time(reset=True)     # warm-up + ramp launches (for the rocprofv3 cross-check)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    enq_max = 0.0
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        step()
+        enq_max = max(enq_max, time.perf_counter() - t1)
+    drain()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    gc.unfreeze()
+    tail_ms = eng.ctx.tail_time()
+    mix_ms, mix_n = eng.ctx.kernel_time()
+    if dist is not None:
+        dt = dist.max(dt)                              # MAX over ranks
+
+    # K = 1 latency mode (the real-time callback shape): Engine::process one block at a time
+    lat = None
+    if rank == 0 and latency_blocks > 0 and dist is None:
+        eng.ctx.set_master_target(None)
+        out = W.AudioBuffer(F, 2)
+        eng.stop()
+        eng.play()
+        for _ in range(5):
+            eng.process(None, out, float(SR))
+        t1 = time.perf_counter()
+        for _ in range(latency_blocks):
+            eng.process(None, out, float(SR))
+        lat = (time.perf_counter() - t1) / latency_blocks
+
+    master_peak = float(np.abs(host_master.array).max()) if rank == 0 else 0.0
+    if dist is not None:
+        dist.shutdown()
+    eng.close()
+    host_master.close()
+    alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
+    achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
+    return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,
+            "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "alg": alg, "achieved": achieved,
+            "desc": desc, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
+            "clip_blocks": clip_blocks, "workload": workload}
+
+
+def roofline_of(r, traffic_table):
+    key = f"{r['workload']}_K{r['K']}_N{r['n_tracks']}" + (f"_L{r['clip_blocks']}" if r["clip_blocks"] else "")
+    traffic = traffic_table.get(key, {}).get("hbm_bytes_per_launch")
+    return {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": r["achieved"] / HBM_PEAK_GBS, "traffic": traffic,
+            # NOT this run's counters: the PMC passes of the same command, committed under profiles/ (tools/pmc_run.sh)
+            "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command)" if traffic else None,
+            "kernel": mix_kernel_name(r["src_rate"], r["fmt"]),
+            "kernel_ms_avg": r["mix_ms"], "kernel_launches": int(r["mix_n"]), "sum_tail_ms_avg": r["tail_ms"],
+            # mean over EVERY launch of the run incl. warm-up and ramp: what `rocprofv3 --stats` averages
+            "kernel_ms_avg_all_launches": (r["pre_ms"] * r["pre_n"] + r["mix_ms"] * r["mix_n"]) / max(1, r["pre_n"] + r["mix_n"]),
+            "kernel_launches_all": int(r["pre_n"] + r["mix_n"]),
+            "algorithmic_bytes_per_launch": r["alg"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,221 +421,91 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
     ap.add_argument("--force-dist-path", action="store_true",
-                    help="run the multi-GPU code path (RCCL reduce + clamp on root) even with one rank")
+                    help="run the multi-GPU code path (RCCL exchange + clamp on root) even with one rank")
+    ap.add_argument("--dist-mode", default="reduce", choices=["reduce", "ordered"],
+                    help="exchange: one ncclReduce, or gather + fixed-order add on the root (bit-reproducible)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other single-GPU configurations "
+                    "(c2, c4, c3 cut into clips, i16r) that fill the line's `configs` object")
     args = ap.parse_args()
     global F
     F = args.block_frames
 
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":     # debugging aid: several ranks on one device
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("WBX_BENCH_SHARE_GPU") == "1":
-            dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one device
-        else:
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True      # the small reduce must not queue behind the next render's mix
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                    pg_options=opts)
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a launch of {world} ranks")
 
     import whitebox_amd as W
     from whitebox_amd import synth
+    if W.lib().wbx_device_count() <= rank_device(rank):
+        raise SystemExit(f"rank {rank}: no gfx950 device {rank_device(rank)} ({W.lib().wbx_device_count()} visible) - "
+                         "the mix path has no CPU implementation")
 
     n_tracks = args.tracks or (256 if args.workload == "c2" else 4096)
-    desc, src_rate, n_buses, fmt = WORKLOADS[args.workload]
     K = args.blocks
-    total_blocks = (args.warmup + args.ramp_steps + args.steps) * K
-    bytes_per_block_src = n_tracks * 2 * FMT_BYTES[fmt] * F * src_rate / SR
-    mem_budget = 96e9
-    session_blocks = int(min(total_blocks, max(2 * K, mem_budget // bytes_per_block_src)))
-    if args.session_blocks:
-        session_blocks = max(K, min(session_blocks, args.session_blocks))
-    session_blocks = (session_blocks // K) * K
-
     use_dist = world > 1 or args.force_dist_path
-    if args.force_dist_path and world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        opts = dist.ProcessGroupNCCL.Options()
-        opts.is_high_priority_stream = True          # the same options as the multi-rank path
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank),
-                                pg_options=opts)
+    r = run_workload(W, synth, args, args.workload, rank, world, n_tracks=n_tracks, K=K, steps=args.steps,
+                     warmup=args.warmup, ramp=args.ramp_steps, clip_blocks=args.clip_blocks, use_dist=use_dist,
+                     dist_mode=1 if args.dist_mode == "ordered" else 0, latency_blocks=args.latency_blocks)
+    if rank != 0:
+        return
 
-    stream = torch.cuda.Stream()
-    # root: clamp of a reduced master into host memory, beside the next renders.  Highest priority: at normal
-    # priority its workgroups only get CU slots as the concurrent mix drains, and the step that reuses the buffer waits
-    fin_stream = torch.cuda.Stream(priority=-1)
-    t_setup = time.perf_counter()
-    with torch.cuda.stream(stream):
-        eng, seed, amp = build_device_session(W, synth, args.workload, n_tracks, K, session_blocks, rank,
-                                              stream.cuda_stream, args.group_size, args.clip_blocks)
-        host_master = torch.zeros(K * 2 * F, dtype=torch.float32).pin_memory()
-        if os.environ.get("WBX_BENCH_VERBOSE"):
-            print(f"[bench] session built in {time.perf_counter() - t_setup:.2f} s", file=sys.stderr, flush=True)
-        if use_dist:
-            from whitebox_amd.dist import MasterReducer
-            NS = 3                                             # master buffers in flight (render / reduce / finalize)
-            masters = [torch.zeros(K * 2 * F, dtype=torch.float32, device="cuda") for _ in range(NS)]
-            fin_done = [torch.cuda.Event() for _ in range(NS)]
-            rendered = [torch.cuda.Event() for _ in range(NS)]
-            eng.ctx.set_clamp(False)                       # partials are clamped on the root AFTER the reduce
-            # root: clamp after the reduce, straight into pinned host memory (plain kernel stores, no copy engine)
-            red = MasterReducer(lambda buf: eng.ctx.finalize_master_into(buf.data_ptr(), host_master.data_ptr(), K, True,
-                                                                         stream=fin_stream.cuda_stream), root=0)
-        else:
-            # single GPU: the sum kernel stores the clamped master straight into pinned host memory
-            eng.ctx.set_master_target(host_master.data_ptr())
-
-        done = 0
-        nstep = 0
-        pace = [torch.cuda.Event() for _ in range(4)]
-
-        def finish(slot):
-            """root: wait for the reduce of `slot`, clamp, copy to the host — all on fin_stream."""
-            with torch.cuda.stream(fin_stream):
-                fin_stream.wait_event(rendered[slot])          # (the reduce already orders after the render; this
-                red.finish(masters[slot], slot)                #  also covers a single-rank run of this path)
-                fin_done[slot].record(fin_stream)
-
-        def step():
-            nonlocal done, nstep
-            if done + K > session_blocks:     # end of the resident session: rewind (Engine::stop + play)
-                eng.stop()
-                eng.play()
-                done = 0
-            if use_dist:
-                slot = nstep % NS
-                if nstep >= NS:
-                    stream.wait_event(fin_done[slot])          # the buffer's previous reduce / finalize is over
-                eng.ctx.set_master_target(masters[slot].data_ptr())
-                eng.render(K)
-                rendered[slot].record(stream)
-                red.reduce(masters[slot], slot)                # RCCL sum over xGMI, asynchronous to this stream
-                if nstep >= 1:
-                    finish((nstep - 1) % NS)
-            else:
-                eng.render(K)
-            # keep the submitting thread at most ~16 steps ahead of the device: far deeper, the HIP runtime stalls a
-            # launch until its queue has drained (tens of ms) and the device then idles
-            if nstep % 4 == 0:
-                slot4 = (nstep // 4) % len(pace)
-                if nstep >= 16:
-                    pace[(slot4 + 1) % len(pace)].synchronize()      # recorded 12 steps ago
-                pace[slot4].record(stream)
-            done += K
-            nstep += 1
-
-        def drain():
-            if use_dist and nstep >= 1:
-                finish((nstep - 1) % NS)
-            torch.cuda.synchronize()
-
-        # the submitting thread must not stall inside the timed region: a cyclic-GC pass over the session's Python
-        # objects (thousands of tracks / clips) costs milliseconds — several steps' worth of GPU time.  Done BEFORE the
-        # warm-up so that no idle gap separates the warm-up from the timed steps (the clocks would drop again).
-        gc.collect()
-        gc.freeze()
-        gc.disable()
-        eng.play()
-        for _ in range(args.warmup + args.ramp_steps):
-            step()
-        drain()
-        pre_ms, pre_n = eng.ctx.kernel_time(reset=True)     # warm-up + ramp launches (for the rocprofv3 cross-check)
-        nstep = 0
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        enq_max = 0.0
-        for _ in range(args.steps):
-            t1 = time.perf_counter()
-            step()
-            enq_max = max(enq_max, time.perf_counter() - t1)
-        drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        gc.enable()
-        tail_ms = eng.ctx.tail_time()
-        mix_ms, mix_n = eng.ctx.kernel_time()
-
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-        # K = 1 latency mode (the real-time callback shape): Engine::process one block at a time
-        lat = None
-        if rank == 0 and args.latency_blocks > 0 and world == 1 and not use_dist:
-            eng.ctx.set_master_target(None)
-            out = W.AudioBuffer(F, 2)
-            eng.stop()
-            eng.play()
-            for _ in range(5):
-                eng.process(None, out, float(SR))
-            t1 = time.perf_counter()
-            for _ in range(args.latency_blocks):
-                eng.process(None, out, float(SR))
-            lat = (time.perf_counter() - t1) / args.latency_blocks
-
+    dt = r["dt"]
     master_frames = args.steps * K * F
     total_tracks = n_tracks * world
     value = (total_tracks / 4096.0) * master_frames / dt if n_tracks == 4096 else master_frames / dt * world
-    alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
-    achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
+    traffic_table = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic_table = json.load(open(tpath))
+        except Exception:
+            traffic_table = {}
+    desc, src_rate, n_buses, fmt = WORKLOADS[args.workload]
+    line = {
+        "metric": "stereo fp32 frames/sec mixed (4096 tracks @ 512-frame blocks)",
+        "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": args.ramp_steps,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
+        "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
+                   "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate, "clip_format": fmt,
+                   "sub_buses": n_buses, "group_size": args.group_size or (64 if n_buses else 128),
+                   "clip_blocks": args.clip_blocks or None,
+                   "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}",
+                   "exchange": (f"libwbx wbx_dist_exchange over RCCL, mode {args.dist_mode}" if use_dist else None)},
+        "master_frames_per_s": master_frames / dt,
+        "track_frames_per_s": total_tracks * master_frames / dt,
+        "realtime_factor": master_frames / dt / SR,
+        "host_enqueue_ms_max": 1e3 * r["enq_max"],
+        "master_peak": r["master_peak"],
+        "roofline": roofline_of(r, traffic_table),
+    }
+    if r["lat"] is not None:
+        line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"]}
 
-    if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"{args.workload}_K{K}_N{n_tracks}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "stereo fp32 frames/sec mixed (4096 tracks @ 512-frame blocks)",
-            "value": value, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": args.ramp_steps,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
-            "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
-                       "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate, "clip_format": fmt,
-                       "sub_buses": n_buses, "group_size": args.group_size or (64 if n_buses else 128),
-                       "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}"},
-            "master_frames_per_s": master_frames / dt,
-            "track_frames_per_s": total_tracks * master_frames / dt,
-            "realtime_factor": master_frames / dt / SR,
-            "host_enqueue_ms_max": 1e3 * enq_max,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": mix_kernel_name(src_rate, fmt),
-                         "kernel_ms_avg": mix_ms, "kernel_launches": int(mix_n), "sum_tail_ms_avg": tail_ms,
-                         # mean over EVERY launch of the run incl. warm-up and ramp: what `rocprofv3 --stats` averages
-                         "kernel_ms_avg_all_launches": (pre_ms * pre_n + mix_ms * mix_n) / max(1, pre_n + mix_n),
-                         "kernel_launches_all": int(pre_n + mix_n),
-                         "algorithmic_bytes_per_launch": alg},
-        }
-        if lat is not None:
-            line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * lat, "frames_per_s": F / lat}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, n_tracks, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-
-    eng.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    # the other single-GPU configurations of BASELINE.json (configs[1], configs[3]), the headline session cut into
+    # clips and the 16-bit resampled session: short runs, each with its own roofline from its own HIP-event kernel times
+    if world == 1 and not use_dist and not args.no_configs and args.workload == "c3" and not args.clip_blocks and F == 512:
+        subs = {}
+        for name, wl, kw in (("c2", "c2", dict(n_tracks=256)), ("c4", "c4", dict(n_tracks=4096)),
+                             ("c3_clips5.3", "c3", dict(n_tracks=4096, clip_blocks=5.3)),
+                             ("i16r", "i16r", dict(n_tracks=4096))):
+            sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=10, warmup=2, ramp=24 if wl != "c2" else 60,
+                              mem_budget=40e9, **kw)
+            d2 = WORKLOADS[wl]
+            subs[name] = {"workload": f"{wl} — {d2[0]}" + (f", every track cut into clips of {kw['clip_blocks']} blocks"
+                                                          if kw.get("clip_blocks") else ""),
+                          "value": 10 * K * F / sr["dt"], "unit": "frames/s", "steps": 10, "blocks_per_step": K,
+                          "tracks": sr["n_tracks"], "ms_per_step": 1e3 * sr["dt"] / 10,
+                          "roofline": roofline_of(sr, traffic_table)}
+        line["configs"] = subs
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.workload, n_tracks, args.cpu_seconds)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -175,6 +175,45 @@ wbx_status wbx_set_clamp(wbx_ctx* ctx, int clamp_on_submit); /* 0: leave the mas
  * max_blocks*C*F floats (e.g. the send buffer of the RCCL reduce); NULL restores the ctx-owned one. */
 wbx_status wbx_set_master_target(wbx_ctx* ctx, void* device_buffer);
 
+/* ---- multi-GPU: tracks sharded over one process per GPU, ONE exchange per render ---------------
+ * The reference has no distributed code; this is the path's only exchange step: every rank mixes its own contiguous
+ * track range into an un-clamped partial master, the partials are summed onto rank 0 over RCCL (xGMI), and the clamp
+ * of engine.cpp:1627-1636 runs there, after the sum.  Protocol per rank:
+ *     wbx_shard_tracks(N, world, rank, &first, &count);          // which tracks this rank builds its session from
+ *     rank 0: wbx_dist_new_id(&id) and hand the 128 bytes to the other ranks (file, socket, MPI, ...)
+ *     wbx_dist_init(ctx, &id, rank, world, WBX_DIST_REDUCE);      // collective: returns when every rank has called
+ *     loop: wbx_engine_render / wbx_submit;  wbx_dist_exchange(ctx, dst);      // dst: rank 0 only
+ *     wbx_dist_sync(ctx);  ...  wbx_dist_shutdown(ctx);
+ * After wbx_dist_init the ctx writes its (un-clamped) masters into an internal ring of three device buffers, so up
+ * to two further renders may be issued while an exchange is in flight; nothing in the loop blocks the host.
+ * WBX_DIST_REDUCE: one ncclReduce(sum) — RCCL's summation order is implementation-defined (inside the 1e-6 RMS budget).
+ * WBX_DIST_ORDERED: ncclGather + a fixed-order add on the root, (((0 + p0) + p1) + ...) in rank = track order:
+ * bit-reproducible on any topology (SURVEY §7 hard part 8). */
+#define WBX_DIST_ID_BYTES 128
+typedef struct wbx_dist_id {
+  char bytes[WBX_DIST_ID_BYTES];
+} wbx_dist_id;
+enum { WBX_DIST_REDUCE = 0, WBX_DIST_ORDERED = 1 };
+void wbx_shard_tracks(uint32_t n_tracks, uint32_t world, uint32_t rank, uint32_t* first, uint32_t* count);
+wbx_status wbx_dist_new_id(wbx_dist_id* out);
+wbx_status wbx_dist_init(wbx_ctx* ctx, const wbx_dist_id* id, uint32_t rank, uint32_t world, int mode);
+wbx_status wbx_dist_info(wbx_ctx* ctx, uint32_t* rank, uint32_t* world, int* mode);
+/* dst (rank 0): [K][C][F] floats, device memory or pinned device-mapped host memory, 16-byte aligned */
+wbx_status wbx_dist_exchange(wbx_ctx* ctx, void* dst);
+wbx_status wbx_dist_sync(wbx_ctx* ctx);                  /* host waits for the renders and exchanges issued so far */
+wbx_status wbx_dist_barrier(wbx_ctx* ctx);               /* all ranks */
+wbx_status wbx_dist_max(wbx_ctx* ctx, double* value);    /* max over all ranks, in place (also a barrier) */
+wbx_status wbx_dist_shutdown(wbx_ctx* ctx);
+
+/* Render-ahead bound for asynchronous hosts: call after each submit / render; the host waits until the render issued
+ * `max_ahead` (1..63) calls earlier has left the main stream.  Far deeper queues stall inside the HIP runtime. */
+wbx_status wbx_pace(wbx_ctx* ctx, uint32_t max_ahead);
+
+/* Pinned, device-mapped host memory (hipHostMalloc): a destination for wbx_set_master_target / wbx_dist_exchange /
+ * wbx_finalize_master_into that the GPU writes with plain stores. */
+wbx_status wbx_host_alloc(size_t bytes, void** out);
+wbx_status wbx_host_free(void* p);
+
 /* Timing of the dominant kernel (HIP events on the ctx stream): average ms per launch since reset. */
 wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t* mix_launches);
 /* Average ms from the end of the mix kernel to the end of the sum kernel over the same launches (launch gap + the

@@ -1,7 +1,12 @@
-"""The N>1 path on CPU: world_size-2 `gloo` processes, tracks sharded in contiguous ranges, un-clamped
-partial masters summed onto rank 0 through whitebox_amd.dist.MasterReducer, clamp after the reduce.
-The per-rank partials come from the oracle (no GPU here); what is under test is the sharding, the
-collective plumbing and the clamp-after-reduce order that bench.py --gpus N uses with RCCL."""
+"""The N>1 path on CPU: world_size-2/3 `gloo` processes, tracks sharded in contiguous ranges by the library's own
+wbx_shard_tracks, un-clamped partial masters in libwbx's [K][C][F] layout summed onto rank 0, clamp after the sum.
+There is no GPU here, so the per-rank partials come from the oracle and the exchange itself is `GlooExchange` below —
+a CPU stand-in with the contract of wbx_dist_exchange (whitebox_amd/csrc/wbx_dist.hip): a ring of three partial
+buffers, the exchange of render i issued asynchronously and completed after render i+1 has been issued, REDUCE mode
+(collective sum, order implementation-defined) or ORDERED mode (gather + (((0 + p0) + p1) + ...) in rank order, the
+arithmetic of ordered_add_kernel).  Under test: the sharding, the buffer protocol, the clamp-after-sum order and the
+ordered mode's bit-reproducibility.  Real RCCL is exercised on the GPU box (tests/test_gpu_dist.py, world 1) and by
+`bench.py --gpus N`."""
 import os
 import socket
 
@@ -42,14 +47,59 @@ def _shard_spec(spec, first, count):
     return sub
 
 
-def _worker(rank, world, port, n_tracks, amp, q):
+class GlooExchange:
+    """CPU stand-in for wbx_dist_exchange over torch.distributed/gloo (see the module docstring)."""
+    RING = 3
+
+    def __init__(self, rank, world, mode, clamp_fn):
+        self.rank, self.world, self.mode, self.clamp_fn = rank, world, mode, clamp_fn
+        self.pending = {}
+
+    def exchange(self, partial: torch.Tensor, slot: int):
+        """asynchronous: returns at once; finish(slot) completes it"""
+        if self.mode == "reduce":
+            w = dist.reduce(partial, dst=0, op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+            self.pending[slot] = (w, partial, None)
+        else:
+            parts = [torch.empty_like(partial) for _ in range(self.world)] if self.rank == 0 else None
+            w = dist.gather(partial, parts, dst=0, async_op=True) if self.world > 1 else None
+            if self.world == 1:
+                parts = [partial.clone()]
+            self.pending[slot] = (w, partial, parts)
+
+    def finish(self, slot: int):
+        w, partial, parts = self.pending.pop(slot)
+        if w is not None:
+            w.wait()
+        if self.rank != 0:
+            return None
+        if parts is not None:                      # ordered_add_kernel: start from the cleared buffer, rank order
+            acc = np.zeros(partial.shape, np.float32)
+            for p in parts:
+                acc = (acc + p.numpy()).astype(np.float32)
+            out = acc
+        else:
+            out = partial.numpy().copy()
+        self.clamp_fn(out)
+        return out
+
+
+def _clamp_with_oracle(O):
+    def clamp(a):      # the root's clamp (engine.cpp:1627-1636); on the GPU: clamp_into_kernel / ordered_add_kernel
+        for b in range(a.shape[0]):
+            chans = [a[b, c] for c in range(a.shape[1])]
+            O.lib().wbo_master_clamp(O.planar_ptrs(chans), a.shape[1], a.shape[2])
+    return clamp
+
+
+def _worker(rank, world, port, n_tracks, amp, mode, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import oracle_ffi as O
-    from whitebox_amd.dist import MasterReducer, shard_tracks
+    from whitebox_amd.dist import shard_tracks
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,44 +109,53 @@ def _worker(rank, world, port, n_tracks, amp, q):
     e.play()
     partial = np.stack([e.process(clamp=False)[0] for _ in range(N_BLOCKS)])       # [K][C][F], un-clamped
     e.close()
-    t = torch.from_numpy(partial.copy())
-
-    def finalize(buf):      # the root's clamp (engine.cpp:1627-1636); on the GPU this is wbx_finalize_master
-        a = buf.numpy()
-        for b in range(a.shape[0]):
-            chans = [a[b, c] for c in range(a.shape[1])]
-            O.lib().wbo_master_clamp(O.planar_ptrs(chans), a.shape[1], a.shape[2])
-
-    red = MasterReducer(finalize, root=0)
-    red.reduce(t, slot=0)
-    red.finish(t, slot=0)
+    ex = GlooExchange(rank, world, mode, _clamp_with_oracle(O))
+    ex.exchange(torch.from_numpy(partial.copy()), 0)
+    out = ex.finish(0)
     if rank == 0:
-        q.put(t.numpy().copy())
+        q.put((out, partial))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_tracks,amp", [(22, None), (23, 0.6)])
-def test_two_rank_shard_reduce_clamp(n_tracks, amp):
-    import oracle_ffi as O
+def _run(world, target, args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_tracks, amp, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("mode", ["reduce", "ordered"])
+@pytest.mark.parametrize("n_tracks,amp", [(22, None), (23, 0.6)])
+def test_two_rank_shard_exchange_clamp(n_tracks, amp, mode):
+    import oracle_ffi as O
+    from whitebox_amd.dist import shard_tracks
+    got, part0 = _run(2, _worker, (n_tracks, amp, mode))
     e = O.build_oracle_engine(_session(n_tracks, amp))
     e.play()
     want = np.stack([e.process()[0] for _ in range(N_BLOCKS)])
     e.close()
     d = got.astype(np.float64) - want.astype(np.float64)
     assert np.sqrt(np.mean(d * d)) <= 1e-6            # shard sums are added in a different order than the track loop
-    if amp:                                           # the hot session really clamps, and only after the reduce
+    if amp:                                           # the hot session really clamps, and only after the sum
         assert (np.abs(want) == 1.0).any() and np.abs(got).max() <= 1.0
+    if mode == "ordered":
+        # bit-reproducible: (0 + p0) + p1 with the shards' own partials, whatever order they arrived in
+        f1, c1 = shard_tracks(n_tracks, 2, 1)
+        e1 = O.build_oracle_engine(_shard_spec(_session(n_tracks, amp), f1, c1))
+        e1.play()
+        part1 = np.stack([e1.process(clamp=False)[0] for _ in range(N_BLOCKS)])
+        e1.close()
+        exp = ((np.zeros_like(part0) + part0).astype(np.float32) + part1).astype(np.float32)
+        _clamp_with_oracle(O)(exp)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
 def test_shard_ranges_cover_all_tracks():
@@ -108,18 +167,43 @@ def test_shard_ranges_cover_all_tracks():
                 f, c = shard_tracks(n, w, r)
                 seen += list(range(f, f + c))
             assert seen == list(range(n))
+    assert shard_tracks(32768, 8, 3) == (12288, 4096)        # BASELINE configs[4]: tracks [4096 g, 4096 (g+1)) on GPU g
 
 
-def _worker_pipelined(rank, world, port, n_tracks, q):
-    """bench.py's N>1 loop shape: one render per step into a ring of three master buffers, the reduce of step i
-    enqueued asynchronously, the finalize (root clamp) of step i-1 issued afterwards, the last one drained."""
+def test_rendezvous_file_hands_the_id_to_the_other_ranks(tmp_path, monkeypatch):
+    """rank 0 publishes the 128-byte communicator id atomically; the other ranks poll for it (no RCCL needed here:
+    the id's origin is patched)"""
+    import ctypes as C
+    import threading
+    from whitebox_amd import _ffi, dist as wd
+    monkeypatch.setenv("WBX_RDZV", str(tmp_path / "rdzv"))
+
+    class FakeLib:
+        def wbx_dist_new_id(self, buf):
+            C.memmove(buf, bytes(range(128)), 128)
+            return 0
+    monkeypatch.setattr(_ffi, "lib", lambda: FakeLib())
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault("id", bytes(wd.exchange_id(1, 2, timeout_s=20))))
+    th.start()
+    root = bytes(wd.exchange_id(0, 2))
+    th.join(timeout=30)
+    assert root == bytes(range(128)) and got["id"] == root
+    with pytest.raises(TimeoutError):
+        monkeypatch.setenv("WBX_RDZV", str(tmp_path / "nobody"))
+        wd.exchange_id(1, 2, timeout_s=0.2)
+
+
+def _worker_pipelined(rank, world, port, n_tracks, mode, q):
+    """bench.py's N>1 loop shape: one render per step into the ring of three partial buffers, the exchange of step i
+    issued asynchronously, completed after the render of step i+1 has been issued, the last one drained."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import oracle_ffi as O
-    from whitebox_amd.dist import MasterReducer, shard_tracks
+    from whitebox_amd.dist import shard_tracks
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -129,25 +213,17 @@ def _worker_pipelined(rank, world, port, n_tracks, q):
     first, count = shard_tracks(n_tracks, world, rank)
     e = O.build_oracle_engine(_shard_spec(spec, first, count))
     e.play()
-    NS, K, steps = 3, 2, 5
+    NS, K, steps = GlooExchange.RING, 2, 5
     masters = [torch.zeros(K, 2, 512) for _ in range(NS)]
     results = []
-
-    def finalize(buf):
-        a = buf.numpy()
-        for b in range(a.shape[0]):
-            chans = [a[b, c] for c in range(a.shape[1])]
-            O.lib().wbo_master_clamp(O.planar_ptrs(chans), a.shape[1], a.shape[2])
-        results.append(a.copy())
-
-    red = MasterReducer(finalize, root=0)
+    ex = GlooExchange(rank, world, mode, _clamp_with_oracle(O))
     for i in range(steps):
         slot = i % NS
         masters[slot].copy_(torch.from_numpy(np.stack([e.process(clamp=False)[0] for _ in range(K)])))   # "render"
-        red.reduce(masters[slot], slot=slot)
+        ex.exchange(masters[slot], slot)
         if i >= 1:
-            red.finish(masters[(i - 1) % NS], slot=(i - 1) % NS)
-    red.finish(masters[(steps - 1) % NS], slot=(steps - 1) % NS)
+            results.append(ex.finish((i - 1) % NS))
+    results.append(ex.finish((steps - 1) % NS))
     e.close()
     if rank == 0:
         q.put(np.concatenate(results))
@@ -155,19 +231,10 @@ def _worker_pipelined(rank, world, port, n_tracks, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_tracks", [(2, 23), (3, 20)])
-def test_pipelined_reduce_ring_of_three(world, n_tracks):
+@pytest.mark.parametrize("world,n_tracks,mode", [(2, 23, "reduce"), (3, 20, "reduce"), (3, 20, "ordered")])
+def test_pipelined_exchange_ring_of_three(world, n_tracks, mode):
     import oracle_ffi as O
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, n_tracks, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _run(world, _worker_pipelined, (n_tracks, mode))
     from whitebox_amd import synth
     spec = synth.make_session("dist", n_tracks, n_blocks=N_BLOCKS, src_rate=44100, seed=0xD157, amp=0.6)
     for s in spec.samples:

@@ -1,0 +1,107 @@
+"""The multi-GPU exchange of libwbx (wbx_dist_*, whitebox_amd/csrc/wbx_dist.hip) on the GPU box: the same code
+path N ranks run — ring of three partial-master buffers, RCCL collective on its own stream, clamp on the root into
+pinned host memory — with a REAL RCCL communicator of world size 1, against the oracle and against the single-GPU
+default path.  (N > 1 ranks need N devices: the driver's scaling run; the CPU side covers the protocol with gloo.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import whitebox_amd as W
+from whitebox_amd import synth
+from whitebox_amd.dist import ORDERED, REDUCE, Dist, PinnedBuffer
+from whitebox_amd.engine import build_engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def oracle_master(spec, n_blocks, clamp=True):
+    e = O.build_oracle_engine(spec)
+    e.play()
+    m = np.stack([e.process(clamp=clamp)[0] for _ in range(n_blocks)])
+    e.close()
+    return m
+
+
+@pytest.mark.parametrize("mode", [REDUCE, ORDERED])
+@pytest.mark.parametrize("K", [4, 16])          # short renders sum in-stream, long ones on the sum stream
+def test_world1_exchange_through_rccl_equals_the_oracle(mode, K):
+    steps = 5
+    spec = synth.make_session("dist1", 40, src_rate=44100, n_blocks=K * steps, seed=0xD151, amp=0.5)   # hot: clamps
+    want = oracle_master(spec, K * steps)
+    assert (np.abs(want) == 1.0).any()
+    eng = build_engine(spec, max_blocks=K)
+    d = Dist(eng.ctx, 0, 1, mode)
+    outs = [PinnedBuffer(K * 2 * 512) for _ in range(steps)]
+    eng.play()
+    for i in range(steps):                       # five renders through the ring of three, no host sync in between
+        eng.render(K)
+        d.exchange(outs[i].ptr)
+    d.sync()
+    for i in range(steps):
+        got = outs[i].array.reshape(K, 2, 512)
+        assert np.array_equal(bits(got), bits(want[i * K:(i + 1) * K])), (mode, i)
+    # the rank's own (un-clamped) partial stays readable the ordinary way
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    un = oracle_master(spec, K * steps, clamp=False)
+    assert np.array_equal(bits(m), bits(un[(steps - 1) * K:]))
+    d.shutdown()
+    # ... and after shutdown the context is a single-GPU context again (clamps itself)
+    eng.stop()
+    eng.play()
+    eng.render(K)
+    m2, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m2), bits(want[:K]))
+    for o in outs:
+        o.close()
+    eng.close()
+
+
+def test_exchange_protocol_errors():
+    spec = synth.make_session("dist2", 4, n_blocks=4, seed=0xD152)
+    eng = build_engine(spec, max_blocks=2)
+    L = W.lib()
+    assert L.wbx_dist_exchange(eng.ctx.h, None) == -4                 # not initialised
+    d = Dist(eng.ctx, 0, 1, REDUCE)
+    assert L.wbx_dist_exchange(eng.ctx.h, None) == -1                 # nothing rendered yet
+    eng.play()
+    eng.render(2)
+    assert L.wbx_dist_exchange(eng.ctx.h, None) == -4                 # the root needs a destination
+    out = PinnedBuffer(2 * 2 * 512)
+    d.exchange(out.ptr)
+    assert L.wbx_dist_exchange(eng.ctx.h, out.ptr) == -1              # one exchange per render
+    import ctypes as C
+    assert L.wbx_dist_init(eng.ctx.h, (C.c_char * 128)(), 0, 1, 0) == -4   # already initialised
+    d.sync()
+    d.shutdown()
+    out.close()
+    eng.close()
+
+
+def test_bench_multi_gpu_launch_paths():
+    """`python bench.py --gpus 2` run plainly on a one-GPU box fails with a clear message (not a launcher error), and
+    --force-dist-path runs the whole multi-GPU loop through RCCL on one rank."""
+    have = W.lib().wbx_device_count()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and f"needs {have + 1} gfx950 devices" in r.stderr, r.stderr[-500:]
+    for mode in ("reduce", "ordered"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--blocks", "64", "--steps", "6",
+                            "--warmup", "1", "--ramp-steps", "4", "--force-dist-path", "--dist-mode", mode,
+                            "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0 and "wbx_dist_exchange" in line["config"]["exchange"]
+        assert 0.0 < line["master_peak"] <= 1.0

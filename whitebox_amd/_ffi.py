@@ -85,6 +85,18 @@ SYMBOLS = {
     "wbx_finalize_master_into": (C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp]),
     "wbx_set_clamp": (C.c_int, [_vp, C.c_int]),
     "wbx_set_master_target": (C.c_int, [_vp, _vp]),
+    "wbx_shard_tracks": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "wbx_dist_new_id": (C.c_int, [_vp]),
+    "wbx_dist_init": (C.c_int, [_vp, _vp, _u32, _u32, C.c_int]),
+    "wbx_dist_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int)]),
+    "wbx_dist_exchange": (C.c_int, [_vp, _vp]),
+    "wbx_dist_sync": (C.c_int, [_vp]),
+    "wbx_dist_barrier": (C.c_int, [_vp]),
+    "wbx_dist_max": (C.c_int, [_vp, C.POINTER(_d)]),
+    "wbx_dist_shutdown": (C.c_int, [_vp]),
+    "wbx_pace": (C.c_int, [_vp, _u32]),
+    "wbx_host_alloc": (C.c_int, [_sz, _pp]),
+    "wbx_host_free": (C.c_int, [_vp]),
     "wbx_kernel_time": (C.c_int, [_vp, C.c_int, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "wbx_tail_time": (C.c_int, [_vp, C.POINTER(_d)]),
     "wbx_engine_create": (C.c_int, [C.POINTER(Config), _pp]),

@@ -36,6 +36,7 @@ constexpr int kEventRing = 64;
 // the mix of render i-3 and the sum of render i-3 are over, i.e. a full render before its own mix — the one-wave-per-
 // track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
 constexpr int kRing = 3;
+constexpr uint32_t kPaceRing = 64;
 constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
 
 struct ClipSlot {
@@ -160,6 +161,8 @@ struct wbx_ctx {
 
   hipStream_t upload_stream = nullptr; // clip uploads of layer 2 run here, outside the engine's editor lock
   hipEvent_t ready_ev = nullptr;       // wbx_master_ready: results of an in-stream sum, for a foreign stream
+  hipEvent_t pace_ev[kPaceRing] = {};  // wbx_pace
+  uint64_t pace_seq = 0;
   // layer 2 back pointer: asks whether a clip list still names a sample (wbx_clip_free), null for a bare ctx
   bool (*sample_in_use)(void* owner, uint32_t sample) = nullptr;
   void* owner = nullptr;
@@ -223,5 +226,10 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows);
 wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
+float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
+
+// wbx_dist.hip
+float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);
+void dist_destroy(wbx_ctx* c);
 
 }  // namespace wbx

@@ -602,7 +602,9 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     // :1619-1623) — silence
     WBX_EHIP(e, join_sum(c));
     WBX_EHIP(e, c->d_master.ensure((size_t)K * C * F));
-    float* master = c->master_target ? c->master_target : c->d_master.p;
+    hipError_t me = hipSuccess;
+    float* master = begin_master(c, s, &me);
+    WBX_EHIP(e, me);
     WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * sizeof(float), s));
     c->last_master = master;
     c->last_master_on_host = false;

@@ -1264,6 +1264,29 @@ __global__ __launch_bounds__(256) void clamp_into_kernel(const float* __restrict
 __device__ __forceinline__ int x86_cvtt_f32(float t) { return (t >= -2147483648.0f && t < 2147483648.0f) ? (int)t : (int)0x80000000; }
 __device__ __forceinline__ int x86_cvtt_f64(double t) { return (t >= -2147483648.0 && t < 2147483648.0) ? (int)t : (int)0x80000000; }
 
+// multi-GPU, ordered mode: the partial masters of all ranks lie behind one another in `g` ([world][n]); the master is
+// their sum in RANK order starting from the cleared output buffer — (((0 + p0) + p1) + ...) — like the reference adds
+// track after track (audio_buffer.h:73-82), then the clamp of engine.cpp:1627-1636 (compare-based: NaN passes)
+__global__ __launch_bounds__(256) void ordered_add_kernel(const float* __restrict__ g, float* __restrict__ dst, size_t n, uint32_t world, int clamp) {
+  const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (i >= n) return;   // (n is a multiple of 4: C*F/4 lanes per block)
+  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (uint32_t r = 0; r < world; r++) {
+    const f4 v = *reinterpret_cast<const f4*>(g + (size_t)r * n + i);
+    acc.x = __fadd_rn(acc.x, v.x);
+    acc.y = __fadd_rn(acc.y, v.y);
+    acc.z = __fadd_rn(acc.z, v.z);
+    acc.w = __fadd_rn(acc.w, v.w);
+  }
+  if (clamp) {
+    acc.x = acc.x > 1.0f ? 1.0f : (acc.x < -1.0f ? -1.0f : acc.x);
+    acc.y = acc.y > 1.0f ? 1.0f : (acc.y < -1.0f ? -1.0f : acc.y);
+    acc.z = acc.z > 1.0f ? 1.0f : (acc.z < -1.0f ? -1.0f : acc.z);
+    acc.w = acc.w > 1.0f ? 1.0f : (acc.w < -1.0f ? -1.0f : acc.w);
+  }
+  *reinterpret_cast<f4*>(dst + i) = acc;
+}
+
 // planar fp32 master [K][C][F] -> interleaved device-format samples [K*F][C]; reference
 // core/audio_format_conv.cpp:5-20 (i16), :45-60 (i24 in 32-bit containers), :62-77 (i32), :79-91 (f32).
 // Packed 24-bit (:22-43): the reference's writer has no channel term in its destination index, so what a block's
@@ -1407,6 +1430,10 @@ void launch_clamp(float* buf, size_t n, hipStream_t s) {
 
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s) {
   hipLaunchKernelGGL(clamp_into_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, s, src, dst, n, clamp);
+}
+
+void launch_ordered_add(const float* gathered, float* dst, size_t n, uint32_t world, int clamp, hipStream_t s) {
+  hipLaunchKernelGGL(ordered_add_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, s, gathered, dst, n, world, clamp);
 }
 
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s) {

@@ -174,6 +174,13 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   return WBX_OK;
 }
 
+// where the master of the render about to be issued goes; `writer` is the stream its last writer runs on
+float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err) {
+  *err = hipSuccess;
+  if (c->dist) return dist_begin_render(c, writer, err);
+  return c->master_target ? c->master_target : c->d_master.p;
+}
+
 // mix + sum over the current plan buffer, on the main stream
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
@@ -220,10 +227,18 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
   WBX_HIP(c, hipEventRecord(c->mix_done[pp], c->stream));
+  // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
+  // hand-overs cost more than the few microseconds of overlap they could buy
+  const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
+  hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
   SumArgs s{};
   s.partial = c->d_partial2[pp].p;
   s.groups = c->d_groups.p;
-  s.master = c->master_target ? c->master_target : c->d_master.p;
+  {
+    hipError_t me = hipSuccess;
+    s.master = begin_master(c, ss, &me);   // the ctx's own buffer, the caller's target, or the multi-GPU ring slot
+    WBX_HIP(c, me);
+  }
   c->last_master = s.master;
   c->last_master_on_host = false;
   s.buses = (c->n_buses && !c->buses_alias_partials) ? c->d_buses.p : nullptr;
@@ -241,10 +256,6 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
     c->buses_clean = true;
   }
-  // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
-  // hand-overs cost more than the few microseconds of overlap they could buy
-  const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
-  hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
   if (sum_beside) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   launch_sum(s, K, ss);
   if (m.n_groups && timed) {
@@ -391,6 +402,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
 extern "C" void wbx_destroy(wbx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
+  dist_destroy(c);
   if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
   if (c->sum_stream) (void)hipStreamSynchronize(c->sum_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -415,6 +427,8 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   if (c->sum_stream) (void)hipStreamDestroy(c->sum_stream);
   if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
   if (c->ready_ev) (void)hipEventDestroy(c->ready_ev);
+  for (auto& ev : c->pace_ev)
+    if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < kRing; i++) {
     if (c->mix_done[i]) (void)hipEventDestroy(c->mix_done[i]);
     if (c->sum_done[i]) (void)hipEventDestroy(c->sum_done[i]);
@@ -966,6 +980,33 @@ extern "C" wbx_status wbx_finalize_master_into(wbx_ctx* c, const void* device_pa
   launch_clamp_into((const float*)device_partial, (float*)dst, (size_t)n_blocks * c->cfg.channels * c->cfg.block_frames, clamp, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
+}
+
+// Bound how far the submitting thread runs ahead of the device: beyond a few dozen queued renders the HIP runtime
+// blocks a launch until its queue has emptied and the device then idles.  Call after each submit / render: the host
+// waits (only) until the render issued `max_ahead` calls ago has left the main stream.
+extern "C" wbx_status wbx_pace(wbx_ctx* c, uint32_t max_ahead) {
+  if (!c || max_ahead == 0 || max_ahead >= kPaceRing) return WBX_ERR_INVALID;
+  (void)hipSetDevice(c->cfg.device);
+  const uint32_t slot = (uint32_t)(c->pace_seq % kPaceRing);
+  if (!c->pace_ev[slot]) WBX_HIP(c, hipEventCreateWithFlags(&c->pace_ev[slot], hipEventDisableTiming));
+  WBX_HIP(c, hipEventRecord(c->pace_ev[slot], c->stream));
+  if (c->pace_seq >= max_ahead) WBX_HIP(c, hipEventSynchronize(c->pace_ev[(c->pace_seq - max_ahead) % kPaceRing]));
+  c->pace_seq++;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return WBX_ERR_INVALID;
+  *out = nullptr;
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return WBX_ERR_OOM;
+  std::memset(*out, 0, bytes);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_host_free(void* p) {
+  if (!p) return WBX_OK;
+  return hipHostFree(p) == hipSuccess ? WBX_OK : WBX_ERR_DEVICE;
 }
 
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {

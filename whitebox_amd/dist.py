@@ -1,62 +1,130 @@
-"""Multi-GPU sharding of the mix path: one process per GPU, tracks partitioned in contiguous ranges, one
-collective per render — the sum of the un-clamped partial masters onto the root (RCCL reduce over xGMI
-with backend "nccl"; gloo on CPU in the tests) — then the master clamp on the root only.
+"""Multi-GPU driver side of the mix path: one process per GPU, tracks sharded in contiguous ranges, one exchange
+per render.  The exchange itself — partial-master ring, RCCL reduce (or gather + fixed-order add) on its own
+high-priority stream, clamp on the root — lives in libwbx.so (whitebox_amd/csrc/wbx_dist.hip, wbx_dist_* in
+include/wbx.h); this module only does what a host process has to: pick the rank's track range, get rank 0's
+128-byte communicator id to the other ranks, and pin host memory for the root's output.
 
-The reference has no distributed code: this is the one exchange step the path has.  Tracks
-are independent (no sends / side-chains in the reference), per-track peaks never leave the GPU that owns
-the track, clamping a partial would be wrong, so the clamp (engine.cpp:1627-1636) runs after the reduce.
+The reference has no distributed code: this is the one exchange step the path has.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+import ctypes as C
+import os
+import time
+from typing import Optional, Tuple
 
-import torch
-import torch.distributed as dist
+import numpy as np
+
+from . import _ffi
+
+REDUCE, ORDERED = 0, 1
 
 
 def shard_tracks(n_tracks: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous range [first, first+count) of global track indices owned by `rank`; ranges are in rank
-    order so that in-GPU summation order equals the reference's track order within a shard."""
-    base, rem = divmod(n_tracks, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+    """Contiguous range [first, first+count) of global track indices owned by `rank` (wbx_shard_tracks): ranges are
+    in rank order, so in-GPU summation order equals the reference's track order within a shard."""
+    first, count = C.c_uint32(), C.c_uint32()
+    _ffi.lib().wbx_shard_tracks(n_tracks, world, rank, C.byref(first), C.byref(count))
+    return first.value, count.value
 
 
-class MasterReducer:
-    """Sum partial masters [K][C][F] onto `root` and finalize (clamp) there.
+def rendezvous_path() -> str:
+    """A file every rank of THIS launch agrees on: the launcher's port and process id (torchrun: the agent is the
+    parent of every worker; bench.py's own launcher passes WBX_RDZV)."""
+    if os.environ.get("WBX_RDZV"):
+        return os.environ["WBX_RDZV"]
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wbx_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
 
-    reduce() is asynchronous with respect to the caller's stream: the collective is enqueued with
-    async_op=True, so the next render can be issued at once; finish(slot) makes the finalize stream wait
-    for it and runs `finalize(buffer)` (the clamp kernel on the root).  Buffers are rotated by the caller
-    (slot = step % n_slots) so that a render never overwrites a buffer a reduce is still reading.
-    """
 
-    def __init__(self, finalize: Callable[[torch.Tensor], None], root: int = 0, group=None):
-        self.finalize = finalize
-        self.root = root
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._work = {}             # slot -> outstanding collective
+def exchange_id(rank: int, world: int, timeout_s: float = 120.0) -> C.Array:
+    """Rank 0 makes the communicator id (wbx_dist_new_id) and publishes it through the rendezvous file; the other
+    ranks wait for it.  128 bytes, written atomically (rename)."""
+    buf = (C.c_char * 128)()
+    path = rendezvous_path()
+    if rank == 0:
+        st = _ffi.lib().wbx_dist_new_id(buf)
+        if st != 0:
+            raise _ffi.WbxError(st, "wbx_dist_new_id", "RCCL could not be loaded" if st == -3 else "")
+        if world > 1:
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(bytes(buf))
+            os.replace(tmp, path)
+        return buf
+    t0 = time.time()
+    while True:
+        try:
+            data = open(path, "rb").read()
+            if len(data) == 128:
+                C.memmove(buf, data, 128)
+                return buf
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout_s:.0f} s")
+        time.sleep(0.02)
 
-    def reduce(self, partial: torch.Tensor, slot: int = 0) -> None:
-        if self.world > 1 and partial.is_cuda and dist.get_backend(self.group) == "gloo":
-            # debugging aid (several ranks sharing one GPU, where RCCL cannot be used): through the host, synchronously
-            torch.cuda.current_stream().synchronize()
-            host = partial.cpu()
-            dist.reduce(host, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
-            if self.rank == self.root:
-                partial.copy_(host)
-            self._work[slot] = None
-        elif self.world > 1:
-            self._work[slot] = dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
-                                           async_op=True)
-        else:
-            self._work[slot] = None
 
-    def finish(self, partial: torch.Tensor, slot: int = 0) -> None:
-        w = self._work.pop(slot, None)
-        if w is not None:
-            w.wait()            # orders the CURRENT stream after the collective (no host block for nccl)
-        if self.rank == self.root:
-            self.finalize(partial)
+class PinnedBuffer:
+    """hipHostMalloc'ed fp32 array (wbx_host_alloc): the GPU writes it with plain stores, numpy reads it in place."""
+
+    def __init__(self, n_floats: int):
+        self.L = _ffi.lib()
+        p = C.c_void_p()
+        st = self.L.wbx_host_alloc(n_floats * 4, C.byref(p))
+        if st != 0:
+            raise _ffi.WbxError(st, "wbx_host_alloc")
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_float * n_floats).from_address(self.ptr))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.L.wbx_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dist:
+    """wbx_dist_* of one rank's context."""
+
+    def __init__(self, ctx, rank: int, world: int, mode: int = REDUCE, id_buf: Optional[C.Array] = None):
+        self.L = _ffi.lib()
+        self.ctx, self.rank, self.world, self.mode = ctx, rank, world, mode
+        if id_buf is None:
+            id_buf = exchange_id(rank, world)
+        self._check(self.L.wbx_dist_init(ctx.h, id_buf, rank, world, mode), "wbx_dist_init")
+        self.active = True
+
+    def _check(self, st, where):
+        if st != 0:
+            raise _ffi.WbxError(st, where, self.L.wbx_last_error(self.ctx.h).decode())
+
+    def exchange(self, dst_ptr: Optional[int]):
+        self._check(self.L.wbx_dist_exchange(self.ctx.h, dst_ptr), "wbx_dist_exchange")
+
+    def sync(self):
+        self._check(self.L.wbx_dist_sync(self.ctx.h), "wbx_dist_sync")
+
+    def barrier(self):
+        self._check(self.L.wbx_dist_barrier(self.ctx.h), "wbx_dist_barrier")
+
+    def max(self, value: float) -> float:
+        v = C.c_double(value)
+        self._check(self.L.wbx_dist_max(self.ctx.h, C.byref(v)), "wbx_dist_max")
+        return v.value
+
+    def shutdown(self):
+        if self.active:
+            self.active = False
+            self._check(self.L.wbx_dist_shutdown(self.ctx.h), "wbx_dist_shutdown")
+            if self.rank == 0 and self.world > 1:
+                try:
+                    os.remove(rendezvous_path())
+                except OSError:
+                    pass
