@@ -298,7 +298,15 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     if use_dist:
         # wbx_dist_*: partial masters in a ring of three device buffers, RCCL reduce (or gather + ordered add) on its own
         # high-priority stream, the root's clamp straight into pinned host memory
-        dist = Dist(eng.ctx, rank, world, dist_mode)
+        # (RCCL prints a version banner on stdout when a communicator is created: keep stdout for the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist = Dist(eng.ctx, rank, world, dist_mode)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     else:
         # single GPU: the sum kernel stores the clamped master straight into pinned host memory
         eng.ctx.set_master_target(host_master.ptr)

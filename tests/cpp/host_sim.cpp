@@ -37,6 +37,7 @@ struct HostSim {
   uint32_t counters[4] = {0, 0, 0, 0};
   uint32_t last_K = 0, last_N = 0;
   bool clips_uploaded = false;
+  uint32_t masked_rows = 0;   // plan as for a mix instance that takes partial rows / ROW_PAIRs in its hot loop
 };
 
 extern "C" {
@@ -51,6 +52,18 @@ HostSim* hsim_create(uint32_t max_tracks, uint32_t max_blocks, uint32_t block_fr
   return s;
 }
 void hsim_destroy(HostSim* s) { delete s; }
+void hsim_set_masked_rows(HostSim* s, uint32_t on) { s->masked_rows = on; }
+
+// (row flags, template kind) of every (block, track) of the last render — how the sequencer classified each track-block
+int hsim_row_kinds(HostSim* s, uint32_t* flags, uint32_t* kinds, size_t cap) {
+  const size_t n = (size_t)s->last_K * s->last_N;
+  if (cap < n) return WBX_ERR_INVALID;
+  for (size_t i = 0; i < n; i++) {
+    flags[i] = s->rows[i].flags;
+    kinds[i] = s->rows[i].tmpl < s->tmpl.size() ? s->tmpl[s->rows[i].tmpl].kind : 0xFFu;
+  }
+  return WBX_OK;
+}
 
 int hsim_set_bpm(HostSim* s, double bpm) {
   if (!(bpm > 0.0)) return WBX_ERR_INVALID;
@@ -269,6 +282,8 @@ int hsim_render(HostSim* s, uint32_t K) {
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
+  a.masked_rows = s->masked_rows;
+  a.tmpl_reserve = HostSession::template_reserve(K);
   a.playhead = hs.playhead;
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;

@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
         L.hsim_destroy.argtypes = [C.c_void_p]
         L.hsim_template_capacity.restype = C.c_uint32
         L.hsim_template_capacity.argtypes = [C.c_void_p]
+        L.hsim_set_masked_rows.restype = None
+        L.hsim_set_masked_rows.argtypes = [C.c_void_p, C.c_uint32]
         sig = {
             "hsim_set_bpm": [C.c_double], "hsim_set_playhead_position": [C.c_double],
             "hsim_add_track": [C.POINTER(C.c_uint32)],
@@ -70,6 +72,7 @@ def lib() -> C.CDLL:
             "hsim_get_clip": [C.c_uint32, C.c_uint32, C.POINTER(_ffi.ClipInfo)],
             "hsim_play": [], "hsim_stop": [], "hsim_render": [C.c_uint32],
             "hsim_plan_counters": [C.POINTER(C.c_uint32)],
+            "hsim_row_kinds": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t],
             "hsim_fetch_plan": [C.POINTER(_ffi.PlanRecord), C.c_size_t, C.POINTER(C.c_size_t)],
             "hsim_gains": [C.POINTER(C.c_float), C.c_uint32],
             "hsim_transport": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)],
@@ -173,6 +176,16 @@ class HostSimEngine:
 
     def template_capacity(self): return self.L.hsim_template_capacity(self.h)
 
+    def set_masked_rows(self, on: bool):
+        """plan as for a mix instance that renders partial-coverage fp32 rows / ROW_PAIRs in its hot loop"""
+        self.L.hsim_set_masked_rows(self.h, int(on))
+
+    def row_kinds(self, n_rows: int):
+        """(row flags, template kind) per (block, track) of the last render"""
+        fl, kd = (C.c_uint32 * n_rows)(), (C.c_uint32 * n_rows)()
+        self._ok(self.L.hsim_row_kinds(self.h, fl, kd, n_rows))
+        return list(fl), list(kd)
+
     def fetch_plan(self):
         n = C.c_size_t()
         self.L.hsim_fetch_plan(self.h, None, 0, C.byref(n))
@@ -200,9 +213,10 @@ class HostSimEngine:
         return seen.value, list(dr[:n])
 
 
-def build_sim_engine(spec, max_blocks=8) -> HostSimEngine:
+def build_sim_engine(spec, max_blocks=8, masked_rows=False) -> HostSimEngine:
     """The same construction sequence as whitebox_amd.engine.build_engine, without audio."""
     eng = HostSimEngine(max(spec.n_tracks, 1), spec.block, spec.sample_rate, spec.channels, max_blocks=max_blocks)
+    eng.set_masked_rows(masked_rows)
     eng.set_bpm(spec.bpm)
     if spec.playhead_start:
         eng.set_playhead_position(spec.playhead_start)

@@ -102,6 +102,9 @@ def test_bench_multi_gpu_launch_paths():
                             "--warmup", "1", "--ramp-steps", "4", "--force-dist-path", "--dist-mode", mode,
                             "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        line = json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                  # ONE JSON line on stdout, nothing of RCCL's banner
+        assert r.stdout.strip().splitlines()[-1] == lines[0]
+        line = json.loads(lines[0])
         assert line["n_gpus"] == 1 and line["value"] > 0 and "wbx_dist_exchange" in line["config"]["exchange"]
         assert 0.0 < line["master_peak"] <= 1.0

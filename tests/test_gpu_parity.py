@@ -414,6 +414,76 @@ class _SpecialValuesSpec(synth.SessionSpec):
         return out
 
 
+def _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels=2, gaps=True, salt=None):
+    """fp32 tracks at 48 and 44.1 kHz cut into clips (touching, or with gaps so that single starts / ends occur), stretch
+    speeds on the window path: every clip boundary lies inside a block."""
+    beat_frames = 48000 * 60.0 / 120.0
+    total = (n_blocks + 1) * block
+    samples, clips, vols, pans = [], [], [], []
+    for t in range(n_tracks):
+        for r in range(2):
+            samples.append(synth.SampleSpec(seed_track=2 * t + r, channels=1 + (t + r) % 2, rate=[48000, 44100][(t + r) % 2],
+                                            frames=int(total * 1.3) + 400, fmt="f32", amp=0.02))
+        v, p = synth.track_params(0xB0D, t)
+        vols.append(float(v))
+        pans.append(float(p))
+        L = clip_blocks * block
+        pos = -((t * 37) % 101) / 101.0 * L
+        k = 0
+        while pos < total:
+            a, b = max(pos, 0.0), pos + L * (0.6 if (gaps and (t + k) % 3 == 0) else 1.0)
+            stretch = [1.0, 1.0, 0.5, 0.8][(t + k) % 4]
+            clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.8 + 0.37 * (k % 3),
+                                        speed=stretch, gain=[1.0, 0.5, 1.7][k % 3], sample=2 * t + k % 2))
+            pos += L
+            k += 1
+    cls = _SpecialValuesSpec if salt else synth.SessionSpec
+    spec = cls(name="bound", n_tracks=n_tracks, seed=0xB0D, samples=samples, clips=clips, volumes_db=vols,
+               pans=pans, mutes=[False] * n_tracks, block=block, channels=channels)
+    if salt:
+        spec.salt = salt
+    return spec
+
+
+@pytest.mark.parametrize("masked", ["1", "0"])
+@pytest.mark.parametrize("clip_blocks,block,channels,n_tracks,group", [(1.3, 512, 2, 40, 0), (0.7, 512, 2, 40, 16), (2.45, 1024, 2, 24, 0),
+                                                                       (3.1, 1024, 1, 24, 5), (1.9, 512, 2, 300, 200)])
+def test_clip_boundaries_in_the_hot_loop(monkeypatch, masked, clip_blocks, block, channels, n_tracks, group):
+    """Track-blocks with a clip start / end inside them — one partial stream call, or two that do not overlap — are
+    rendered by mix_kernel itself as masked rows (ROW_PAIRs staged as two records; WBX_MASKED_ROWS=0 sends them through
+    the pre-render pass as before): stream-call log, peaks and master equal the oracle's either way.  group 200 of 300
+    tracks: groups longer than one staged chunk, pairs on both sides of a chunk seam."""
+    monkeypatch.setenv("WBX_MASKED_ROWS", masked)
+    n_blocks = 7
+    spec = _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels)
+    if group == 0:
+        check_against_oracle(spec, n_blocks, group_size=n_tracks if n_tracks <= 128 else 0, expect_exact=n_tracks <= 128)
+    else:
+        check_against_oracle(spec, n_blocks, group_size=group)
+
+
+@pytest.mark.parametrize("salt", ["denormals_and_zeros", "nonfinite"])
+def test_masked_rows_with_special_float_values(salt):
+    """non-finite and denormal samples right at clip boundaries: a masked-out frame contributes an exact +0.0 whatever
+    was loaded for it, a unity row inside a chunk of resampled rows copies its sample (no 0 * inf)"""
+    n_blocks = 6
+    spec = _boundary_session(20, n_blocks, 512, 0.9, salt=salt)
+    om, opk, _, orows, _ = run_oracle(spec, n_blocks)
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=20)
+    eng.play()
+    eng.render(n_blocks)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert plan_rows(eng.fetch_plan()) == orows
+    if salt != "nonfinite":
+        assert np.array_equal(bits(m), bits(om))
+        assert np.array_equal(pk, opk[..., :spec.channels])
+    else:                                             # NaN where the reference has NaN, the same bits elsewhere
+        assert np.array_equal(np.isnan(m), np.isnan(om))
+        ok = ~np.isnan(om)
+        assert np.array_equal(bits(m)[ok], bits(om)[ok])
+    eng.close()
+
+
 @pytest.mark.parametrize("salt", ["denormals_and_zeros", "huge", "nonfinite"])
 @pytest.mark.parametrize("src_rate", [48000, 44100, 96000])
 def test_special_float_values(salt, src_rate):

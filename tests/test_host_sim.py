@@ -25,7 +25,7 @@ def oracle_rows(e, block):
             for (t, ds, ln, off, spd, g, smp) in e.seglog()]
 
 
-def check_session(spec, n_blocks, batch):
+def check_session(spec, n_blocks, batch, masked=False):
     e = O.build_oracle_engine(spec)
     e.enable_seglog()
     e.play()
@@ -33,7 +33,7 @@ def check_session(spec, n_blocks, batch):
     for b in range(n_blocks):
         e.process()
         rows += oracle_rows(e, b)
-    sim = HS.build_sim_engine(spec, max_blocks=n_blocks)
+    sim = HS.build_sim_engine(spec, max_blocks=n_blocks, masked_rows=masked)
     sim.play()
     if batch:
         sim.render(n_blocks)
@@ -52,18 +52,62 @@ def check_session(spec, n_blocks, batch):
     sim.close()
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("seed", range(0, 160))
-def test_host_sequencer_random_sessions_batched(seed):
-    """the 160 fuzz sessions of the GPU suite, all blocks in one plan (steady runs, templates, overflow pool)"""
+def test_host_sequencer_random_sessions_batched(seed, masked):
+    """the 160 fuzz sessions of the GPU suite, all blocks in one plan (steady runs, templates, overflow pool); `masked`:
+    planned for a mix instance that renders clip boundaries in its hot loop (masked rows, ROW_PAIRs)"""
     spec, n_blocks = FZ.random_session(seed)
-    check_session(spec, n_blocks, batch=True)
+    check_session(spec, n_blocks, batch=True, masked=masked)
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("seed", range(0, 40))
-def test_host_sequencer_random_sessions_block_by_block(seed):
+def test_host_sequencer_random_sessions_block_by_block(seed, masked):
     """the second generator's sessions one block per plan (the audio-callback shape)"""
     spec, n_blocks = FZ.random_session(seed + 100000)
-    check_session(spec, n_blocks, batch=False)
+    check_session(spec, n_blocks, batch=False, masked=masked)
+
+
+def test_clip_boundaries_stay_out_of_the_pre_render_queue():
+    """An fp32 session cut into back-to-back clips (one clip ends and the next starts inside a block every few blocks):
+    planned for a masked-row mix instance, every boundary block is a ROW_PAIR of two single-segment templates — nothing
+    is queued for the pre-render pass, no overflow-pool chunk is taken — and the stream-call log still equals the
+    oracle's.  Planned the old way, the same blocks are all queued."""
+    n_tracks, K, L = 12, 40, 3.3 * 512
+    spec = synth.make_session("cut", n_tracks, src_rate=44100, n_blocks=K, seed=0x0A74)
+    beat = 24000.0
+    clips = []
+    for t in range(n_tracks):
+        pos = -((t * 37) % 512) / 512.0 * L
+        while pos < (K + 1) * 512:
+            a, b = max(pos, 0.0), pos + L
+            clips.append(synth.ClipSpec(t, a / beat, b / beat, start_offset=float(int(a * 0.91875)), speed=1.0, gain=1.0))
+            pos = b
+    spec.clips = clips
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    rows = []
+    for b in range(K):
+        e.process()
+        rows += oracle_rows(e, b)
+    e.close()
+    stats = {}
+    for masked in (False, True):
+        sim = HS.build_sim_engine(spec, max_blocks=K, masked_rows=masked)
+        sim.play()
+        sim.render(K)
+        assert plan_rows(sim.fetch_plan()) == rows, masked
+        pc = sim.plan_counters()
+        assert pc[1] == 0
+        fl, kd = sim.row_kinds(K * n_tracks)
+        stats[masked] = (pc[0], pc[2], sum(1 for f in fl if f & 4))
+        sim.close()
+    pool0, gen0, pairs0 = stats[False]
+    pool1, gen1, pairs1 = stats[True]
+    assert gen0 > n_tracks * 8 and pool0 == gen0 and pairs0 == 0     # old way: every boundary block pre-rendered
+    assert gen1 == 0 and pool1 == 0 and pairs1 == gen0               # masked rows: all of them ROW_PAIRs in the hot loop
 
 
 @pytest.mark.parametrize("name,kw", [("c1", dict(n_tracks=8, channels_src=1)), ("seek", dict(n_tracks=24, seek=True)),
@@ -83,7 +127,7 @@ def test_host_clip_edits_match_oracle(seed):
     lists and the plan of the following block stay bit-equal to the oracle's"""
     spec = FZ.edit_session_spec(seed)
     e = O.build_oracle_engine(spec)
-    sim = HS.build_sim_engine(spec, max_blocks=2)
+    sim = HS.build_sim_engine(spec, max_blocks=2, masked_rows=bool(seed & 1))
     e.enable_seglog()
 
     def on_block(step, op):
@@ -122,7 +166,7 @@ def test_clip_outlasting_its_audio_shares_one_template():
     assert plan_rows(sim.fetch_plan()) == rows          # every finished call is still in the plan
     pc = sim.plan_counters()
     assert pc[1] == 0, f"plan status bits {pc[1]}"
-    assert pc[3] <= 4 * n_tracks, f"{pc[3]} templates for {n_tracks} tracks"
+    assert pc[3] <= 8 * n_tracks, f"{pc[3]} templates for {n_tracks} tracks"   # one reservation of 8 per track
     assert sim.template_capacity() < K * n_tracks       # the budget really is smaller than one template per block
     sim.close()
 

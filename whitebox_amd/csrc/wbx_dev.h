@@ -29,6 +29,8 @@ enum : uint8_t {
   KIND_UNITY = 1,    // one fp32 segment covering the whole block at playback_speed == 1.0 (sampler.cpp:145-156)
   KIND_WINDOW = 2,   // one fp32 (or 24/32-bit PCM: `format`) segment covering the whole block, 0 < playback_speed <= 0.999
                      // (linear, sampler.cpp:34-59)
+                     // (with PlanArgs::masked_rows, fp32 KIND_UNITY / KIND_WINDOW records may cover only frames
+                     //  [dst_start, dst_start + len) of the block: "masked rows")
   KIND_GENERIC = 3,  // anything else: several segments, partial coverage, playback speed above 4096
   KIND_UNITY_I16 = 4,  // one 16-bit PCM segment covering the whole block at playback_speed == 1.0 (sampler.cpp:109-120)
   KIND_UNITY_I32 = 5,  // the same for 24-bit (in 32-bit containers) and 32-bit PCM (sampler.cpp:121-144)
@@ -122,7 +124,10 @@ struct DRow {
 };
 enum : uint32_t {
   ROW_SILENT = 1,    // nothing to render for this track in this block
-  ROW_POS = 2        // the template is shared by a run of blocks: take the position from the row
+  ROW_POS = 2,       // the template is shared by a run of blocks: take the position from the row
+  ROW_PAIR = 4       // a clip boundary inside the block: TWO stream calls that do not overlap (one clip ends, the next
+                     // starts), as two single-segment templates at tmpl and tmpl + 1 — the mix kernel renders both as
+                     // masked rows in its hot loop (no pre-render pass, no overflow-pool entry)
 };
 static_assert(sizeof(DRow) == 16, "DRow must be 16 bytes");
 
@@ -160,6 +165,9 @@ struct PlanArgs {
   double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
   uint32_t playing;
   uint32_t clips_changed;       // the clip lists were edited since the previous plan: re-read the current clip's gain
+  uint32_t masked_rows;         // the mix instance of this render takes partial-coverage fp32 rows (one segment, or a
+                                // ROW_PAIR) in its hot loop: do not queue them for the pre-render pass
+  uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders)
 };
 
 struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows
@@ -185,6 +193,7 @@ struct MixArgs {
   uint32_t n_tracks, n_groups, block_frames, channels;
   uint32_t tiles;               // ceil(C*F/4 / 256)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
+  uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
 };
 
 struct SumArgs {

@@ -733,6 +733,10 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
+  // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
+  c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
+  a.masked_rows = c->masked_rows ? 1u : 0u;
+  a.tmpl_reserve = HostSession::template_reserve(K);
   a.playhead = hs.playhead;
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;

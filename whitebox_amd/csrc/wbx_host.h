@@ -455,10 +455,12 @@ struct HostSession {
     const size_t all = (size_t)K * n_tracks();
     return any_slow_clip ? all : std::min(all, 4 * total_clips + 2 * (size_t)n_tracks() + 64);
   }
+  // (a ROW_PAIR block takes two templates; every track may strand part of a reservation of `reserve` templates)
+  static uint32_t template_reserve(uint32_t K) { return K >= 8u ? 8u : 1u; }
   size_t template_hint(uint32_t K) const {
-    const size_t all = (size_t)K * n_tracks();
-    if (any_crawl_clip) return all + n_tracks();
-    return std::min(all, gen_rows_hint(K) + 3 * (size_t)n_tracks() + 64) + (size_t)n_tracks();
+    const size_t all = (size_t)K * n_tracks(), stranded = (size_t)(template_reserve(K) + 1u) * n_tracks();
+    if (any_crawl_clip) return 2 * all + stranded;
+    return std::min(2 * all, 2 * gen_rows_hint(K) + 3 * (size_t)n_tracks() + 64) + stranded;
   }
 
   // the transport advance of Engine::process for K blocks (engine.cpp:1578-1585, :1619-1623), the arithmetic the plan

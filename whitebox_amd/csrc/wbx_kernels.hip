@@ -491,11 +491,19 @@ template <int U, bool FULL, int W, bool G, int SB, int CW = 1>
 __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
   static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
-  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kStage;   // records staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS)
-  constexpr uint32_t kRecs = kSt + 2 * U + 4;      // staged records + null padding for the last batches
+  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kStage;   // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS)
+  // EXP: the instance takes the sequencer's masked rows (MixArgs::masked_rows): a track-block with a clip boundary in
+  // it is a ROW_PAIR of two single-segment records, so a chunk of kSt tracks stages up to 2 * kSt rows
+  constexpr bool EXP = SB == 1 && FULL && kSt == 128;
+  constexpr uint32_t kMaxRows = EXP ? 2 * kSt : kSt;
+  constexpr uint32_t kRecs = kMaxRows + 2 * U + 4;      // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
   __shared__ uint32_t s_pk[SB * kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[4];           // FULL: sub-block * C + channel each wave works on
+  __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? kSt : 1];   // EXP: the chunk's plan rows
+  __shared__ uint16_t s_map[EXP ? 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
+  __shared__ uint16_t s_off[EXP ? kSt + 1 : 1];   // EXP: local track -> its first staged row
+  __shared__ uint32_t s_wpairs[3];                // EXP: pairs in waves 0 and 1, staged rows of the chunk
 
   // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
   // of a group read adjacent pieces of the same clip rows (they share the cache line at the seam), so give every
@@ -541,6 +549,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     double pos, speed;
     float gain, gc;    // clip gain, fl(volume * pan_c)
     uint32_t kind, format;
+    uint32_t d, n;     // EXP: the stream call covers frames [d, d + n) of the block (whole-block records: 0, F)
   };
   auto load_urec = [&](uint32_t rec) {
     const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rb + rec])[lane & 15u];
@@ -563,10 +572,26 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
     r.gain = __uint_as_float(rl(8));
     r.gc = __uint_as_float(rl(9u + cs));
-    r.kind = (rl(11) >> 8) & 0xFFu;
+    const uint32_t q11 = rl(11);
+    r.kind = (q11 >> 8) & 0xFFu;
     r.format = rl(13) & 0xFFu;
+    if (EXP) {
+      r.d = q11 >> 16;
+      r.n = rl(12) & 0xFFFFu;
+    }
     return r;
   };
+  // Masked rows (EXP).  Frame j0+e of the block is frame (j0+e-d) of the stream call; clamped into the call, so that
+  // what the masked-out frames of a lane load stays inside the clip — they are zeroed afterwards.  For a whole-block
+  // record (d = 0, n = F) this is j0+e itself.
+  auto call_frame = [&](uint32_t e, uint32_t d, uint32_t n) {
+    const int x = (int)(j0 + e) - (int)d, hi = (int)n - 1;
+    const int lo = x > 0 ? x : 0;
+    return lo < hi ? lo : hi;
+  };
+  // all-ones when frame j0+e lies inside [d, d+n), zero otherwise
+  auto frame_mask = [&](uint32_t e, uint32_t d, uint32_t n) { return (uint32_t)0 - (uint32_t)((j0 + e - d) < n); };
+  auto and_mask = [&](float v, uint32_t m) { return __uint_as_float(__float_as_uint(v) & m); };
 
   // ---- per-row arithmetic (each returns the 4 frames of one track AFTER clip gain and track gain) ----
   // fp32 row at unity speed: sampler.cpp:151-152, track.cpp:731
@@ -626,8 +651,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return f4{q[0], q[1], q[2], q[3]};
   };
   // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
-  auto load_window = [&](const void* src_c, double pos, double speed, Pre& p) {
-    const double x0 = __dadd_rn(pos, __dmul_rn(j0d, speed));                              // sampler.cpp:50, frame j0
+  auto load_window = [&](const void* src_c, double pos, double speed, Pre& p, double jd0) {
+    const double x0 = __dadd_rn(pos, __dmul_rn(jd0, speed));                              // sampler.cpp:50, frame j0 (of the call)
     const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
     const float WBX_GLOBAL* src = as_global<float>(src_c) + ix0;
     if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
@@ -769,6 +794,43 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
     return f4{m[0], m[1], m[2], m[3]};
   };
+  // fp32 unity row covering only [d, d+n): the lane's load starts at call frame jb = call_frame(0), frame e reads
+  // sample call_frame(e) - jb of it (0..e; the same sample again for frames clamped at the call's ends)
+  auto row_f32_masked = [&](const f4& v, uint32_t d, uint32_t n, float cg, float gc) {
+    const int jb = call_frame(0u, d, n);
+    float q[4];
+    q[0] = and_mask(__fmul_rn(__fmul_rn(v.x, cg), gc), frame_mask(0u, d, n));
+#pragma unroll
+    for (uint32_t e = 1; e < 4; e++) {
+      const int k = call_frame(e, d, n) - jb;
+      float sv = sel_neg(k - 1, v.x, v.y);
+      if (e >= 2) sv = sel_neg(k - 2, sv, v.z);
+      if (e >= 3) sv = sel_neg(k - 3, sv, v.w);
+      q[e] = and_mask(__fmul_rn(__fmul_rn(sv, cg), gc), frame_mask(e, d, n));                    // sampler.cpp:151-152, track.cpp:731
+    }
+    return f4{q[0], q[1], q[2], q[3]};
+  };
+  // the same for a row read through the 5-sample window (the window loads started at call frame call_frame(0)): a
+  // resampled row (sampler.cpp:34-59) or, `unity`, a unity-speed row inside a chunk of window rows
+  auto row_window_masked = [&](const Pre& p, double pos, double speed, bool unity, uint32_t d, uint32_t n, float cg, float gc) {
+    float q[4];
+    {
+      const float lin = __fadd_rn(p.v.x, __fmul_rn(p.fx0, __fsub_rn(p.v.y, p.v.x)));             // :55
+      q[0] = and_mask(__fmul_rn(__fmul_rn(unity ? p.v.x : lin, cg), gc), frame_mask(0u, d, n));
+    }
+#define WBX_MTAP(E)                                                                                       \
+  {                                                                                                       \
+    const double x = __dadd_rn(pos, __dmul_rn((double)call_frame(E, d, n), speed));   /* sampler.cpp:50 */ \
+    const float fx = (float)__builtin_amdgcn_fract(x);                                /* :52 */           \
+    float sa, sb;                                                                                         \
+    taps<E>(p.v, p.w4, (int)x - p.ix0, sa, sb);                                       /* :51 */           \
+    const float lin = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));                /* :55 */           \
+    q[E] = and_mask(__fmul_rn(__fmul_rn(unity ? sa : lin, cg), gc), frame_mask(E, d, n));                 \
+  }
+    WBX_MTAP(1) WBX_MTAP(2) WBX_MTAP(3)
+#undef WBX_MTAP
+    return f4{q[0], q[1], q[2], q[3]};
+  };
   auto add_row = [&](const f4& m0) {
     f4 m = m0;
     if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -836,7 +898,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       if constexpr (MODE == MODE_G) {
         load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
-        load_window(r.src, r.pos, r.speed, pre[u]);
+        if (EXP)
+          load_window(r.src, r.pos, r.speed, pre[u], (double)call_frame(0u, r.d, r.n));
+        else
+          load_window(r.src, r.pos, r.speed, pre[u], j0d);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
         load_window16(r.src, r.pos, r.speed, pre[u]);
       } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
@@ -866,7 +931,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         const char WBX_GLOBAL* p = as_global<char>(r.src) + ((size_t)off << sh);
         if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
       } else {
-        const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
+        // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
+        const uint32_t off = (uint32_t)r.pos + ((EXP && MODE == MODE_U) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
         if (MODE == MODE_I16) {
           typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
           const short WBX_GLOBAL* p = as_global<short>(r.src) + off;
@@ -911,7 +977,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_WN> narrow{};
-        if (k == KIND_WINDOW) {
+        if (EXP && (r.d != 0u || r.n != F)) {   // a stream call that covers part of the block (wave-uniform)
+          m = row_window_masked(pre[u], r.pos, r.speed, k != KIND_WINDOW, r.d, r.n, cg, gc);
+        } else if (k == KIND_WINDOW) {
           if (G && fmt != FMT_F32) {   // 24/32-bit PCM through the same window loads (G instances only)
             if constexpr (G) m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
           } else {
@@ -958,7 +1026,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       } else if constexpr (MODE == MODE_I32) {
         m = row_i32(pre[u].v, r.format, cg, gc);
       } else {
-        m = row_f32(pre[u].v, cg, gc);
+        if (EXP && (r.d != 0u || r.n != F))
+          m = row_f32_masked(pre[u].v, r.d, r.n, cg, gc);
+        else
+          m = row_f32(pre[u].v, cg, gc);
       }
       pk[u] = add_row(m);
     }
@@ -1005,7 +1076,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
       if (k == KIND_WINDOW) {
         Pre p;
-        load_window(r.src[c], r.pos, r.speed, p);
+        load_window(r.src[c], r.pos, r.speed, p, j0d);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
@@ -1022,11 +1093,62 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   };
 
   for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kSt) {
-    const uint32_t cn = (grp.count - chunk0) < kSt ? (grp.count - chunk0) : kSt;
+    const uint32_t cn = (grp.count - chunk0) < kSt ? (grp.count - chunk0) : kSt;   // tracks of this chunk
+    uint32_t cn2 = cn;                                                                  // staged rows of this chunk
     __syncthreads();
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
     // A record = the template its 16-B plan row points at, with the row's position patched in when the template
     // is shared by a run of blocks; silent rows become all-zero records (kind 0).
+    if (EXP && a.masked_rows) {
+      // Rows may be ROW_PAIRs (a clip boundary inside the block: two single-segment templates).  Pass 1, one lane per
+      // track: fetch the 16-B plan row, count a pair as two staged rows, wave-ballot prefix sum -> the track's first
+      // staged row.  Pass 2 copies the records as before, through the staged-row -> (track, record) map.
+      uint32_t before = 0u;
+      bool is_pair = false;
+      if (tid < kSt) {
+        DRow row;
+        row.pos = 0.0;
+        row.tmpl = 0xFFFFFFFFu;
+        row.flags = ROW_SILENT;
+        if (tid < cn) row = a.rows[(size_t)bx * N + a.order[grp.first + chunk0 + tid]];
+        *reinterpret_cast<uint4*>(&s_rows[tid]) = *reinterpret_cast<const uint4*>(&row);
+        is_pair = (row.flags & (ROW_PAIR | ROW_SILENT)) == ROW_PAIR;
+        const unsigned long long bal = __ballot(is_pair);
+        before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0u) s_wpairs[tid >> 6] = (uint32_t)__popcll(bal);
+      }
+      __syncthreads();
+      if (tid < cn) {
+        const uint32_t off = tid + before + (tid >= 64u ? s_wpairs[0] : 0u);
+        s_off[tid] = (uint16_t)off;
+        s_map[off] = (uint16_t)tid;
+        if (is_pair) s_map[off + 1u] = (uint16_t)(tid | 0x8000u);
+      }
+      if (tid == 0u) {
+        const uint32_t total = cn + s_wpairs[0] + s_wpairs[1];
+        s_off[cn] = (uint16_t)total;
+        s_wpairs[2] = total;
+      }
+      __syncthreads();
+      cn2 = s_wpairs[2];
+      for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
+        const uint32_t rec = i >> 2, q = i & 3u;
+        uint4 w = {0u, 0u, 0u, 0u};
+        if (rec < cn2) {
+          const uint32_t mp = s_map[rec];
+          const DRow row = s_rows[mp & 0x7FFFu];
+          if (!(row.flags & ROW_SILENT)) {
+            w = reinterpret_cast<const uint4*>(a.tmpl + row.tmpl + (mp >> 15))[q];
+            if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
+              const uint2 pb = *reinterpret_cast<const uint2*>(&row.pos);
+              w.x = pb.x;
+              w.y = pb.y;
+            }
+          }
+        }
+        reinterpret_cast<uint4*>(s_tb)[i] = w;
+      }
+    } else {
     for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) {
       const uint32_t sb = SB > 1 ? i / (kRecs * 4u) : 0u;
       const uint32_t rec = (i - sb * kRecs * 4u) >> 2, q = i & 3u;
@@ -1046,13 +1168,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }
+    }
     for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) s_pk[i] = 0u;
     if (FULL && lane == 0u) s_wc[tid >> 6] = sub * C + c;
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
-    for (uint32_t i0 = tid; i0 < SB * cn; i0 += 256u) {
-      const uint32_t i = SB > 1 ? (i0 / cn) * kRecs + i0 % cn : i0;
+    for (uint32_t i0 = tid; i0 < SB * cn2; i0 += 256u) {
+      const uint32_t i = SB > 1 ? (i0 / cn2) * kRecs + i0 % cn2 : i0;
       const int k = s_tb[i].kind;
       shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? (s_tb[i].format == FMT_F32 ? 2 : 128) : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8
                : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
@@ -1083,7 +1206,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // of the chunk's own shape, so that the load phase stays straight-line
     for (uint32_t i = tid; i < SB * kRecs; i += 256u) {
       DTrackBlock& r = s_tb[i];
-      if ((SB > 1 ? i % kRecs : i) >= cn || r.kind == KIND_SILENT) {
+      if ((SB > 1 ? i % kRecs : i) >= cn2 || r.kind == KIND_SILENT) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -1091,6 +1214,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.gain = 0.0f;
         r.g[0] = 0.0f;
         r.g[1] = 0.0f;
+        r.dst_start = 0;                 // (a whole-block row for the masked-row arithmetic of the EXP instances)
+        r.len = (uint16_t)F;
         const bool m16 = mode == MODE_I16 || mode == MODE_WI || mode == MODE_WIN;
         r.format = m16 ? FMT_I16 : mode == MODE_I32 ? FMT_I32 : FMT_F32;
         r.kind = m16 ? KIND_UNITY_I16 : mode == MODE_I32 ? KIND_UNITY_I32 : KIND_UNITY;
@@ -1099,28 +1224,28 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     __syncthreads();
 
     switch (mode) {
-      case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn); break;
-      case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn); break;
-      case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn); break;
+      case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn2); break;
+      case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn2); break;
+      case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn2); break;
       case MODE_G:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn);
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn2);
         break;
       case MODE_WI:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_WI>{}, cn);
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_WI>{}, cn2);
         break;
       case MODE_WIN:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn);
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn2);
         break;
-      case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn); break;
+      case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn2); break;
       case MODE_MW:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_MW>{}, cn);
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_MW>{}, cn2);
         break;
       case MODE_MWN:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_MWN>{}, cn);
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_MWN>{}, cn2);
         break;
-      case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn); break;
-      case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn); break;
-      default: mixed(cn); break;
+      case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn2); break;
+      case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn2); break;
+      default: mixed(cn2); break;
     }
 
     __syncthreads();
@@ -1136,10 +1261,15 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       if (FULL && CW == 2) {
         pk = s_pk[(sb * kRecs + rec) * 4u + ch];
       } else if (FULL) {
-        const uint32_t* slots = &s_pk[(sb * kRecs + rec) * 4u];
+        // (EXP with masked rows: the track's staged row, or the two of its pair — one peak over both stream calls)
+        const uint32_t r0 = (EXP && a.masked_rows) ? s_off[rec] : rec;
+        const uint32_t r1 = (EXP && a.masked_rows) ? s_off[rec + 1u] : rec + 1u;
+        for (uint32_t rr = r0; rr < r1; rr++) {
+          const uint32_t* slots = &s_pk[(sb * kRecs + rr) * 4u];
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; w++)
-          if (s_wc[w] == sb * C + ch) pk = pk > slots[w] ? pk : slots[w];
+          for (uint32_t w = 0; w < 4u; w++)
+            if (s_wc[w] == sb * C + ch) pk = pk > slots[w] ? pk : slots[w];
+        }
       } else {
         pk = s_pk[rec * 2u + ch];
       }
@@ -1410,8 +1540,8 @@ void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_ro
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
 #define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W, false, 1>), grid, block, 0, s, a); break;
-    WBX_V(1, 6) WBX_V(1, 8)
-    WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6) WBX_V(2, 8)
+    WBX_V(1, 6)
+    WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6)
     WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
     WBX_V(8, 2)
 #undef WBX_V

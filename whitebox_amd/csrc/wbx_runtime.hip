@@ -174,6 +174,18 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   return WBX_OK;
 }
 
+// Can the mix instance a render of this shape will launch take masked rows (partial-coverage fp32 records, ROW_PAIRs)
+// in its hot loop?  Only the lean whole-workgroup-per-block instances do (mix_kernel<U, true, W, false, 1>): blocks of
+// C*F/4 lanes a multiple of 256, sessions without integer-PCM or per-frame-tap clips.
+bool mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
+  (void)window_clips;
+  const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
+  const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  if (const char* e = std::getenv("WBX_MASKED_ROWS"))
+    if (e[0] == '0') return false;   // A/B aid: send every boundary row through the pre-render pass
+  return full && !c->force_g && !stride_clips && !c->has_integer_clips;
+}
+
 // where the master of the render about to be issued goes; `writer` is the stream its last writer runs on
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err) {
   *err = hipSuccess;
@@ -205,6 +217,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.channels = C;
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
+  m.masked_rows = c->masked_rows ? 1u : 0u;
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(c->d_peaks.p, 0, (size_t)K * N * C * sizeof(float), c->stream));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
@@ -857,6 +870,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   st = launch_pre_render(c, K, c->stream);
   if (st != WBX_OK) return st;
+  c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
   return launch_mix_sum(c, K, N);
 }
 

@@ -109,7 +109,11 @@ struct TrackCache {
   // (sampler.cpp:99-100) for the rest of the region, every one with the same record: they share one template.
   DTrackBlock fin;     // the record of the last such block
   uint32_t fin_tmpl;   // its template index, 0xFFFFFFFF = none yet
+  // templates are reserved kTmplReserve at a time: one atomic round trip per reservation instead of one per block
+  // with events (a session cut into short clips has an event in every few blocks of every track)
+  uint32_t tmpl_next, tmpl_end;
 };
+constexpr uint32_t kTmplReserve = 8;   // PlanArgs::tmpl_reserve of batch renders (1 for the one-block callback)
 
 struct BlockWalker {
   DTrackState* st;
@@ -127,26 +131,33 @@ struct BlockWalker {
   uint32_t nseg;
   uint32_t chunk;
 
-  // where call number `nseg` (>= 1) of this block goes in the overflow pool
+  // The second stream call of a block is kept in `seg1` (the usual clip boundary: one clip ends, the next starts —
+  // it becomes template tmpl + 1 of a ROW_PAIR and never touches the pool); the overflow pool is only allocated
+  // when a third call arrives (or, for a pair the hot loop cannot take, when the block is finished).
+  DSeg seg1;
+  __host__ __device__ bool alloc_chunk() {
+    uint32_t c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    c = atomicAdd(pool_count, 1u);
+#else
+    c = (*pool_count)++;
+#endif
+    if (c >= pool_chunks) {
+      if (status) status[0] |= 1u;
+      return false;
+    }
+    chunk = c;
+    tb->extra = c;
+    pool[(size_t)chunk * kChunk] = seg1;
+    return true;
+  }
+  // where call number `nseg` (>= 2) of this block goes in the overflow pool
   __host__ __device__ DSeg* slot() {
     if (nseg >= kMaxSegs) {
       if (status) status[0] |= 2u;
       return nullptr;
     }
-    if (nseg == 1) {
-      uint32_t c;
-#if defined(__HIP_DEVICE_COMPILE__)
-      c = atomicAdd(pool_count, 1u);
-#else
-      c = (*pool_count)++;
-#endif
-      if (c >= pool_chunks) {
-        if (status) status[0] |= 1u;
-        return nullptr;
-      }
-      chunk = c;
-      tb->extra = c;
-    }
+    if (nseg == 2 && !alloc_chunk()) return nullptr;
     if (chunk == 0xFFFFFFFFu) return nullptr;
     return &pool[(size_t)chunk * kChunk + (nseg - 1)];
   }
@@ -162,7 +173,7 @@ struct BlockWalker {
 
   __host__ __device__ void stream(uint32_t num_samples, uint32_t buffer_offset) {
     const DSample& smp = sample_of(st->cur_sample);
-    DSeg* s = nseg ? slot() : nullptr;
+    DSeg* s = nseg >= 2 ? slot() : nullptr;
     DSeg seg;
     seg.src[0] = smp.ch[0];
     seg.src[1] = smp.ch[n_channels > 1 ? 1 : 0];
@@ -203,6 +214,9 @@ struct BlockWalker {
     if (nseg == 0) {
       set_seg0(tb, seg);
       nseg = 1;
+    } else if (nseg == 1) {
+      seg1 = seg;
+      nseg = 2;
     } else if (s) {
       *s = seg;
       nseg++;
@@ -360,19 +374,39 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
   return KIND_GENERIC;
 }
 
-// a slot in the render's template array (0xFFFFFFFF + status bit 4 when the array is full)
-__host__ __device__ inline uint32_t alloc_template(const PlanArgs& a) {
-  uint32_t i;
+// `n` adjacent slots in the render's template array (0xFFFFFFFF + status bit 4 when the array is full), taken from
+// the track's current reservation
+__host__ __device__ inline uint32_t alloc_template(const PlanArgs& a, TrackCache* cache, uint32_t n = 1u) {
+  if (cache->tmpl_next + n > cache->tmpl_end) {
+    uint32_t base;
+    const uint32_t take = a.tmpl_reserve > n ? a.tmpl_reserve : n;
 #if defined(__HIP_DEVICE_COMPILE__)
-  i = atomicAdd(a.tmpl_count, 1u);
+    base = atomicAdd(a.tmpl_count, take);
 #else
-  i = (*a.tmpl_count)++;
+    base = *a.tmpl_count;
+    *a.tmpl_count += take;
 #endif
-  if (i >= a.tmpl_cap) {
-    if (a.status) a.status[0] |= 16u;
-    return 0xFFFFFFFFu;
+    if (base + take > a.tmpl_cap) {
+      if (a.status) a.status[0] |= 16u;
+      return 0xFFFFFFFFu;
+    }
+    cache->tmpl_next = base;
+    cache->tmpl_end = base + take;
   }
+  const uint32_t i = cache->tmpl_next;
+  cache->tmpl_next += n;
   return i;
+}
+
+// What the hot loop can render of ONE stream call that covers only part of the block (PlanArgs::masked_rows): fp32,
+// source positions below 2^31, unity speed or a speed the 5-sample window holds.  KIND_GENERIC: it cannot.
+__host__ __device__ inline uint8_t masked_kind(const DSeg& s, uint32_t block_frames) {
+  if (s.len == 0) return KIND_SILENT;
+  if (s.format != FMT_F32 || !(s.pos >= 0.0 && s.pos < 2147483000.0)) return KIND_GENERIC;
+  if ((uint32_t)s.dst_start + s.len > block_frames) return KIND_GENERIC;
+  if (s.speed == 1.0) return KIND_UNITY;
+  if (s.speed > 0.0 && s.speed <= 0.999) return KIND_WINDOW;
+  return KIND_GENERIC;
 }
 
 // One track, one block: Track::process minus the per-sample work (track.cpp:587-736).
@@ -428,6 +462,23 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   tb->nseg = (uint8_t)w.nseg;
   tb->_pad = 0;
   tb->kind = classify(*tb, a.block_frames);
+  // A clip start / end inside the block as the hot loop takes it (PlanArgs::masked_rows): one partial fp32 stream
+  // call becomes a masked KIND_UNITY / KIND_WINDOW record, two calls that do not overlap become a ROW_PAIR.
+  bool pair = false;
+  uint8_t kind1 = KIND_SILENT;
+  if (a.masked_rows && tb->kind == KIND_GENERIC && w.nseg <= 2u) {
+    const uint8_t kind0 = masked_kind(get_seg0(rec), a.block_frames);
+    if (w.nseg == 1u) {
+      if (kind0 != KIND_GENERIC) tb->kind = kind0;
+    } else {
+      kind1 = masked_kind(w.seg1, a.block_frames);
+      if (kind0 != KIND_GENERIC && kind1 != KIND_GENERIC && (uint32_t)rec.dst_start + rec.len <= w.seg1.dst_start) {
+        pair = true;
+        tb->kind = kind0;
+      }
+    }
+  }
+  if (w.nseg == 2u && !pair) (void)w.alloc_chunk();   // the pre-render pass and the read-back find call 1 in the pool
   uint32_t tmpl_index = 0xFFFFFFFFu;
   {
     const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
@@ -435,7 +486,27 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
     row.pos = rec.pos;
     row.tmpl = 0xFFFFFFFFu;
     row.flags = ROW_SILENT;
-    if (rec.nseg != 0) {   // also for calls that render nothing (finished clip): the plan keeps every stream call
+    if (pair) {
+      const uint32_t ti = alloc_template(a, cache, 2u);
+      if (ti != 0xFFFFFFFFu) {
+        DTrackBlock rec1;
+        set_seg0(&rec1, w.seg1);
+        rec1.g[0] = gl;
+        rec1.g[1] = gr;
+        rec1.nseg = 1;
+        rec1.kind = kind1;
+        rec1._pad = 0;
+        rec1.extra = 0;
+        const uint4* srcq1 = reinterpret_cast<const uint4*>(&rec1);
+        uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
+        for (int q = 0; q < 4; q++) {
+          dstq[q] = srcq[q];
+          dstq[4 + q] = srcq1[q];
+        }
+        row.tmpl = ti;
+        row.flags = ROW_PAIR | ((rec.kind == KIND_SILENT && kind1 == KIND_SILENT) ? ROW_SILENT : 0u);
+      }
+    } else if (rec.nseg != 0) {   // also for calls that render nothing (finished clip): the plan keeps every stream call
       const bool finished = rec.nseg == 1 && rec.len == 0 && (rec.flags & SEG_FINISHED);
       const uint4* fq = reinterpret_cast<const uint4*>(&cache->fin);
       bool same = finished && cache->fin_tmpl != 0xFFFFFFFFu;
@@ -444,7 +515,7 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
       if (same) {          // the same finished call as in the block before: no new template
         row.tmpl = cache->fin_tmpl;
       } else {
-        const uint32_t ti = alloc_template(a);
+        const uint32_t ti = alloc_template(a, cache);
         if (ti != 0xFFFFFFFFu) {
           uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
           dstq[0] = srcq[0];
@@ -485,7 +556,7 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
 // what plan_track_block produces (the parity tests compare them with the oracle's call log).  Returns the
 // number of blocks planned (0: the general path must handle block b).
 __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
-                                                    uint32_t num_clips, const TrackCache* cache,
+                                                    uint32_t num_clips, TrackCache* cache,
                                                     const DBlockTime* times, float gl, float gr) {
   if (!(a.playing && st->cur_type == EV_PLAY && st->has_clip_idx && !st->refresh_voice && st->partially_ended &&
         st->clip_idx < num_clips && cache->clip_idx == st->clip_idx && !cache->clip.internal_state_changed &&
@@ -537,7 +608,7 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   rec.pos = off;
   rec.kind = classify(rec, F);
   if (rec.kind == KIND_GENERIC || rec.kind == KIND_SILENT) return 0;   // general path (pre-render queue)
-  const uint32_t ti = alloc_template(a);
+  const uint32_t ti = alloc_template(a, cache);
   if (ti == 0xFFFFFFFFu) return 0;
   {
     const uint4* srcq = reinterpret_cast<const uint4*>(&rec);
@@ -626,6 +697,7 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
   cache.clip_idx = 0xFFFFFFFFu;
   cache.smp_idx = 0xFFFFFFFFu;
   cache.fin_tmpl = 0xFFFFFFFFu;
+  cache.tmpl_next = cache.tmpl_end = 0u;
   const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
   uint32_t b = 0;
   while (b < a.n_blocks) {
@@ -650,9 +722,12 @@ inline size_t plan_records(uint32_t K, uint32_t N, const DRow* rows, const DTrac
       if (row.tmpl >= n_tmpl) continue;   // no stream call at all in this track-block
       DTrackBlock r = tmpl[row.tmpl];
       if (row.flags & ROW_POS) r.pos = row.pos;
+      const bool pair = (row.flags & ROW_PAIR) && (size_t)row.tmpl + 1 < n_tmpl;   // call 1 is the template behind
+      const DSeg s1 = pair ? get_seg0(tmpl[row.tmpl + 1]) : DSeg{};
       for (uint32_t i = 0; i < r.nseg; i++) {
         const DSeg s0 = get_seg0(r);
-        const DSeg* sg = (i == 0) ? &s0 : (r.extra < pool_used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
+        const DSeg* sg = (i == 0) ? &s0 : (pair && i == 1) ? &s1
+                         : (r.extra < pool_used ? &pool[(size_t)r.extra * kChunk + (i - 1)] : nullptr);
         if (!sg) continue;
         if (out && n < cap) {
           Rec& o = out[n];
