@@ -305,6 +305,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
         try:
             dist = Dist(eng.ctx, rank, world, dist_mode)
         finally:
+            C.CDLL(None).fflush(None)      # RCCL writes through C stdio: empty its buffer while fd 1 still points at stderr
             os.dup2(saved, 1)
             os.close(saved)
     else:

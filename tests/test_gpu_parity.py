@@ -433,8 +433,9 @@ def _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels=2, gaps=T
         while pos < total:
             a, b = max(pos, 0.0), pos + L * (0.6 if (gaps and (t + k) % 3 == 0) else 1.0)
             stretch = [1.0, 1.0, 0.5, 0.8][(t + k) % 4]
-            clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.8 + 0.37 * (k % 3),
-                                        speed=stretch, gain=[1.0, 0.5, 1.7][k % 3], sample=2 * t + k % 2))
+            if b > a:
+                clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.8 + 0.37 * (k % 3),
+                                            speed=stretch, gain=[1.0, 0.5, 1.7][k % 3], sample=2 * t + k % 2))
             pos += L
             k += 1
     cls = _SpecialValuesSpec if salt else synth.SessionSpec

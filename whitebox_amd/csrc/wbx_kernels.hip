@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256, 6) void gen_kernel(GenArgs a) {
       u.pos = 0.0;
       u.speed = 1.0;
       u.gain = 1.0f;
+      u.dst_start = 0;             // the row holds the whole block (the record's own segment bounds live on in `saved`)
+      u.len = (uint16_t)F;
       u.kind = KIND_UNITY;
       u.format = FMT_F32;   // the row is fp32 whatever the clip's storage format (MODE_G reads by format)
       a.tmpl[idx] = u;
