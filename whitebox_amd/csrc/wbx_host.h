@@ -456,7 +456,7 @@ struct HostSession {
     return any_slow_clip ? all : std::min(all, 4 * total_clips + 2 * (size_t)n_tracks() + 64);
   }
   // (a ROW_PAIR block takes two templates; every track may strand part of a reservation of `reserve` templates)
-  static uint32_t template_reserve(uint32_t K) { return K >= 8u ? 8u : 1u; }
+  static uint32_t template_reserve(uint32_t K) { return K >= 64u ? 32u : K >= 8u ? 8u : 1u; }
   size_t template_hint(uint32_t K) const {
     const size_t all = (size_t)K * n_tracks(), stranded = (size_t)(template_reserve(K) + 1u) * n_tracks();
     if (any_crawl_clip) return 2 * all + stranded;

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
     return r;
   };
+  const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);   // FULL: the wave's first frame
   // Masked rows (EXP).  Frame j0+e of the block is frame (j0+e-d) of the stream call; clamped into the call, so that
   // what the masked-out frames of a lane load stays inside the clip — they are zeroed afterwards.  For a whole-block
   // record (d = 0, n = F) this is j0+e itself.
@@ -628,8 +629,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return m;
   };
   // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
-  auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+  auto row_window_at = [&](auto narrow, auto shifted, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
     constexpr bool NARROW = decltype(narrow)::value;
+    constexpr bool SHIFTED = decltype(shifted)::value;   // the stream call starts at block frame d0: call frame = j - d0
     const int ix0 = p.ix0;
     float q[4];
     {   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
 #define WBX_TAP(E, JD)                                                                                  \
   {                                                                                                     \
-    const double x = __dadd_rn(pos, __dmul_rn((JD), speed));              /* sampler.cpp:50 */          \
+    const double x = __dadd_rn(pos, __dmul_rn(SHIFTED ? (JD) - d0 : (JD), speed));   /* sampler.cpp:50 */ \
     const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
     float sa, sb;                                                                                       \
     if (NARROW)                                                           /* :51 */                     \
@@ -651,6 +653,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
 #undef WBX_TAP
     return f4{q[0], q[1], q[2], q[3]};
+  };
+  auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+    return row_window_at(narrow, std::false_type{}, p, pos, speed, 0.0, cg, gc);
   };
   // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
   auto load_window = [&](const void* src_c, double pos, double speed, Pre& p, double jd0) {
@@ -980,7 +985,16 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_WN> narrow{};
         if (EXP && (r.d != 0u || r.n != F)) {   // a stream call that covers part of the block (wave-uniform)
-          m = row_window_masked(pre[u], r.pos, r.speed, k != KIND_WINDOW, r.d, r.n, cg, gc);
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
+            m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
+            if (k == KIND_WINDOW)
+              m = row_window_at(narrow, std::true_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
+            else
+              m = row_f32(pre[u].v, cg, gc);
+          } else {
+            m = row_window_masked(pre[u], r.pos, r.speed, k != KIND_WINDOW, r.d, r.n, cg, gc);
+          }
         } else if (k == KIND_WINDOW) {
           if (G && fmt != FMT_F32) {   // 24/32-bit PCM through the same window loads (G instances only)
             if constexpr (G) m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
@@ -1028,10 +1042,14 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       } else if constexpr (MODE == MODE_I32) {
         m = row_i32(pre[u].v, r.format, cg, gc);
       } else {
-        if (EXP && (r.d != 0u || r.n != F))
-          m = row_f32_masked(pre[u].v, r.d, r.n, cg, gc);
-        else
+        if (EXP && (r.d != 0u || r.n != F) && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base)
+            m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          else
+            m = row_f32_masked(pre[u].v, r.d, r.n, cg, gc);
+        } else {
           m = row_f32(pre[u].v, cg, gc);
+        }
       }
       pk[u] = add_row(m);
     }

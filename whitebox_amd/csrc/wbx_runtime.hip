@@ -169,7 +169,9 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   ga.channels = C;
   // one wave per queued row, grid-stride: no more workgroups than the device holds at once (256 CUs x 6 workgroups at
   // the kernel's register budget), or the surplus would start when the first ones have finished their whole share
-  launch_gen(ga, K < kOverlapMinBlocks ? 64u * K : 1536u, on);
+  // (a plan made for a masked-row mix instance queues only what is left over: blocks with three or more stream calls,
+  //  overlapping calls — a handful per render at most)
+  launch_gen(ga, K < kOverlapMinBlocks ? 64u * K : c->masked_rows ? 128u : 1536u, on);
   WBX_HIP(c, hipGetLastError());
   return WBX_OK;
 }
@@ -810,7 +812,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
       BlockWalker w{};
       DTrackBlock scratch{};
       TrackCache tc{};
-      tc.clip_idx = tc.smp_idx = tc.fin_tmpl = 0xFFFFFFFFu;
+      tc.clip_idx = tc.next_idx = tc.smp_idx = tc.fin_tmpl = 0xFFFFFFFFu;
       uint32_t pc = 0, stbits = 0;
       w.st = &ts;
       w.cache = &tc;
@@ -868,9 +870,9 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
   st = launch_pre_render(c, K, c->stream);
   if (st != WBX_OK) return st;
-  c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
   return launch_mix_sum(c, K, N);
 }
 

@@ -105,9 +105,17 @@ struct TrackCache {
   DSample smp;
   uint32_t clip_idx;   // index within the track's clip list, 0xFFFFFFFF = empty
   uint32_t smp_idx;    // sample id, 0xFFFFFFFF = empty
+  // The clip BEHIND the current one is fetched when the current one is: a track is one lane, so a clip boundary would
+  // otherwise wait a full global-memory round trip for the next clip's record, with nothing else to run meanwhile.
+  DClip next;
+  uint32_t next_idx;   // 0xFFFFFFFF = empty
   // A clip whose timeline region outlasts its audio makes one zero-length "finished" stream call per block
   // (sampler.cpp:99-100) for the rest of the region, every one with the same record: they share one template.
-  DTrackBlock fin;     // the record of the last such block
+  // (what identifies the record of the last such block — kept field by field, in registers: a 64-B struct compared
+  //  through a pointer would put the sequencer's locals into scratch memory)
+  double fin_pos, fin_speed;
+  float fin_gain;
+  uint32_t fin_sample, fin_shape;   // shape = dst_start << 16 | req_len
   uint32_t fin_tmpl;   // its template index, 0xFFFFFFFF = none yet
   // templates are reserved kTmplReserve at a time: one atomic round trip per reservation instead of one per block
   // with events (a session cut into short clips has an event in every few blocks of every track)
@@ -257,6 +265,13 @@ __host__ __device__ inline void clear_state_changed(DClip* cached, DClip* global
   }
 }
 
+// (uint32)((uint64)sample_offset % buffer_size), track.cpp:359-361,423-425.  A 64-bit remainder by a run-time value is
+// a long software routine on the GPU; buffer sizes are powers of two in practice.
+__host__ __device__ inline uint32_t mod_buffer(uint64_t x, uint32_t buffer_size) {
+  if ((buffer_size & (buffer_size - 1u)) == 0u) return (uint32_t)x & (buffer_size - 1u);
+  return (uint32_t)(x % (uint64_t)buffer_size);
+}
+
 // Track::process_event, audio branch — track.cpp:258-451.  MIDI clips and recording are out of scope.
 __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint32_t num_clips, double start_time,
                                               double end_time, double sample_position, double beat_duration,
@@ -305,8 +320,16 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
   TrackCache* cc = w.cache;
   while (next_clip < num_clips) {                                // :349-446
     if (cc->clip_idx != next_clip) {
-      cc->clip = clips[next_clip];
+      // (always through `next`: choosing between a copy from the cache and a load from HBM would make the compiler
+      //  select between ADDRESSES and keep the whole cache in scratch memory instead of registers)
+      if (cc->next_idx != next_clip) cc->next = clips[next_clip];
+      cc->clip = cc->next;
       cc->clip_idx = next_clip;
+      cc->next_idx = 0xFFFFFFFFu;
+      if (next_clip + 1u < num_clips) {   // (not needed before the next boundary: the load's latency is hidden)
+        cc->next = clips[next_clip + 1u];
+        cc->next_idx = next_clip + 1u;
+      }
     }
     DClip* clip = &cc->clip;
     double min_time = clip->min_time;
@@ -317,7 +340,7 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
     if (min_time >= start_time) {                                // :357-374 started from the beginning
       double offset_from_start = beat_to_samples(min_time - start_time, sample_rate, beat_duration);
       double sample_offset = sample_position + offset_from_start;
-      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      uint32_t buffer_offset = mod_buffer((uint64_t)sample_offset, buffer_size);
       w.on_event(EV_PLAY, buffer_offset, clip->speed, (uint64_t)clip->start_offset, clip);
       clear_state_changed(clip, &clips[next_clip]);
     } else if (start_time > min_time && !st->partially_ended) {  // :375-393 started in the middle
@@ -338,7 +361,7 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
     if (max_time <= end_time) {                                  // :421-434 reaching the end of the clip
       double offset_from_start = beat_to_samples(max_time - start_time, sample_rate, beat_duration);
       double sample_offset = sample_position + offset_from_start;
-      uint32_t buffer_offset = (uint32_t)((uint64_t)sample_offset % (uint64_t)buffer_size);
+      uint32_t buffer_offset = mod_buffer((uint64_t)sample_offset, buffer_size);
       w.on_event(EV_STOP, buffer_offset, 0.0, 0, nullptr);
       st->partially_ended = 0;
     } else {                                                     // :435-442
@@ -499,19 +522,23 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
         rec1.extra = 0;
         const uint4* srcq1 = reinterpret_cast<const uint4*>(&rec1);
         uint4* dstq = reinterpret_cast<uint4*>(&a.tmpl[ti]);
-        for (int q = 0; q < 4; q++) {
-          dstq[q] = srcq[q];
-          dstq[4 + q] = srcq1[q];
-        }
+        dstq[0] = srcq[0];
+        dstq[1] = srcq[1];
+        dstq[2] = srcq[2];
+        dstq[3] = srcq[3];
+        dstq[4] = srcq1[0];
+        dstq[5] = srcq1[1];
+        dstq[6] = srcq1[2];
+        dstq[7] = srcq1[3];
         row.tmpl = ti;
         row.flags = ROW_PAIR | ((rec.kind == KIND_SILENT && kind1 == KIND_SILENT) ? ROW_SILENT : 0u);
       }
     } else if (rec.nseg != 0) {   // also for calls that render nothing (finished clip): the plan keeps every stream call
-      const bool finished = rec.nseg == 1 && rec.len == 0 && (rec.flags & SEG_FINISHED);
-      const uint4* fq = reinterpret_cast<const uint4*>(&cache->fin);
-      bool same = finished && cache->fin_tmpl != 0xFFFFFFFFu;
-      for (int q = 0; q < 4 && same; q++)
-        same = srcq[q].x == fq[q].x && srcq[q].y == fq[q].y && srcq[q].z == fq[q].z && srcq[q].w == fq[q].w;
+      // (gains, format, source pointers and flags follow from the sample and from the render: the same for the run)
+      const bool finished = rec.nseg == 1 && rec.len == 0 && rec.flags == SEG_FINISHED;
+      const uint32_t shape = ((uint32_t)rec.dst_start << 16) | rec.req_len;
+      const bool same = finished && cache->fin_tmpl != 0xFFFFFFFFu && cache->fin_pos == rec.pos && cache->fin_speed == rec.speed &&
+                        cache->fin_gain == rec.gain && cache->fin_sample == rec.sample && cache->fin_shape == shape;
       if (same) {          // the same finished call as in the block before: no new template
         row.tmpl = cache->fin_tmpl;
       } else {
@@ -525,7 +552,11 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
           row.tmpl = ti;
           row.flags = rec.kind == KIND_SILENT ? ROW_SILENT : 0u;
           if (finished) {
-            cache->fin = rec;
+            cache->fin_pos = rec.pos;
+            cache->fin_speed = rec.speed;
+            cache->fin_gain = rec.gain;
+            cache->fin_sample = rec.sample;
+            cache->fin_shape = shape;
             cache->fin_tmpl = ti;
           }
         }
@@ -695,6 +726,7 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
   }
   TrackCache cache;
   cache.clip_idx = 0xFFFFFFFFu;
+  cache.next_idx = 0xFFFFFFFFu;
   cache.smp_idx = 0xFFFFFFFFu;
   cache.fin_tmpl = 0xFFFFFFFFu;
   cache.tmpl_next = cache.tmpl_end = 0u;
