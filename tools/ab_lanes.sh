@@ -1,0 +1,4 @@
+for LN in 64 32 16 8; do for L in 5.3 20; do
+WBX_PLAN_LANES=$LN python bench.py --clip-blocks $L --steps 10 --warmup 2 --ramp-steps 30 --no-cpu-baseline --no-configs --latency-blocks 0 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('lanes=$LN L=$L', '%.4g frames/s' % d['value'], 'step %.3f ms' % d['ms_per_step'], 'mix %.3f ms' % d['roofline']['kernel_ms_avg'])"
+done; done
+python bench.py --steps 10 --warmup 2 --ramp-steps 30 --no-cpu-baseline --no-configs --latency-blocks 0 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('uncut', '%.4g frames/s' % d['value'], 'step %.3f ms' % d['ms_per_step'], 'mix %.3f ms' % d['roofline']['kernel_ms_avg'])"

@@ -168,6 +168,9 @@ struct PlanArgs {
   uint32_t masked_rows;         // the mix instance of this render takes partial-coverage fp32 rows (one segment, or a
                                 // ROW_PAIR) in its hot loop: do not queue them for the pre-render pass
   uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders)
+  uint32_t lanes;               // tracks per wave of plan_kernel (64, or fewer for sessions cut into many clips: a wave
+                                // executes every branch any of its tracks takes, so its time is set by the number of
+                                // clip boundaries in the wave — fewer tracks per wave, more waves side by side)
 };
 
 struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows

@@ -737,6 +737,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   a.masked_rows = c->masked_rows ? 1u : 0u;
   a.tmpl_reserve = HostSession::template_reserve(K);
+  a.lanes = hs.plan_lanes(K);
   a.playhead = hs.playhead;
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <numbers>
 #include <thread>
@@ -456,6 +457,16 @@ struct HostSession {
     return any_slow_clip ? all : std::min(all, 4 * total_clips + 2 * (size_t)n_tracks() + 64);
   }
   // (a ROW_PAIR block takes two templates; every track may strand part of a reservation of `reserve` templates)
+  // tracks per wave of the plan kernel: a session cut into many clips meets a clip boundary every few blocks on every
+  // track, and a wave runs the (long) boundary path whenever ANY of its tracks does
+  uint32_t plan_lanes(uint32_t K) const {
+    (void)K;
+    if (const char* e = std::getenv("WBX_PLAN_LANES")) {   // tuning knob; measured on c3 cut into clips of 5.3 / 20 blocks:
+      const int v = std::atoi(e);                          // 64, 32, 16 and 8 tracks per wave within 2 % of each other
+      if (v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
+    }
+    return 64u;
+  }
   static uint32_t template_reserve(uint32_t K) { return K >= 64u ? 32u : K >= 8u ? 8u : 1u; }
   size_t template_hint(uint32_t K) const {
     const size_t all = (size_t)K * n_tracks(), stranded = (size_t)(template_reserve(K) + 1u) * n_tracks();

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
   DBlockTime* s_times = reinterpret_cast<DBlockTime*>(s_raw);
   if (threadIdx.x == 0) block_times(a, s_times);
   __syncthreads();
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x >= a.lanes) return;
+  const uint32_t t = blockIdx.x * a.lanes + threadIdx.x;
   if (t >= a.n_tracks) return;
   plan_track(a, t, s_times);   // wbx_seq.h: the same source runs on the host in the CPU-side tests
 }
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(256) void synth_kernel(void* dst, uint64_t frames, 
 // launch wrappers (called from wbx_runtime.hip)
 // ------------------------------------------------------------------------------------------------
 void launch_plan(const PlanArgs& a, hipStream_t s) {
-  const uint32_t nb = (a.n_tracks + 63u) / 64u;
+  const uint32_t nb = (a.n_tracks + a.lanes - 1u) / a.lanes;
   hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.n_blocks * sizeof(DBlockTime), s, a);
 }
 

@@ -347,6 +347,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (c->cfg.group_size == 0) c->cfg.group_size = c->cfg.max_blocks == 1 ? kStage / 2 : kStage;
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
+  if (const char* u = std::getenv("WBX_KERNEL_TIMER")) c->profiling = std::atoi(u) != 0;   // 0: no HIP-event kernel timer
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {
