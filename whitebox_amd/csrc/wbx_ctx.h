@@ -159,6 +159,7 @@ struct wbx_ctx {
   bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
   bool masked_rows = false;           // the current plan holds partial-coverage rows / ROW_PAIRs for the hot loop (layer 2)
+  double uniform_speed = 0.0;         // MixArgs::uniform_speed of the next launch (layer 2; 0 for host-sequenced plans)
 
   hipStream_t upload_stream = nullptr; // clip uploads of layer 2 run here, outside the engine's editor lock
   hipEvent_t ready_ev = nullptr;       // wbx_master_ready: results of an in-stream sum, for a foreign stream

@@ -33,6 +33,8 @@ struct wbx_engine {
   // and the plan status lands in — the callback path then needs no copy-engine transfer at all
   float* h_block = nullptr;             // [C][F]
   uint32_t* h_status = nullptr;         // plan counters [4]
+  bool in_process = false;              // render_locked runs inside wbx_engine_process, which waits for the block: the
+                                        // pinned tables need no completion events
   size_t d_clips_count = 0;
   bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
   uint32_t state_tracks = 0;            // tracks that have device state
@@ -167,6 +169,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   // the destination rate enters every clip's playback speed: which clips the hot loop streams directly is re-derived
   e->hs.dst_rate = sample_rate;
   e->hs.any_slow_clip = e->hs.any_window_clip = e->hs.any_stride_clip = e->hs.any_crawl_clip = false;
+  e->hs.window_speed = 0.0;
   for (auto& t : e->hs.tracks)
     for (auto& hc : t->clips) e->hs.note_clip(hc.d);
   return WBX_OK;
@@ -742,12 +745,14 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;
   launch_plan(a, ps);
-  if (patch_slot >= 0) {
-    WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
-    e->patch_valid[patch_slot] = true;
+  if (!e->in_process) {
+    if (patch_slot >= 0) {
+      WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
+      e->patch_valid[patch_slot] = true;
+    }
+    WBX_EHIP(e, hipEventRecord(e->gains_done[e->gains_slot], ps));   // (re-recorded by every plan that reads the buffer)
+    e->gains_valid[e->gains_slot] = true;
   }
-  WBX_EHIP(e, hipEventRecord(e->gains_done[e->gains_slot], ps));   // (re-recorded by every plan that reads the buffer)
-  e->gains_valid[e->gains_slot] = true;
   st = launch_pre_render(c, K, ps);
   if (st != WBX_OK) return cfail(e, st);
   if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
@@ -757,6 +762,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
+  c->uniform_speed = hs.uniform_window_speed();
   const int mix_parity = (int)(c->render_seq % kRing);
   st = launch_mix_sum(c, K, N);
   if (st != WBX_OK) return cfail(e, st);
@@ -791,12 +797,15 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
   if (!e->h_status) WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
   c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
   c->status_dst = e->h_status;            // and it drops the plan status next to it
+  e->in_process = true;
   wbx_status st = render_locked(e, 1);
+  e->in_process = false;
   c->master_target = nullptr;
   c->status_dst = nullptr;
   if (st != WBX_OK) return st;
   WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < kRing; i++) e->patch_valid[i] = e->gains_valid[i] = false;   // every plan that read them is over
   drain_events(c);
   for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
   c->last_master_on_host = true;   // set after launch_mix_sum cleared it: the master of this block is e->h_block

@@ -141,11 +141,15 @@ struct HostSession {
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
   bool any_stride_clip = false;         // per-frame taps: fp32 played faster than recorded, resampled integer PCM
   bool any_crawl_clip = false;          // (count - offset) / speed may exceed 2^32: every block owns a plan template
+  // the one playback speed of all resampled clips seen so far (44.1 kHz clips in a 48 kHz session ...), for the mix
+  // kernel's hoisted position products: 0 = none yet, < 0 = several / outside the narrow-window range
+  double window_speed = 0.0;
   size_t total_clips = 0;
   uint32_t next_clip_uid = 0;
   uint64_t edit_seq = 0;                // locked edits completed so far (UI thread, under the lock)
   uint64_t render_edit_seq = 0;         // edit_seq as the last process / render saw it
 
+  double uniform_window_speed() const { return window_speed > 0.0 ? window_speed : 0.0; }
   uint32_t n_tracks() const { return (uint32_t)tracks.size(); }
   bool valid_track(uint32_t t) const { return t < tracks.size(); }
   bool valid_sample(uint32_t s) const { return s < samples.size() && samples[s].used; }
@@ -209,7 +213,13 @@ struct HostSession {
     const SampleMeta& smp = samples[c.sample];
     const double ps = ((double)smp.sample_rate / (double)dst_rate) * c.speed;   // sampler.h:24
     if (!(ps > 0.0 && ps <= 4096.0)) any_slow_clip = true;
-    if (ps != 1.0) any_window_clip = true;
+    if (ps != 1.0) {
+      any_window_clip = true;
+      if (!(ps >= 0.67 && ps <= 0.999) || (window_speed != 0.0 && window_speed != ps))
+        window_speed = -1.0;
+      else
+        window_speed = ps;
+    }
     if ((ps > 0.999 || smp.format != FMT_F32) && ps != 1.0) any_stride_clip = true;
     // BlockWalker::stream / plan_steady_run leave the shared-template path when (count - offset) >= speed * 2^32
     if (!(ps * 4294967040.0 > (double)smp.count)) any_crawl_clip = true;

@@ -455,7 +455,8 @@ __device__ __forceinline__ void wave_max_quad_halves(uint32_t p0, uint32_t p1, u
   ch1 = w;
 }
 
-enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9, MODE_MW = 10, MODE_MWN = 11 };   // row shapes of a staged chunk
+enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9, MODE_MW = 10, MODE_MWN = 11,
+             MODE_WNU = 12, MODE_WINU = 13 };   // row shapes of a staged chunk (…U: every resampled row at MixArgs::uniform_speed)
 
 // the loads of one track that are in flight while other tracks are being rendered
 struct Pre {
@@ -542,6 +543,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
+  // The usual session has ONE resampling ratio (44.1 kHz clips in a 48 kHz session): the products fl(j * speed) of
+  // sampler.cpp:50 then depend on the lane only, not on the track — once per lane instead of four fp64 multiplies per
+  // track (the loop is VALU-bound and fp64 runs at half rate).  MixArgs::uniform_speed (> 0) is the host's word that
+  // every KIND_WINDOW / KIND_WINDOW_I16 row of this render plays at exactly that speed (bit for bit).
+  const double us = a.uniform_speed;
+  const double up0 = __dmul_rn(j0d, us), up1 = __dmul_rn(jd1, us), up2 = __dmul_rn(jd2, us), up3 = __dmul_rn(jd3, us);
 
   // A staged record is wave-uniform.  Instead of broadcast-reading its fields from LDS one by one (every such read
   // returns 64 x 8..16 B through the LDS data path), each lane reads ONE dword of the 64-B record and the fields
@@ -630,8 +637,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return m;
   };
   // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
-  auto row_window_at = [&](auto narrow, auto shifted, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
+  auto row_window_at = [&](auto narrow, auto shifted, auto uni, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
     constexpr bool NARROW = decltype(narrow)::value;
+    constexpr bool UNI = decltype(uni)::value;   // the row plays at MixArgs::uniform_speed: products hoisted (not with SHIFTED)
     constexpr bool SHIFTED = decltype(shifted)::value;   // the stream call starts at block frame d0: call frame = j - d0
     const int ix0 = p.ix0;
     float q[4];
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
 #define WBX_TAP(E, JD)                                                                                  \
   {                                                                                                     \
-    const double x = __dadd_rn(pos, __dmul_rn(SHIFTED ? (JD) - d0 : (JD), speed));   /* sampler.cpp:50 */ \
+    const double x = __dadd_rn(pos, (UNI && !SHIFTED) ? up##E : __dmul_rn(SHIFTED ? (JD) - d0 : (JD), speed));   /* sampler.cpp:50 */ \
     const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
     float sa, sb;                                                                                       \
     if (NARROW)                                                           /* :51 */                     \
@@ -656,11 +664,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return f4{q[0], q[1], q[2], q[3]};
   };
   auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
-    return row_window_at(narrow, std::false_type{}, p, pos, speed, 0.0, cg, gc);
+    return row_window_at(narrow, std::false_type{}, std::false_type{}, p, pos, speed, 0.0, cg, gc);
   };
   // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
-  auto load_window = [&](const void* src_c, double pos, double speed, Pre& p, double jd0) {
-    const double x0 = __dadd_rn(pos, __dmul_rn(jd0, speed));                              // sampler.cpp:50, frame j0 (of the call)
+  auto load_window = [&](const void* src_c, double pos, double prod0, Pre& p) {
+    const double x0 = __dadd_rn(pos, prod0);                                              // sampler.cpp:50, frame j0 (of the call): prod0 = fl(j * speed)
     const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
     const float WBX_GLOBAL* src = as_global<float>(src_c) + ix0;
     if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
@@ -674,10 +682,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   };
   // the same window for a 16-bit PCM row: samples ix0..ix0+3 in one 8-B load (2-byte aligned), ix0+4 in the low half
   // of a 4-B load; the halves stay packed until the render phase
-  auto load_window16 = [&](const void* src_c, double pos, double speed, Pre& p) {
+  auto load_window16 = [&](const void* src_c, double pos, double prod0, Pre& p) {
     typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
     typedef int i1w __attribute__((aligned(2)));
-    const double x0 = __dadd_rn(pos, __dmul_rn(j0d, speed));                              // sampler.cpp:50, frame j0
+    const double x0 = __dadd_rn(pos, prod0);                                              // sampler.cpp:50, frame j0
     const int ix0 = (int)x0;                                                              // :51
     const short WBX_GLOBAL* src = as_global<short>(src_c) + ix0;
     if (active) {
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     p.fx0 = (float)__builtin_amdgcn_fract(x0);                                            // :52
   };
   // 16-bit PCM row, linear resample: taps a = norm * (float)src[ix] (sampler.cpp:9-10,53-54), then as fp32
-  auto row_window16 = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+  auto row_window16 = [&](auto narrow, auto uni, const Pre& p, double pos, double speed, float cg, float gc) {
     const float norm = (float)(1.0 / 32767.0);
     const int lo = __float_as_int(p.v.x), hi = __float_as_int(p.v.y), tl = __float_as_int(p.w4);
     Pre f;
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     f.w4 = __fmul_rn(norm, (float)(short)(tl & 0xFFFF));
     f.ix0 = p.ix0;
     f.fx0 = p.fx0;
-    return row_window(narrow, f, pos, speed, cg, gc);
+    return row_window_at(narrow, std::false_type{}, uni, f, pos, speed, 0.0, cg, gc);
   };
   // 24/32-bit PCM row (4-byte containers: the fp32 window loads), linear resample: taps a = (float)(norm * (double)src[ix])
   // (sampler.cpp:11-14,53-54), then as fp32
@@ -905,13 +913,25 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       if constexpr (MODE == MODE_G) {
         load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
-      } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
-        if (EXP)
-          load_window(r.src, r.pos, r.speed, pre[u], (double)call_frame(0u, r.d, r.n));
+      } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
+        double prod0;
+        if (MODE == MODE_WNU) {   // whole-block resampled rows: the hoisted product (wave-uniform choice)
+          const bool whole = !EXP || (r.d == 0u && r.n == F);
+          if (whole && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
+            prod0 = up0;
+          else
+            prod0 = __dmul_rn(EXP ? (double)call_frame(0u, r.d, r.n) : j0d, r.speed);
+        } else {
+          prod0 = __dmul_rn(EXP ? (double)call_frame(0u, r.d, r.n) : j0d, r.speed);
+        }
+        load_window(r.src, r.pos, prod0, pre[u]);
+      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
+        double prod0;
+        if (MODE == MODE_WINU && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
+          prod0 = up0;
         else
-          load_window(r.src, r.pos, r.speed, pre[u], j0d);
-      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
-        load_window16(r.src, r.pos, r.speed, pre[u]);
+          prod0 = __dmul_rn(j0d, r.speed);
+        load_window16(r.src, r.pos, prod0, pre[u]);
       } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
         // unity and window rows of several storage formats (16-bit loops at another rate next to 24-bit stems ...):
         // every row reads 16 B + 4 B at its first sample — the five window samples of a 4-byte format, the low
@@ -981,16 +1001,17 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       if constexpr (MODE == MODE_G) {
         m = row_stride(pre[u], (uint32_t)__builtin_amdgcn_readfirstlane((int)r.kind),
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
-      } else if constexpr (MODE == MODE_W || MODE == MODE_WN) {
+      } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
-        constexpr std::integral_constant<bool, MODE == MODE_WN> narrow{};
+        constexpr std::integral_constant<bool, MODE != MODE_W> narrow{};
+        constexpr std::integral_constant<bool, MODE == MODE_WNU> uni{};
         if (EXP && (r.d != 0u || r.n != F)) {   // a stream call that covers part of the block (wave-uniform)
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
             m = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
             if (k == KIND_WINDOW)
-              m = row_window_at(narrow, std::true_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
+              m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
               m = row_f32(pre[u].v, cg, gc);
           } else {
@@ -1000,16 +1021,17 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
           if (G && fmt != FMT_F32) {   // 24/32-bit PCM through the same window loads (G instances only)
             if constexpr (G) m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
           } else {
-            m = row_window(narrow, pre[u], r.pos, r.speed, cg, gc);
+            m = row_window_at(narrow, std::false_type{}, uni, pre[u], r.pos, r.speed, 0.0, cg, gc);
           }
         } else if (G && k == KIND_UNITY_I32) {
           if constexpr (G) m = row_i32(pre[u].v, fmt, cg, gc);
         } else {
           m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
         }
-      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN) {
+      } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
-          m = row_window16(std::integral_constant<bool, MODE == MODE_WIN>{}, pre[u], r.pos, r.speed, cg, gc);
+          m = row_window16(std::integral_constant<bool, MODE != MODE_WI>{}, std::integral_constant<bool, MODE == MODE_WINU>{}, pre[u],
+                           r.pos, r.speed, cg, gc);
         else
           m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);   // unity, silent, padding
       } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
@@ -1019,7 +1041,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         if (k == KIND_WINDOW_I16) {
           Pre q = pre[u];
           q.w4 = pre[u].v.z;   // the fifth sample of a 16-bit window is the low half of the load's third dword
-          m = row_window16(narrow, q, r.pos, r.speed, cg, gc);
+          m = row_window16(narrow, std::false_type{}, q, r.pos, r.speed, cg, gc);
         } else if (k == KIND_WINDOW) {
           m = fmt == FMT_F32 ? row_window(narrow, pre[u], r.pos, r.speed, cg, gc)
                              : row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
@@ -1097,7 +1119,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
       if (k == KIND_WINDOW) {
         Pre p;
-        load_window(r.src[c], r.pos, r.speed, p, j0d);
+        load_window(r.src[c], r.pos, __dmul_rn(j0d, r.speed), p);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
       } else if (k == KIND_UNITY_I16) {
         typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
@@ -1213,13 +1235,13 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     if (has_stride) {
       mode = MODE_G;             // reads every kind and format, whatever else the chunk holds
     } else if (has_win16) {
-      mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : MODE_WIN) : (has_wide ? MODE_MW : MODE_MWN);
+      mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : us > 0.0 ? MODE_WINU : MODE_WIN) : (has_wide ? MODE_MW : MODE_MWN);
     } else if (has_i16) {
       mode = (has_win32 || (G && has_win)) ? (has_wide ? MODE_MW : MODE_MWN)
              : (!has_i32 && !has_f32) ? MODE_I16 : has_win ? MODE_MIXED : MODE_MU;
     } else if (has_win || has_win32) {
       // fp32 unity + window rows; in G instances also 24/32-bit PCM unity + window rows (all 4-byte containers)
-      mode = (G || !has_i32) ? (has_wide ? MODE_W : MODE_WN) : MODE_MIXED;
+      mode = (G || !has_i32) ? (has_wide ? MODE_W : (us > 0.0 && !has_win32) ? MODE_WNU : MODE_WN) : MODE_MIXED;
     } else {
       mode = !has_i32 ? MODE_U : !has_f32 ? MODE_I32 : MODE_MU;   // unity rows of several formats
     }
@@ -1237,7 +1259,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.g[1] = 0.0f;
         r.dst_start = 0;                 // (a whole-block row for the masked-row arithmetic of the EXP instances)
         r.len = (uint16_t)F;
-        const bool m16 = mode == MODE_I16 || mode == MODE_WI || mode == MODE_WIN;
+        const bool m16 = mode == MODE_I16 || mode == MODE_WI || mode == MODE_WIN || mode == MODE_WINU;
         r.format = m16 ? FMT_I16 : mode == MODE_I32 ? FMT_I32 : FMT_F32;
         r.kind = m16 ? KIND_UNITY_I16 : mode == MODE_I32 ? KIND_UNITY_I32 : KIND_UNITY;
       }
@@ -1248,6 +1270,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn2); break;
       case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn2); break;
       case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn2); break;
+      case MODE_WNU: pipeline(std::integral_constant<int, MODE_WNU>{}, cn2); break;
       case MODE_G:
         if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn2);
         break;
@@ -1256,6 +1279,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         break;
       case MODE_WIN:
         if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn2);
+        break;
+      case MODE_WINU:
+        if constexpr (G) pipeline(std::integral_constant<int, MODE_WINU>{}, cn2);
         break;
       case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn2); break;
       case MODE_MW:

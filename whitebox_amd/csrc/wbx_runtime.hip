@@ -220,6 +220,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
+  m.uniform_speed = std::getenv("WBX_NO_UNIFORM") ? 0.0 : c->uniform_speed;   // (A/B aid)
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(c->d_peaks.p, 0, (size_t)K * N * C * sizeof(float), c->stream));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
@@ -872,6 +873,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
+  c->uniform_speed = 0.0;   // ... and make no promise about their playback speeds
   st = launch_pre_render(c, K, c->stream);
   if (st != WBX_OK) return st;
   return launch_mix_sum(c, K, N);
