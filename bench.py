@@ -366,25 +366,28 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     if dist is not None:
         dt = dist.max(dt)                              # MAX over ranks
 
-    # K = 1 latency mode (the real-time callback shape): Engine::process one block at a time
-    lat = None
-    if rank == 0 and latency_blocks > 0 and dist is None:
-        eng.ctx.set_master_target(None)
-        out = W.AudioBuffer(F, 2)
-        eng.stop()
-        eng.play()
-        for _ in range(5):
-            eng.process(None, out, float(SR))
-        t1 = time.perf_counter()
-        for _ in range(latency_blocks):
-            eng.process(None, out, float(SR))
-        lat = (time.perf_counter() - t1) / latency_blocks
-
     master_peak = float(np.abs(host_master.array).max()) if rank == 0 else 0.0
     if dist is not None:
         dist.shutdown()
     eng.close()
     host_master.close()
+
+    # K = 1 latency mode, the drop-in's real operating point: the audio callback, Engine::process one block at a time,
+    # on an engine configured the way a callback host configures it (max_blocks = 1: 64-track groups)
+    lat = None
+    if rank == 0 and latency_blocks > 0 and dist is None:
+        eng, _, _ = build_device_session(W, synth, workload, n_tracks, 1, latency_blocks + 16, rank, world, args.group_size,
+                                         clip_blocks)
+        out = W.AudioBuffer(F, 2)
+        eng.play()
+        for _ in range(8):
+            eng.process(None, out, float(SR))
+        t1 = time.perf_counter()
+        for _ in range(latency_blocks):
+            eng.process(None, out, float(SR))
+        lat = (time.perf_counter() - t1) / latency_blocks
+        eng.close()
+
     alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
     achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
     return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,

@@ -8,7 +8,7 @@ Corrections (MI355X_MICROARCH.md §HBM + own calibration, profiles/r01_fetch_cal
     pattern -> factor 2.000; the unaligned window pattern -> 2 x FETCH = 1.07 x unique bytes (line overlap).
   * WRITE_SIZE (KB) is used as reported: for the mix kernel it matches the known store volume
     (partial sums + peaks + level atomics) to within the atomics' share.
-usage: tools/pmc_traffic.py <pmc dir> <workload> <K> <N> [kernel substring]"""
+usage: tools/pmc_traffic.py <pmc dir> <workload> <K> <N> [kernel substring] [key suffix, e.g. _L5.3]"""
 import csv
 import glob
 import json
@@ -28,11 +28,12 @@ def mean_counter(root, counter, kernel):
 def main():
     root, workload, K, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     kernel = sys.argv[5] if len(sys.argv) > 5 else "mix_kernel"
+    suffix = sys.argv[6] if len(sys.argv) > 6 else ""
     fetch = mean_counter(root, "FETCH_SIZE", kernel)
     write = mean_counter(root, "WRITE_SIZE", kernel)
     out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    data[f"{workload}_K{K}_N{N}"] = {
+    data[f"{workload}_K{K}_N{N}{suffix}"] = {
         "kernel": kernel,
         "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
         "fetch_bytes": fetch * 1024 * 2 if fetch is not None else None,
@@ -42,7 +43,7 @@ def main():
         "source": os.path.relpath(root, os.path.dirname(out_path) + "/.."),
     }
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
-    print(json.dumps(data[f"{workload}_K{K}_N{N}"], indent=1))
+    print(json.dumps(data[f"{workload}_K{K}_N{N}{suffix}"], indent=1))
 
 
 if __name__ == "__main__":
