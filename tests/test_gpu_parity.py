@@ -1166,3 +1166,56 @@ def test_pipelined_renders_large():
     assert np.array_equal(pk, opk[-K:, :, :spec.channels])
     eng.ctx.set_master_target(None)
     eng.close()
+
+
+def test_set_audio_channel_config_on_a_live_engine():
+    """Engine::set_audio_channel_config (engine.cpp:43-57) when the audio backend is reconfigured: new block size, channel
+    count and device rate — tracks, clips and samples stay; the next play renders like a fresh engine of that shape."""
+    spec = synth.make_session("reconf", 40, seek=True, src_rate=44100, n_blocks=12, seed=0x76)
+    eng = build_engine(spec, max_blocks=4)
+    eng.play()
+    eng.render(4)                                    # state on the device, renders in flight
+    for block, channels, rate in ((256, 2, 48000), (1024, 1, 48000), (512, 2, 44100), (512, 2, 48000)):
+        eng.stop()
+        eng.set_audio_channel_config(0, channels, block, rate)
+        sp2 = dataclasses.replace(spec, block=block, channels=channels, sample_rate=rate)
+        om, opk, _, orows, otr = run_oracle(sp2, 4)
+        eng.play()
+        eng.render(4)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert plan_rows(eng.fetch_plan()) == orows, (block, channels, rate)
+        assert np.array_equal(pk, opk[..., :channels]), (block, channels, rate)
+        assert np.array_equal(bits(m), bits(om)), (block, channels, rate)
+    eng.close()
+
+
+@pytest.mark.parametrize("alt", ["0", "1"])
+def test_alternating_mix_streams_keep_every_render_intact(monkeypatch, alt):
+    """WBX_MIX_ALT=1: batch renders of layer 2 alternate between two streams so that consecutive mixes overlap; peaks
+    live in one buffer per stream.  Twelve renders issued back to back without a host sync, results of each one checked
+    (the master through pinned targets, the peaks of the last two through fetch)."""
+    from whitebox_amd.dist import PinnedBuffer
+    monkeypatch.setenv("WBX_MIX_ALT", alt)
+    K, R = 8, 12
+    spec = synth.make_session("alt", 70, seek=True, src_rate=44100, n_blocks=K * R, seed=0x77)
+    om, opk, _, _, _ = run_oracle(spec, K * R)
+    eng = build_engine(spec, max_blocks=K, group_size=70)
+    outs = [PinnedBuffer(K * 2 * 512) for _ in range(R)]
+    eng.play()
+    for r in range(R):
+        eng.ctx.set_master_target(outs[r].ptr)
+        eng.render(K)
+        if r == R - 2:
+            _, pk_prev, _ = eng.ctx.fetch(peaks=True)          # joins everything so far
+            assert np.array_equal(pk_prev, opk[r * K:(r + 1) * K, :, :2])
+    eng.ctx.sync()
+    for r in range(R):
+        assert np.array_equal(bits(outs[r].array.reshape(K, 2, 512)), bits(om[r * K:(r + 1) * K])), r
+    _, pk, _ = eng.ctx.fetch(peaks=True)
+    assert np.array_equal(pk, opk[(R - 1) * K:, :, :2])
+    assert np.array_equal(eng.levels(), opk.max(axis=0)[:, :2])
+    eng.ctx.set_master_target(None)
+    for o in outs:
+        o.close()
+    eng.close()
+

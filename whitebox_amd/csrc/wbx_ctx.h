@@ -120,7 +120,17 @@ struct wbx_ctx {
   DevBuf<float> d_zero;               // zero page (F+8 floats)
   uint32_t* levels_target = nullptr;  // [N][C] running per-track maxima (VUMeter::level), or null
   DevBuf<float> d_partial2[kRing];    // group partials, one per render in flight (a sum may still read an older one)
-  DevBuf<float> d_master, d_buses, d_peaks, d_gains;
+  DevBuf<float> d_master, d_buses, d_gains;
+  DevBuf<float> d_peaks[2];           // per-track-block peaks: one buffer per mix stream (two mixes may be in flight)
+  float* last_peaks = nullptr;        // where the last render / submit put its peaks
+  // WBX_MIX_ALT=1 (experiment, off by default): consecutive batch renders of layer 2 alternate between the main stream
+  // and `alt_stream`, so that nothing orders mix i+1 after mix i and the head of one can fill the CUs the tail of the
+  // other leaves idle.  Everything else stays on the main stream, which joins the alternate one (join_alt) wherever it
+  // joins the sum stream.  Measured: no gain in step time, each kernel's own interval grows by ~45 %.
+  hipStream_t alt_stream = nullptr;
+  hipStream_t cur_mix_stream = nullptr;   // the stream of the mix about to be / last launched
+  int alt_pending = -1;                   // partial-buffer index of a mix on alt_stream the main stream has not joined
+  bool mix_alternate = false;             // WBX_MIX_ALT=1
   // The sum of render i runs on its own stream beside the mix of render i+1 (it is PCIe-bound when the master goes to
   // host memory and needs few CUs).  sum_pending: a sum has been issued that the main stream has not waited for yet.
   hipStream_t sum_stream = nullptr;
@@ -220,6 +230,9 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
 wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s);
 void clip_release(ClipSlot& s);
 hipError_t join_sum(wbx_ctx* c);
+hipError_t join_alt(wbx_ctx* c);
+hipError_t sync_main(wbx_ctx* c);          // the host waits for the main stream and every mix / sum beside it
+hipStream_t pick_mix_stream(wbx_ctx* c, uint32_t K, bool alternate);
 void drain_events(wbx_ctx* c);
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks);
 wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N);

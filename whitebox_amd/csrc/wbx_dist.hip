@@ -153,7 +153,7 @@ extern "C" wbx_status wbx_dist_init(wbx_ctx* c, const wbx_dist_id* id, uint32_t 
   if (!r->err.empty()) return fail(c, WBX_ERR_UNSUPPORTED, r->err.c_str());
   (void)hipSetDevice(c->cfg.device);
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   DistState* d = new (std::nothrow) DistState();
   if (!d) return WBX_ERR_OOM;
   c->dist = d;
@@ -193,7 +193,7 @@ extern "C" wbx_status wbx_dist_shutdown(wbx_ctx* c) {
   if (!c->dist) return WBX_OK;
   (void)hipSetDevice(c->cfg.device);
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   dist_destroy(c);
   c->clamp = true;
   return WBX_OK;
@@ -247,7 +247,7 @@ extern "C" wbx_status wbx_dist_sync(wbx_ctx* c) {
   if (!c->dist) return wbx_sync(c);
   (void)hipSetDevice(c->cfg.device);
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   WBX_HIP(c, hipStreamSynchronize(c->dist->comm_stream));
   drain_events(c);
   return WBX_OK;

@@ -102,7 +102,7 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
   if (e->ctx) {
     (void)hipSetDevice(e->ctx->cfg.device);
     (void)hipStreamSynchronize(e->ctx->plan_stream);
-    (void)hipStreamSynchronize(e->ctx->stream);
+    (void)sync_main(e->ctx);
   }
   e->d_clips.release();
   e->d_clip_first.release();
@@ -137,7 +137,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
   WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, hipStreamSynchronize(c->sum_stream));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   drain_events(c);
   c->cfg.channels = output_channels;
   c->cfg.block_frames = buffer_size;
@@ -155,7 +155,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   c->sum_pending = -1;
   c->d_master.release();
   c->d_buses.release();
-  c->d_peaks.release();
+  for (auto& P : c->d_peaks) P.release();
   c->buses_clean = false;
   c->d_zero.release();
   WBX_EHIP(e, c->d_zero.ensure(buffer_size + 8));
@@ -245,7 +245,7 @@ wbx_status permute_tracks_locked(wbx_engine* e, const std::vector<uint32_t>& ord
   (void)hipSetDevice(c->cfg.device);
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
   WBX_EHIP(e, join_sum(c));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   const uint32_t new_n = (uint32_t)order.size();
   if (e->state_tracks) {
     const uint32_t C = c->cfg.channels;
@@ -565,7 +565,7 @@ wbx_status ensure_pinned_tables(wbx_engine* e, uint32_t N) {
   wbx_ctx* c = e->ctx;
   if (e->gains_cap >= N && e->patch_cap[0] >= N) return WBX_OK;
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   const uint32_t cap = std::max<uint32_t>(N, c->cfg.max_tracks);
   for (int i = 0; i < kRing; i++) {
     if (e->h_patch[i]) WBX_EHIP(e, hipHostFree(e->h_patch[i]));
@@ -633,7 +633,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   // -- clip lists
   if (hs.clips_dirty) {
     WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, sync_main(c));
     // Clip::internal_state_changed is cleared by the sequencer on the device (track.cpp:373,392,418): before
     // the table is replaced, take the live flags back for every clip no edit has touched since the last upload
     if (e->clips_uploaded && e->d_clips_count) {
@@ -655,7 +655,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     DevBuf<DTrackState> grown;
     WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
     WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, hipStreamSynchronize(s));
+    WBX_EHIP(e, sync_main(c));
     WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
     if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
     e->d_state.release();
@@ -700,6 +700,8 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   wbx_ctx::PlanBuf& B = PB(c);
   const bool plan_beside = c->overlap && K >= kOverlapMinBlocks;
   hipStream_t ps = plan_beside ? c->plan_stream : s;
+  hipStream_t ms = pick_mix_stream(c, K, true);   // main stream, or the alternate one for every other batch render
+  const bool plan_event = ps != ms;               // the mix runs on another stream than its plan
   if (B.consumed_valid) WBX_EHIP(e, hipStreamWaitEvent(ps, B.consumed, 0));   // the mix that read this buffer two renders ago
   {
     const int pp = (int)(c->render_seq % kRing);
@@ -755,10 +757,10 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   }
   st = launch_pre_render(c, K, ps);
   if (st != WBX_OK) return cfail(e, st);
-  if (plan_beside) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (in-stream: the mix simply follows)
+  if (plan_event) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (plan and mix on one stream: the mix simply follows)
 
-  // -- mix + sum on the main stream, after the plan
-  if (plan_beside) WBX_EHIP(e, hipStreamWaitEvent(s, B.planned, 0));
+  // -- mix (main stream, or the alternate one for every other batch render) + sum, after the plan
+  if (plan_event) WBX_EHIP(e, hipStreamWaitEvent(ms, B.planned, 0));
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
@@ -804,7 +806,7 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
   c->status_dst = nullptr;
   if (st != WBX_OK) return st;
   WBX_EHIP(e, join_sum(c));
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   for (int i = 0; i < kRing; i++) e->patch_valid[i] = e->gains_valid[i] = false;   // every plan that read them is over
   drain_events(c);
   for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
@@ -829,9 +831,10 @@ extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n
   wbx_ctx* c = e->ctx;
   const size_t n = (size_t)n_tracks * c->cfg.channels;
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+  WBX_EHIP(e, join_alt(c));   // a mix on the alternate stream may still be raising the levels
   WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   return WBX_OK;
 }
 
@@ -857,7 +860,7 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   if (c->last_K == 0) return efail(e, WBX_ERR_FAILED, "nothing rendered");
   const uint32_t K = c->last_K, N = c->last_N;
   uint32_t pc[4] = {0, 0, 0, 0};
-  WBX_EHIP(e, hipStreamSynchronize(c->stream));
+  WBX_EHIP(e, sync_main(c));
   WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   std::vector<DRow> rows((size_t)K * N);
   const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);

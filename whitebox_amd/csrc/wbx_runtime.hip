@@ -11,12 +11,34 @@ using namespace wbx;
 namespace wbx {
 
 // make the main stream wait for the sum that is still running beside it (device-side; a following
-// hipStreamSynchronize(c->stream) then covers it)
+// sync_main(c) then covers it)
 hipError_t join_sum(wbx_ctx* c) {
   if (c->sum_pending < 0) return hipSuccess;
   const hipError_t e = hipStreamWaitEvent(c->stream, c->sum_done[c->sum_pending], 0);
   c->sum_pending = -1;
   return e;
+}
+
+// the same for a mix that runs on the alternate stream
+hipError_t join_alt(wbx_ctx* c) {
+  if (c->alt_pending < 0) return hipSuccess;
+  const hipError_t e = hipStreamWaitEvent(c->stream, c->mix_done[c->alt_pending], 0);
+  c->alt_pending = -1;
+  return e;
+}
+
+hipError_t sync_main(wbx_ctx* c) {
+  hipError_t e = join_sum(c);
+  if (e == hipSuccess) e = join_alt(c);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  return e;
+}
+
+// which stream the next mix runs on: batch renders of layer 2 alternate (see wbx_ctx::alt_stream)
+hipStream_t pick_mix_stream(wbx_ctx* c, uint32_t K, bool alternate) {
+  const bool alt = alternate && c->mix_alternate && c->alt_stream && K >= kOverlapMinBlocks && c->cur_mix_stream == c->stream;
+  c->cur_mix_stream = alt ? c->alt_stream : c->stream;
+  return c->cur_mix_stream;
 }
 
 void drain_events(wbx_ctx* c) {
@@ -73,7 +95,7 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
   }
   if (c->routing_dirty) {
     WBX_HIP(c, join_sum(c));                          // a sum beside the main stream may still read d_groups
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     WBX_HIP(c, c->d_order.ensure(std::max<size_t>(1, c->order.size())));
     WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size())));
     if (!c->order.empty())
@@ -82,7 +104,7 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
     if (!c->groups.empty())
       WBX_HIP(c, hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(DGroup),
                                 hipMemcpyHostToDevice, c->stream));
-    WBX_HIP(c, hipStreamSynchronize(c->stream));   // host vectors may change right after
+    WBX_HIP(c, sync_main(c));   // host vectors may change right after
     c->routing_dirty = false;
   }
   if (c->samples_dirty) {
@@ -104,21 +126,21 @@ wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N) {
   for (auto& B : c->pb)
     if (B.prows.cap < (size_t)K * N) {
       WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
-      WBX_HIP(c, hipStreamSynchronize(c->stream));
+      WBX_HIP(c, sync_main(c));
       WBX_HIP(c, B.prows.ensure((size_t)K * N));
     }
   const size_t need_partial = (size_t)K * std::max<size_t>(1, c->groups.size()) * CF;
   if (c->d_partial2[0].cap < need_partial || c->d_master.cap < (size_t)K * CF ||
-      c->d_peaks.cap < (size_t)K * N * c->cfg.channels || (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF)) {
+      c->d_peaks[0].cap < (size_t)K * N * c->cfg.channels || (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF)) {
     WBX_HIP(c, join_sum(c));                          // a sum may still be using the buffers about to be replaced
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     for (auto& v : c->sum_valid) v = false;
   }
   for (auto& P : c->d_partial2) WBX_HIP(c, P.ensure(need_partial));
   WBX_HIP(c, c->d_master.ensure((size_t)K * CF));
-  WBX_HIP(c, c->d_peaks.ensure((size_t)K * N * c->cfg.channels));
+  for (auto& P : c->d_peaks) WBX_HIP(c, P.ensure((size_t)K * N * c->cfg.channels));
   if (c->n_buses && c->d_buses.cap < (size_t)K * c->n_buses * CF) {
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     WBX_HIP(c, c->d_buses.ensure((size_t)K * c->n_buses * CF));
     c->buses_clean = false;
   }
@@ -131,7 +153,7 @@ wbx_status ensure_template_capacity(wbx_ctx* c, size_t n) {
   for (auto& B : c->pb) {
     if (n <= B.tmpl_cap) continue;
     WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     WBX_HIP(c, B.tmpl.ensure(n));
     B.tmpl_cap = (uint32_t)n;
   }
@@ -145,7 +167,7 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
   for (auto& B : c->pb) {
     if (rows <= B.gen_cap) continue;
     WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     WBX_HIP(c, B.gen_list.ensure(rows));
     WBX_HIP(c, B.rows.ensure(rows * row_floats));
     WBX_HIP(c, B.saved.ensure(rows));
@@ -208,10 +230,14 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   const int pp = (int)(c->render_seq % kRing);
   // this partial buffer was last read by the sum of kRing renders ago; the engine path has already made the PLAN
   // stream wait for that sum (the mix waits for the plan), which keeps the barrier off the main stream
-  if (c->sum_valid[pp] && !c->partial_wait_done) WBX_HIP(c, hipStreamWaitEvent(c->stream, c->sum_done[pp], 0));
+  if (!c->cur_mix_stream) c->cur_mix_stream = c->stream;
+  hipStream_t ms = c->cur_mix_stream;             // the main stream, or the alternate one (pick_mix_stream)
+  const int pk = ms == c->stream ? 0 : 1;         // its peaks buffer
+  if (c->sum_valid[pp] && !c->partial_wait_done) WBX_HIP(c, hipStreamWaitEvent(ms, c->sum_done[pp], 0));
   c->partial_wait_done = false;
   m.partial = c->d_partial2[pp].p;
-  m.peaks = c->d_peaks.p;
+  m.peaks = c->d_peaks[pk].p;
+  c->last_peaks = m.peaks;
   m.levels = c->levels_target;
   m.n_tracks = N;
   m.n_groups = (uint32_t)c->groups.size();
@@ -221,7 +247,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
   m.uniform_speed = std::getenv("WBX_NO_UNIFORM") ? 0.0 : c->uniform_speed;   // (A/B aid)
-  if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(c->d_peaks.p, 0, (size_t)K * N * C * sizeof(float), c->stream));
+  if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(m.peaks, 0, (size_t)K * N * C * sizeof(float), ms));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
   if (m.n_groups) {
@@ -230,19 +256,20 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
         WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
         drain_events(c);
       }
-      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], c->stream));
+      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     }
     launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
-               c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), c->stream);
+               c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), ms);
     if (timed) {
-      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], c->stream));
+      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
     }
   }
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
-  WBX_HIP(c, hipEventRecord(c->mix_done[pp], c->stream));
+  WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));
+  if (ms != c->stream) c->alt_pending = pp;
   // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
   // hand-overs cost more than the few microseconds of overlap they could buy
   const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
@@ -269,10 +296,11 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   if (c->n_buses && !c->buses_alias_partials && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
-    WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), c->stream));
+    WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), ms));
     c->buses_clean = true;
   }
-  if (sum_beside) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  if (ss == c->stream && ms != c->stream) c->alt_pending = -1;            // (the main stream has just joined that mix)
   launch_sum(s, K, ss);
   if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
@@ -391,6 +419,11 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
       ok = hipEventCreateWithFlags(&c->mix_done[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking) == hipSuccess;
+    // measured (tools/ab_alt.sh): with consecutive mixes on alternating streams the two kernels share the device for
+    // their whole length (each takes 1.05-1.2 ms instead of 0.74) and the step time does not move — off by default
+    const char* ma = std::getenv("WBX_MIX_ALT");
+    c->mix_alternate = ma && ma[0] == '1';
     if (!ok) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
@@ -422,6 +455,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   dist_destroy(c);
   if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
   if (c->sum_stream) (void)hipStreamSynchronize(c->sum_stream);
+  if (c->alt_stream) (void)hipStreamSynchronize(c->alt_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->clips) {
     if (s.base) (void)hipFree(s.base);
@@ -443,6 +477,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
   if (c->sum_stream) (void)hipStreamDestroy(c->sum_stream);
   if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+  if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
   if (c->ready_ev) (void)hipEventDestroy(c->ready_ev);
   for (auto& ev : c->pace_ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -453,7 +488,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   for (auto& P : c->d_partial2) P.release();
   c->d_master.release();
   c->d_buses.release();
-  c->d_peaks.release();
+  for (auto& P : c->d_peaks) P.release();
   c->d_gains.release();
   c->d_conv.release();
   c->d_zero.release();
@@ -583,7 +618,7 @@ wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s) {
   if (dst.base) {
     (void)hipStreamSynchronize(c->plan_stream);
     (void)join_sum(c);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_main(c);
     clip_release(dst);
   }
   dst = std::move(s);
@@ -644,7 +679,7 @@ extern "C" wbx_status wbx_clip_download(wbx_ctx* c, uint32_t clip, uint32_t chan
   if (!c || !dst || clip >= c->clips.size() || !c->clips[clip].used) return WBX_ERR_INVALID;
   const ClipSlot& s = c->clips[clip];
   if (channel >= s.d.channels) return fail(c, WBX_ERR_INVALID, "channel out of range");
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   WBX_HIP(c, hipMemcpy(dst, (const char*)s.base + s.stride * channel, (size_t)s.d.count * fmt_bytes((int)s.d.format), hipMemcpyDeviceToHost));
   return WBX_OK;
 }
@@ -675,7 +710,7 @@ extern "C" wbx_status wbx_clip_build_mipmaps(wbx_ctx* c, uint32_t clip, int qual
   const int bits = quality ? 16 : 8;
   const size_t esz = bits / 8;
   if (s.mip) {
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     (void)hipFree(s.mip);
     s.mip = nullptr;
   }
@@ -727,7 +762,7 @@ extern "C" wbx_status wbx_clip_fetch_mipmap(wbx_ctx* c, uint32_t clip, uint32_t 
   if (st != WBX_OK) return st;
   if (!dst) return WBX_ERR_INVALID;
   const ClipSlot& s = c->clips[clip];
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   WBX_HIP(c, hipMemcpy(dst, p, (size_t)n * s.d.channels * (s.mip_bits / 8), hipMemcpyDeviceToHost));
   return WBX_OK;
 }
@@ -740,7 +775,7 @@ extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
   (void)hipSetDevice(c->cfg.device);
   WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   clip_release(c->clips[clip]);
   c->samples_dirty = true;
   return WBX_OK;
@@ -782,7 +817,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (st != WBX_OK) return st;
   st = ensure_result_buffers(c, K, N);
   if (st != WBX_OK) return st;
-  WBX_HIP(c, hipStreamSynchronize(c->stream));   // staging vectors are reused
+  WBX_HIP(c, sync_main(c));   // staging vectors are reused
   const uint32_t F = c->cfg.block_frames, C = c->cfg.channels;
   c->h_tb.assign((size_t)K * N, DTrackBlock{});
   c->h_rows.assign((size_t)K * N, DRow{});
@@ -862,7 +897,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
     WBX_HIP(c, hipMemcpyAsync(PB(c).counters, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
     if (!gen_idx.empty())
       WBX_HIP(c, hipMemcpyAsync(PB(c).gen_list.p, gen_idx.data(), gen_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    WBX_HIP(c, hipStreamSynchronize(c->stream));   // counters / gen_idx are stack / local storage
+    WBX_HIP(c, sync_main(c));   // counters / gen_idx are stack / local storage
   }
   if (chunks > PB(c).pool_chunks) {
     WBX_HIP(c, PB(c).pool.ensure((size_t)chunks * kChunk));
@@ -872,6 +907,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
   c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
   c->uniform_speed = 0.0;   // ... and make no promise about their playback speeds
   st = launch_pre_render(c, K, c->stream);
@@ -881,8 +917,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
 
 extern "C" wbx_status wbx_sync(wbx_ctx* c) {
   if (!c) return WBX_ERR_INVALID;
-  WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   drain_events(c);
   return WBX_OK;
 }
@@ -920,7 +955,7 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
     // device [K][C][F] -> host planar[c][b*F + j]
     for (uint32_t ch = 0; ch < C; ch++)
       if (c->last_master_on_host) {   // Engine::process: the block is already on the host
-        WBX_HIP(c, hipStreamSynchronize(c->stream));
+        WBX_HIP(c, sync_main(c));
         for (uint32_t b = 0; b < K; b++)
           std::memcpy(master_planar[ch] + (size_t)b * F, c->last_master + ((size_t)b * C + ch) * F, F * sizeof(float));
       } else {
@@ -928,12 +963,12 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
                                     (size_t)C * F * sizeof(float), F * sizeof(float), K, hipMemcpyDeviceToHost, c->stream));
       }
   }
-  if (peaks) WBX_HIP(c, hipMemcpyAsync(peaks, c->d_peaks.p, (size_t)K * N * C * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (peaks) WBX_HIP(c, hipMemcpyAsync(peaks, c->last_peaks, (size_t)K * N * C * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (buses) {
     if (!c->n_buses) return fail(c, WBX_ERR_INVALID, "no buses configured");
     WBX_HIP(c, hipMemcpyAsync(buses, c->last_buses, (size_t)K * c->n_buses * C * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   drain_events(c);
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_HIP(c, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
@@ -961,14 +996,14 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
     WBX_HIP(c, c->d_conv.ensure((size_t)K * F * 3));
     launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);
     WBX_HIP(c, hipMemcpy2DAsync(dst, (size_t)F * C * 3, c->d_conv.p, (size_t)F * 3, (size_t)F * 3, K, hipMemcpyDeviceToHost, c->stream));
-    WBX_HIP(c, hipStreamSynchronize(c->stream));
+    WBX_HIP(c, sync_main(c));
     return WBX_OK;
   }
   const size_t bytes = (size_t)K * F * C * eb;
   WBX_HIP(c, c->d_conv.ensure(bytes));
   launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);   // pinned staging is device-readable too
   WBX_HIP(c, hipMemcpyAsync(dst, c->d_conv.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   return WBX_OK;
 }
 
@@ -1009,7 +1044,7 @@ extern "C" wbx_status wbx_pace(wbx_ctx* c, uint32_t max_ahead) {
   (void)hipSetDevice(c->cfg.device);
   const uint32_t slot = (uint32_t)(c->pace_seq % kPaceRing);
   if (!c->pace_ev[slot]) WBX_HIP(c, hipEventCreateWithFlags(&c->pace_ev[slot], hipEventDisableTiming));
-  WBX_HIP(c, hipEventRecord(c->pace_ev[slot], c->stream));
+  WBX_HIP(c, hipEventRecord(c->pace_ev[slot], c->cur_mix_stream ? c->cur_mix_stream : c->stream));
   if (c->pace_seq >= max_ahead) WBX_HIP(c, hipEventSynchronize(c->pace_ev[(c->pace_seq - max_ahead) % kPaceRing]));
   c->pace_seq++;
   return WBX_OK;
@@ -1031,7 +1066,7 @@ extern "C" wbx_status wbx_host_free(void* p) {
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
   if (!c) return WBX_ERR_INVALID;
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   drain_events(c);
   if (mix_ms_avg) *mix_ms_avg = c->mix_launches ? c->mix_ms_total / (double)c->mix_launches : 0.0;
   if (mix_launches) *mix_launches = c->mix_launches;
@@ -1046,7 +1081,7 @@ extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg,
 extern "C" wbx_status wbx_tail_time(wbx_ctx* c, double* tail_ms_avg) {
   if (!c || !tail_ms_avg) return WBX_ERR_INVALID;
   WBX_HIP(c, join_sum(c));
-  WBX_HIP(c, hipStreamSynchronize(c->stream));
+  WBX_HIP(c, sync_main(c));
   drain_events(c);
   *tail_ms_avg = c->mix_launches ? c->tail_ms_total / (double)c->mix_launches : 0.0;
   return WBX_OK;
