@@ -1219,3 +1219,31 @@ def test_alternating_mix_streams_keep_every_render_intact(monkeypatch, alt):
         o.close()
     eng.close()
 
+
+@pytest.mark.parametrize("clip_blocks", [0.7, 1.3])
+def test_callback_mode_with_and_without_queued_pre_render_rows(clip_blocks):
+    """Engine::process on an fp32 session leaves the pre-render launch out (clip boundaries stay in the hot loop, the
+    queue is expected to be empty) and clears the plan counters in the sum kernel.  Clips shorter than a block put three
+    stream calls into some blocks: those are queued after all, and the block is pre-rendered and mixed again — every
+    block still equals the oracle's, peaks, levels and stream-call log included."""
+    n_blocks = 9
+    spec = _boundary_session(30, n_blocks, 512, clip_blocks)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    eng = build_engine(spec, max_blocks=1, group_size=30)
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    lv = np.zeros((30, 2), np.float32)
+    for b in range(n_blocks):
+        om, _ = e.process()
+        eng.process(None, out, float(spec.sample_rate))
+        assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om)), b
+        assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0], e.peaks()[:, :2]), b
+        lv = np.maximum(lv, e.peaks()[:, :2])
+    assert np.array_equal(eng.levels(), lv)
+    e.close()
+    eng.close()
+

@@ -106,6 +106,7 @@ struct wbx_ctx {
     uint32_t pool_chunks = 0;
     uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued,
                                       // [3] templates allocated
+    bool counters_zero = true;        // cleared already (at creation, or by the sum kernel of a callback block)
     DevBuf<uint32_t> gen_list;        // pre-render queue of KIND_GENERIC records
     DevBuf<float> rows;               // [gen_cap][C][F+8] pre-rendered mixing buffers
     DevBuf<DTrackBlock> saved;        // original records of the queue (plan read-back)
@@ -147,6 +148,7 @@ struct wbx_ctx {
 
   uint32_t last_K = 0, last_N = 0;
   uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
+  bool zero_status = false;           // ... and whether it clears the counters for the buffer's next plan
   bool buses_alias_partials = false;  // see build_routing
   const float* last_buses = nullptr;  // where the last render's bus sums are: d_buses or the partial buffer
   bool buses_clean = false;           // d_buses zeroed since the last routing change / reallocation

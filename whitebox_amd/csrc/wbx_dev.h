@@ -208,8 +208,10 @@ struct SumArgs {
   float* buses;                 // [K][NB][C][F] or null
   uint32_t n_groups, n_buses, block_frames, channels;
   uint32_t clamp;
-  const uint32_t* status_src;   // optional: the plan's 4 counters, copied to status_dst (pinned host memory) so that
+  uint32_t* status_src;         // optional: the plan's 4 counters, copied to status_dst (pinned host memory) so that
   uint32_t* status_dst;         // the one-block callback path learns the plan status without another launch
+  uint32_t zero_status;         // ... and cleared for the next plan that uses this buffer (no memset launch per block),
+                                // unless the pre-render queue is not empty (the host then repeats pre-render + mix)
 };
 
 // ---- waveform mip-maps (wbx_media.hip) ----

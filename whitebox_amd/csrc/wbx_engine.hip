@@ -35,6 +35,8 @@ struct wbx_engine {
   uint32_t* h_status = nullptr;         // plan counters [4]
   bool in_process = false;              // render_locked runs inside wbx_engine_process, which waits for the block: the
                                         // pinned tables need no completion events
+  bool gen_skipped = false;             // ... and left the pre-render launch out (expecting an empty queue)
+  bool plan_status_on_host = false;     // the counters of the last plan are in h_status (the device copy was cleared)
   size_t d_clips_count = 0;
   bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
   uint32_t state_tracks = 0;            // tracks that have device state
@@ -710,7 +712,9 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
       c->partial_wait_done = true;
     }
   }
-  WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
+  if (!B.counters_zero) WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
+  B.counters_zero = false;
+  e->plan_status_on_host = false;
   const double sample_rate = (double)c->cfg.sample_rate;
   PlanArgs a{};
   a.clips = e->d_clips.p;
@@ -755,8 +759,14 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, hipEventRecord(e->gains_done[e->gains_slot], ps));   // (re-recorded by every plan that reads the buffer)
     e->gains_valid[e->gains_slot] = true;
   }
-  st = launch_pre_render(c, K, ps);
-  if (st != WBX_OK) return cfail(e, st);
+  // The one-block callback of a session whose clip boundaries stay in the hot loop: the pre-render queue is empty
+  // unless a block holds three or more stream calls or overlapping ones.  Leave the launch out; wbx_engine_process
+  // looks at the queue counter afterwards and repeats pre-render + mix for the (rare) block that needed it.
+  e->gen_skipped = e->in_process && c->masked_rows && !hs.any_slow_clip;
+  if (!e->gen_skipped) {
+    st = launch_pre_render(c, K, ps);
+    if (st != WBX_OK) return cfail(e, st);
+  }
   if (plan_event) WBX_EHIP(e, hipEventRecord(B.planned, ps));   // (plan and mix on one stream: the mix simply follows)
 
   // -- mix (main stream, or the alternate one for every other batch render) + sum, after the plan
@@ -800,12 +810,30 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
   c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
   c->status_dst = e->h_status;            // and it drops the plan status next to it
   e->in_process = true;
+  c->zero_status = true;
   wbx_status st = render_locked(e, 1);
   e->in_process = false;
+  if (st == WBX_OK && e->hs.n_tracks() != 0) {
+    if (hipError_t he = sync_main(c); he != hipSuccess) st = WBX_ERR_DEVICE;
+    if (st == WBX_OK) {
+      PB(c).counters_zero = e->h_status[2] == 0u;   // (sum_kernel cleared them unless something was queued)
+      e->plan_status_on_host = true;
+    }
+    if (st == WBX_OK && e->gen_skipped && e->h_status[2] != 0u) {
+      // the block did queue records for the pre-render pass: run it now and mix again (the plan is untouched; the
+      // first pass counted those records as silence, so the running levels hold nothing wrong)
+      c->zero_status = false;
+      st = launch_pre_render(c, 1, c->stream);
+      if (st == WBX_OK) st = launch_mix_sum(c, 1, e->hs.n_tracks());
+      if (st == WBX_OK && sync_main(c) != hipSuccess) st = WBX_ERR_DEVICE;
+      PB(c).counters_zero = false;
+      if (st != WBX_OK) tls_err = c->err;
+    }
+  }
+  c->zero_status = false;
   c->master_target = nullptr;
   c->status_dst = nullptr;
   if (st != WBX_OK) return st;
-  WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, sync_main(c));
   for (int i = 0; i < kRing; i++) e->patch_valid[i] = e->gains_valid[i] = false;   // every plan that read them is over
   drain_events(c);
@@ -861,7 +889,10 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   const uint32_t K = c->last_K, N = c->last_N;
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_EHIP(e, sync_main(c));
-  WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
+  if (e->plan_status_on_host)
+    std::memcpy(pc, e->h_status, sizeof(pc));
+  else
+    WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   std::vector<DRow> rows((size_t)K * N);
   const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);
   std::vector<DTrackBlock> tmpl(nt);

@@ -1249,7 +1249,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     // of the chunk's own shape, so that the load phase stays straight-line
     for (uint32_t i = tid; i < SB * kRecs; i += 256u) {
       DTrackBlock& r = s_tb[i];
-      if ((SB > 1 ? i % kRecs : i) >= cn2 || r.kind == KIND_SILENT) {
+      // (KIND_GENERIC: only when the one-block callback skipped the pre-render pass on the expectation of an empty queue;
+      //  the host then repeats pre-render + mix for that block — here the record counts as silence)
+      if ((SB > 1 ? i % kRecs : i) >= cn2 || r.kind == KIND_SILENT || r.kind == KIND_GENERIC) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -1341,7 +1343,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
-  if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) a.status_dst[threadIdx.x] = a.status_src[threadIdx.x];
+  if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {
+    const uint32_t queued = a.status_src[2];
+    a.status_dst[threadIdx.x] = a.status_src[threadIdx.x];
+    if (a.zero_status && queued == 0u) a.status_src[threadIdx.x] = 0u;
+  }
   const uint32_t b = blockIdx.x;
   const uint32_t F = a.block_frames, C = a.channels;
   const uint32_t slot = blockIdx.y * 64u + threadIdx.x;

@@ -293,6 +293,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.clamp = c->clamp ? 1u : 0u;
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
+  s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
   if (c->n_buses && !c->buses_alias_partials && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)

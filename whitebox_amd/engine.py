@@ -58,8 +58,13 @@ class AudioBuffer:
         self.n_channels = channel_count
 
     def _ptrs(self):
-        arr_t = C.POINTER(C.c_float) * self.n_channels
-        return arr_t(*[b.ctypes.data_as(C.POINTER(C.c_float)) for b in self.channel_buffers])
+        # (cached: the audio callback calls process() with the same buffer every block)
+        key = tuple(b.ctypes.data for b in self.channel_buffers)
+        if getattr(self, "_ptr_key", None) != key:
+            arr_t = C.POINTER(C.c_float) * self.n_channels
+            self._ptr_arr = arr_t(*[b.ctypes.data_as(C.POINTER(C.c_float)) for b in self.channel_buffers])
+            self._ptr_key = key
+        return self._ptr_arr
 
 
 def _check(st: int, where: str, handle=None, engine: bool = False):
@@ -405,7 +410,9 @@ class Engine:
         """Engine::process(const AudioBuffer<float>&, AudioBuffer<float>&, double) — one block."""
         assert output_buffer.n_samples == self.audio_buffer_size and output_buffer.n_channels == self.num_output_channels
         assert float(sample_rate) == float(self.audio_sample_rate)
-        _check(self.L.wbx_engine_process(self.h, output_buffer._ptrs()), "Engine::process", self.h, True)
+        st = self.L.wbx_engine_process(self.h, output_buffer._ptrs())
+        if st != 0:
+            _check(st, "Engine::process", self.h, True)
         self.ctx.last = (1, len(self.tracks))
 
     def render(self, n_blocks: int):
