@@ -42,6 +42,41 @@ def random_session(seed):
 
 
 
+def random_masked_session(seed):
+    """Sessions the masked-row path of the mix kernel takes: fp32 clips only, 44.1 / 48 kHz sources, stretch speeds on the
+    unity and 5-sample-window paths, stereo 512-frame (or mono / stereo 1024-frame) blocks — with everything a clip list
+    can do to a block: touching clips, gaps, clips shorter than a block (three and more stream calls: those still go to
+    the pre-render pass), clips that outlast their audio, random start offsets and gains, mutes, sub-buses, more tracks
+    than one staged chunk."""
+    rng = np.random.default_rng(0xA5C0 + seed)
+    n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
+    block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1)][int(rng.integers(0, 4))]
+    n_blocks = int(rng.integers(2, 7))
+    sr = 48000
+    bpm = float(rng.choice([120.0, 97.0, 140.5]))
+    beat_frames = sr * 60.0 / bpm
+    total_beats = n_blocks * block / beat_frames
+    samples, clips = [], []
+    for t in range(n_tracks):
+        samples.append(synth.SampleSpec(seed_track=t, channels=int(rng.integers(1, 3)), rate=int(rng.choice([44100, 48000])),
+                                        frames=int(rng.integers(600, 9000)), fmt="f32", amp=0.05))
+        pos = -0.2 * total_beats * rng.random() if rng.random() < 0.3 else total_beats * rng.random() * 0.3
+        for _ in range(int(rng.integers(0, 6))):
+            length = total_beats * (0.02 + 0.45 * rng.random())
+            speed = float(rng.choice([1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 0.3, 0.67]))
+            clips.append(synth.ClipSpec(track=t, min_beat=float(pos), max_beat=float(pos + length),
+                                        start_offset=float(rng.integers(0, 400)), speed=speed, gain=float(rng.choice([1.0, 0.5, 1.3]))))
+            pos += length + (0.0 if rng.random() < 0.5 else total_beats * 0.1 * rng.random())   # touching or a gap
+    n_buses = int(rng.choice([0, 0, 3]))
+    return synth.SessionSpec(name=f"mfuzz{seed}", n_tracks=n_tracks, seed=0xF0330000 + seed, samples=samples, clips=clips,
+                             volumes_db=[float(rng.uniform(-30, 3)) for _ in range(n_tracks)],
+                             pans=[float(rng.uniform(-1, 1)) for _ in range(n_tracks)],
+                             mutes=[bool(rng.random() < 0.1) for _ in range(n_tracks)],
+                             n_buses=n_buses, track_bus=[int(rng.integers(-1, n_buses)) for _ in range(n_tracks)] if n_buses else None,
+                             bpm=bpm, sample_rate=sr, block=block, channels=channels,
+                             playhead_start=float(rng.choice([0.0, 0.0, total_beats * 0.1]))), n_blocks
+
+
 def clip_rows(clips):
     return [(O.f64_bits(a), O.f64_bits(b), O.f64_bits(c), O.f64_bits(d), O.f32_bits(g), s) for (a, b, c, d, g, s) in clips]
 

@@ -1247,3 +1247,30 @@ def test_callback_mode_with_and_without_queued_pre_render_rows(clip_blocks):
     e.close()
     eng.close()
 
+
+# WBX_FUZZ4_FROM / WBX_FUZZ4_TO widen the seed range for a soak run (default: seeds 0..59)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ4_FROM", "0")), int(os.environ.get("WBX_FUZZ4_TO", "60"))))
+def test_random_masked_row_sessions(seed):
+    """Random sessions the masked-row path takes (fuzz_util.random_masked_session): rendered as one batch — peaks, plan,
+    transport bit-equal, the master bit-equal when one group holds all tracks — and, every third seed, block by block
+    through Engine::process against the same oracle blocks."""
+    spec, n_blocks = FZ.random_masked_session(seed)
+    one_group = spec.n_tracks <= 128
+    gs = spec.n_tracks if one_group else [0, 50, 128][seed % 3]
+    check_against_oracle(spec, n_blocks, group_size=gs, expect_exact=one_group and not spec.n_buses)
+    if seed % 3 == 0:
+        om, opk, _, _, _ = run_oracle(spec, n_blocks)
+        eng = build_engine(spec, max_blocks=1, group_size=gs)
+        eng.play()
+        out = W.AudioBuffer(spec.block, spec.channels)
+        for b in range(n_blocks):
+            eng.process(None, out, float(spec.sample_rate))
+            m = np.stack(out.channel_buffers)
+            if one_group and not spec.n_buses:
+                assert np.array_equal(bits(m), bits(om[b])), b
+            else:
+                assert rms(m, om[b]) <= RMS_TOL
+            _, pk, _ = eng.ctx.fetch(peaks=True)
+            assert np.array_equal(pk[0], opk[b][:, :spec.channels]), b
+        eng.close()
+

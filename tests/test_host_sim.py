@@ -110,6 +110,13 @@ def test_clip_boundaries_stay_out_of_the_pre_render_queue():
     assert gen1 == 0 and pool1 == 0 and pairs1 == gen0               # masked rows: all of them ROW_PAIRs in the hot loop
 
 
+@pytest.mark.parametrize("seed", range(0, 80))
+def test_host_sequencer_masked_row_sessions(seed):
+    """the third generator: sessions the masked-row path takes (fp32, unity / window speeds, 512- and 1024-frame blocks)"""
+    spec, n_blocks = FZ.random_masked_session(seed)
+    check_session(spec, n_blocks, batch=bool(seed & 1), masked=True)
+
+
 @pytest.mark.parametrize("name,kw", [("c1", dict(n_tracks=8, channels_src=1)), ("seek", dict(n_tracks=24, seek=True)),
                                      ("seek441", dict(n_tracks=24, seek=True, src_rate=44100)),
                                      ("d96", dict(n_tracks=8, src_rate=96000)), ("long", dict(n_tracks=5, src_rate=44100))])
