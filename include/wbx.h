@@ -68,8 +68,8 @@ typedef struct wbx_config {
   uint32_t block_frames;   /* F, Engine::audio_buffer_size (reference default 512, src/config.cpp:146); multiple of 4 */
   uint32_t channels;       /* C, output channels: 1 or 2 (reference: 2, src/config.cpp:224) */
   uint32_t sample_rate;    /* destination rate, Engine::audio_sample_rate */
-  uint32_t group_size;     /* tracks summed in index order by one workgroup (0 = default: 128, or 64 when
-                              max_blocks == 1, the audio-callback configuration).  The
+  uint32_t group_size;     /* tracks summed in index order by one workgroup (0 = default: 128; when max_blocks == 1,
+                              the audio-callback configuration: 64, and 32 for sessions of more than 64 tracks).  The
                               master is the in-order sum of the group sums; group_size >= N reproduces
                               the reference's strictly sequential order bit-for-bit. */
   uint32_t max_segments;   /* extra (beyond one per track-block) segment slots per launch; 0 = default */

@@ -170,6 +170,7 @@ struct wbx_ctx {
   bool has_integer_clips = false;
   bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
+  bool auto_group = false;            // wbx_config.group_size was 0: the library picks the track-group size
   bool masked_rows = false;           // the current plan holds partial-coverage rows / ROW_PAIRs for the hot loop (layer 2)
   double uniform_speed = 0.0;         // MixArgs::uniform_speed of the next launch (layer 2; 0 for host-sequenced plans)
 

@@ -41,6 +41,11 @@ enum : uint8_t {
                        // window of a lane's 4 frames is one 8-B and one 4-B load
 };
 
+// flag in DTrackBlock::kind: the record covers only frames [dst_start, dst_start + len) of the block (a masked row of the
+// mix kernel's hot loop, PlanArgs::masked_rows); whole-block records — nearly all — are recognised without their bounds
+constexpr uint8_t KIND_PARTIAL = 0x80;
+constexpr uint8_t KIND_MASK = 0x7F;
+
 enum : uint8_t {
   SEG_FINISHED = 1,  // Sampler::stream returned early: sample_offset_ >= count (sampler.cpp:99-100)
   SEG_CLIPPED = 2    // reference would have written past the block (uint32 wrap of event_length, track.cpp:669)

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 6) void gen_kernel(GenArgs a) {
       rec.g[1] = __uint_as_float(rl(10));
       const uint32_t q = rl(11), h = rl(12), m = rl(13);
       rec.nseg = (uint8_t)(q & 0xFFu);
-      rec.kind = (uint8_t)((q >> 8) & 0xFFu);
+      rec.kind = (uint8_t)((q >> 8) & 0xFFu);   // (queued records are KIND_GENERIC: never flagged KIND_PARTIAL)
       rec.dst_start = (uint16_t)(q >> 16);
       rec.len = (uint16_t)(h & 0xFFFFu);
       rec.req_len = (uint16_t)(h >> 16);
@@ -560,6 +560,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     float gain, gc;    // clip gain, fl(volume * pan_c)
     uint32_t kind, format;
     uint32_t d, n;     // EXP: the stream call covers frames [d, d + n) of the block (whole-block records: 0, F)
+    bool partial;      // EXP: KIND_PARTIAL
   };
   auto load_urec = [&](uint32_t rec) {
     const int w = (int)reinterpret_cast<const uint32_t*>(&s_tb[rb + rec])[lane & 15u];
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
       r.gain = __uint_as_float(rl(8));
       r.gc = __uint_as_float(c ? rl(10) : rl(9));
-      r.kind = (rl(11) >> 8) & 0xFFu;
+      r.kind = (rl(11) >> 8) & KIND_MASK;
       r.format = rl(13) & 0xFFu;
       return r;
     }
@@ -583,11 +584,17 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     r.gain = __uint_as_float(rl(8));
     r.gc = __uint_as_float(rl(9u + cs));
     const uint32_t q11 = rl(11);
-    r.kind = (q11 >> 8) & 0xFFu;
+    r.kind = (q11 >> 8) & KIND_MASK;
     r.format = rl(13) & 0xFFu;
     if (EXP) {
-      r.d = q11 >> 16;
-      r.n = rl(12) & 0xFFFFu;
+      // whole-block records (no KIND_PARTIAL flag) need neither their bounds nor the arithmetic that goes with them
+      r.partial = ((q11 >> 15) & 1u) != 0u;
+      r.d = 0u;
+      r.n = F;
+      if (r.partial) {
+        r.d = q11 >> 16;
+        r.n = rl(12) & 0xFFFFu;
+      }
     }
     return r;
   };
@@ -606,12 +613,20 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 
   // ---- per-row arithmetic (each returns the 4 frames of one track AFTER clip gain and track gain) ----
   // fp32 row at unity speed: sampler.cpp:151-152, track.cpp:731
+  // (clip gain exactly 1.0 — the usual case — is wave-uniform: s * 1.0f is s, bit for bit, so that multiply is left out)
   auto row_f32 = [&](const f4& v, float cg, float gc) {
     f4 m;
-    m.x = __fmul_rn(__fmul_rn(v.x, cg), gc);
-    m.y = __fmul_rn(__fmul_rn(v.y, cg), gc);
-    m.z = __fmul_rn(__fmul_rn(v.z, cg), gc);
-    m.w = __fmul_rn(__fmul_rn(v.w, cg), gc);
+    if (__float_as_uint(cg) == 0x3F800000u) {
+      m.x = __fmul_rn(v.x, gc);
+      m.y = __fmul_rn(v.y, gc);
+      m.z = __fmul_rn(v.z, gc);
+      m.w = __fmul_rn(v.w, gc);
+    } else {
+      m.x = __fmul_rn(__fmul_rn(v.x, cg), gc);
+      m.y = __fmul_rn(__fmul_rn(v.y, cg), gc);
+      m.z = __fmul_rn(__fmul_rn(v.z, cg), gc);
+      m.w = __fmul_rn(__fmul_rn(v.w, cg), gc);
+    }
     return m;
   };
   // 16-bit PCM row at unity speed, sampler.cpp:109-120: clamp((float)d * (1.0f/32767), -1, 1) * gain
@@ -637,7 +652,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     return m;
   };
   // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
-  auto row_window_at = [&](auto narrow, auto shifted, auto uni, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
+  auto row_window_g = [&](auto narrow, auto shifted, auto uni, auto unitg, const Pre& p, double pos, double speed, double d0, float cg,
+                          float gc) {
+    constexpr bool UNITG = decltype(unitg)::value;   // clip gain == 1.0f: fl(s * 1) = s, the multiply is left out
     constexpr bool NARROW = decltype(narrow)::value;
     constexpr bool UNI = decltype(uni)::value;   // the row plays at MixArgs::uniform_speed: products hoisted (not with SHIFTED)
     constexpr bool SHIFTED = decltype(shifted)::value;   // the stream call starts at block frame d0: call frame = j - d0
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     float q[4];
     {   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
       const float s = __fadd_rn(p.v.x, __fmul_rn(p.fx0, __fsub_rn(p.v.y, p.v.x)));        // :55
-      q[0] = __fmul_rn(__fmul_rn(s, cg), gc);                                             // :56, track.cpp:731
+      q[0] = __fmul_rn(UNITG ? s : __fmul_rn(s, cg), gc);                                 // :56, track.cpp:731
     }
 #define WBX_TAP(E, JD)                                                                                  \
   {                                                                                                     \
@@ -657,11 +674,16 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     else                                                                                                \
       taps<E>(p.v, p.w4, (int)x - ix0, sa, sb);                                                         \
     const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
-    q[E] = __fmul_rn(__fmul_rn(s, cg), gc);                               /* :56, track.cpp:731 */      \
+    q[E] = __fmul_rn(UNITG ? s : __fmul_rn(s, cg), gc);                   /* :56, track.cpp:731 */      \
   }
     WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
 #undef WBX_TAP
     return f4{q[0], q[1], q[2], q[3]};
+  };
+  auto row_window_at = [&](auto narrow, auto shifted, auto uni, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
+    if (__float_as_uint(cg) == 0x3F800000u)   // wave-uniform
+      return row_window_g(narrow, shifted, uni, std::true_type{}, p, pos, speed, d0, cg, gc);
+    return row_window_g(narrow, shifted, uni, std::false_type{}, p, pos, speed, d0, cg, gc);
   };
   auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
     return row_window_at(narrow, std::false_type{}, std::false_type{}, p, pos, speed, 0.0, cg, gc);
@@ -909,21 +931,19 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.pos = t.pos;
         r.speed = t.speed;
         r.format = t.format;
-        r.kind = t.kind;
+        r.kind = t.kind & KIND_MASK;
       }
       if constexpr (MODE == MODE_G) {
         load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
         double prod0;
-        if (MODE == MODE_WNU) {   // whole-block resampled rows: the hoisted product (wave-uniform choice)
-          const bool whole = !EXP || (r.d == 0u && r.n == F);
-          if (whole && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
-            prod0 = up0;
-          else
-            prod0 = __dmul_rn(EXP ? (double)call_frame(0u, r.d, r.n) : j0d, r.speed);
-        } else {
-          prod0 = __dmul_rn(EXP ? (double)call_frame(0u, r.d, r.n) : j0d, r.speed);
-        }
+        const bool part = EXP && r.partial;
+        if (MODE == MODE_WNU && !part && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
+          prod0 = up0;   // whole-block resampled rows: the hoisted product (wave-uniform choice)
+        else if (part)
+          prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
+        else
+          prod0 = __dmul_rn(j0d, r.speed);
         load_window(r.src, r.pos, prod0, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         double prod0;
@@ -960,7 +980,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
       } else {
         // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
-        const uint32_t off = (uint32_t)r.pos + ((EXP && MODE == MODE_U) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
+        const uint32_t off = (uint32_t)r.pos + ((EXP && MODE == MODE_U && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
         if (MODE == MODE_I16) {
           typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
           const short WBX_GLOBAL* p = as_global<short>(r.src) + off;
@@ -992,7 +1012,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.speed = t.speed;
         r.gain = t.gain;
         r.gc = t.g[c];
-        r.kind = t.kind;
+        r.kind = t.kind & KIND_MASK;
         r.format = t.format;
       }
       const float cg = r.gain;
@@ -1006,7 +1026,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE != MODE_W> narrow{};
         constexpr std::integral_constant<bool, MODE == MODE_WNU> uni{};
-        if (EXP && (r.d != 0u || r.n != F)) {   // a stream call that covers part of the block (wave-uniform)
+        if (EXP && r.partial) {   // a stream call that covers part of the block (wave-uniform)
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
             m = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
@@ -1065,7 +1085,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       } else if constexpr (MODE == MODE_I32) {
         m = row_i32(pre[u].v, r.format, cg, gc);
       } else {
-        if (EXP && (r.d != 0u || r.n != F) && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {
+        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base)
             m = f4{0.0f, 0.0f, 0.0f, 0.0f};
           else
@@ -1113,7 +1133,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   auto mixed = [&](uint32_t cn) {
     for (uint32_t tl = 0; tl < cn; tl++) {
       const DTrackBlock& r = s_tb[rb + tl];
-      const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
+      const int k = __builtin_amdgcn_readfirstlane((int)(r.kind & KIND_MASK));
       const float cg = r.gain, gc = r.g[c];
       const uint32_t off = (uint32_t)r.pos + j0;
       f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1219,7 +1239,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     int shape = 0;
     for (uint32_t i0 = tid; i0 < SB * cn2; i0 += 256u) {
       const uint32_t i = SB > 1 ? (i0 / cn2) * kRecs + i0 % cn2 : i0;
-      const int k = s_tb[i].kind;
+      const int k = s_tb[i].kind & KIND_MASK;
       shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? (s_tb[i].format == FMT_F32 ? 2 : 128) : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8
                : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
       if ((k == KIND_WINDOW || k == KIND_WINDOW_I16) && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
@@ -1251,7 +1271,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       DTrackBlock& r = s_tb[i];
       // (KIND_GENERIC: only when the one-block callback skipped the pre-render pass on the expectation of an empty queue;
       //  the host then repeats pre-render + mix for that block — here the record counts as silence)
-      if ((SB > 1 ? i % kRecs : i) >= cn2 || r.kind == KIND_SILENT || r.kind == KIND_GENERIC) {
+      if ((SB > 1 ? i % kRecs : i) >= cn2 || (r.kind & KIND_MASK) == KIND_SILENT || (r.kind & KIND_MASK) == KIND_GENERIC) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -1342,6 +1362,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 // with bus u = in-order sum of its groups (AudioBuffer::mix order, audio_buffer.h:73-82), then the
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
+// PF = group partials in flight per lane: 16 for batch renders (the kernel runs beside the next mix and must stay small),
+// 32 for the one-block callback, whose sum is a chain of dependent HBM round trips — 128 groups are four of them, not eight
+template <int PF, bool BUSES>
 __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {
     const uint32_t queued = a.status_src[2];
@@ -1359,7 +1382,28 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   f4 master = {0.0f, 0.0f, 0.0f, 0.0f};
   f4 busacc = {0.0f, 0.0f, 0.0f, 0.0f};
   int cur = -1;
-  constexpr int PF = 16;
+  if constexpr (!BUSES) {
+    // no sub-buses (the reference's own topology): every group goes straight into the master, in order — nothing but
+    // the loads, PF of them in flight, and the adds
+    for (uint32_t g0 = 0; g0 < a.n_groups; g0 += PF) {
+      f4 v[PF];
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        const uint32_t g = g0 + i < a.n_groups ? g0 + i : a.n_groups - 1u;   // (clamped: straight-line loads)
+        v[i] = *reinterpret_cast<const f4*>(p + (size_t)g * stride);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // all PF loads are issued before the first add waits for one
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        if (g0 + i < a.n_groups) {   // (a predicate, not a break: the unrolled array must stay in registers)
+          master.x = __fadd_rn(master.x, v[i].x);
+          master.y = __fadd_rn(master.y, v[i].y);
+          master.z = __fadd_rn(master.z, v[i].z);
+          master.w = __fadd_rn(master.w, v[i].w);
+        }
+      }
+    }
+  } else
   for (uint32_t g0 = 0; g0 < a.n_groups; g0 += PF) {
     f4 v[PF];
 #pragma unroll
@@ -1604,7 +1648,12 @@ void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_ro
 
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
   const uint32_t tiles = (((a.channels * a.block_frames) >> 2) + 63u) / 64u;
-  hipLaunchKernelGGL(sum_kernel, dim3(n_blocks, tiles), dim3(64), 0, s, a);
+  if (a.n_buses != 0u)
+    hipLaunchKernelGGL((sum_kernel<16, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+  else if (n_blocks < 8u && a.n_groups > 16u)
+    hipLaunchKernelGGL((sum_kernel<32, false>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL((sum_kernel<16, false>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
 }
 
 void launch_clamp(float* buf, size_t n, hipStream_t s) {

@@ -55,7 +55,8 @@ void drain_events(wbx_ctx* c) {
 
 // default routing: identity order, groups of group_size, everything straight into the master
 void build_routing(wbx_ctx* c, uint32_t n_tracks) {
-  const uint32_t G = c->cfg.group_size;
+  uint32_t G = c->cfg.group_size;
+  if (c->auto_group && c->cfg.max_blocks == 1 && n_tracks > 64u) G = kStage / 4;   // the callback configuration, large session
   c->order.clear();
   c->groups.clear();
   auto emit = [&](const std::vector<uint32_t>& members, int32_t bus) {
@@ -373,7 +374,10 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
   // default 128: one staging round per workgroup; a context that can only render one block per call (the audio
-  // callback) takes 64 — twice the workgroups for the one block, ≈15 % less latency at 4096 tracks
+  // callback) takes 64, and 32 for sessions of more than 64 tracks (build_routing) — more workgroups for the one block,
+  // whose mix is a latency chain per workgroup; the block's group sums are then added by sum_kernel<32> in four rounds
+  // of loads.  Sessions of up to 64 tracks stay one group: the reference's summation order, bit for bit.
+  c->auto_group = c->cfg.group_size == 0;
   if (c->cfg.group_size == 0) c->cfg.group_size = c->cfg.max_blocks == 1 ? kStage / 2 : kStage;
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances

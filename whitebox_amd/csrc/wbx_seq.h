@@ -492,12 +492,13 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   if (a.masked_rows && tb->kind == KIND_GENERIC && w.nseg <= 2u) {
     const uint8_t kind0 = masked_kind(get_seg0(rec), a.block_frames);
     if (w.nseg == 1u) {
-      if (kind0 != KIND_GENERIC) tb->kind = kind0;
+      if (kind0 != KIND_GENERIC) tb->kind = kind0 == KIND_SILENT ? kind0 : (uint8_t)(kind0 | KIND_PARTIAL);
     } else {
       kind1 = masked_kind(w.seg1, a.block_frames);
       if (kind0 != KIND_GENERIC && kind1 != KIND_GENERIC && (uint32_t)rec.dst_start + rec.len <= w.seg1.dst_start) {
         pair = true;
-        tb->kind = kind0;
+        tb->kind = kind0 == KIND_SILENT ? kind0 : (uint8_t)(kind0 | KIND_PARTIAL);
+        if (kind1 != KIND_SILENT) kind1 |= KIND_PARTIAL;
       }
     }
   }
