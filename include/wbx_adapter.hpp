@@ -23,23 +23,35 @@
 
 namespace wbx {
 
-// Planar sample buffer with the reference's fields and semantics (audio_buffer.h:19-23,28-82).
+enum class AudioFormat : int {   // values of the reference's enum, src/core/audio_format.h:7-20 (= WBX_FMT_* / WBX_OUT_*)
+  I16 = WBX_OUT_I16, I24 = WBX_OUT_I24, I24_X8 = WBX_OUT_I24_X8, I32 = WBX_OUT_I32, F32 = WBX_OUT_F32
+};
+
+// Planar sample buffer with the reference's fields, layout and semantics (audio_buffer.h:14-175): the first 16 channel
+// pointers live inside the object (`internal_channel_buffers`), `channel_buffers` points at them or, beyond 16
+// channels, at a heap array; every channel is a separate 32-byte aligned, zero-filled allocation.
 template <typename T>
 struct AudioBuffer {
   static_assert(sizeof(T) == 4, "the mix path is fp32");
+  static constexpr uint32_t internal_buffer_capacity = 16;
+  static constexpr uint32_t alignment = 32;
+
   uint32_t n_samples{};
   uint32_t n_channels{};
-  std::vector<T*> channel_buffers;
+  uint32_t channel_capacity = internal_buffer_capacity;
+  T* internal_channel_buffers[internal_buffer_capacity]{};
+  T** channel_buffers{};
 
-  AudioBuffer() = default;
-  AudioBuffer(uint32_t sample_count, uint32_t channel_count) : n_samples(sample_count), n_channels(channel_count) {
-    channel_buffers.resize(channel_count);
-    for (auto& p : channel_buffers) p = alloc_channel(sample_count);
+  AudioBuffer() : channel_buffers(internal_channel_buffers) {}
+  AudioBuffer(uint32_t sample_count, uint32_t channel_count) : n_samples(sample_count), channel_buffers(internal_channel_buffers) {
+    resize_channel_array_(channel_count);
+    for (uint32_t i = 0; i < n_channels; i++) channel_buffers[i] = alloc_channel(sample_count);
   }
   AudioBuffer(const AudioBuffer&) = delete;
   AudioBuffer& operator=(const AudioBuffer&) = delete;
   ~AudioBuffer() {
-    for (auto p : channel_buffers) std::free(p);
+    for (uint32_t i = 0; i < n_channels; i++) std::free(channel_buffers[i]);
+    if (channel_buffers != internal_channel_buffers) std::free(channel_buffers);
   }
   T* get_write_pointer(uint32_t channel, uint32_t sample_offset = 0) {
     assert(channel < n_channels && "Channel out of range");
@@ -49,19 +61,24 @@ struct AudioBuffer {
     assert(channel < n_channels && "Channel out of range");
     return channel_buffers[channel] + sample_offset;
   }
-  void clear() {   // audio_buffer.h:67-71
-    for (auto p : channel_buffers) std::memset(p, 0, n_samples * sizeof(T));
-  }
   void set_sample(uint32_t channel, uint32_t sample_offset, T sample) const { channel_buffers[channel][sample_offset] = sample; }
   void mix_sample(uint32_t channel, uint32_t sample_offset, T sample) const { channel_buffers[channel][sample_offset] += sample; }
+  void clear() {   // audio_buffer.h:67-71
+    for (uint32_t i = 0; i < n_channels; i++) std::memset(channel_buffers[i], 0, n_samples * sizeof(T));
+  }
+  void mix(const AudioBuffer<T>& other) {   // audio_buffer.h:73-82: iterates THIS buffer's channels
+    assert(n_samples == other.n_samples);
+    for (uint32_t i = 0; i < n_channels; i++)
+      for (uint32_t j = 0; j < n_samples; j++) channel_buffers[i][j] += other.channel_buffers[i][j];
+  }
   // resize(samples, clear): keeps the old contents unless `clear`, zero-fills the growth (audio_buffer.h:84-110)
   void resize(uint32_t samples, bool clear = false) {
     if (samples == n_samples) return;
-    for (auto& p : channel_buffers) {
+    for (uint32_t i = 0; i < n_channels; i++) {
       T* fresh = alloc_channel(samples);
-      if (!clear) std::memcpy(fresh, p, (samples < n_samples ? samples : n_samples) * sizeof(T));
-      std::free(p);
-      p = fresh;
+      if (!clear) std::memcpy(fresh, channel_buffers[i], (samples < n_samples ? samples : n_samples) * sizeof(T));
+      std::free(channel_buffers[i]);
+      channel_buffers[i] = fresh;
     }
     n_samples = samples;
   }
@@ -69,36 +86,51 @@ struct AudioBuffer {
   void resize_channel(uint32_t channel_count) {
     assert(n_samples != 0);
     if (channel_count == n_channels) return;
-    for (uint32_t i = channel_count; i < n_channels; i++) std::free(channel_buffers[i]);
     const uint32_t old = n_channels;
-    channel_buffers.resize(channel_count, nullptr);
+    for (uint32_t i = channel_count; i < old; i++) {
+      std::free(channel_buffers[i]);
+      channel_buffers[i] = nullptr;
+    }
+    resize_channel_array_(channel_count);
     for (uint32_t i = old; i < channel_count; i++) channel_buffers[i] = alloc_channel(n_samples);
+  }
+  // planar -> interleaved (audio_buffer.h:143-160).  The fp32 case is a copy and stays on the host
+  // (convert_to_interleaved_f32, audio_format_conv.cpp:79-91); the integer device formats are produced on the GPU from
+  // the master it already holds: wbx_fetch_interleaved(ctx, WBX_OUT_*, dst) — nothing of the path computes on the CPU.
+  void interleave_samples_to(void* dst, uint32_t offset, uint32_t count, AudioFormat format = AudioFormat::F32) const {
+    assert(format == AudioFormat::F32 && "integer formats: wbx_fetch_interleaved");
+    (void)format;
+    float* out = static_cast<float*>(dst);
+    for (uint32_t c = 0; c < n_channels; c++)
+      for (uint32_t i = 0; i < count; i++) out[(size_t)i * n_channels + c] = channel_buffers[c][offset + i];
+  }
+  // interleaved f32 -> planar (convert_to_deinterleaved_f32, audio_format_conv.cpp:93-105; the reference has no other case)
+  void deinterleave_samples_from(const void* src, uint32_t dst_offset, uint32_t count, AudioFormat format = AudioFormat::F32) {
+    assert(format == AudioFormat::F32);
+    (void)format;
+    const float* in = static_cast<const float*>(src);
+    for (uint32_t c = 0; c < n_channels; c++)
+      for (uint32_t i = 0; i < count; i++) channel_buffers[c][dst_offset + i] = in[(size_t)i * n_channels + c];
+  }
+  // audio_buffer.h:162-174 (the pointer array moves to the heap beyond `channel_capacity` channels)
+  void resize_channel_array_(uint32_t channel_count) {
+    if (channel_count > channel_capacity) {
+      T** grown = static_cast<T**>(std::calloc(channel_count, sizeof(T*)));
+      assert(grown && "Cannot allocate memory for audio channel array");
+      std::memcpy(grown, channel_buffers, (n_channels < channel_count ? n_channels : channel_count) * sizeof(T*));
+      if (channel_buffers != internal_channel_buffers) std::free(channel_buffers);
+      channel_buffers = grown;
+      channel_capacity = channel_count;
+    }
     n_channels = channel_count;
-  }
-  // planar -> interleaved f32 (convert_to_interleaved_f32, audio_format_conv.cpp:79-91); integer device formats
-  // come from the GPU: wbx_fetch_interleaved
-  void interleave_samples_to(float* dst, uint32_t offset, uint32_t count) const {
-    for (uint32_t c = 0; c < n_channels; c++)
-      for (uint32_t i = 0; i < count; i++) dst[(size_t)i * n_channels + c] = channel_buffers[c][offset + i];
-  }
-  // interleaved f32 -> planar (convert_to_deinterleaved_f32, audio_format_conv.cpp:93-105)
-  void deinterleave_samples_from(const float* src, uint32_t dst_offset, uint32_t count) {
-    for (uint32_t c = 0; c < n_channels; c++)
-      for (uint32_t i = 0; i < count; i++) channel_buffers[c][dst_offset + i] = src[(size_t)i * n_channels + c];
   }
 
  private:
   static T* alloc_channel(uint32_t samples) {
-    T* p = static_cast<T*>(std::aligned_alloc(32, ((samples * sizeof(T) + 31) / 32) * 32 + 32));
+    T* p = static_cast<T*>(std::aligned_alloc(alignment, ((samples * sizeof(T) + alignment - 1) / alignment) * alignment + alignment));
+    assert(p && "Cannot allocate memory for audio buffer");
     std::memset(p, 0, samples * sizeof(T));
     return p;
-  }
-
- public:
-  void mix(const AudioBuffer<T>& other) {   // audio_buffer.h:73-82
-    assert(n_samples == other.n_samples);
-    for (uint32_t i = 0; i < n_channels; i++)
-      for (uint32_t j = 0; j < n_samples; j++) channel_buffers[i][j] += other.channel_buffers[i][j];
   }
 };
 
@@ -239,7 +271,7 @@ struct Engine {
     assert(output_buffer.n_samples == audio_buffer_size && output_buffer.n_channels == num_output_channels);
     assert(sample_rate == (double)audio_sample_rate);
     (void)sample_rate;
-    const wbx_status st = wbx_engine_process(h, output_buffer.channel_buffers.data());
+    const wbx_status st = wbx_engine_process(h, output_buffer.channel_buffers);
     if (st != WBX_OK) {
       output_buffer.clear();
       process_error = wbx_engine_last_error(h);

@@ -76,6 +76,22 @@ int main() {
     a.clear();
     REQUIRE(a.get_read_pointer(0)[3] == 0.0f);
   }
+  {   // the reference's layout (audio_buffer.h:19-23): 16 channel pointers inside the object, a heap array beyond
+    wbx::AudioBuffer<float> e;
+    REQUIRE(e.channel_buffers == e.internal_channel_buffers && e.channel_capacity == 16 && e.n_channels == 0);
+    wbx::AudioBuffer<float> b(32, 2);
+    REQUIRE(b.channel_buffers == b.internal_channel_buffers);
+    REQUIRE(((uintptr_t)b.channel_buffers[0] % wbx::AudioBuffer<float>::alignment) == 0);
+    b.get_write_pointer(1)[7] = 3.0f;
+    b.resize_channel(20);   // past the internal capacity: the pointers move, the channels stay
+    REQUIRE(b.n_channels == 20 && b.channel_buffers != b.internal_channel_buffers && b.channel_capacity >= 20);
+    REQUIRE(b.get_read_pointer(1)[7] == 3.0f && b.get_read_pointer(19)[31] == 0.0f);
+    b.resize_channel(3);
+    REQUIRE(b.n_channels == 3 && b.get_read_pointer(1)[7] == 3.0f);
+    std::vector<float> inter(3 * 32);
+    b.interleave_samples_to(inter.data(), 0, 32, wbx::AudioFormat::F32);
+    REQUIRE(inter[7 * 3 + 1] == 3.0f);
+  }
   std::printf("audio_buffer ok\n");
   return 0;
 }
