@@ -20,9 +20,14 @@
  *
  * Conventions: every call returns wbx_status (0 = ok; negatives mirror the reference's
  * PluginResult, src/plughost/plugin_interface.h:24-29, plus device errors); host pointers are
- * caller-owned, device memory is ctx-owned; one submitting thread per ctx (the reference has exactly
- * one audio thread, engine.cpp:1587); no callbacks into the host; nothing here falls back to the CPU
+ * caller-owned, device memory is ctx-owned; no callbacks into the host; nothing here falls back to the CPU
  * — without a gfx950 device wbx_create/wbx_engine_create return WBX_ERR_NO_DEVICE.
+ * Threads: layer 1 (wbx_ctx) has one submitting thread per ctx.  Layer 2 (wbx_engine) has the reference's
+ * contract: ONE audio thread in wbx_engine_process / wbx_engine_render, which hold the engine's editor lock for
+ * the host side of the block (Engine::process, engine.cpp:1587-1651), and ONE UI thread for everything else —
+ * its edits take the same lock, wbx_track_set_volume / _pan / _mute and wbx_engine_solo_track go through a
+ * per-track single-producer ring of 64 messages without it (track.cpp:47-79, core/queue.h:142-196),
+ * wbx_engine_set_bpm is an atomic store (engine.cpp:24-30).
  */
 #ifndef WBX_H
 #define WBX_H
@@ -287,6 +292,8 @@ wbx_status wbx_engine_add_sample_interleaved(wbx_engine* e, int format, uint32_t
 wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uint32_t channels, uint32_t sample_rate,
                                        uint64_t frames, uint64_t seed, uint32_t key_track, float amp,
                                        uint32_t* sample_out);
+/* drop a sample no clip names any more (under the editor lock: use this, not wbx_clip_free, on an engine's pool) */
+wbx_status wbx_engine_delete_sample(wbx_engine* e, uint32_t sample);
 /* Engine::add_audio_clip (engine.cpp:293-309 -> add_to_cliplist :409-461).  A clip that overlaps existing ones
  * trims / splits / deletes them through reserve_track_region (engine.cpp:478-569), like the reference. */
 wbx_status wbx_engine_add_audio_clip(wbx_engine* e, uint32_t track, double min_time, double max_time,

@@ -728,8 +728,13 @@ def test_abi_rejects_what_would_fault_the_device():
     with pytest.raises(W.WbxError) as ei:
         _check_free(eng, 0)
     assert ei.value.status == -4
+    with pytest.raises(W.WbxError) as ei:
+        eng.delete_sample(1)                                 # the engine-side form (takes the editor lock): same rule
+    assert ei.value.status == -4
     eng.delete_clip(eng.tracks[0], 0)
     _check_free(eng, 0)                                      # no clip names it any more
+    eng.delete_clip(eng.tracks[1], 0)
+    eng.delete_sample(1)
     eng.play()
     out = W.AudioBuffer(spec.block, spec.channels)
     eng.process(None, out, float(spec.sample_rate))          # still usable

@@ -123,6 +123,7 @@ SYMBOLS = {
     "wbx_engine_add_sample_interleaved": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, _vp, C.POINTER(_u32)]),
     "wbx_engine_add_sample_synth": (C.c_int, [_vp, C.c_int, _u32, _u32, C.c_uint64, C.c_uint64, _u32, _f,
                                               C.POINTER(_u32)]),
+    "wbx_engine_delete_sample": (C.c_int, [_vp, _u32]),
     "wbx_engine_add_audio_clip": (C.c_int, [_vp, _u32, _d, _d, _d, _u32, _d, _f]),
     "wbx_engine_move_clip": (C.c_int, [_vp, _u32, _u32, _d]),
     "wbx_engine_resize_clip": (C.c_int, [_vp, _u32, _u32, _d, _d, _d, C.c_int, C.c_int, C.c_int]),

@@ -135,6 +135,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   e->hs.note_edit_locked();
   wbx_ctx* c = e->ctx;
   if (c->cfg.channels == output_channels && c->cfg.block_frames == buffer_size && c->cfg.sample_rate == sample_rate) return WBX_OK;
+  if (c->dist) return efail(e, WBX_ERR_UNSUPPORTED, "set_audio_channel_config: shut the multi-GPU exchange down first (its buffers have the old shape)");
   (void)hipSetDevice(c->cfg.device);
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
   WBX_EHIP(e, join_sum(c));
@@ -418,6 +419,20 @@ extern "C" wbx_status wbx_engine_add_sample_synth(wbx_engine* e, int format, uin
   f.key_track = key_track;
   f.amp = amp;
   return add_sample_common(e, format, channels, sample_rate, frames, f, sample_out);
+}
+
+// Drop a sample asset (SampleAsset::release when its last reference goes, assets_table.h:22-35): refused while a clip
+// list still names it.  The engine-side form of wbx_clip_free: it takes the editor lock.
+extern "C" wbx_status wbx_engine_delete_sample(wbx_engine* e, uint32_t sample) {
+  if (!e) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  e->hs.note_edit_locked();
+  if (!e->hs.valid_sample(sample)) return efail(e, WBX_ERR_INVALID, "unknown sample");
+  if (e->hs.sample_referenced(sample)) return efail(e, WBX_ERR_INVALID, "sample is still referenced by a clip (delete the clips first)");
+  const wbx_status st = wbx_clip_free(e->ctx, sample);
+  if (st != WBX_OK) return cfail(e, st);
+  e->hs.samples[sample] = SampleMeta{};
+  return WBX_OK;
 }
 
 // Engine::add_audio_clip -> add_to_cliplist, engine.cpp:293-309, :409-461

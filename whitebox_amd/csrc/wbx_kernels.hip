@@ -938,10 +938,10 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
         double prod0;
         const bool part = EXP && r.partial;
-        if (MODE == MODE_WNU && !part && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW)
-          prod0 = up0;   // whole-block resampled rows: the hoisted product (wave-uniform choice)
-        else if (part)
+        if (part)
           prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
+        else if (MODE == MODE_WNU)   // whole-block rows of a one-ratio chunk: the hoisted product for the resampled ones, j * 1.0
+          prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW ? up0 : j0d;   // for the unity ones — no multiply
         else
           prod0 = __dmul_rn(j0d, r.speed);
         load_window(r.src, r.pos, prod0, pre[u]);

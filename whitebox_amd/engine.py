@@ -366,6 +366,9 @@ class Engine:
                                                   np.float32(amp), C.byref(sid)), "wbx_engine_add_sample_synth", self.h, True)
         return sid.value
 
+    def delete_sample(self, sample: int):
+        _check(self.L.wbx_engine_delete_sample(self.h, sample), "wbx_engine_delete_sample", self.h, True)
+
     def add_audio_clip(self, track: Track, name: str, min_time: float, max_time: float, start_offset: float,
                        sample: int, speed: float = 1.0, gain: float = 1.0):
         _check(self.L.wbx_engine_add_audio_clip(self.h, track.index, min_time, max_time, start_offset, sample, speed,
