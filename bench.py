@@ -227,22 +227,6 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
-def mix_kernel_name(src_rate, fmt):
-    """Template instance libwbx launches for the workload: mix_kernel<U, FULL, W, G, SB, CW> (wbx_kernels.hip;
-    WBX_MIX_VARIANT=10*U+W overrides U and W).  Sessions with per-frame-tap / resampled integer rows (fp32 played
-    faster than recorded, integer PCM at another rate) take the G instance; 256- and 128-frame stereo blocks the
-    instances with 2 / 4 blocks per workgroup."""
-    sb, cw = {512: (1, 1), 256: (2, 1), 128: (4, 2)}.get(F, (1, 1))
-    if F % 512 and F not in (256, 128):
-        return "wbx::mix_kernel<2, false, 1, true, 1, 1>"
-    if (src_rate > SR and fmt == "f32") or (src_rate != SR and fmt != "f32") or fmt == "mixr":
-        return f"wbx::mix_kernel<2, true, 4, true, {sb}, {cw}>"
-    if sb > 1:
-        return f"wbx::mix_kernel<2, true, 4, false, {sb}, {cw}>"
-    v = int(os.environ.get("WBX_MIX_VARIANT", "0")) or (24 if (src_rate != SR or fmt != "f32") else 43)
-    return f"wbx::mix_kernel<{v // 10}, true, {v % 10}, false, 1, 1>"
-
-
 def free_port():
     import socket
     s = socket.socket()
@@ -363,6 +347,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     gc.unfreeze()
     tail_ms = eng.ctx.tail_time()
     mix_ms, mix_n = eng.ctx.kernel_time()
+    kernel_name = eng.ctx.kernel_name()                 # the instance the library launched (as rocprofv3 names it)
     if dist is not None:
         dt = dist.max(dt)                              # MAX over ranks
 
@@ -396,7 +381,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
     return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,
             "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "alg": alg, "achieved": achieved,
-            "desc": desc, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
+            "desc": desc, "kernel_name": kernel_name, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
             "clip_blocks": clip_blocks, "workload": workload}
 
 
@@ -407,7 +392,7 @@ def roofline_of(r, traffic_table):
             "frac": r["achieved"] / HBM_PEAK_GBS, "traffic": traffic,
             # NOT this run's counters: the PMC passes of the same command, committed under profiles/ (tools/pmc_run.sh)
             "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command)" if traffic else None,
-            "kernel": mix_kernel_name(r["src_rate"], r["fmt"]),
+            "kernel": r["kernel_name"],
             "kernel_ms_avg": r["mix_ms"], "kernel_launches": int(r["mix_n"]), "sum_tail_ms_avg": r["tail_ms"],
             # mean over EVERY launch of the run incl. warm-up and ramp: what `rocprofv3 --stats` averages
             "kernel_ms_avg_all_launches": (r["pre_ms"] * r["pre_n"] + r["mix_ms"] * r["mix_n"]) / max(1, r["pre_n"] + r["mix_n"]),

@@ -224,6 +224,9 @@ wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t
 /* Average ms from the end of the mix kernel to the end of the sum kernel over the same launches (launch gap + the
  * group/bus/master sum including its stores to a host-resident master target); read before resetting. */
 wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
+/* The template instance of the dominant kernel that the last render launched, as rocprofv3 prints it
+ * ("wbx::mix_kernel<2, true, 3, false, 1, 1, 2>"); "" before the first render. */
+const char* wbx_kernel_name(wbx_ctx* ctx);
 
 /* ---- layer 2: the engine surface -----------------------------------------------------------
  * Mirrors wb::Engine / wb::Track (src/engine/engine.h, track.h).  Beats are doubles as in the

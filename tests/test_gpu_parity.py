@@ -833,7 +833,28 @@ def test_kernel_timer_reports():
     eng.render(2)
     ms, n = eng.ctx.kernel_time()
     assert n == 2 and ms > 0.0
+    # the instance the library launched, as rocprofv3 prints it: a unity-speed stereo 512-frame session takes U = 4, W = 3
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<4, true, 3, false, 1, 1, 1>"
     eng.close()
+
+
+def test_kernel_name_follows_the_session(monkeypatch):
+    """wbx_kernel_name: resampled stereo 512-frame sessions take the instance with both channels of a frame in one lane
+    (CL = 2), WBX_NO_CL2 the one-channel-per-wave instance; both give the same master bit for bit."""
+    spec = synth.make_session("r", 200, n_blocks=6, src_rate=44100, seek=True)   # (seek: clip boundaries inside blocks)
+    outs = {}
+    for no_cl2 in (False, True):
+        if no_cl2:
+            monkeypatch.setenv("WBX_NO_CL2", "1")
+        eng = build_engine(spec, max_blocks=6)
+        eng.play()
+        eng.render(6)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        outs[no_cl2] = (m.copy(), pk.copy(), eng.ctx.kernel_name())
+        eng.close()
+    assert outs[False][2] == "wbx::mix_kernel<2, true, 3, false, 1, 1, 2>"
+    assert outs[True][2] == "wbx::mix_kernel<2, true, 4, false, 1, 1, 1>"
+    assert np.array_equal(outs[False][0], outs[True][0]) and np.array_equal(outs[False][1], outs[True][1])
 
 
 def test_cpp_host_through_the_adapter(tmp_path):

@@ -18,7 +18,7 @@
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
-void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);   // -> the instance's name
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
@@ -164,6 +164,7 @@ struct wbx_ctx {
   double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
   uint64_t mix_launches = 0;
   bool profiling = true;
+  const char* mix_kernel_name = "";   // the instance launch_mix chose last (wbx_kernel_name)
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
                                       // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;

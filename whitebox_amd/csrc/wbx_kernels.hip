@@ -458,15 +458,25 @@ __device__ __forceinline__ void wave_max_quad_halves(uint32_t p0, uint32_t p1, u
 enum : int { MODE_U = 0, MODE_W = 1, MODE_I16 = 2, MODE_I32 = 3, MODE_MIXED = 4, MODE_WN = 5, MODE_G = 6, MODE_WI = 7, MODE_WIN = 8, MODE_MU = 9, MODE_MW = 10, MODE_MWN = 11,
              MODE_WNU = 12, MODE_WINU = 13 };   // row shapes of a staged chunk (…U: every resampled row at MixArgs::uniform_speed)
 
-// the loads of one track that are in flight while other tracks are being rendered
-struct Pre {
+// the loads of one track that are in flight while other tracks are being rendered (CL = channels per lane)
+struct Win {
   f4 v;        // UNITY: the 4 source frames; WINDOW: window samples 0..3
   float w4;    // WINDOW: window sample 4
+};
+template <int CL>
+struct PreT {
+  Win w[CL];   // one window per channel of the lane
   int ix0;     // WINDOW: integer source position of v.x
   float fx0;   // WINDOW: interpolation fraction of frame j0
 };
-struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = fraction of each of the lane's 4 frames
-  f4 v, b, fx;
+template <int CL>
+struct PreGT {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = fraction of each of the lane's 4 frames
+  f4 v[CL], b[CL], fx;
+};
+// the rendered frames of one track: a lane's four frames of each of its channels
+template <int CL>
+struct RowT {
+  f4 c[CL];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -490,11 +500,17 @@ struct PreG {  // MODE_G (per-frame taps): v = first tap, b = second tap, fx = f
 //         without such clips run the instance without them
 //   SB    consecutive blocks per workgroup (1: C*F/4 is a multiple of 256; 2 / 4: blocks of 128 / 64 lanes)
 //   CW    channels per wave (1: the channel is a scalar; 2: 128-frame stereo, a channel per 32-lane half)
+//   CL    channels per lane (1: a wave renders one channel of its frames; 2: stereo, both channels of a lane's four
+//         frames — the position / fraction arithmetic of sampler.cpp:50-52 is per frame, not per sample, so a resampled
+//         row costs it once instead of once per channel, and one set of record scalars serves both.  Workgroups of
+//         128 lanes = one 512-frame block)
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, bool G, int SB, int CW = 1>
-__global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
+template <int U, bool FULL, int W, bool G, int SB, int CW = 1, int CL = 1>
+__global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
   static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
+  static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo 512-frame blocks");
+  constexpr uint32_t kT = 256u / CL;   // lanes per workgroup
   constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kStage;   // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS)
   // EXP: the instance takes the sequencer's masked rows (MixArgs::masked_rows): a track-block with a clip boundary in
   // it is a ROW_PAIR of two single-segment records, so a chunk of kSt tracks stages up to 2 * kSt rows
@@ -525,10 +541,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   const uint32_t rb = sub * kRecs;                 // this wave's records in s_tb
   const uint32_t b = bx * SB + sub;
   const bool bvalid = SB == 1 || b < a.n_blocks;   // the last workgroup of an odd render has an empty sub-block
-  const uint32_t slot = SB > 1 ? tid - sub * (C * S4) : tile * 256u + tid;
+  const uint32_t slot = SB > 1 ? tid - sub * (C * S4) : tile * kT + tid;
   const bool active = FULL ? true : (slot < C * S4);
   uint32_t c = active ? slot / S4 : 0u;
   if (FULL && CW == 1) c = __builtin_amdgcn_readfirstlane(c);   // CW == 2: lanes 0-31 channel 0, lanes 32-63 channel 1
+  if (CL == 2) c = 0u;                                          // both channels in every lane: element ch of the arrays below
   const uint32_t j0 = active ? (slot - c * S4) * 4u : 0u;
   // lanes of an aligned `span`-lane group share a channel (span = largest power of two dividing F/4, <= 64)
   uint32_t span = 64u;
@@ -539,7 +556,12 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   const uint32_t lane = tid & 63u;
   const double j0d = (double)(int32_t)j0;
 
-  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  using Pre = PreT<CL>;
+  using PreG = PreGT<CL>;
+  using Row = RowT<CL>;
+  Row acc;
+#pragma unroll
+  for (int ch = 0; ch < CL; ch++) acc.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
@@ -555,9 +577,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   // are pulled into scalar registers with v_readlane: one 4-B LDS read per (track, phase), and the values feed the
   // vector ALU as scalar operands.
   struct URec {
-    const void* src;   // src[c]
+    const void* src[CL];   // src[c] (CL == 2: both channels)
     double pos, speed;
-    float gain, gc;    // clip gain, fl(volume * pan_c)
+    float gain, gc[CL];    // clip gain, fl(volume * pan_c)
     uint32_t kind, format;
     uint32_t d, n;     // EXP: the stream call covers frames [d, d + n) of the block (whole-block records: 0, F)
     bool partial;      // EXP: KIND_PARTIAL
@@ -568,21 +590,25 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     URec r;
     if (CW == 2) {   // both channels' pointer and gain as scalars, a per-lane select between them
       const uint64_t s0 = ((uint64_t)rl(1) << 32) | rl(0), s1 = ((uint64_t)rl(3) << 32) | rl(2);
-      r.src = (const void*)(c ? s1 : s0);
+      r.src[0] = (const void*)(c ? s1 : s0);
       r.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
       r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
       r.gain = __uint_as_float(rl(8));
-      r.gc = __uint_as_float(c ? rl(10) : rl(9));
+      r.gc[0] = __uint_as_float(c ? rl(10) : rl(9));
       r.kind = (rl(11) >> 8) & KIND_MASK;
       r.format = rl(13) & 0xFFu;
       return r;
     }
     const uint32_t cs = FULL ? c : 0u;   // (only used when FULL: the channel is wave-uniform)
-    r.src = (const void*)(((uint64_t)rl(2u * cs + 1u) << 32) | rl(2u * cs));
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      const uint32_t cc = CL == 2 ? (uint32_t)ch : cs;
+      r.src[ch] = (const void*)(((uint64_t)rl(2u * cc + 1u) << 32) | rl(2u * cc));
+      r.gc[ch] = __uint_as_float(rl(9u + cc));
+    }
     r.pos = __longlong_as_double((long long)(((uint64_t)rl(5) << 32) | rl(4)));
     r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
     r.gain = __uint_as_float(rl(8));
-    r.gc = __uint_as_float(rl(9u + cs));
     const uint32_t q11 = rl(11);
     r.kind = (q11 >> 8) & KIND_MASK;
     r.format = rl(13) & 0xFFu;
@@ -651,51 +677,78 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     m.w = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.w), norm), -1.0, 1.0), cg), gc);
     return m;
   };
-  // fp32 row, linear resample (sampler.cpp:34-59) from the 5-sample window in `p`
-  auto row_window_g = [&](auto narrow, auto shifted, auto uni, auto unitg, const Pre& p, double pos, double speed, double d0, float cg,
-                          float gc) {
+  // Linear resample (sampler.cpp:34-59) of a lane's four frames from a 5-sample window per channel.  Position, integer
+  // part and fraction of a frame (:50-52) belong to the frame, not to the sample: win_pos works them out once, win_row
+  // applies them to one channel's window.
+  struct WPos {
+    float fx[4];   // interpolation fraction of frames j0..j0+3
+    int k[4];      // window sample the frame starts at: (int)x - ix0 (k[0] = 0)
+  };
+  auto win_pos = [&](auto shifted, auto uni, int ix0, float fx0, double pos, double speed, double d0) {
+    constexpr bool UNI = decltype(uni)::value;           // the row plays at MixArgs::uniform_speed: products hoisted (not with SHIFTED)
+    constexpr bool SHIFTED = decltype(shifted)::value;   // the stream call starts at block frame d0: call frame = j - d0
+    WPos wp;
+    wp.fx[0] = fx0;   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
+    wp.k[0] = 0;
+#define WBX_POS(E, JD)                                                                                   \
+  {                                                                                                      \
+    const double x = __dadd_rn(pos, (UNI && !SHIFTED) ? up##E : __dmul_rn(SHIFTED ? (JD) - d0 : (JD), speed));   /* sampler.cpp:50 */ \
+    wp.fx[E] = (float)__builtin_amdgcn_fract(x);                          /* :52 (x >= 0, exact) */      \
+    wp.k[E] = (int)x - ix0;                                               /* :51 */                      \
+  }
+    WBX_POS(1, jd1) WBX_POS(2, jd2) WBX_POS(3, jd3)
+#undef WBX_POS
+    return wp;
+  };
+  auto win_row = [&](auto narrow, auto unitg, const Win& w, const WPos& wp, float cg, float gc) {
     constexpr bool UNITG = decltype(unitg)::value;   // clip gain == 1.0f: fl(s * 1) = s, the multiply is left out
     constexpr bool NARROW = decltype(narrow)::value;
-    constexpr bool UNI = decltype(uni)::value;   // the row plays at MixArgs::uniform_speed: products hoisted (not with SHIFTED)
-    constexpr bool SHIFTED = decltype(shifted)::value;   // the stream call starts at block frame d0: call frame = j - d0
-    const int ix0 = p.ix0;
     float q[4];
-    {   // frame j0: position and fraction already known from the load phase; its taps are window samples 0 and 1
-      const float s = __fadd_rn(p.v.x, __fmul_rn(p.fx0, __fsub_rn(p.v.y, p.v.x)));        // :55
+    {
+      const float s = __fadd_rn(w.v.x, __fmul_rn(wp.fx[0], __fsub_rn(w.v.y, w.v.x)));     // :55
       q[0] = __fmul_rn(UNITG ? s : __fmul_rn(s, cg), gc);                                 // :56, track.cpp:731
     }
-#define WBX_TAP(E, JD)                                                                                  \
+#define WBX_TAP(E)                                                                                      \
   {                                                                                                     \
-    const double x = __dadd_rn(pos, (UNI && !SHIFTED) ? up##E : __dmul_rn(SHIFTED ? (JD) - d0 : (JD), speed));   /* sampler.cpp:50 */ \
-    const float fx = (float)__builtin_amdgcn_fract(x);                    /* :52 (x >= 0, exact) */     \
     float sa, sb;                                                                                       \
-    if (NARROW)                                                           /* :51 */                     \
-      taps_narrow<E>(p.v, p.w4, (int)x - ix0, sa, sb);                                                  \
+    if (NARROW)                                                                                         \
+      taps_narrow<E>(w.v, w.w4, wp.k[E], sa, sb);                                                       \
     else                                                                                                \
-      taps<E>(p.v, p.w4, (int)x - ix0, sa, sb);                                                         \
-    const float s = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));      /* :55 */                     \
-    q[E] = __fmul_rn(UNITG ? s : __fmul_rn(s, cg), gc);                   /* :56, track.cpp:731 */      \
+      taps<E>(w.v, w.w4, wp.k[E], sa, sb);                                                              \
+    const float s = __fadd_rn(sa, __fmul_rn(wp.fx[E], __fsub_rn(sb, sa)));  /* :55 */                   \
+    q[E] = __fmul_rn(UNITG ? s : __fmul_rn(s, cg), gc);                     /* :56, track.cpp:731 */    \
   }
-    WBX_TAP(1, jd1) WBX_TAP(2, jd2) WBX_TAP(3, jd3)
+    WBX_TAP(1) WBX_TAP(2) WBX_TAP(3)
 #undef WBX_TAP
     return f4{q[0], q[1], q[2], q[3]};
   };
-  auto row_window_at = [&](auto narrow, auto shifted, auto uni, const Pre& p, double pos, double speed, double d0, float cg, float gc) {
-    if (__float_as_uint(cg) == 0x3F800000u)   // wave-uniform
-      return row_window_g(narrow, shifted, uni, std::true_type{}, p, pos, speed, d0, cg, gc);
-    return row_window_g(narrow, shifted, uni, std::false_type{}, p, pos, speed, d0, cg, gc);
+  auto row_window_at = [&](auto narrow, auto shifted, auto uni, const Pre& p, double pos, double speed, double d0, float cg,
+                           const float (&gc)[CL]) {
+    const WPos wp = win_pos(shifted, uni, p.ix0, p.fx0, pos, speed, d0);
+    Row m;
+    if (__float_as_uint(cg) == 0x3F800000u) {   // wave-uniform
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) m.c[ch] = win_row(narrow, std::true_type{}, p.w[ch], wp, cg, gc[ch]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) m.c[ch] = win_row(narrow, std::false_type{}, p.w[ch], wp, cg, gc[ch]);
+    }
+    return m;
   };
-  auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, float gc) {
+  auto row_window = [&](auto narrow, const Pre& p, double pos, double speed, float cg, const float (&gc)[CL]) {
     return row_window_at(narrow, std::false_type{}, std::false_type{}, p, pos, speed, 0.0, cg, gc);
   };
   // the window (5-sample) loads of one fp32 row; also valid for unity rows (pos integral, speed 1.0)
-  auto load_window = [&](const void* src_c, double pos, double prod0, Pre& p) {
+  auto load_window = [&](const void* const (&src_c)[CL], double pos, double prod0, Pre& p) {
     const double x0 = __dadd_rn(pos, prod0);                                              // sampler.cpp:50, frame j0 (of the call): prod0 = fl(j * speed)
     const int ix0 = (int)x0;                                                              // :51 (x >= 0: truncation)
-    const float WBX_GLOBAL* src = as_global<float>(src_c) + ix0;
     if (active) {   // both loads unconditional: straight-line code lets the compiler count outstanding loads exactly
-      p.v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(src));   // the taps of frames j0..j0+3 lie in src[0..4]
-      p.w4 = src[4];
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) {
+        const float WBX_GLOBAL* src = as_global<float>(src_c[ch]) + ix0;
+        p.w[ch].v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(src));   // the taps of frames j0..j0+3 lie in src[0..4]
+        p.w[ch].w4 = src[4];
+      }
     }
     p.ix0 = ix0;
     // :52 fx = (float)(x - (double)ix): for x >= 0 that difference is x - floor(x), which v_fract_f64
@@ -704,57 +757,66 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   };
   // the same window for a 16-bit PCM row: samples ix0..ix0+3 in one 8-B load (2-byte aligned), ix0+4 in the low half
   // of a 4-B load; the halves stay packed until the render phase
-  auto load_window16 = [&](const void* src_c, double pos, double prod0, Pre& p) {
+  auto load_window16 = [&](const void* const (&src_c)[CL], double pos, double prod0, Pre& p) {
     typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
     typedef int i1w __attribute__((aligned(2)));
     const double x0 = __dadd_rn(pos, prod0);                                              // sampler.cpp:50, frame j0
     const int ix0 = (int)x0;                                                              // :51
-    const short WBX_GLOBAL* src = as_global<short>(src_c) + ix0;
     if (active) {
-      const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(src));
-      p.v.x = __int_as_float(w.x);
-      p.v.y = __int_as_float(w.y);
-      p.w4 = __int_as_float(*reinterpret_cast<const i1w WBX_GLOBAL*>(src + 4));
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) {
+        const short WBX_GLOBAL* src = as_global<short>(src_c[ch]) + ix0;
+        const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(src));
+        p.w[ch].v.x = __int_as_float(w.x);
+        p.w[ch].v.y = __int_as_float(w.y);
+        p.w[ch].w4 = __int_as_float(*reinterpret_cast<const i1w WBX_GLOBAL*>(src + 4));
+      }
     }
     p.ix0 = ix0;
     p.fx0 = (float)__builtin_amdgcn_fract(x0);                                            // :52
   };
   // 16-bit PCM row, linear resample: taps a = norm * (float)src[ix] (sampler.cpp:9-10,53-54), then as fp32
-  auto row_window16 = [&](auto narrow, auto uni, const Pre& p, double pos, double speed, float cg, float gc) {
+  auto row_window16 = [&](auto narrow, auto uni, const Pre& p, double pos, double speed, float cg, const float (&gc)[CL]) {
     const float norm = (float)(1.0 / 32767.0);
-    const int lo = __float_as_int(p.v.x), hi = __float_as_int(p.v.y), tl = __float_as_int(p.w4);
     Pre f;
-    f.v.x = __fmul_rn(norm, (float)(short)(lo & 0xFFFF));
-    f.v.y = __fmul_rn(norm, (float)(short)((unsigned)lo >> 16));
-    f.v.z = __fmul_rn(norm, (float)(short)(hi & 0xFFFF));
-    f.v.w = __fmul_rn(norm, (float)(short)((unsigned)hi >> 16));
-    f.w4 = __fmul_rn(norm, (float)(short)(tl & 0xFFFF));
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      const int lo = __float_as_int(p.w[ch].v.x), hi = __float_as_int(p.w[ch].v.y), tl = __float_as_int(p.w[ch].w4);
+      f.w[ch].v.x = __fmul_rn(norm, (float)(short)(lo & 0xFFFF));
+      f.w[ch].v.y = __fmul_rn(norm, (float)(short)((unsigned)lo >> 16));
+      f.w[ch].v.z = __fmul_rn(norm, (float)(short)(hi & 0xFFFF));
+      f.w[ch].v.w = __fmul_rn(norm, (float)(short)((unsigned)hi >> 16));
+      f.w[ch].w4 = __fmul_rn(norm, (float)(short)(tl & 0xFFFF));
+    }
     f.ix0 = p.ix0;
     f.fx0 = p.fx0;
     return row_window_at(narrow, std::false_type{}, uni, f, pos, speed, 0.0, cg, gc);
   };
   // 24/32-bit PCM row (4-byte containers: the fp32 window loads), linear resample: taps a = (float)(norm * (double)src[ix])
   // (sampler.cpp:11-14,53-54), then as fp32
-  auto row_window32 = [&](auto narrow, const Pre& p, uint32_t fmt, double pos, double speed, float cg, float gc) {
+  auto row_window32 = [&](auto narrow, const Pre& p, uint32_t fmt, double pos, double speed, float cg, const float (&gc)[CL]) {
     const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;
     Pre f;
-    f.v.x = (float)__dmul_rn(norm, (double)__float_as_int(p.v.x));
-    f.v.y = (float)__dmul_rn(norm, (double)__float_as_int(p.v.y));
-    f.v.z = (float)__dmul_rn(norm, (double)__float_as_int(p.v.z));
-    f.v.w = (float)__dmul_rn(norm, (double)__float_as_int(p.v.w));
-    f.w4 = (float)__dmul_rn(norm, (double)__float_as_int(p.w4));
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      f.w[ch].v.x = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.x));
+      f.w[ch].v.y = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.y));
+      f.w[ch].v.z = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.z));
+      f.w[ch].v.w = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.w));
+      f.w[ch].w4 = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].w4));
+    }
     f.ix0 = p.ix0;
     f.fx0 = p.fx0;
     return row_window(narrow, f, pos, speed, cg, gc);
   };
   // per-frame taps for any playback speed and storage format (sampler.cpp:50-52 for each of the lane's 4 frames):
-  // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v); also valid
-  // for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
+  // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v) per channel; also
+  // valid for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
   typedef int i1u __attribute__((aligned(2)));
-  auto load_stride = [&](const void* src_c, double pos, double speed, uint32_t fmt, PreG& p) {
+  auto load_stride = [&](const void* const (&src_c)[CL], double pos, double speed, uint32_t fmt, PreG& p) {
     const double jd[4] = {j0d, jd1, jd2, jd3};
-    float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, f4x[4];
+    float f4x[4];
     int ix[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -762,30 +824,34 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       ix[k] = (int)x;                                                                     // :51
       f4x[k] = (float)__builtin_amdgcn_fract(x);                                          // :52
     }
-    if (fmt == FMT_I16) {
-      const short WBX_GLOBAL* base = as_global<short>(src_c);
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (active) a4[k] = __int_as_float(*reinterpret_cast<const i1u WBX_GLOBAL*>(base + ix[k]));
-    } else {   // fp32 and 24/32-bit PCM: 4-byte containers
-      const float WBX_GLOBAL* base = as_global<float>(src_c);
+    for (int ch = 0; ch < CL; ch++) {
+      float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (fmt == FMT_I16) {
+        const short WBX_GLOBAL* base = as_global<short>(src_c[ch]);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (active) {
-          const f2u t = *reinterpret_cast<const f2u WBX_GLOBAL*>(base + ix[k]);
-          a4[k] = t.x;
-          b4[k] = t.y;
+        for (int k = 0; k < 4; k++)
+          if (active) a4[k] = __int_as_float(*reinterpret_cast<const i1u WBX_GLOBAL*>(base + ix[k]));
+      } else {   // fp32 and 24/32-bit PCM: 4-byte containers
+        const float WBX_GLOBAL* base = as_global<float>(src_c[ch]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (active) {
+            const f2u t = *reinterpret_cast<const f2u WBX_GLOBAL*>(base + ix[k]);
+            a4[k] = t.x;
+            b4[k] = t.y;
+          }
         }
       }
+      p.v[ch] = f4{a4[0], a4[1], a4[2], a4[3]};
+      p.b[ch] = f4{b4[0], b4[1], b4[2], b4[3]};
     }
-    p.v = f4{a4[0], a4[1], a4[2], a4[3]};
-    p.b = f4{b4[0], b4[1], b4[2], b4[3]};
     p.fx = f4{f4x[0], f4x[1], f4x[2], f4x[3]};
   };
-  // the row of a per-frame-tap record; kind and fmt are wave-uniform
-  auto row_stride = [&](const PreG& p, uint32_t kind, uint32_t fmt, float cg, float gc) {
-    const float va[4] = {p.v.x, p.v.y, p.v.z, p.v.w}, vb[4] = {p.b.x, p.b.y, p.b.z, p.b.w};
-    const float fx[4] = {p.fx.x, p.fx.y, p.fx.z, p.fx.w};
+  // one channel of the row of a per-frame-tap record; kind and fmt are wave-uniform
+  auto row_stride = [&](const f4& pv, const f4& pb, const f4& pfx, uint32_t kind, uint32_t fmt, float cg, float gc) {
+    const float va[4] = {pv.x, pv.y, pv.z, pv.w}, vb[4] = {pb.x, pb.y, pb.z, pb.w};
+    const float fx[4] = {pfx.x, pfx.y, pfx.z, pfx.w};
     float m[4];
     if (kind == KIND_UNITY) {                     // fp32 at unity speed, pre-rendered rows, silent and padding records
 #pragma unroll
@@ -850,43 +916,68 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   };
   // the same for a row read through the 5-sample window (the window loads started at call frame call_frame(0)): a
   // resampled row (sampler.cpp:34-59) or, `unity`, a unity-speed row inside a chunk of window rows
-  auto row_window_masked = [&](const Pre& p, double pos, double speed, bool unity, uint32_t d, uint32_t n, float cg, float gc) {
-    float q[4];
-    {
-      const float lin = __fadd_rn(p.v.x, __fmul_rn(p.fx0, __fsub_rn(p.v.y, p.v.x)));             // :55
-      q[0] = and_mask(__fmul_rn(__fmul_rn(unity ? p.v.x : lin, cg), gc), frame_mask(0u, d, n));
-    }
-#define WBX_MTAP(E)                                                                                       \
+  auto row_window_masked = [&](const Pre& p, double pos, double speed, bool unity, uint32_t d, uint32_t n, float cg,
+                               const float (&gc)[CL]) {
+    WPos wp;
+    wp.fx[0] = p.fx0;
+    wp.k[0] = 0;
+#define WBX_MPOS(E)                                                                                       \
   {                                                                                                       \
     const double x = __dadd_rn(pos, __dmul_rn((double)call_frame(E, d, n), speed));   /* sampler.cpp:50 */ \
-    const float fx = (float)__builtin_amdgcn_fract(x);                                /* :52 */           \
-    float sa, sb;                                                                                         \
-    taps<E>(p.v, p.w4, (int)x - p.ix0, sa, sb);                                       /* :51 */           \
-    const float lin = __fadd_rn(sa, __fmul_rn(fx, __fsub_rn(sb, sa)));                /* :55 */           \
-    q[E] = and_mask(__fmul_rn(__fmul_rn(unity ? sa : lin, cg), gc), frame_mask(E, d, n));                 \
+    wp.fx[E] = (float)__builtin_amdgcn_fract(x);                                      /* :52 */           \
+    wp.k[E] = (int)x - p.ix0;                                                         /* :51 */           \
   }
-    WBX_MTAP(1) WBX_MTAP(2) WBX_MTAP(3)
+    WBX_MPOS(1) WBX_MPOS(2) WBX_MPOS(3)
+#undef WBX_MPOS
+    Row m;
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      const Win& w = p.w[ch];
+      float q[4];
+      {
+        const float lin = __fadd_rn(w.v.x, __fmul_rn(wp.fx[0], __fsub_rn(w.v.y, w.v.x)));         // :55
+        q[0] = and_mask(__fmul_rn(__fmul_rn(unity ? w.v.x : lin, cg), gc[ch]), frame_mask(0u, d, n));
+      }
+#define WBX_MTAP(E)                                                                                       \
+  {                                                                                                       \
+    float sa, sb;                                                                                         \
+    taps<E>(w.v, w.w4, wp.k[E], sa, sb);                                                                  \
+    const float lin = __fadd_rn(sa, __fmul_rn(wp.fx[E], __fsub_rn(sb, sa)));          /* :55 */           \
+    q[E] = and_mask(__fmul_rn(__fmul_rn(unity ? sa : lin, cg), gc[ch]), frame_mask(E, d, n));             \
+  }
+      WBX_MTAP(1) WBX_MTAP(2) WBX_MTAP(3)
 #undef WBX_MTAP
-    return f4{q[0], q[1], q[2], q[3]};
+      m.c[ch] = f4{q[0], q[1], q[2], q[3]};
+    }
+    return m;
   };
-  auto add_row = [&](const f4& m0) {
-    f4 m = m0;
-    if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    acc.x = __fadd_rn(acc.x, m.x);                                                        // audio_buffer.h:73-82
-    acc.y = __fadd_rn(acc.y, m.y);
-    acc.z = __fadd_rn(acc.z, m.z);
-    acc.w = __fadd_rn(acc.w, m.w);
-    return absmax4(m);                                                                    // vu_meter.h:20-25
+  // accumulate a row; pk[ch] = the lane's max |m| of channel ch
+  auto add_row = [&](const Row& m0, float (&pk)[CL]) {
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      f4 m = m0.c[ch];
+      if (!FULL && !active) m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      acc.c[ch].x = __fadd_rn(acc.c[ch].x, m.x);                                          // audio_buffer.h:73-82
+      acc.c[ch].y = __fadd_rn(acc.c[ch].y, m.y);
+      acc.c[ch].z = __fadd_rn(acc.c[ch].z, m.z);
+      acc.c[ch].w = __fadd_rn(acc.c[ch].w, m.w);
+      pk[ch] = absmax4(m);                                                                // vu_meter.h:20-25
+    }
   };
+  // FULL: the slot of s_pk[record][4] that takes the wave's peak of channel element ch — the wave itself (CL == 1:
+  // four waves, one channel each) or 2 * channel + wave (CL == 2: two waves, both channels each); s_wc[slot] names
+  // the channel a slot holds
+  const uint32_t wave = tid >> 6;
+  auto pk_slot = [&](int ch) { return CL == 2 ? 2u * (uint32_t)ch + wave : wave; };
   // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes that
   // share a channel otherwise; then one LDS atomic per wave / lane group
-  auto post_peak = [&](float pk, uint32_t tl) {
+  auto post_peak = [&](float pk, uint32_t tl, int ch) {
     if (FULL && CW == 2) {
       for (uint32_t off = 1; off < 32u; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
       if ((lane & 31u) == 0u) s_pk[(rb + tl) * 4u + c] = __float_as_uint(pk);      // slot = channel: one wave per sub-block
     } else if (FULL) {
       pk = wave_max_lane63(pk);
-      if (lane == 63u) s_pk[(rb + tl) * 4u + (tid >> 6)] = __float_as_uint(pk);   // this wave's own slot: no atomic
+      if (lane == 63u) s_pk[(rb + tl) * 4u + pk_slot(ch)] = __float_as_uint(pk);   // this wave's own slot: no atomic
     } else {
       for (uint32_t off = 1; off < span; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
       if ((lane & (span - 1u)) == 0u && active) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
@@ -895,9 +986,9 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
 
   // the same for four consecutive tracks tl..tl+3 at once (FULL only): lane 0 of row r stores the wave maximum
   // of track tl + kQuadRowTrack[r] into this wave's slot
-  const uint32_t quad_slot = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * 4u + (tid >> 6);   // rows hold tracks 0,2,1,3
+  const uint32_t quad_row = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * 4u;   // rows hold tracks 0,2,1,3
   const bool quad_writer = (lane & 15u) == 0u;
-  auto post_peak4 = [&](const float (&pk)[4], uint32_t tl) {
+  auto post_peak4 = [&](const float (&pk)[4], uint32_t tl, int ch) {
     if (CW == 2) {
       uint32_t v0, v1;
       wave_max_quad_halves(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]), v0, v1);
@@ -909,7 +1000,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       return;
     }
     const uint32_t v = wave_max_quad(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]));
-    if (quad_writer) s_pk[(rb + tl) * 4u + quad_slot] = v;
+    if (quad_writer) s_pk[(rb + tl) * 4u + quad_row + pk_slot(ch)] = v;
   };
 
   // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line per mode) ----
@@ -917,6 +1008,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   //  MODE_W    fp32 rows, some linearly resampled: 16-B + 4-B load per track (unity rows use the same formula)
   //  MODE_I16  every row is 16-bit PCM at unity speed: one 8-B load per track (half the bytes of fp32)
   //  MODE_I32  every row is 24/32-bit PCM at unity speed: one 16-B load per track
+  //  (CL == 2: per track and channel)
   auto issue = [&](auto mode, uint32_t u0, auto& pre) {
     constexpr int MODE = decltype(mode)::value;
     constexpr int D = (int)std::extent_v<std::remove_reference_t<decltype(pre)>>;
@@ -927,7 +1019,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r = load_urec(u0 + u);
       } else {
         const DTrackBlock& t = s_tb[u0 + u];
-        r.src = t.src[c];
+        r.src[0] = t.src[c];
         r.pos = t.pos;
         r.speed = t.speed;
         r.format = t.format;
@@ -947,8 +1039,8 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         load_window(r.src, r.pos, prod0, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         double prod0;
-        if (MODE == MODE_WINU && __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
-          prod0 = up0;
+        if (MODE == MODE_WINU)   // one-ratio chunk: the hoisted product for the resampled rows, j * 1.0 for the unity ones
+          prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16 ? up0 : j0d;
         else
           prod0 = __dmul_rn(j0d, r.speed);
         load_window16(r.src, r.pos, prod0, pre[u]);
@@ -963,10 +1055,13 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                      // sampler.cpp:50, frame j0
         const bool win = k == KIND_WINDOW || k == KIND_WINDOW_I16;
         const int ix0 = win ? (int)x0 : (int)((uint32_t)r.pos + j0);                      // :51 / :107
-        const char WBX_GLOBAL* p = as_global<char>(r.src) + ((size_t)(uint32_t)ix0 << sh);
         if (active) {
-          pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
-          pre[u].w4 = *reinterpret_cast<const f1a2 WBX_GLOBAL*>(p + 16);
+#pragma unroll
+          for (int ch = 0; ch < CL; ch++) {
+            const char WBX_GLOBAL* p = as_global<char>(r.src[ch]) + ((size_t)(uint32_t)ix0 << sh);
+            pre[u].w[ch].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
+            pre[u].w[ch].w4 = *reinterpret_cast<const f1a2 WBX_GLOBAL*>(p + 16);
+          }
         }
         pre[u].ix0 = ix0;
         pre[u].fx0 = (float)__builtin_amdgcn_fract(x0);                                   // :52
@@ -976,29 +1071,37 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         typedef float f4a2 __attribute__((ext_vector_type(4), aligned(2)));
         const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
         const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
-        const char WBX_GLOBAL* p = as_global<char>(r.src) + ((size_t)off << sh);
-        if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
+        if (active) {
+#pragma unroll
+          for (int ch = 0; ch < CL; ch++) {
+            const char WBX_GLOBAL* p = as_global<char>(r.src[ch]) + ((size_t)off << sh);
+            pre[u].w[ch].v = __builtin_nontemporal_load(reinterpret_cast<const f4a2 WBX_GLOBAL*>(p));
+          }
+        }
       } else {
         // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
         const uint32_t off = (uint32_t)r.pos + ((EXP && MODE == MODE_U && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
-        if (MODE == MODE_I16) {
-          typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
-          const short WBX_GLOBAL* p = as_global<short>(r.src) + off;
-          if (active) {
-            const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(p));
-            pre[u].v.x = __int_as_float(w.x);
-            pre[u].v.y = __int_as_float(w.y);
+#pragma unroll
+        for (int ch = 0; ch < CL; ch++) {
+          if (MODE == MODE_I16) {
+            typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
+            const short WBX_GLOBAL* p = as_global<short>(r.src[ch]) + off;
+            if (active) {
+              const i2u w = __builtin_nontemporal_load(reinterpret_cast<const i2u WBX_GLOBAL*>(p));
+              pre[u].w[ch].v.x = __int_as_float(w.x);
+              pre[u].w[ch].v.y = __int_as_float(w.y);
+            }
+          } else {   // MODE_U, MODE_I32: 4 x 32-bit
+            const float WBX_GLOBAL* p = as_global<float>(r.src[ch]) + off;
+            if (active) pre[u].w[ch].v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(p));
           }
-        } else {   // MODE_U, MODE_I32: 4 x 32-bit
-          const float WBX_GLOBAL* p = as_global<float>(r.src) + off;
-          if (active) pre[u].v = __builtin_nontemporal_load(reinterpret_cast<const f4u WBX_GLOBAL*>(p));
         }
       }
     }
   };
 
-  // ---- phase B: render, scale, accumulate — strictly in track order; pk[u] = per-lane max |m| of track u0+u
-  auto render = [&](auto mode, uint32_t u0, auto& pre, float* pk) {
+  // ---- phase B: render, scale, accumulate — strictly in track order; pk[u][ch] = per-lane max |m| of track u0+u
+  auto render = [&](auto mode, uint32_t u0, auto& pre, float (*pk)[CL]) {
     constexpr int MODE = decltype(mode)::value;
     constexpr int D = (int)std::extent_v<std::remove_reference_t<decltype(pre)>>;
 #pragma unroll
@@ -1011,29 +1114,42 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         r.pos = t.pos;
         r.speed = t.speed;
         r.gain = t.gain;
-        r.gc = t.g[c];
+        r.gc[0] = t.g[c];
         r.kind = t.kind & KIND_MASK;
         r.format = t.format;
       }
       const float cg = r.gain;
-      const float gc = r.gc;
-      f4 m;
+      const float (&gc)[CL] = r.gc;
+      Row m;
       if constexpr (MODE == MODE_G) {
-        m = row_stride(pre[u], (uint32_t)__builtin_amdgcn_readfirstlane((int)r.kind),
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
-      } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.kind);
+        const uint32_t ff = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
+#pragma unroll
+        for (int ch = 0; ch < CL; ch++) m.c[ch] = row_stride(pre[u].v[ch], pre[u].b[ch], pre[u].fx, kk, ff, cg, gc[ch]);
+      } else {
+      // per channel: the rows whose arithmetic has nothing to share between the channels of a frame
+      auto each_of = [&](const auto& pu, auto f) {
+#pragma unroll
+        for (int ch = 0; ch < CL; ch++) m.c[ch] = f(pu.w[ch], gc[ch]);
+      };
+      auto each = [&](auto f) { each_of(pre[u], f); };
+      auto each_f32 = [&]() { each([&](const Win& w, float g) { return row_f32(w.v, cg, g); }); };
+      auto each_i16 = [&]() { each([&](const Win& w, float g) { return row_i16(__float_as_int(w.v.x), __float_as_int(w.v.y), cg, g); }); };
+      auto each_i32 = [&](uint32_t fmt) { each([&](const Win& w, float g) { return row_i32(w.v, fmt, cg, g); }); };
+      if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE != MODE_W> narrow{};
         constexpr std::integral_constant<bool, MODE == MODE_WNU> uni{};
         if (EXP && r.partial) {   // a stream call that covers part of the block (wave-uniform)
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
-            m = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
             if (k == KIND_WINDOW)
               m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
-              m = row_f32(pre[u].v, cg, gc);
+              each_f32();
           } else {
             m = row_window_masked(pre[u], r.pos, r.speed, k != KIND_WINDOW, r.d, r.n, cg, gc);
           }
@@ -1044,57 +1160,63 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
             m = row_window_at(narrow, std::false_type{}, uni, pre[u], r.pos, r.speed, 0.0, cg, gc);
           }
         } else if (G && k == KIND_UNITY_I32) {
-          if constexpr (G) m = row_i32(pre[u].v, fmt, cg, gc);
+          if constexpr (G) each_i32(fmt);
         } else {
-          m = row_f32(pre[u].v, cg, gc);   // KIND_UNITY (also pre-rendered rows, silent and padding records)
+          each_f32();   // KIND_UNITY (also pre-rendered rows, silent and padding records)
         }
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
           m = row_window16(std::integral_constant<bool, MODE != MODE_WI>{}, std::integral_constant<bool, MODE == MODE_WINU>{}, pre[u],
                            r.pos, r.speed, cg, gc);
         else
-          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);   // unity, silent, padding
+          each_i16();   // unity, silent, padding
       } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_MWN> narrow{};
         if (k == KIND_WINDOW_I16) {
           Pre q = pre[u];
-          q.w4 = pre[u].v.z;   // the fifth sample of a 16-bit window is the low half of the load's third dword
+#pragma unroll
+          for (int ch = 0; ch < CL; ch++) q.w[ch].w4 = pre[u].w[ch].v.z;   // the fifth sample of a 16-bit window is the low half of the load's third dword
           m = row_window16(narrow, std::false_type{}, q, r.pos, r.speed, cg, gc);
         } else if (k == KIND_WINDOW) {
-          m = fmt == FMT_F32 ? row_window(narrow, pre[u], r.pos, r.speed, cg, gc)
-                             : row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
+          if (fmt == FMT_F32)
+            m = row_window(narrow, pre[u], r.pos, r.speed, cg, gc);
+          else
+            m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
         } else if (k == KIND_UNITY_I16) {
-          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+          each_i16();
         } else if (k == KIND_UNITY_I32) {
-          m = row_i32(pre[u].v, fmt, cg, gc);
+          each_i32(fmt);
         } else {
-          m = row_f32(pre[u].v, cg, gc);
+          each_f32();
         }
       } else if constexpr (MODE == MODE_MU) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         if (k == KIND_UNITY_I16)
-          m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+          each_i16();
         else if (k == KIND_UNITY_I32)
-          m = row_i32(pre[u].v, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), cg, gc);
+          each_i32((uint32_t)__builtin_amdgcn_readfirstlane((int)r.format));
         else
-          m = row_f32(pre[u].v, cg, gc);
+          each_f32();
       } else if constexpr (MODE == MODE_I16) {
-        m = row_i16(__float_as_int(pre[u].v.x), __float_as_int(pre[u].v.y), cg, gc);
+        each_i16();
       } else if constexpr (MODE == MODE_I32) {
-        m = row_i32(pre[u].v, r.format, cg, gc);
+        each_i32(r.format);
       } else {
         if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base)
-            m = f4{0.0f, 0.0f, 0.0f, 0.0f};
-          else
-            m = row_f32_masked(pre[u].v, r.d, r.n, cg, gc);
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {
+#pragma unroll
+            for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else {
+            each([&](const Win& w, float g) { return row_f32_masked(w.v, r.d, r.n, cg, g); });
+          }
         } else {
-          m = row_f32(pre[u].v, cg, gc);
+          each_f32();
         }
       }
-      pk[u] = add_row(m);
+      }
+      add_row(m, pk[u]);
     }
   };
 
@@ -1107,7 +1229,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     std::conditional_t<decltype(mode)::value == MODE_G, PreG, Pre> pa[D], pb[D];
     issue(mode, 0, pa);
     for (uint32_t u0 = 0; u0 < cn; u0 += kIter) {
-      float pk[kIter];
+      float pk[kIter][CL];
 #pragma unroll
       for (int h = 0; h < kIter; h += 2 * D) {
         issue(mode, u0 + h + D, pb);
@@ -1115,15 +1237,18 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         issue(mode, u0 + h + 2 * D, pa);
         render(mode, u0 + h + D, pb, pk + h + D);
       }
-      if (FULL) {
 #pragma unroll
-        for (int q = 0; q < kIter; q += 4) {
-          const float quad[4] = {pk[q], pk[q + 1], pk[q + 2], pk[q + 3]};
-          post_peak4(quad, u0 + q);
+      for (int ch = 0; ch < CL; ch++) {
+        if (FULL) {
+#pragma unroll
+          for (int q = 0; q < kIter; q += 4) {
+            const float quad[4] = {pk[q][ch], pk[q + 1][ch], pk[q + 2][ch], pk[q + 3][ch]};
+            post_peak4(quad, u0 + q, ch);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < kIter; q++) post_peak(pk[q][ch], u0 + q, ch);
         }
-      } else {
-#pragma unroll
-        for (int q = 0; q < kIter; q++) post_peak(pk[q], u0 + q);
       }
     }
   };
@@ -1134,24 +1259,40 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     for (uint32_t tl = 0; tl < cn; tl++) {
       const DTrackBlock& r = s_tb[rb + tl];
       const int k = __builtin_amdgcn_readfirstlane((int)(r.kind & KIND_MASK));
-      const float cg = r.gain, gc = r.g[c];
+      const float cg = r.gain;
       const uint32_t off = (uint32_t)r.pos + j0;
-      f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+      Row m;
+      float gcs[CL];
+      const void* srcs[CL];
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) {
+        const uint32_t cc = CL == 2 ? (uint32_t)ch : c;
+        gcs[ch] = r.g[cc];
+        srcs[ch] = r.src[cc];
+      }
       if (k == KIND_WINDOW) {
         Pre p;
-        load_window(r.src[c], r.pos, __dmul_rn(j0d, r.speed), p);
-        m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gc);
-      } else if (k == KIND_UNITY_I16) {
-        typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
-        i2u w = {0, 0};
-        if (active) w = *reinterpret_cast<const i2u WBX_GLOBAL*>(as_global<short>(r.src[c]) + off);
-        m = row_i16(w.x, w.y, cg, gc);
+        load_window(srcs, r.pos, __dmul_rn(j0d, r.speed), p);
+        m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gcs);
       } else {
-        f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (active) v = *reinterpret_cast<const f4u WBX_GLOBAL*>(as_global<float>(r.src[c]) + off);
-        m = (k == KIND_UNITY_I32) ? row_i32(v, r.format, cg, gc) : row_f32(v, cg, gc);
+#pragma unroll
+        for (int ch = 0; ch < CL; ch++) {
+          if (k == KIND_UNITY_I16) {
+            typedef int i2u __attribute__((ext_vector_type(2), aligned(2)));
+            i2u w = {0, 0};
+            if (active) w = *reinterpret_cast<const i2u WBX_GLOBAL*>(as_global<short>(srcs[ch]) + off);
+            m.c[ch] = row_i16(w.x, w.y, cg, gcs[ch]);
+          } else {
+            f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (active) v = *reinterpret_cast<const f4u WBX_GLOBAL*>(as_global<float>(srcs[ch]) + off);
+            m.c[ch] = (k == KIND_UNITY_I32) ? row_i32(v, r.format, cg, gcs[ch]) : row_f32(v, cg, gcs[ch]);
+          }
+        }
       }
-      post_peak(add_row(m), tl);
+      float pk[CL];
+      add_row(m, pk);
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) post_peak(pk[ch], tl, ch);
     }
   };
 
@@ -1194,7 +1335,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       }
       __syncthreads();
       cn2 = s_wpairs[2];
-      for (uint32_t i = tid; i < kRecs * 4u; i += 256u) {
+      for (uint32_t i = tid; i < kRecs * 4u; i += kT) {
         const uint32_t rec = i >> 2, q = i & 3u;
         uint4 w = {0u, 0u, 0u, 0u};
         if (rec < cn2) {
@@ -1212,7 +1353,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
         reinterpret_cast<uint4*>(s_tb)[i] = w;
       }
     } else {
-    for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) {
+    for (uint32_t i = tid; i < SB * kRecs * 4u; i += kT) {
       const uint32_t sb = SB > 1 ? i / (kRecs * 4u) : 0u;
       const uint32_t rec = (i - sb * kRecs * 4u) >> 2, q = i & 3u;
       const uint32_t bb = bx * SB + sb;
@@ -1232,12 +1373,19 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }
     }
-    for (uint32_t i = tid; i < SB * kRecs * 4u; i += 256u) s_pk[i] = 0u;
-    if (FULL && lane == 0u) s_wc[tid >> 6] = sub * C + c;
+    for (uint32_t i = tid; i < SB * kRecs * 4u; i += kT) s_pk[i] = 0u;
+    if (FULL && lane == 0u) {
+      if (CL == 2) {   // slot 2 * channel + wave
+        s_wc[wave] = 0u;
+        s_wc[2u + wave] = 1u;
+      } else {
+        s_wc[wave] = sub * C + c;
+      }
+    }
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
-    for (uint32_t i0 = tid; i0 < SB * cn2; i0 += 256u) {
+    for (uint32_t i0 = tid; i0 < SB * cn2; i0 += kT) {
       const uint32_t i = SB > 1 ? (i0 / cn2) * kRecs + i0 % cn2 : i0;
       const int k = s_tb[i].kind & KIND_MASK;
       shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? (s_tb[i].format == FMT_F32 ? 2 : 128) : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8
@@ -1267,7 +1415,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
     // silent records and the padding up to a whole number of batches become "read the zero page, gain 0" rows
     // of the chunk's own shape, so that the load phase stays straight-line
-    for (uint32_t i = tid; i < SB * kRecs; i += 256u) {
+    for (uint32_t i = tid; i < SB * kRecs; i += kT) {
       DTrackBlock& r = s_tb[i];
       // (KIND_GENERIC: only when the one-block callback skipped the pre-render pass on the expectation of an empty queue;
       //  the host then repeats pre-render + mix for that block — here the record counts as silence)
@@ -1318,7 +1466,7 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
     }
 
     __syncthreads();
-    for (uint32_t i0 = tid; i0 < SB * cn * C; i0 += 256u) {
+    for (uint32_t i0 = tid; i0 < SB * cn * C; i0 += kT) {
       const uint32_t sb = SB > 1 ? i0 / (cn * C) : 0u;
       const uint32_t i = i0 - sb * cn * C;
       const uint32_t rec = i / C, ch = i - rec * C;
@@ -1352,8 +1500,11 @@ __global__ __launch_bounds__(256, W) void mix_kernel(MixArgs a) {
   }
 
   if (active && bvalid) {
-    float* out = a.partial + (((size_t)b * a.n_groups + g) * C + c) * F + j0;
-    *reinterpret_cast<f4*>(out) = acc;
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      float* out = a.partial + (((size_t)b * a.n_groups + g) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;
+      *reinterpret_cast<f4*>(out) = acc.c[ch];
+    }
   }
 }
 
@@ -1592,7 +1743,13 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
-void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s) {
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s) {
+  const char* name = "";   // the instance as rocprofv3 prints it (wbx_kernel_name)
+#define WBX_MIX(U, FULL, W, G, SB, CW, CL, GRID, BLOCK)                                                  \
+  {                                                                                                      \
+    name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #G ", " #SB ", " #CW ", " #CL ">";              \
+    hipLaunchKernelGGL((mix_kernel<U, FULL, W, G, SB, CW, CL>), GRID, BLOCK, 0, s, a);                   \
+  }
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
@@ -1603,47 +1760,58 @@ void launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_ro
     if (S4 == 32u && a.channels == 2u) {   // 128-frame stereo blocks: one block per wave, a channel per half-wave
       const dim3 g4((n_blocks + 3u) / 4u, a.n_groups, 1);
       if (stride_rows)
-        hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 4, 2>), g4, block, 0, s, a);
+        WBX_MIX(2, true, 4, true, 4, 2, 1, g4, block)
       else
-        hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 4, 2>), g4, block, 0, s, a);
-      return;
+        WBX_MIX(2, true, 4, false, 4, 2, 1, g4, block)
+      return name;
     }
     if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) {
       const uint32_t sb = 256u / lanes;
       const dim3 g2((n_blocks + sb - 1u) / sb, a.n_groups, 1);
       if (sb == 2u) {
         if (stride_rows)
-          hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 2>), g2, block, 0, s, a);
+          WBX_MIX(2, true, 4, true, 2, 1, 1, g2, block)
         else
-          hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 2>), g2, block, 0, s, a);
+          WBX_MIX(2, true, 4, false, 2, 1, 1, g2, block)
       } else {
         if (stride_rows)
-          hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 4>), g2, block, 0, s, a);
+          WBX_MIX(2, true, 4, true, 4, 1, 1, g2, block)
         else
-          hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 4>), g2, block, 0, s, a);
+          WBX_MIX(2, true, 4, false, 4, 1, 1, g2, block)
       }
-      return;
+      return name;
     }
-    hipLaunchKernelGGL((mix_kernel<2, false, 1, true, 1>), grid, block, 0, s, a);
-    return;
+    WBX_MIX(2, false, 1, true, 1, 1, 1, grid, block)
+    return name;
   }
   // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
   // per-frame-tap mode; every other session keeps the leaner code
   if (stride_rows) {
-    hipLaunchKernelGGL((mix_kernel<2, true, 4, true, 1>), grid, block, 0, s, a);
-    return;
+    WBX_MIX(2, true, 4, true, 1, 1, 1, grid, block)
+    return name;
+  }
+  // variant >= 1000: stereo 512-frame blocks with both channels of a frame in one lane (workgroups of 128 lanes = one
+  // block; 24 KiB of LDS each: three waves per SIMD)
+  if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u) {
+    if (variant == 1013)
+      WBX_MIX(1, true, 3, false, 1, 1, 2, grid, dim3(128))
+    else
+      WBX_MIX(2, true, 3, false, 1, 1, 2, grid, dim3(128))
+    return name;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
-#define WBX_V(U, W) case 10 * U + W: hipLaunchKernelGGL((mix_kernel<U, true, W, false, 1>), grid, block, 0, s, a); break;
+#define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, false, 1, 1, 1, grid, block) break;
     WBX_V(1, 6)
     WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6)
     WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
     WBX_V(8, 2)
 #undef WBX_V
-    default: hipLaunchKernelGGL((mix_kernel<2, true, 4, false, 1>), grid, block, 0, s, a); break;
+    default: WBX_MIX(2, true, 4, false, 1, 1, 1, grid, block) break;
   }
+#undef WBX_MIX
+  return name;
 }
 
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {

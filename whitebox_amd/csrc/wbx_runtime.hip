@@ -259,7 +259,9 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     }
-    launch_mix(m, K, c->mix_unroll ? c->mix_unroll : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
+    // resampled rows of stereo 512-frame sessions: both channels of a frame in one lane (position arithmetic once per frame)
+    const bool cl2 = c->has_window_clips && C == 2u && F == 512u && !std::getenv("WBX_NO_CL2");
+    c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : cl2 ? 1023 : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
                c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), ms);
     if (timed) {
@@ -1067,6 +1069,8 @@ extern "C" wbx_status wbx_host_free(void* p) {
   if (!p) return WBX_OK;
   return hipHostFree(p) == hipSuccess ? WBX_OK : WBX_ERR_DEVICE;
 }
+
+extern "C" const char* wbx_kernel_name(wbx_ctx* c) { return c ? c->mix_kernel_name : ""; }
 
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
   if (!c) return WBX_ERR_INVALID;

@@ -216,6 +216,10 @@ class MixContext:
         return ms.value, n.value
 
 
+    def kernel_name(self) -> str:
+        """The mix_kernel instance the last render launched, as rocprofv3 prints it."""
+        return (self.L.wbx_kernel_name(self.h) or b"").decode()
+
     def tail_time(self) -> float:
         ms = C.c_double()
         _check(self.L.wbx_tail_time(self.h, C.byref(ms)), "wbx_tail_time", self.h)
