@@ -176,9 +176,10 @@ class HostSimEngine:
 
     def template_capacity(self): return self.L.hsim_template_capacity(self.h)
 
-    def set_masked_rows(self, on: bool):
-        """plan as for a mix instance that renders partial-coverage fp32 rows / ROW_PAIRs in its hot loop"""
-        self.L.hsim_set_masked_rows(self.h, int(on))
+    def set_masked_rows(self, level):
+        """plan as for a mix instance that renders partial-coverage rows / ROW_PAIRs in its hot loop (PlanArgs::masked_rows:
+        1 / True fp32 rows, 2 also integer PCM at unity speed)"""
+        self.L.hsim_set_masked_rows(self.h, int(level))
 
     def row_kinds(self, n_rows: int):
         """(row flags, template kind) per (block, track) of the last render"""

@@ -1280,7 +1280,18 @@ def test_random_masked_row_sessions(seed):
     """Random sessions the masked-row path takes (fuzz_util.random_masked_session): rendered as one batch — peaks, plan,
     transport bit-equal, the master bit-equal when one group holds all tracks — and, every third seed, block by block
     through Engine::process against the same oracle blocks."""
-    spec, n_blocks = FZ.random_masked_session(seed)
+    check_masked_session(*FZ.random_masked_session(seed), seed)
+
+
+# WBX_FUZZ5_FROM / WBX_FUZZ5_TO widen the seed range for a soak run (default: seeds 0..59)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ5_FROM", "0")), int(os.environ.get("WBX_FUZZ5_TO", "60"))))
+def test_random_masked_row_sessions_integer_pcm(seed):
+    """The same for sessions of 16 / 24 / 32-bit PCM clips (and fp32 among them) recorded at the session rate: their clip
+    boundaries are partial KIND_UNITY_I16 / KIND_UNITY_I32 records in the hot loop (MODE_I16 / MODE_I32 / MODE_MU)."""
+    check_masked_session(*FZ.random_masked_session(seed, integer_unity=True), seed)
+
+
+def check_masked_session(spec, n_blocks, seed):
     one_group = spec.n_tracks <= 128
     gs = spec.n_tracks if one_group else [0, 50, 128][seed % 3]
     check_against_oracle(spec, n_blocks, group_size=gs, expect_exact=one_group and not spec.n_buses)

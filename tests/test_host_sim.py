@@ -117,6 +117,23 @@ def test_host_sequencer_masked_row_sessions(seed):
     check_session(spec, n_blocks, batch=bool(seed & 1), masked=True)
 
 
+@pytest.mark.parametrize("seed", range(0, 60))
+def test_host_sequencer_masked_integer_unity_sessions(seed):
+    """sessions of integer-PCM clips at the session rate, planned at masked-row level 2: their clip boundaries are
+    partial KIND_UNITY_I16 / KIND_UNITY_I32 records (ROW_PAIRs) for the hot loop, and the stream-call log is the oracle's"""
+    spec, n_blocks = FZ.random_masked_session(seed, integer_unity=True)
+    check_session(spec, n_blocks, batch=bool(seed & 1), masked=2)
+    if seed < 8:   # and the boundary blocks really stay out of the pre-render queue (queued: blocks of 3+ stream calls only)
+        stats = {}
+        for level in (0, 2):
+            sim = HS.build_sim_engine(spec, max_blocks=n_blocks, masked_rows=level)
+            sim.play()
+            sim.render(n_blocks)
+            stats[level] = sim.plan_counters()
+            sim.close()
+        assert stats[2][2] <= stats[0][2]
+
+
 @pytest.mark.parametrize("name,kw", [("c1", dict(n_tracks=8, channels_src=1)), ("seek", dict(n_tracks=24, seek=True)),
                                      ("seek441", dict(n_tracks=24, seek=True, src_rate=44100)),
                                      ("d96", dict(n_tracks=8, src_rate=96000)), ("long", dict(n_tracks=5, src_rate=44100))])

@@ -172,7 +172,7 @@ struct wbx_ctx {
   bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
   bool auto_group = false;            // wbx_config.group_size was 0: the library picks the track-group size
-  bool masked_rows = false;           // the current plan holds partial-coverage rows / ROW_PAIRs for the hot loop (layer 2)
+  uint32_t masked_rows = 0;           // the current plan holds partial-coverage rows / ROW_PAIRs for the hot loop (layer 2; PlanArgs level)
   double uniform_speed = 0.0;         // MixArgs::uniform_speed of the next launch (layer 2; 0 for host-sequenced plans)
 
   hipStream_t upload_stream = nullptr; // clip uploads of layer 2 run here, outside the engine's editor lock
@@ -246,7 +246,7 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
-bool mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
+uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 
 // wbx_dist.hip
 float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);

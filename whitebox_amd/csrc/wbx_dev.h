@@ -170,8 +170,9 @@ struct PlanArgs {
   double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
   uint32_t playing;
   uint32_t clips_changed;       // the clip lists were edited since the previous plan: re-read the current clip's gain
-  uint32_t masked_rows;         // the mix instance of this render takes partial-coverage fp32 rows (one segment, or a
-                                // ROW_PAIR) in its hot loop: do not queue them for the pre-render pass
+  uint32_t masked_rows;         // the mix instance of this render takes partial-coverage rows (one segment, or a
+                                // ROW_PAIR) in its hot loop: do not queue them for the pre-render pass.  1: fp32 rows
+                                // (unity / window); 2: also integer PCM at unity speed (masked_kind, wbx_seq.h)
   uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders)
   uint32_t lanes;               // tracks per wave of plan_kernel (64, or fewer for sessions cut into many clips: a wave
                                 // executes every branch any of its tracks takes, so its time is set by the number of

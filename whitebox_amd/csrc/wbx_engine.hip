@@ -759,7 +759,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   hs.clips_edited = false;
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
-  a.masked_rows = c->masked_rows ? 1u : 0u;
+  a.masked_rows = c->masked_rows;
   a.tmpl_reserve = HostSession::template_reserve(K);
   a.lanes = hs.plan_lanes(K);
   a.playhead = hs.playhead;

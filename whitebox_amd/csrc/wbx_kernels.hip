@@ -655,27 +655,33 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
     }
     return m;
   };
-  // 16-bit PCM row at unity speed, sampler.cpp:109-120: clamp((float)d * (1.0f/32767), -1, 1) * gain
-  auto row_i16 = [&](int lo, int hi, float cg, float gc) {
+  // 16-bit PCM at unity speed, sampler.cpp:109-120: clamp((float)d * (1.0f/32767), -1, 1) * gain — the four samples
+  // before the gains ...
+  auto norm_i16 = [&](int lo, int hi) {
     const float norm = 1.0f / 32767.0f;                                                   // :95
     const float d0 = (float)(short)(lo & 0xFFFF), d1 = (float)(short)((unsigned)lo >> 16);
     const float d2 = (float)(short)(hi & 0xFFFF), d3 = (float)(short)((unsigned)hi >> 16);
-    f4 m;
-    m.x = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d0, norm), -1.0f, 1.0f), cg), gc);
-    m.y = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d1, norm), -1.0f, 1.0f), cg), gc);
-    m.z = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d2, norm), -1.0f, 1.0f), cg), gc);
-    m.w = __fmul_rn(__fmul_rn(clampf(__fmul_rn(d3, norm), -1.0f, 1.0f), cg), gc);
-    return m;
+    return f4{clampf(__fmul_rn(d0, norm), -1.0f, 1.0f), clampf(__fmul_rn(d1, norm), -1.0f, 1.0f),
+              clampf(__fmul_rn(d2, norm), -1.0f, 1.0f), clampf(__fmul_rn(d3, norm), -1.0f, 1.0f)};
   };
-  // 24-bit (32-bit containers) / 32-bit PCM row at unity speed, sampler.cpp:121-144: (float)clamp((double)d * norm, -1, 1) * gain
-  auto row_i32 = [&](const f4& bits, uint32_t format, float cg, float gc) {
+  // ... and the row (clip gain, then track gain: two roundings also when the clip gain is 1.0 — s * 1.0f is s)
+  auto row_i16 = [&](int lo, int hi, float cg, float gc) {
+    const f4 x = norm_i16(lo, hi);
+    return f4{__fmul_rn(__fmul_rn(x.x, cg), gc), __fmul_rn(__fmul_rn(x.y, cg), gc), __fmul_rn(__fmul_rn(x.z, cg), gc),
+              __fmul_rn(__fmul_rn(x.w, cg), gc)};
+  };
+  // 24-bit (32-bit containers) / 32-bit PCM at unity speed, sampler.cpp:121-144: (float)clamp((double)d * norm, -1, 1) * gain
+  auto norm_i32 = [&](const f4& bits, uint32_t format) {
     const double norm = format == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;         // :96-97
-    f4 m;
-    m.x = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.x), norm), -1.0, 1.0), cg), gc);
-    m.y = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.y), norm), -1.0, 1.0), cg), gc);
-    m.z = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.z), norm), -1.0, 1.0), cg), gc);
-    m.w = __fmul_rn(__fmul_rn((float)clampd(__dmul_rn((double)__float_as_int(bits.w), norm), -1.0, 1.0), cg), gc);
-    return m;
+    return f4{(float)clampd(__dmul_rn((double)__float_as_int(bits.x), norm), -1.0, 1.0),
+              (float)clampd(__dmul_rn((double)__float_as_int(bits.y), norm), -1.0, 1.0),
+              (float)clampd(__dmul_rn((double)__float_as_int(bits.z), norm), -1.0, 1.0),
+              (float)clampd(__dmul_rn((double)__float_as_int(bits.w), norm), -1.0, 1.0)};
+  };
+  auto row_i32 = [&](const f4& bits, uint32_t format, float cg, float gc) {
+    const f4 x = norm_i32(bits, format);
+    return f4{__fmul_rn(__fmul_rn(x.x, cg), gc), __fmul_rn(__fmul_rn(x.y, cg), gc), __fmul_rn(__fmul_rn(x.z, cg), gc),
+              __fmul_rn(__fmul_rn(x.w, cg), gc)};
   };
   // Linear resample (sampler.cpp:34-59) of a lane's four frames from a 5-sample window per channel.  Position, integer
   // part and fraction of a frame (:50-52) belong to the frame, not to the sample: win_pos works them out once, win_row
@@ -1069,7 +1075,8 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         // unity rows of several storage formats: one 16-B load per row whatever the format (a 16-bit row uses its
         // low half; the rest is its neighbour's samples or the clip's padding), so the loads stay straight-line
         typedef float f4a2 __attribute__((ext_vector_type(4), aligned(2)));
-        const uint32_t off = (uint32_t)r.pos + j0;                                        // sampler.cpp:107
+        // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
+        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
         const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
         if (active) {
 #pragma unroll
@@ -1080,7 +1087,7 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         }
       } else {
         // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
-        const uint32_t off = (uint32_t)r.pos + ((EXP && MODE == MODE_U && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
+        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
 #pragma unroll
         for (int ch = 0; ch < CL; ch++) {
           if (MODE == MODE_I16) {
@@ -1191,26 +1198,28 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         } else {
           each_f32();
         }
-      } else if constexpr (MODE == MODE_MU) {
-        const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
-        if (k == KIND_UNITY_I16)
-          each_i16();
-        else if (k == KIND_UNITY_I32)
-          each_i32((uint32_t)__builtin_amdgcn_readfirstlane((int)r.format));
-        else
-          each_f32();
-      } else if constexpr (MODE == MODE_I16) {
-        each_i16();
-      } else if constexpr (MODE == MODE_I32) {
-        each_i32(r.format);
       } else {
-        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {
+        // unity rows: MODE_U fp32, MODE_I16 / MODE_I32 integer PCM, MODE_MU any of them by the record's kind
+        const int k = MODE == MODE_U ? KIND_UNITY : MODE == MODE_I16 ? KIND_UNITY_I16 : MODE == MODE_I32 ? KIND_UNITY_I32
+                                                  : __builtin_amdgcn_readfirstlane((int)r.kind);
+        const uint32_t fmt = (MODE == MODE_I32 || MODE == MODE_MU) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) : 0u;
+        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {   // a stream call that covers part of the block
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else if (k == KIND_UNITY_I16) {   // ... some: normalise the four loaded samples, then select and mask as for fp32
+            each([&](const Win& w, float g) {
+              return row_f32_masked(norm_i16(__float_as_int(w.v.x), __float_as_int(w.v.y)), r.d, r.n, cg, g);
+            });
+          } else if (k == KIND_UNITY_I32) {
+            each([&](const Win& w, float g) { return row_f32_masked(norm_i32(w.v, fmt), r.d, r.n, cg, g); });
           } else {
             each([&](const Win& w, float g) { return row_f32_masked(w.v, r.d, r.n, cg, g); });
           }
+        } else if (k == KIND_UNITY_I16) {
+          each_i16();
+        } else if (k == KIND_UNITY_I32) {
+          each_i32(fmt);
         } else {
           each_f32();
         }

@@ -199,16 +199,19 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   return WBX_OK;
 }
 
-// Can the mix instance a render of this shape will launch take masked rows (partial-coverage fp32 records, ROW_PAIRs)
-// in its hot loop?  Only the lean whole-workgroup-per-block instances do (mix_kernel<U, true, W, false, 1>): blocks of
-// C*F/4 lanes a multiple of 256, sessions without integer-PCM or per-frame-tap clips.
-bool mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
-  (void)window_clips;
+// Can the mix instance a render of this shape will launch take masked rows (partial-coverage records, ROW_PAIRs) in its
+// hot loop, and which (PlanArgs::masked_rows)?  Only the lean whole-workgroup-per-block instances do
+// (mix_kernel<U, true, W, false, 1, ...>): blocks of C*F/4 lanes a multiple of 256, sessions without per-frame-tap clips.
+// 1: fp32 rows, unity or resampled; 2: also integer PCM at unity speed — sessions whose integer clips all play at the
+// session rate and that hold no resampled clip (those take the instances with the mixed-format window modes).
+uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
   const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
-    if (e[0] == '0') return false;   // A/B aid: send every boundary row through the pre-render pass
-  return full && !c->force_g && !stride_clips && !c->has_integer_clips;
+    if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
+  if (!full || c->force_g || stride_clips) return 0u;
+  if (!c->has_integer_clips) return 1u;
+  return window_clips ? 0u : 2u;
 }
 
 // where the master of the render about to be issued goes; `writer` is the stream its last writer runs on
@@ -915,7 +918,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
-  c->masked_rows = false;   // host-sequenced plans send every partial row through the pre-render pass
+  c->masked_rows = 0u;   // host-sequenced plans send every partial row through the pre-render pass
   c->uniform_speed = 0.0;   // ... and make no promise about their playback speeds
   st = launch_pre_render(c, K, c->stream);
   if (st != WBX_OK) return st;

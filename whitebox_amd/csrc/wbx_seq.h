@@ -421,12 +421,17 @@ __host__ __device__ inline uint32_t alloc_template(const PlanArgs& a, TrackCache
   return i;
 }
 
-// What the hot loop can render of ONE stream call that covers only part of the block (PlanArgs::masked_rows): fp32,
-// source positions below 2^31, unity speed or a speed the 5-sample window holds.  KIND_GENERIC: it cannot.
-__host__ __device__ inline uint8_t masked_kind(const DSeg& s, uint32_t block_frames) {
+// What the hot loop can render of ONE stream call that covers only part of the block (PlanArgs::masked_rows = level):
+// source positions below 2^31; fp32 at unity speed or at a speed the 5-sample window holds (level >= 1), integer PCM at
+// unity speed (level 2: sessions whose integer clips all play at the session rate).  KIND_GENERIC: it cannot.
+__host__ __device__ inline uint8_t masked_kind(const DSeg& s, uint32_t block_frames, uint32_t level) {
   if (s.len == 0) return KIND_SILENT;
-  if (s.format != FMT_F32 || !(s.pos >= 0.0 && s.pos < 2147483000.0)) return KIND_GENERIC;
+  if (!(s.pos >= 0.0 && s.pos < 2147483000.0)) return KIND_GENERIC;
   if ((uint32_t)s.dst_start + s.len > block_frames) return KIND_GENERIC;
+  if (s.format != FMT_F32) {
+    if (level < 2u || s.speed != 1.0) return KIND_GENERIC;
+    return s.format == FMT_I16 ? KIND_UNITY_I16 : KIND_UNITY_I32;
+  }
   if (s.speed == 1.0) return KIND_UNITY;
   if (s.speed > 0.0 && s.speed <= 0.999) return KIND_WINDOW;
   return KIND_GENERIC;
@@ -490,11 +495,11 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   bool pair = false;
   uint8_t kind1 = KIND_SILENT;
   if (a.masked_rows && tb->kind == KIND_GENERIC && w.nseg <= 2u) {
-    const uint8_t kind0 = masked_kind(get_seg0(rec), a.block_frames);
+    const uint8_t kind0 = masked_kind(get_seg0(rec), a.block_frames, a.masked_rows);
     if (w.nseg == 1u) {
       if (kind0 != KIND_GENERIC) tb->kind = kind0 == KIND_SILENT ? kind0 : (uint8_t)(kind0 | KIND_PARTIAL);
     } else {
-      kind1 = masked_kind(w.seg1, a.block_frames);
+      kind1 = masked_kind(w.seg1, a.block_frames, a.masked_rows);
       if (kind0 != KIND_GENERIC && kind1 != KIND_GENERIC && (uint32_t)rec.dst_start + rec.len <= w.seg1.dst_start) {
         pair = true;
         tb->kind = kind0 == KIND_SILENT ? kind0 : (uint8_t)(kind0 | KIND_PARTIAL);
