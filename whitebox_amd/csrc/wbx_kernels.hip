@@ -1795,7 +1795,7 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool st
   }
   // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
   // per-frame-tap mode; every other session keeps the leaner code
-  if (stride_rows) {
+  if (stride_rows) {   // (W = 4 although this instance spills a few registers there: at W = 3 it is 5-10 % slower)
     WBX_MIX(2, true, 4, true, 1, 1, 1, grid, block)
     return name;
   }

@@ -262,8 +262,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     }
-    // resampled rows of stereo 512-frame sessions: both channels of a frame in one lane (position arithmetic once per frame)
-    const bool cl2 = c->has_window_clips && C == 2u && F == 512u && !std::getenv("WBX_NO_CL2");
+    // stereo 512-frame sessions with resampled or integer-PCM clips: both channels of a frame in one lane (position and
+    // masked-row arithmetic once per frame; measured equal or better on every such workload, tools/ab_cl2.sh — fp32
+    // sessions at unity speed keep the U = 4 instance)
+    const bool cl2 = (c->has_window_clips || c->has_integer_clips) && C == 2u && F == 512u && !std::getenv("WBX_NO_CL2");
     c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : cl2 ? 1023 : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
                c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), ms);
