@@ -42,15 +42,16 @@ def random_session(seed):
 
 
 
-def random_masked_session(seed, integer_unity=False):
+def random_masked_session(seed, integer_unity=False, lean16=False):
     """Sessions the masked-row path of the mix kernel takes: fp32 clips only, 44.1 / 48 kHz sources, stretch speeds on the
     unity and 5-sample-window paths, stereo 512-frame (or mono / stereo 1024-frame) blocks — with everything a clip list
     can do to a block: touching clips, gaps, clips shorter than a block (three and more stream calls: those still go to
     the pre-render pass), clips that outlast their audio, random start offsets and gains, mutes, sub-buses, more tracks
     than one staged chunk.  `integer_unity`: the second kind of session that path takes — clips of every storage format
-    (16 / 24 / 32-bit PCM, fp32; some sessions one format only), all recorded at the session rate and played at speed 1."""
-    rng = np.random.default_rng((0xA5C0 if not integer_unity else 0x1C70000) + seed)
-    fmts = ["f32"]
+    (16 / 24 / 32-bit PCM, fp32; some sessions one format only), all recorded at the session rate and played at speed 1.
+    `lean16`: the third kind — 16-bit PCM only, 44.1 / 48 kHz sources, the same stretch speeds as the fp32 sessions."""
+    rng = np.random.default_rng((0x16B0000 if lean16 else 0x1C70000 if integer_unity else 0xA5C0) + seed)
+    fmts = ["i16"] if lean16 else ["f32"]
     if integer_unity:
         fmts = [["i16"], ["i24"], ["i32"], ["i16", "i24", "i32", "f32"], ["i16", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
@@ -73,7 +74,7 @@ def random_masked_session(seed, integer_unity=False):
                                         start_offset=float(rng.integers(0, 400)), speed=speed, gain=float(rng.choice([1.0, 0.5, 1.3]))))
             pos += length + (0.0 if rng.random() < 0.5 else total_beats * 0.1 * rng.random())   # touching or a gap
     n_buses = int(rng.choice([0, 0, 3]))
-    return synth.SessionSpec(name=f"{'ifuzz' if integer_unity else 'mfuzz'}{seed}", n_tracks=n_tracks, seed=0xF0330000 + seed, samples=samples, clips=clips,
+    return synth.SessionSpec(name=f"{'sfuzz' if lean16 else 'ifuzz' if integer_unity else 'mfuzz'}{seed}", n_tracks=n_tracks, seed=0xF0330000 + seed, samples=samples, clips=clips,
                              volumes_db=[float(rng.uniform(-30, 3)) for _ in range(n_tracks)],
                              pans=[float(rng.uniform(-1, 1)) for _ in range(n_tracks)],
                              mutes=[bool(rng.random() < 0.1) for _ in range(n_tracks)],

@@ -834,7 +834,7 @@ def test_kernel_timer_reports():
     ms, n = eng.ctx.kernel_time()
     assert n == 2 and ms > 0.0
     # the instance the library launched, as rocprofv3 prints it: a unity-speed stereo 512-frame session takes U = 4, W = 3
-    assert eng.ctx.kernel_name() == "wbx::mix_kernel<4, true, 3, false, 1, 1, 1>"
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<4, true, 3, 0, 1, 1, 1>"
     eng.close()
 
 
@@ -852,8 +852,8 @@ def test_kernel_name_follows_the_session(monkeypatch):
         m, pk, _ = eng.ctx.fetch(peaks=True)
         outs[no_cl2] = (m.copy(), pk.copy(), eng.ctx.kernel_name())
         eng.close()
-    assert outs[False][2] == "wbx::mix_kernel<2, true, 3, false, 1, 1, 2>"
-    assert outs[True][2] == "wbx::mix_kernel<2, true, 4, false, 1, 1, 1>"
+    assert outs[False][2] == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2>"
+    assert outs[True][2] == "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1>"
     assert np.array_equal(outs[False][0], outs[True][0]) and np.array_equal(outs[False][1], outs[True][1])
 
 
@@ -1289,6 +1289,15 @@ def test_random_masked_row_sessions_integer_pcm(seed):
     """The same for sessions of 16 / 24 / 32-bit PCM clips (and fp32 among them) recorded at the session rate: their clip
     boundaries are partial KIND_UNITY_I16 / KIND_UNITY_I32 records in the hot loop (MODE_I16 / MODE_I32 / MODE_MU)."""
     check_masked_session(*FZ.random_masked_session(seed, integer_unity=True), seed)
+
+
+# WBX_FUZZ6_FROM / WBX_FUZZ6_TO widen the seed range for a soak run (default: seeds 0..59)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ6_FROM", "0")), int(os.environ.get("WBX_FUZZ6_TO", "60"))))
+def test_random_masked_row_sessions_16bit_resampled(seed):
+    """Sessions of 16-bit PCM only, 44.1 / 48 kHz sources at stretch speeds up to 0.999 or exactly 1: the lean 16-bit family
+    (mix_kernel<.., FAM = 2, ..>) with partial KIND_WINDOW_I16 / KIND_UNITY_I16 records in MODE_WI / MODE_WIN / MODE_WINU /
+    MODE_I16, the chunks that hold a pre-rendered fp32 row in its one-row-at-a-time mode."""
+    check_masked_session(*FZ.random_masked_session(seed, lean16=True), seed)
 
 
 def check_masked_session(spec, n_blocks, seed):

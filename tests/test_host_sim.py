@@ -134,6 +134,14 @@ def test_host_sequencer_masked_integer_unity_sessions(seed):
         assert stats[2][2] <= stats[0][2]
 
 
+@pytest.mark.parametrize("seed", range(0, 60))
+def test_host_sequencer_masked_16bit_sessions(seed):
+    """sessions of 16-bit PCM only, resampled at speeds up to 0.999 or not at all, planned at masked-row level 3 (the lean
+    16-bit family of mix_kernel): partial KIND_WINDOW_I16 / KIND_UNITY_I16 records, the oracle's stream-call log"""
+    spec, n_blocks = FZ.random_masked_session(seed, lean16=True)
+    check_session(spec, n_blocks, batch=bool(seed & 1), masked=3)
+
+
 @pytest.mark.parametrize("name,kw", [("c1", dict(n_tracks=8, channels_src=1)), ("seek", dict(n_tracks=24, seek=True)),
                                      ("seek441", dict(n_tracks=24, seek=True, src_rate=44100)),
                                      ("d96", dict(n_tracks=8, src_rate=96000)), ("long", dict(n_tracks=5, src_rate=44100))])

@@ -18,7 +18,7 @@
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
-const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s);   // -> the instance's name
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s);   // -> the instance's name
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
@@ -169,6 +169,8 @@ struct wbx_ctx {
                                       // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;
   bool has_integer_clips = false;
+  bool has_non16_clips = false;       // a clip asset that is not 16-bit PCM
+  bool has_lean16_clips = false;      // resampled clips exist and all of them are 16-bit PCM at speeds up to 0.999 (layer 2)
   bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
   bool auto_group = false;            // wbx_config.group_size was 0: the library picks the track-group size
@@ -246,6 +248,7 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
+int mix_family(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 
 // wbx_dist.hip

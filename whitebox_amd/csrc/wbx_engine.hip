@@ -172,6 +172,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   // the destination rate enters every clip's playback speed: which clips the hot loop streams directly is re-derived
   e->hs.dst_rate = sample_rate;
   e->hs.any_slow_clip = e->hs.any_window_clip = e->hs.any_stride_clip = e->hs.any_crawl_clip = false;
+  e->hs.any_win16_clip = e->hs.any_other_window_clip = false;
   e->hs.window_speed = 0.0;
   for (auto& t : e->hs.tracks)
     for (auto& hc : t->clips) e->hs.note_clip(hc.d);
@@ -758,6 +759,9 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
+  c->has_window_clips = hs.any_window_clip;
+  c->has_stride_clips = hs.any_stride_clip;
+  c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   a.masked_rows = c->masked_rows;
   a.tmpl_reserve = HostSession::template_reserve(K);
@@ -789,6 +793,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
+  c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->uniform_speed = hs.uniform_window_speed();
   const int mix_parity = (int)(c->render_seq % kRing);
   st = launch_mix_sum(c, K, N);

@@ -140,6 +140,8 @@ struct HostSession {
   bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (playback speed > 4096)
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
   bool any_stride_clip = false;         // per-frame taps: fp32 played faster than recorded, resampled integer PCM
+  bool any_win16_clip = false;          // 16-bit PCM resampled at a speed up to 0.999 (the 5-sample-window path)
+  bool any_other_window_clip = false;   // any other clip at a speed != 1
   bool any_crawl_clip = false;          // (count - offset) / speed may exceed 2^32: every block owns a plan template
   // the one playback speed of all resampled clips seen so far (44.1 kHz clips in a 48 kHz session ...), for the mix
   // kernel's hoisted position products: 0 = none yet, < 0 = several / outside the narrow-window range
@@ -215,6 +217,10 @@ struct HostSession {
     if (!(ps > 0.0 && ps <= 4096.0)) any_slow_clip = true;
     if (ps != 1.0) {
       any_window_clip = true;
+      if (smp.format == FMT_I16 && ps > 0.0 && ps <= 0.999)
+        any_win16_clip = true;
+      else
+        any_other_window_clip = true;
       if (!(ps >= 0.67 && ps <= 0.999) || (window_speed != 0.0 && window_speed != ps))
         window_speed = -1.0;
       else

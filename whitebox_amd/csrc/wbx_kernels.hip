@@ -505,8 +505,16 @@ struct RowT {
 //         row costs it once instead of once per channel, and one set of record scalars serves both.  Workgroups of
 //         128 lanes = one 512-frame block)
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, bool G, int SB, int CW = 1, int CL = 1>
+template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1>
 __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
+  // FAM: which chunk modes the instance carries — every mode it carries costs registers in all the others.
+  //   0  fp32 (unity / window) and integer PCM at unity speed: U, W, WN, WNU, I16, I32, MU, MIXED
+  //   1  everything: also per-frame taps, 16-bit / 24-bit / 32-bit window rows, windows of several formats in one chunk
+  //   2  sessions whose clips are all 16-bit PCM at speeds up to 0.999 or exactly 1 (CD-rate files in a 48 kHz project): U,
+  //      I16, MU, WI, WIN, WINU; a chunk that holds fp32 rows next to 16-bit window rows (a pre-rendered block) -> MIXED
+  constexpr bool G = FAM == 1;
+  constexpr bool W16 = FAM >= 1;      // the 16-bit window modes
+  constexpr bool LEAN16 = FAM == 2;
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
   static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
   static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo 512-frame blocks");
@@ -782,21 +790,34 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
     p.fx0 = (float)__builtin_amdgcn_fract(x0);                                            // :52
   };
   // 16-bit PCM row, linear resample: taps a = norm * (float)src[ix] (sampler.cpp:9-10,53-54), then as fp32
-  auto row_window16 = [&](auto narrow, auto uni, const Pre& p, double pos, double speed, float cg, const float (&gc)[CL]) {
-    const float norm = (float)(1.0 / 32767.0);
+  // (the packed window of load_window16 as floats.  `unity`: the samples of a unity-speed row read through the window
+  //  loads — sampler.cpp:109-120 normalises those with 1.0f / 32767 and clamps, the linear path does neither)
+  auto unpack16 = [&](const Pre& p, bool unity) {
+    const float norm = unity ? 1.0f / 32767.0f : (float)(1.0 / 32767.0);
     Pre f;
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
       const int lo = __float_as_int(p.w[ch].v.x), hi = __float_as_int(p.w[ch].v.y), tl = __float_as_int(p.w[ch].w4);
-      f.w[ch].v.x = __fmul_rn(norm, (float)(short)(lo & 0xFFFF));
-      f.w[ch].v.y = __fmul_rn(norm, (float)(short)((unsigned)lo >> 16));
-      f.w[ch].v.z = __fmul_rn(norm, (float)(short)(hi & 0xFFFF));
-      f.w[ch].v.w = __fmul_rn(norm, (float)(short)((unsigned)hi >> 16));
-      f.w[ch].w4 = __fmul_rn(norm, (float)(short)(tl & 0xFFFF));
+      float s5[5] = {(float)(short)(lo & 0xFFFF), (float)(short)((unsigned)lo >> 16), (float)(short)(hi & 0xFFFF),
+                     (float)(short)((unsigned)hi >> 16), (float)(short)(tl & 0xFFFF)};
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        s5[i] = unity ? __fmul_rn(s5[i], norm) : __fmul_rn(norm, s5[i]);
+        if (unity) s5[i] = clampf(s5[i], -1.0f, 1.0f);
+      }
+      f.w[ch].v = f4{s5[0], s5[1], s5[2], s5[3]};
+      f.w[ch].w4 = s5[4];
     }
     f.ix0 = p.ix0;
     f.fx0 = p.fx0;
-    return row_window_at(narrow, std::false_type{}, uni, f, pos, speed, 0.0, cg, gc);
+    return f;
+  };
+  auto row_window16 = [&](auto narrow, auto uni, const Pre& p, double pos, double speed, float cg, const float (&gc)[CL]) {
+    return row_window_at(narrow, std::false_type{}, uni, unpack16(p, false), pos, speed, 0.0, cg, gc);
+  };
+  // ... of a stream call that starts at block frame d0 and covers all of this wave's frames
+  auto row_window16_shifted = [&](auto narrow, const Pre& p, double pos, double speed, double d0, float cg, const float (&gc)[CL]) {
+    return row_window_at(narrow, std::true_type{}, std::false_type{}, unpack16(p, false), pos, speed, d0, cg, gc);
   };
   // 24/32-bit PCM row (4-byte containers: the fp32 window loads), linear resample: taps a = (float)(norm * (double)src[ix])
   // (sampler.cpp:11-14,53-54), then as fp32
@@ -957,6 +978,10 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
     }
     return m;
   };
+  auto row_window16_masked = [&](const Pre& p, double pos, double speed, bool unity, uint32_t d, uint32_t n, float cg,
+                                 const float (&gc)[CL]) {
+    return row_window_masked(unpack16(p, unity), pos, speed, unity, d, n, cg, gc);
+  };
   // accumulate a row; pk[ch] = the lane's max |m| of channel ch
   auto add_row = [&](const Row& m0, float (&pk)[CL]) {
 #pragma unroll
@@ -1045,7 +1070,9 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         load_window(r.src, r.pos, prod0, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         double prod0;
-        if (MODE == MODE_WINU)   // one-ratio chunk: the hoisted product for the resampled rows, j * 1.0 for the unity ones
+        if (EXP && LEAN16 && r.partial)    // the lane's first frame inside the stream call (partial 16-bit window rows: family 2 only)
+          prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
+        else if (MODE == MODE_WINU)   // one-ratio chunk: the hoisted product for the resampled rows, j * 1.0 for the unity ones
           prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16 ? up0 : j0d;
         else
           prod0 = __dmul_rn(j0d, r.speed);
@@ -1172,9 +1199,22 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
           each_f32();   // KIND_UNITY (also pre-rendered rows, silent and padding records)
         }
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
-        if (__builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16)
-          m = row_window16(std::integral_constant<bool, MODE != MODE_WI>{}, std::integral_constant<bool, MODE == MODE_WINU>{}, pre[u],
-                           r.pos, r.speed, cg, gc);
+        const bool win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16;
+        constexpr std::integral_constant<bool, MODE != MODE_WI> narrow{};
+        if (EXP && LEAN16 && r.partial) {   // a stream call that covers part of the block (wave-uniform)
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+#pragma unroll
+            for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of them
+            if (win)
+              m = row_window16_shifted(narrow, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
+            else
+              each_i16();
+          } else {
+            m = row_window16_masked(pre[u], r.pos, r.speed, !win, r.d, r.n, cg, gc);
+          }
+        } else if (win)
+          m = row_window16(narrow, std::integral_constant<bool, MODE == MODE_WINU>{}, pre[u], r.pos, r.speed, cg, gc);
         else
           each_i16();   // unity, silent, padding
       } else if constexpr (MODE == MODE_MW || MODE == MODE_MWN) {
@@ -1283,6 +1323,18 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         Pre p;
         load_window(srcs, r.pos, __dmul_rn(j0d, r.speed), p);
         m = row_window(std::false_type{}, p, r.pos, r.speed, cg, gcs);
+      } else if (W16 && (k == KIND_WINDOW_I16 || (EXP && LEAN16 && k == KIND_UNITY_I16 && (r.kind & KIND_PARTIAL)))) {
+        // 16-bit rows through the window loads; family 2 also meets partial ones here (a chunk that holds a pre-rendered
+        // fp32 row next to the masked rows of its other tracks): every wave takes the masked arithmetic
+        Pre p;
+        if (EXP && LEAN16 && (r.kind & KIND_PARTIAL)) {
+          const uint32_t d = r.dst_start, n = r.len;
+          load_window16(srcs, r.pos, __dmul_rn((double)call_frame(0u, d, n), r.speed), p);
+          m = row_window16_masked(p, r.pos, r.speed, k != KIND_WINDOW_I16, d, n, cg, gcs);
+        } else {
+          load_window16(srcs, r.pos, __dmul_rn(j0d, r.speed), p);
+          m = row_window16(std::false_type{}, std::false_type{}, p, r.pos, r.speed, cg, gcs);
+        }
       } else {
 #pragma unroll
         for (int ch = 0; ch < CL; ch++) {
@@ -1406,10 +1458,17 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
     const int has_wide = __syncthreads_or(shape & 16);
     // (G instances only: sessions without such clips run the instance that does not carry these modes)
     const int has_stride = G ? __syncthreads_or(shape & 64) : 0;    // per-frame taps
-    const int has_win16 = G ? __syncthreads_or(shape & 32) : 0;     // 16-bit PCM window rows
+    const int has_win16 = W16 ? __syncthreads_or(shape & 32) : 0;   // 16-bit PCM window rows
     const int has_win32 = G ? __syncthreads_or(shape & 128) : 0;    // 24/32-bit PCM window rows
     int mode;
-    if (has_stride) {
+    if (LEAN16) {
+      if (has_win16)
+        mode = (!has_f32 && !has_i32) ? (has_wide ? MODE_WI : us > 0.0 ? MODE_WINU : MODE_WIN) : MODE_MIXED;
+      else if (has_i16)
+        mode = (!has_f32 && !has_i32) ? MODE_I16 : (has_win || has_i32) ? MODE_MIXED : MODE_MU;
+      else
+        mode = (has_win || has_i32) ? MODE_MIXED : MODE_U;
+    } else if (has_stride) {
       mode = MODE_G;             // reads every kind and format, whatever else the chunk holds
     } else if (has_win16) {
       mode = (!has_f32 && !has_i32 && !has_win32) ? (has_wide ? MODE_WI : us > 0.0 ? MODE_WINU : MODE_WIN) : (has_wide ? MODE_MW : MODE_MWN);
@@ -1447,20 +1506,26 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
 
     switch (mode) {
       case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn2); break;
-      case MODE_W: pipeline(std::integral_constant<int, MODE_W>{}, cn2); break;
-      case MODE_WN: pipeline(std::integral_constant<int, MODE_WN>{}, cn2); break;
-      case MODE_WNU: pipeline(std::integral_constant<int, MODE_WNU>{}, cn2); break;
+      case MODE_W:
+        if constexpr (!LEAN16) pipeline(std::integral_constant<int, MODE_W>{}, cn2);
+        break;
+      case MODE_WN:
+        if constexpr (!LEAN16) pipeline(std::integral_constant<int, MODE_WN>{}, cn2);
+        break;
+      case MODE_WNU:
+        if constexpr (!LEAN16) pipeline(std::integral_constant<int, MODE_WNU>{}, cn2);
+        break;
       case MODE_G:
         if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn2);
         break;
       case MODE_WI:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_WI>{}, cn2);
+        if constexpr (W16) pipeline(std::integral_constant<int, MODE_WI>{}, cn2);
         break;
       case MODE_WIN:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_WIN>{}, cn2);
+        if constexpr (W16) pipeline(std::integral_constant<int, MODE_WIN>{}, cn2);
         break;
       case MODE_WINU:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_WINU>{}, cn2);
+        if constexpr (W16) pipeline(std::integral_constant<int, MODE_WINU>{}, cn2);
         break;
       case MODE_MU: pipeline(std::integral_constant<int, MODE_MU>{}, cn2); break;
       case MODE_MW:
@@ -1470,7 +1535,9 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         if constexpr (G) pipeline(std::integral_constant<int, MODE_MWN>{}, cn2);
         break;
       case MODE_I16: pipeline(std::integral_constant<int, MODE_I16>{}, cn2); break;
-      case MODE_I32: pipeline(std::integral_constant<int, MODE_I32>{}, cn2); break;
+      case MODE_I32:
+        if constexpr (!LEAN16) pipeline(std::integral_constant<int, MODE_I32>{}, cn2);
+        break;
       default: mixed(cn2); break;
     }
 
@@ -1752,26 +1819,27 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
-const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool stride_rows, hipStream_t s) {
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s) {
   const char* name = "";   // the instance as rocprofv3 prints it (wbx_kernel_name)
-#define WBX_MIX(U, FULL, W, G, SB, CW, CL, GRID, BLOCK)                                                  \
+#define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, GRID, BLOCK)                                                  \
   {                                                                                                      \
-    name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #G ", " #SB ", " #CW ", " #CL ">";              \
-    hipLaunchKernelGGL((mix_kernel<U, FULL, W, G, SB, CW, CL>), GRID, BLOCK, 0, s, a);                   \
+    name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ">";              \
+    hipLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL>), GRID, BLOCK, 0, s, a);                   \
   }
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  const bool stride_rows = family != 0;   // (the short-block instances: everything or the lean fp32 family)
   if (!full) {
     // blocks shorter than a workgroup whose waves are still channel-uniform (256 frames; 512 mono): 2 or 4
     // consecutive blocks per workgroup, same code as the full instances
     if (S4 == 32u && a.channels == 2u) {   // 128-frame stereo blocks: one block per wave, a channel per half-wave
       const dim3 g4((n_blocks + 3u) / 4u, a.n_groups, 1);
       if (stride_rows)
-        WBX_MIX(2, true, 4, true, 4, 2, 1, g4, block)
+        WBX_MIX(2, true, 4, 1, 4, 2, 1, g4, block)
       else
-        WBX_MIX(2, true, 4, false, 4, 2, 1, g4, block)
+        WBX_MIX(2, true, 4, 0, 4, 2, 1, g4, block)
       return name;
     }
     if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) {
@@ -1779,45 +1847,52 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, bool st
       const dim3 g2((n_blocks + sb - 1u) / sb, a.n_groups, 1);
       if (sb == 2u) {
         if (stride_rows)
-          WBX_MIX(2, true, 4, true, 2, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 1, 2, 1, 1, g2, block)
         else
-          WBX_MIX(2, true, 4, false, 2, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 0, 2, 1, 1, g2, block)
       } else {
         if (stride_rows)
-          WBX_MIX(2, true, 4, true, 4, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 1, 4, 1, 1, g2, block)
         else
-          WBX_MIX(2, true, 4, false, 4, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 0, 4, 1, 1, g2, block)
       }
       return name;
     }
-    WBX_MIX(2, false, 1, true, 1, 1, 1, grid, block)
+    WBX_MIX(2, false, 1, 1, 1, 1, 1, grid, block)
     return name;
   }
   // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
   // per-frame-tap mode; every other session keeps the leaner code
-  if (stride_rows) {   // (W = 4 although this instance spills a few registers there: at W = 3 it is 5-10 % slower)
-    WBX_MIX(2, true, 4, true, 1, 1, 1, grid, block)
+  if (family == 1) {   // (W = 4 although this instance spills a few registers there: at W = 3 it is 5-10 % slower)
+    WBX_MIX(2, true, 4, 1, 1, 1, 1, grid, block)
+    return name;
+  }
+  if (family == 2) {   // all-16-bit sessions at speeds up to 0.999 or 1: the lean 16-bit family
+    if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
+      WBX_MIX(2, true, 3, 2, 1, 1, 2, grid, dim3(128))
+    else
+      WBX_MIX(2, true, 4, 2, 1, 1, 1, grid, block)
     return name;
   }
   // variant >= 1000: stereo 512-frame blocks with both channels of a frame in one lane (workgroups of 128 lanes = one
   // block; 24 KiB of LDS each: three waves per SIMD)
   if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u) {
     if (variant == 1013)
-      WBX_MIX(1, true, 3, false, 1, 1, 2, grid, dim3(128))
+      WBX_MIX(1, true, 3, 0, 1, 1, 2, grid, dim3(128))
     else
-      WBX_MIX(2, true, 3, false, 1, 1, 2, grid, dim3(128))
+      WBX_MIX(2, true, 3, 0, 1, 1, 2, grid, dim3(128))
     return name;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
-#define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, false, 1, 1, 1, grid, block) break;
+#define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, 0, 1, 1, 1, grid, block) break;
     WBX_V(1, 6)
     WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6)
     WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
     WBX_V(8, 2)
 #undef WBX_V
-    default: WBX_MIX(2, true, 4, false, 1, 1, 1, grid, block) break;
+    default: WBX_MIX(2, true, 4, 0, 1, 1, 1, grid, block) break;
   }
 #undef WBX_MIX
   return name;

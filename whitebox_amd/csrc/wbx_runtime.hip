@@ -111,9 +111,11 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
   if (c->samples_dirty) {
     std::vector<DSample> tab(c->clips.size());
     c->has_integer_clips = false;
+    c->has_non16_clips = false;
     for (size_t i = 0; i < c->clips.size(); i++) {
       tab[i] = c->clips[i].d;
       if (c->clips[i].used && c->clips[i].d.format != FMT_F32) c->has_integer_clips = true;
+      if (c->clips[i].used && c->clips[i].d.format != FMT_I16) c->has_non16_clips = true;
     }
     WBX_HIP(c, c->d_samples.ensure(std::max<size_t>(1, tab.size())));
     if (!tab.empty()) WBX_HIP(c, hipMemcpy(c->d_samples.p, tab.data(), tab.size() * sizeof(DSample), hipMemcpyHostToDevice));
@@ -199,6 +201,15 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   return WBX_OK;
 }
 
+// which chunk modes the mix instance of the next launch carries (mix_kernel<.., FAM, ..>): 1 (everything) also holds the
+// pipelined modes for chunks that mix storage formats with resampled rows; 2: sessions of 16-bit PCM only, resampled at
+// speeds up to 0.999 or not at all
+int mix_family(const wbx_ctx* c) {
+  if (c->force_g) return 1;
+  if (c->has_lean16_clips && !c->has_non16_clips && !std::getenv("WBX_NO_LEAN16")) return 2;
+  return (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips)) ? 1 : 0;
+}
+
 // Can the mix instance a render of this shape will launch take masked rows (partial-coverage records, ROW_PAIRs) in its
 // hot loop, and which (PlanArgs::masked_rows)?  Only the lean whole-workgroup-per-block instances do
 // (mix_kernel<U, true, W, false, 1, ...>): blocks of C*F/4 lanes a multiple of 256, sessions without per-frame-tap clips.
@@ -209,7 +220,9 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
-  if (!full || c->force_g || stride_clips) return 0u;
+  if (!full || c->force_g) return 0u;
+  if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
+  if (stride_clips) return 0u;
   if (!c->has_integer_clips) return 1u;
   return window_clips ? 0u : 2u;
 }
@@ -267,8 +280,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     // sessions at unity speed keep the U = 4 instance)
     const bool cl2 = (c->has_window_clips || c->has_integer_clips) && C == 2u && F == 512u && !std::getenv("WBX_NO_CL2");
     c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : cl2 ? 1023 : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
-               // the G instances also carry the pipelined modes for chunks that mix storage formats with resampled rows
-               c->force_g || c->has_stride_clips || (c->has_window_clips && c->has_integer_clips), ms);
+               mix_family(c), ms);
     if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
     }
