@@ -19,6 +19,8 @@ timeout 300 python bench.py --clip-blocks 5.3 --no-cpu-baseline --no-configs > $
 timeout 300 python bench.py --clip-blocks 20 --no-cpu-baseline --no-configs > $O/bench_c3_L20.json 2>> $O/bench_default.err
 timeout 300 python bench.py --workload i16 --clip-blocks 5.3 --no-cpu-baseline --no-configs > $O/bench_i16_L5.3.json 2>> $O/bench_default.err
 timeout 300 python bench.py --workload i16 --clip-blocks 20 --no-cpu-baseline --no-configs > $O/bench_i16_L20.json 2>> $O/bench_default.err
+timeout 300 python bench.py --workload i16r --clip-blocks 5.3 --no-cpu-baseline --no-configs > $O/bench_i16r_L5.3.json 2>> $O/bench_default.err
+timeout 300 python bench.py --workload i16r --clip-blocks 20 --no-cpu-baseline --no-configs > $O/bench_i16r_L20.json 2>> $O/bench_default.err
 timeout 300 python bench.py --force-dist-path --no-cpu-baseline --no-configs > $O/bench_dist1_reduce.json 2>> $O/bench_default.err
 timeout 300 python bench.py --force-dist-path --dist-mode ordered --no-cpu-baseline --no-configs > $O/bench_dist1_ordered.json 2>> $O/bench_default.err
 cd /tmp
