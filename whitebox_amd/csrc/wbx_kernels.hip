@@ -1887,10 +1887,7 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
 #define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, 0, 1, 1, 1, grid, block) break;
-    WBX_V(1, 6)
-    WBX_V(2, 4) WBX_V(2, 5) WBX_V(2, 6)
-    WBX_V(4, 3) WBX_V(4, 4) WBX_V(4, 5)
-    WBX_V(8, 2)
+    WBX_V(2, 4) WBX_V(4, 3) WBX_V(8, 2)   // (1/6, 2/5, 2/6, 4/4, 4/5 spill and were 10-60 % slower: tools/ab_variants.sh at 4af5b77)
 #undef WBX_V
     default: WBX_MIX(2, true, 4, 0, 1, 1, 1, grid, block) break;
   }
