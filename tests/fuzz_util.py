@@ -55,7 +55,7 @@ def random_masked_session(seed, integer_unity=False, lean16=False):
     if integer_unity:
         fmts = [["i16"], ["i24"], ["i32"], ["i16", "i24", "i32", "f32"], ["i16", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
-    block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1)][int(rng.integers(0, 4))]
+    block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2)][int(rng.integers(0, 5))]
     n_blocks = int(rng.integers(2, 7))
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))

@@ -171,6 +171,7 @@ struct wbx_ctx {
   bool has_integer_clips = false;
   bool has_non16_clips = false;       // a clip asset that is not 16-bit PCM
   bool has_lean16_clips = false;      // resampled clips exist and all of them are 16-bit PCM at speeds up to 0.999 (layer 2)
+  bool has_cut_tracks = true;         // some track holds more than one clip (layer 1: unknown, assume so)
   bool force_g = false;
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
   bool auto_group = false;            // wbx_config.group_size was 0: the library picks the track-group size
@@ -249,6 +250,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
 int mix_family(const wbx_ctx* c);
+bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 
 // wbx_dist.hip

@@ -762,6 +762,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
+  c->has_cut_tracks = hs.cut_tracks != 0;
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   a.masked_rows = c->masked_rows;
   a.tmpl_reserve = HostSession::template_reserve(K);

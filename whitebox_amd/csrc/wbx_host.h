@@ -147,6 +147,7 @@ struct HostSession {
   // kernel's hoisted position products: 0 = none yet, < 0 = several / outside the narrow-window range
   double window_speed = 0.0;
   size_t total_clips = 0;
+  size_t cut_tracks = 0;                // tracks that hold more than one clip (clip boundaries inside blocks are the rule there)
   uint32_t next_clip_uid = 0;
   uint64_t edit_seq = 0;                // locked edits completed so far (UI thread, under the lock)
   uint64_t render_edit_seq = 0;         // edit_seq as the last process / render saw it
@@ -207,7 +208,11 @@ struct HostSession {
 
   void recount_clips() {
     total_clips = 0;
-    for (auto& tr : tracks) total_clips += tr->clips.size();
+    cut_tracks = 0;
+    for (auto& tr : tracks) {
+      total_clips += tr->clips.size();
+      if (tr->clips.size() > 1) cut_tracks++;
+    }
   }
 
   // which clips the hot loop can stream directly, and how much plan storage a render may need

@@ -505,8 +505,8 @@ struct RowT {
 //         row costs it once instead of once per channel, and one set of record scalars serves both.  Workgroups of
 //         128 lanes = one 512-frame block)
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1>
-__global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
+template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1, int T = 256 / CL>
+__global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   // FAM: which chunk modes the instance carries — every mode it carries costs registers in all the others.
   //   0  fp32 (unity / window) and integer PCM at unity speed: U, W, WN, WNU, I16, I32, MU, MIXED
   //   1  everything: also per-frame taps, 16-bit / 24-bit / 32-bit window rows, windows of several formats in one chunk
@@ -517,17 +517,22 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
   constexpr bool LEAN16 = FAM == 2;
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
   static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
-  static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo 512-frame blocks");
-  constexpr uint32_t kT = 256u / CL;   // lanes per workgroup
-  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kStage;   // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS)
+  static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo blocks of 4 * T frames");
+  static_assert(T == 256 / CL || (CL == 2 && (T == 64 || T == 256)), "lanes per workgroup");
+  constexpr uint32_t kT = (uint32_t)T;   // lanes per workgroup (CL = 2: one block of 4 * T frames — 256, 512 or 1024)
+  // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS; one-wave workgroups: a quarter,
+  // so that twelve of them fit)
+  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kT == 64u ? kStage / 4 : kStage;
   // EXP: the instance takes the sequencer's masked rows (MixArgs::masked_rows): a track-block with a clip boundary in
   // it is a ROW_PAIR of two single-segment records, so a chunk of kSt tracks stages up to 2 * kSt rows
-  constexpr bool EXP = SB == 1 && FULL && kSt == 128;
+  constexpr bool EXP = SB == 1 && FULL && (kSt == 128 || kT == 64u);
   constexpr uint32_t kMaxRows = EXP ? 2 * kSt : kSt;
   constexpr uint32_t kRecs = kMaxRows + 2 * U + 4;      // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
-  __shared__ uint32_t s_pk[SB * kRecs * 4];   // FULL: one slot per (record, wave), plain stores; else (record, channel), atomics
-  __shared__ uint32_t s_wc[4];           // FULL: sub-block * C + channel each wave works on
+  constexpr uint32_t kWaves = kT / 64u;
+  constexpr uint32_t kPS = (CL == 2 && kWaves == 4u) ? 8u : 4u;   // peak slots per record: one per (wave, channel of the wave)
+  __shared__ uint32_t s_pk[SB * kRecs * kPS];   // FULL: one slot per (record, wave[, channel]), plain stores; else (record, channel), atomics
+  __shared__ uint32_t s_wc[kPS];         // FULL: sub-block * C + channel a slot holds (unused slots: none)
   __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? kSt : 1];   // EXP: the chunk's plan rows
   __shared__ uint16_t s_map[EXP ? 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
   __shared__ uint16_t s_off[EXP ? kSt + 1 : 1];   // EXP: local track -> its first staged row
@@ -995,20 +1000,20 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
       pk[ch] = absmax4(m);                                                                // vu_meter.h:20-25
     }
   };
-  // FULL: the slot of s_pk[record][4] that takes the wave's peak of channel element ch — the wave itself (CL == 1:
-  // four waves, one channel each) or 2 * channel + wave (CL == 2: two waves, both channels each); s_wc[slot] names
+  // FULL: the slot of s_pk[record][kPS] that takes the wave's peak of channel element ch — the wave itself (CL == 1:
+  // four waves, one channel each) or channel * waves + wave (CL == 2: every wave holds both channels); s_wc[slot] names
   // the channel a slot holds
   const uint32_t wave = tid >> 6;
-  auto pk_slot = [&](int ch) { return CL == 2 ? 2u * (uint32_t)ch + wave : wave; };
+  auto pk_slot = [&](int ch) { return CL == 2 ? kWaves * (uint32_t)ch + wave : wave; };
   // per-track peak: wavefront max (DPP) when the wave is channel-uniform, shuffle-max across the lanes that
   // share a channel otherwise; then one LDS atomic per wave / lane group
   auto post_peak = [&](float pk, uint32_t tl, int ch) {
     if (FULL && CW == 2) {
       for (uint32_t off = 1; off < 32u; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
-      if ((lane & 31u) == 0u) s_pk[(rb + tl) * 4u + c] = __float_as_uint(pk);      // slot = channel: one wave per sub-block
+      if ((lane & 31u) == 0u) s_pk[(rb + tl) * kPS + c] = __float_as_uint(pk);      // slot = channel: one wave per sub-block
     } else if (FULL) {
       pk = wave_max_lane63(pk);
-      if (lane == 63u) s_pk[(rb + tl) * 4u + pk_slot(ch)] = __float_as_uint(pk);   // this wave's own slot: no atomic
+      if (lane == 63u) s_pk[(rb + tl) * kPS + pk_slot(ch)] = __float_as_uint(pk);   // this wave's own slot: no atomic
     } else {
       for (uint32_t off = 1; off < span; off <<= 1) pk = fmaxf(pk, __shfl_xor(pk, (int)off, 64));
       if ((lane & (span - 1u)) == 0u && active) atomicMax(&s_pk[tl * 2u + c], __float_as_uint(pk));
@@ -1017,21 +1022,21 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
 
   // the same for four consecutive tracks tl..tl+3 at once (FULL only): lane 0 of row r stores the wave maximum
   // of track tl + kQuadRowTrack[r] into this wave's slot
-  const uint32_t quad_row = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * 4u;   // rows hold tracks 0,2,1,3
+  const uint32_t quad_row = (((lane >> 4) & 1u) * 2u + (lane >> 5)) * kPS;   // rows hold tracks 0,2,1,3
   const bool quad_writer = (lane & 15u) == 0u;
   auto post_peak4 = [&](const float (&pk)[4], uint32_t tl, int ch) {
     if (CW == 2) {
       uint32_t v0, v1;
       wave_max_quad_halves(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]), v0, v1);
       if (quad_writer) {
-        uint32_t* slots = &s_pk[(rb + tl + (((lane >> 4) & 1u) * 2u + (lane >> 5))) * 4u];
+        uint32_t* slots = &s_pk[(rb + tl + (((lane >> 4) & 1u) * 2u + (lane >> 5))) * kPS];
         slots[0] = v0;
         slots[1] = v1;
       }
       return;
     }
     const uint32_t v = wave_max_quad(__float_as_uint(pk[0]), __float_as_uint(pk[1]), __float_as_uint(pk[2]), __float_as_uint(pk[3]));
-    if (quad_writer) s_pk[(rb + tl) * 4u + quad_row + pk_slot(ch)] = v;
+    if (quad_writer) s_pk[(rb + tl) * kPS + quad_row + pk_slot(ch)] = v;
   };
 
   // ---- phase A: the clip loads of the U tracks starting at local index u0 (straight-line per mode) ----
@@ -1381,6 +1386,7 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
         const unsigned long long bal = __ballot(is_pair);
         before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0u) s_wpairs[tid >> 6] = (uint32_t)__popcll(bal);
+        if (kSt <= 64u && tid == 0u) s_wpairs[1] = 0u;   // (one wave fetches all rows)
       }
       __syncthreads();
       if (tid < cn) {
@@ -1434,11 +1440,15 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
       reinterpret_cast<uint4*>(s_tb)[i] = w;
     }
     }
-    for (uint32_t i = tid; i < SB * kRecs * 4u; i += kT) s_pk[i] = 0u;
+    for (uint32_t i = tid; i < SB * kRecs * kPS; i += kT) s_pk[i] = 0u;
     if (FULL && lane == 0u) {
-      if (CL == 2) {   // slot 2 * channel + wave
+      if (CL == 2) {   // slot channel * waves + wave
         s_wc[wave] = 0u;
-        s_wc[2u + wave] = 1u;
+        s_wc[kWaves + wave] = 1u;
+        if (2u * kWaves < kPS && wave == 0u) {   // (one-wave workgroups: slots 2 and 3 stay empty)
+          s_wc[2] = 0xFFFFFFFFu;
+          s_wc[3] = 0xFFFFFFFFu;
+        }
       } else {
         s_wc[wave] = sub * C + c;
       }
@@ -1552,15 +1562,15 @@ __global__ __launch_bounds__(256 / CL, W) void mix_kernel(MixArgs a) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)bb * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
       if (FULL && CW == 2) {
-        pk = s_pk[(sb * kRecs + rec) * 4u + ch];
+        pk = s_pk[(sb * kRecs + rec) * kPS + ch];
       } else if (FULL) {
         // (EXP with masked rows: the track's staged row, or the two of its pair — one peak over both stream calls)
         const uint32_t r0 = (EXP && a.masked_rows) ? s_off[rec] : rec;
         const uint32_t r1 = (EXP && a.masked_rows) ? s_off[rec + 1u] : rec + 1u;
         for (uint32_t rr = r0; rr < r1; rr++) {
-          const uint32_t* slots = &s_pk[(sb * kRecs + rr) * 4u];
+          const uint32_t* slots = &s_pk[(sb * kRecs + rr) * kPS];
 #pragma unroll
-          for (uint32_t w = 0; w < 4u; w++)
+          for (uint32_t w = 0; w < kPS; w++)
             if (s_wc[w] == sb * C + ch) pk = pk > slots[w] ? pk : slots[w];
         }
       } else {
@@ -1831,6 +1841,12 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   const bool stride_rows = family != 0;   // (the short-block instances: everything or the lean fp32 family)
+  // variant >= 1000, stereo 256-frame blocks (family 0): one wave = one block with both channels of a frame in a lane
+  if (variant >= 1000 && family == 0 && a.channels == 2u && S4 == 64u) {
+    name = "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>";
+    hipLaunchKernelGGL((mix_kernel<2, true, 3, 0, 1, 1, 2, 64>), grid, dim3(64), 0, s, a);
+    return name;
+  }
   if (!full) {
     // blocks shorter than a workgroup whose waves are still channel-uniform (256 frames; 512 mono): 2 or 4
     // consecutive blocks per workgroup, same code as the full instances
@@ -1881,6 +1897,13 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
       WBX_MIX(1, true, 3, 0, 1, 1, 2, grid, dim3(128))
     else
       WBX_MIX(2, true, 3, 0, 1, 1, 2, grid, dim3(128))
+    return name;
+  }
+  // ... and 1024-frame ones: workgroups of 256 lanes = one block
+  if (variant >= 1000 && a.channels == 2u && S4 == 256u) {
+    const dim3 g1(n_blocks, a.n_groups, 1);
+    name = "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 256>";
+    hipLaunchKernelGGL((mix_kernel<2, true, 3, 0, 1, 1, 2, 256>), g1, dim3(256), 0, s, a);
     return name;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for

@@ -210,6 +210,18 @@ int mix_family(const wbx_ctx* c) {
   return (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips)) ? 1 : 0;
 }
 
+// stereo sessions with resampled or integer-PCM clips, blocks of 256 / 512 / 1024 frames: the instances with both channels
+// of a frame in one lane (position and masked-row arithmetic once per frame; measured equal or better on every such
+// workload, tools/ab_cl2.sh — fp32 sessions at unity speed keep the U = 4 instance)
+bool mix_two_channels_per_lane(const wbx_ctx* c) {
+  const uint32_t F = c->cfg.block_frames;
+  if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
+  if (!(c->has_window_clips || c->has_integer_clips) || c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
+  // 256-frame blocks: the one-wave workgroups are 8 % behind the two-blocks-per-workgroup instance on fp32 sessions of one
+  // clip per track (tools/ab_blocks.sh) and twice as fast as soon as tracks are cut into clips — which is what decides
+  return F == 512u || F == 1024u || (F == 256u && (c->has_cut_tracks || c->has_integer_clips));
+}
+
 // Can the mix instance a render of this shape will launch take masked rows (partial-coverage records, ROW_PAIRs) in its
 // hot loop, and which (PlanArgs::masked_rows)?  Only the lean whole-workgroup-per-block instances do
 // (mix_kernel<U, true, W, false, 1, ...>): blocks of C*F/4 lanes a multiple of 256, sessions without per-frame-tap clips.
@@ -217,11 +229,13 @@ int mix_family(const wbx_ctx* c) {
 // session rate and that hold no resampled clip (those take the instances with the mixed-format window modes).
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
   const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
-  const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  // (256-frame stereo blocks: the one-wave instance with both channels per lane, lean fp32 family only)
+  if (!full && c->cfg.channels == 2u && S4 == 64u && mix_family(c) == 0 && mix_two_channels_per_lane(c)) full = true;
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
   if (!full || c->force_g) return 0u;
-  if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
+  if (mix_family(c) == 2) return (lanes % 256u == 0u) ? 3u : 0u;   // sessions of 16-bit PCM only: also their resampled rows
   if (stride_clips) return 0u;
   if (!c->has_integer_clips) return 1u;
   return window_clips ? 0u : 2u;
@@ -275,11 +289,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
       }
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     }
-    // stereo 512-frame sessions with resampled or integer-PCM clips: both channels of a frame in one lane (position and
-    // masked-row arithmetic once per frame; measured equal or better on every such workload, tools/ab_cl2.sh — fp32
-    // sessions at unity speed keep the U = 4 instance)
-    const bool cl2 = (c->has_window_clips || c->has_integer_clips) && C == 2u && F == 512u && !std::getenv("WBX_NO_CL2");
-    c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : cl2 ? 1023 : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
+    c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : mix_two_channels_per_lane(c) ? 1023
+                                          : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                mix_family(c), ms);
     if (timed) {
       WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
