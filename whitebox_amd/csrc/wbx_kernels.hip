@@ -520,9 +520,9 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo blocks of 4 * T frames");
   static_assert(T == 256 / CL || (CL == 2 && (T == 64 || T == 256)), "lanes per workgroup");
   constexpr uint32_t kT = (uint32_t)T;   // lanes per workgroup (CL = 2: one block of 4 * T frames — 256, 512 or 1024)
-  // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS; one-wave workgroups: a quarter,
-  // so that twelve of them fit)
-  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kT == 64u ? kStage / 4 : kStage;
+  // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS; one-wave workgroups: half, so
+  // that twelve of them fit — 12.6 KiB each)
+  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kT == 64u ? kStage / 2 : kStage;
   // EXP: the instance takes the sequencer's masked rows (MixArgs::masked_rows): a track-block with a clip boundary in
   // it is a ROW_PAIR of two single-segment records, so a chunk of kSt tracks stages up to 2 * kSt rows
   constexpr bool EXP = SB == 1 && FULL && (kSt == 128 || kT == 64u);
