@@ -225,7 +225,7 @@ wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t
  * group/bus/master sum including its stores to a host-resident master target); read before resetting. */
 wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
 /* The template instance of the dominant kernel that the last render launched, as rocprofv3 prints it
- * ("wbx::mix_kernel<2, true, 3, false, 1, 1, 2>"); "" before the first render. */
+ * ("wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"); "" before the first render. */
 const char* wbx_kernel_name(wbx_ctx* ctx);
 
 /* ---- layer 2: the engine surface -----------------------------------------------------------

@@ -834,7 +834,7 @@ def test_kernel_timer_reports():
     ms, n = eng.ctx.kernel_time()
     assert n == 2 and ms > 0.0
     # the instance the library launched, as rocprofv3 prints it: a unity-speed stereo 512-frame session takes U = 4, W = 3
-    assert eng.ctx.kernel_name() == "wbx::mix_kernel<4, true, 3, 0, 1, 1, 1>"
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<4, true, 3, 0, 1, 1, 1, 256>"
     eng.close()
 
 
@@ -852,8 +852,8 @@ def test_kernel_name_follows_the_session(monkeypatch):
         m, pk, _ = eng.ctx.fetch(peaks=True)
         outs[no_cl2] = (m.copy(), pk.copy(), eng.ctx.kernel_name())
         eng.close()
-    assert outs[False][2] == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2>"
-    assert outs[True][2] == "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1>"
+    assert outs[False][2] == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"
+    assert outs[True][2] == "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1, 256>"
     assert np.array_equal(outs[False][0], outs[True][0]) and np.array_equal(outs[False][1], outs[True][1])
 
 

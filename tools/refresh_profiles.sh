@@ -31,5 +31,11 @@ for k, n in m.items():
     d[k]['source'] = f'profiles/r02_{n}_K256_mix_pmc.txt (tools/profile_r02.sh; raw rocprofv3 --pmc CSVs in gpurun_out/{tag}/pmc_{n}, scratch)'
 json.dump(d, open(p, 'w'), indent=1, sort_keys=True); open(p, 'a').write('\n')
 for k, v in d.items(): print(k, v['hbm_bytes_per_launch'])
+# the kernel a bench line names is the kernel rocprofv3 saw in the same run
+for n in m.values():
+    name = json.load(open(f'profiles/r02_{n}_K256_bench_line_of_profiled_run.json'))['roofline']['kernel']
+    stats = open(f'profiles/r02_{n}_K256_kernel_stats_rocprofv3.csv').read()
+    assert name in stats, (n, name)
+    print(n, 'bench line and rocprofv3 agree on', name)
 PY
 cat profiles/r02_kernel_summary.txt

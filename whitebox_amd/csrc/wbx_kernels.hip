@@ -1831,10 +1831,10 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
 
 const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s) {
   const char* name = "";   // the instance as rocprofv3 prints it (wbx_kernel_name)
-#define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, GRID, BLOCK)                                                  \
+#define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, T, GRID, BLOCK)                                                  \
   {                                                                                                      \
-    name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ">";              \
-    hipLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL>), GRID, BLOCK, 0, s, a);                   \
+    name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ", " #T ">";              \
+    hipLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, a);                   \
   }
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;
@@ -1843,8 +1843,7 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   const bool stride_rows = family != 0;   // (the short-block instances: everything or the lean fp32 family)
   // variant >= 1000, stereo 256-frame blocks (family 0): one wave = one block with both channels of a frame in a lane
   if (variant >= 1000 && family == 0 && a.channels == 2u && S4 == 64u) {
-    name = "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>";
-    hipLaunchKernelGGL((mix_kernel<2, true, 3, 0, 1, 1, 2, 64>), grid, dim3(64), 0, s, a);
+    WBX_MIX(2, true, 3, 0, 1, 1, 2, 64, grid, dim3(64))
     return name;
   }
   if (!full) {
@@ -1853,9 +1852,9 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
     if (S4 == 32u && a.channels == 2u) {   // 128-frame stereo blocks: one block per wave, a channel per half-wave
       const dim3 g4((n_blocks + 3u) / 4u, a.n_groups, 1);
       if (stride_rows)
-        WBX_MIX(2, true, 4, 1, 4, 2, 1, g4, block)
+        WBX_MIX(2, true, 4, 1, 4, 2, 1, 256, g4, block)
       else
-        WBX_MIX(2, true, 4, 0, 4, 2, 1, g4, block)
+        WBX_MIX(2, true, 4, 0, 4, 2, 1, 256, g4, block)
       return name;
     }
     if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) {
@@ -1863,56 +1862,55 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
       const dim3 g2((n_blocks + sb - 1u) / sb, a.n_groups, 1);
       if (sb == 2u) {
         if (stride_rows)
-          WBX_MIX(2, true, 4, 1, 2, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 1, 2, 1, 1, 256, g2, block)
         else
-          WBX_MIX(2, true, 4, 0, 2, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 0, 2, 1, 1, 256, g2, block)
       } else {
         if (stride_rows)
-          WBX_MIX(2, true, 4, 1, 4, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 1, 4, 1, 1, 256, g2, block)
         else
-          WBX_MIX(2, true, 4, 0, 4, 1, 1, g2, block)
+          WBX_MIX(2, true, 4, 0, 4, 1, 1, 256, g2, block)
       }
       return name;
     }
-    WBX_MIX(2, false, 1, 1, 1, 1, 1, grid, block)
+    WBX_MIX(2, false, 1, 1, 1, 1, 1, 256, grid, block)
     return name;
   }
   // sessions with clips played faster than recorded (KIND_STRIDE rows) take the instance that carries the
   // per-frame-tap mode; every other session keeps the leaner code
   if (family == 1) {   // (W = 4 although this instance spills a few registers there: at W = 3 it is 5-10 % slower)
-    WBX_MIX(2, true, 4, 1, 1, 1, 1, grid, block)
+    WBX_MIX(2, true, 4, 1, 1, 1, 1, 256, grid, block)
     return name;
   }
   if (family == 2) {   // all-16-bit sessions at speeds up to 0.999 or 1: the lean 16-bit family
     if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
-      WBX_MIX(2, true, 3, 2, 1, 1, 2, grid, dim3(128))
+      WBX_MIX(2, true, 3, 2, 1, 1, 2, 128, grid, dim3(128))
     else
-      WBX_MIX(2, true, 4, 2, 1, 1, 1, grid, block)
+      WBX_MIX(2, true, 4, 2, 1, 1, 1, 256, grid, block)
     return name;
   }
   // variant >= 1000: stereo 512-frame blocks with both channels of a frame in one lane (workgroups of 128 lanes = one
   // block; 24 KiB of LDS each: three waves per SIMD)
   if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u) {
     if (variant == 1013)
-      WBX_MIX(1, true, 3, 0, 1, 1, 2, grid, dim3(128))
+      WBX_MIX(1, true, 3, 0, 1, 1, 2, 128, grid, dim3(128))
     else
-      WBX_MIX(2, true, 3, 0, 1, 1, 2, grid, dim3(128))
+      WBX_MIX(2, true, 3, 0, 1, 1, 2, 128, grid, dim3(128))
     return name;
   }
   // ... and 1024-frame ones: workgroups of 256 lanes = one block
   if (variant >= 1000 && a.channels == 2u && S4 == 256u) {
     const dim3 g1(n_blocks, a.n_groups, 1);
-    name = "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 256>";
-    hipLaunchKernelGGL((mix_kernel<2, true, 3, 0, 1, 1, 2, 256>), g1, dim3(256), 0, s, a);
+    WBX_MIX(2, true, 3, 0, 1, 1, 2, 256, g1, dim3(256))
     return name;
   }
   // variant = 10*U + W: U tracks per pipeline stage, W = waves per SIMD the register budget is capped for
   // (tuning knob WBX_MIX_VARIANT; every variant computes identical results)
   switch (variant) {
-#define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, 0, 1, 1, 1, grid, block) break;
+#define WBX_V(U, W) case 10 * U + W: WBX_MIX(U, true, W, 0, 1, 1, 1, 256, grid, block) break;
     WBX_V(2, 4) WBX_V(4, 3) WBX_V(8, 2)   // (1/6, 2/5, 2/6, 4/4, 4/5 spill and were 10-60 % slower: tools/ab_variants.sh at 4af5b77)
 #undef WBX_V
-    default: WBX_MIX(2, true, 4, 0, 1, 1, 1, grid, block) break;
+    default: WBX_MIX(2, true, 4, 0, 1, 1, 1, 256, grid, block) break;
   }
 #undef WBX_MIX
   return name;
