@@ -1320,3 +1320,29 @@ def check_masked_session(spec, n_blocks, seed):
             assert np.array_equal(pk[0], opk[b][:, :spec.channels]), b
         eng.close()
 
+
+
+def test_clip_storage_slabs_grow_and_are_reused():
+    """Clip audio lives in slabs (64 MiB, 256 MiB, 1 GiB ...) carved up in order: clips that spill over several slabs, a clip
+    larger than a quarter slab (an allocation of its own), freeing and uploading again — every clip reads back what was
+    uploaded."""
+    ctx = W.MixContext(8, max_blocks=1)
+    rng = np.random.default_rng(7)
+    frames = 3_000_000                                     # 2 channels x 12 MB = 24 MB per clip: three clips fill the first slab
+    data = {}
+    for clip in range(9):
+        data[clip] = [rng.standard_normal(frames).astype(np.float32) for _ in range(2)]
+        ctx.clip_upload(clip, "f32", 48000, data[clip])
+    big = [rng.integers(-30000, 30000, 80_000_000).astype(np.int16) for _ in range(2)]   # 320 MB: its own allocation
+    ctx.clip_upload(9, "i16", 44100, big)
+    for clip in (1, 4, 7):                                 # free some, upload others in their place
+        st = ctx.L.wbx_clip_free(ctx.h, clip)
+        assert st == 0
+        data[clip] = [rng.standard_normal(frames // 2).astype(np.float32)]
+        ctx.clip_upload(clip, "f32", 44100, data[clip])
+    for clip, chans in data.items():
+        for ch, a in enumerate(chans):
+            assert np.array_equal(ctx.clip_download(clip, ch, len(a), np.float32), a), (clip, ch)
+    for ch in range(2):
+        assert np.array_equal(ctx.clip_download(9, ch, len(big[ch]), np.int16), big[ch])
+    ctx.close()

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -39,8 +41,21 @@ constexpr int kRing = 3;
 constexpr uint32_t kPaceRing = 64;
 constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
 
+// Clip audio lives in slabs of 1 GiB carved up in order (64-KiB granules): a session of thousands of clips is a few
+// dozen large allocations, which the driver backs with large contiguous fragments (measured: the mix kernel's launch time
+// is bimodal from process to process with one allocation per clip, 3-5 % apart, and stays at the fast end with slabs,
+// tools/ab_arena.sh).  A slab's space is reused when the last clip in it has been freed; slabs go back to the
+// driver with the context.  Clips above 256 MiB get an allocation of their own.
+struct ClipSlab {
+  char* mem = nullptr;
+  size_t size = 0, used = 0;
+  uint32_t live = 0;        // clips inside
+};
+
 struct ClipSlot {
-  void* base = nullptr;     // one allocation holding all channels
+  void* alloc = nullptr;    // an allocation of its own (hipFree), or
+  ClipSlab* slab = nullptr; // the slab it lives in
+  void* base = nullptr;     // first channel row; all channels in one piece
   size_t stride = 0;        // bytes between channel rows
   DSample d{};
   bool used = false;
@@ -84,6 +99,8 @@ struct wbx_ctx {
   std::string err;
 
   std::vector<ClipSlot> clips;
+  std::vector<std::unique_ptr<ClipSlab>> slabs;   // clip storage (slab_mu: clips are built outside the editor lock)
+  std::mutex slab_mu;
   DevBuf<DSample> d_samples;
   bool samples_dirty = true;
 
@@ -235,7 +252,7 @@ struct ClipFill {           // where a new clip's audio comes from
 wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, uint32_t sample_rate, uint64_t frames,
                       const ClipFill& f, hipStream_t on);
 wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s);
-void clip_release(ClipSlot& s);
+void clip_release(wbx_ctx* c, ClipSlot& s);
 hipError_t join_sum(wbx_ctx* c);
 hipError_t join_alt(wbx_ctx* c);
 hipError_t sync_main(wbx_ctx* c);          // the host waits for the main stream and every mix / sum beside it

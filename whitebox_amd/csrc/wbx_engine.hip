@@ -375,7 +375,7 @@ wbx_status add_sample_common(wbx_engine* e, int format, uint32_t channels, uint3
   ClipSlot s;
   wbx_status st = clip_build(c, s, format, channels, sample_rate, frames, f, c->upload_stream);
   if (st == WBX_OK && hipStreamSynchronize(c->upload_stream) != hipSuccess) {
-    clip_release(s);
+    clip_release(c, s);
     st = WBX_ERR_DEVICE;
   }
   LockGuard g(e->hs.editor_lock);

@@ -495,9 +495,11 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   if (c->alt_stream) (void)hipStreamSynchronize(c->alt_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->clips) {
-    if (s.base) (void)hipFree(s.base);
+    if (s.alloc) (void)hipFree(s.alloc);
     if (s.mip) (void)hipFree(s.mip);
   }
+  for (auto& sl : c->slabs)
+    if (sl->mem) (void)hipFree(sl->mem);
   c->d_samples.release();
   c->d_order.release();
   c->d_groups.release();
@@ -542,8 +544,12 @@ extern "C" const char* wbx_last_error(const wbx_ctx* c) { return c ? c->err.c_st
 
 namespace wbx {
 
-void clip_release(ClipSlot& s) {
-  if (s.base) (void)hipFree(s.base);
+void clip_release(wbx_ctx* c, ClipSlot& s) {
+  if (s.alloc) (void)hipFree(s.alloc);
+  if (s.slab) {
+    std::lock_guard<std::mutex> g(c->slab_mu);
+    if (s.slab->live && --s.slab->live == 0) s.slab->used = 0;   // the slab's space is free again
+  }
   if (s.mip) (void)hipFree(s.mip);
   s = ClipSlot{};
 }
@@ -564,7 +570,34 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
   (void)hipSetDevice(c->cfg.device);
   s = ClipSlot{};
   const size_t stride = align_up((frames + kPad) * eb, 256);
-  WBX_HIP(c, hipMalloc(&s.base, stride * channels));
+  {
+    static const bool use_slabs = !(std::getenv("WBX_CLIP_ARENA") && std::getenv("WBX_CLIP_ARENA")[0] == '0');   // A/B aid
+    constexpr size_t kSlab = (size_t)1 << 30, kGranule = (size_t)64 << 10;
+    const size_t need = align_up(stride * channels, kGranule);
+    if (use_slabs && need <= kSlab / 4) {   // (slab sizes grow 64 MiB, 256 MiB, 1 GiB, 1 GiB ...: small sessions stay small)
+      std::lock_guard<std::mutex> g(c->slab_mu);
+      ClipSlab* sl = nullptr;
+      for (auto it = c->slabs.rbegin(); it != c->slabs.rend() && !sl; ++it)   // the newest slab first
+        if ((*it)->size - (*it)->used >= need) sl = it->get();
+      if (!sl) {
+        std::unique_ptr<ClipSlab> fresh(new (std::nothrow) ClipSlab());
+        if (!fresh) return WBX_ERR_OOM;
+        const size_t grown = c->slabs.size() >= 2 ? kSlab : ((size_t)64 << 20) << (2 * c->slabs.size());
+        const size_t sz = std::max(grown, need);
+        WBX_HIP(c, hipMalloc((void**)&fresh->mem, sz));
+        fresh->size = sz;
+        c->slabs.push_back(std::move(fresh));
+        sl = c->slabs.back().get();
+      }
+      s.slab = sl;
+      s.base = sl->mem + sl->used;
+      sl->used += need;
+      sl->live++;
+    } else {
+      WBX_HIP(c, hipMalloc(&s.alloc, stride * channels));
+      s.base = s.alloc;
+    }
+  }
   s.d.ch[0] = s.base;
   s.d.ch[1] = channels > 1 ? (const void*)((const char*)s.base + stride) : s.base;   // mono wraps (i % channels)
   s.d.count = frames;
@@ -638,7 +671,7 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
   }
   if (err != hipSuccess) {
     (void)hipStreamSynchronize(on);
-    clip_release(s);
+    clip_release(c, s);
     return fail(c, WBX_ERR_DEVICE, "clip upload", err);
   }
   return WBX_OK;
@@ -647,7 +680,7 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
 // make slot `clip` of the pool hold `s` (an earlier clip of that id is freed once the device is done with it)
 wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s) {
   if (clip >= (1u << 24)) {
-    clip_release(s);
+    clip_release(c, s);
     return fail(c, WBX_ERR_INVALID, "clip id");
   }
   if (clip >= c->clips.size()) c->clips.resize(clip + 1);
@@ -656,7 +689,7 @@ wbx_status clip_publish(wbx_ctx* c, uint32_t clip, ClipSlot& s) {
     (void)hipStreamSynchronize(c->plan_stream);
     (void)join_sum(c);
     (void)sync_main(c);
-    clip_release(dst);
+    clip_release(c, dst);
   }
   dst = std::move(s);
   s = ClipSlot{};
@@ -813,7 +846,7 @@ extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
   WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
   WBX_HIP(c, join_sum(c));
   WBX_HIP(c, sync_main(c));
-  clip_release(c->clips[clip]);
+  clip_release(c, c->clips[clip]);
   c->samples_dirty = true;
   return WBX_OK;
 }
