@@ -572,7 +572,7 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
   const size_t stride = align_up((frames + kPad) * eb, 256);
   {
     static const bool use_slabs = !(std::getenv("WBX_CLIP_ARENA") && std::getenv("WBX_CLIP_ARENA")[0] == '0');   // A/B aid
-    constexpr size_t kSlab = (size_t)1 << 30, kGranule = (size_t)64 << 10;
+    constexpr size_t kSlab = (size_t)1 << 30, kGranule = (size_t)64 << 10;   // (8-GiB slabs, 2-MiB granules: no difference)
     const size_t need = align_up(stride * channels, kGranule);
     if (use_slabs && need <= kSlab / 4) {   // (slab sizes grow 64 MiB, 256 MiB, 1 GiB, 1 GiB ...: small sessions stay small)
       std::lock_guard<std::mutex> g(c->slab_mu);
