@@ -252,9 +252,20 @@ def self_launch(n):
                    MASTER_PORT=str(port), WBX_RDZV=rdzv)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes here
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # wait for all ranks; a rank that fails takes the others with it (they would sit in the RCCL rendezvous for ever)
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in alive:
+                    q.terminate()        # (the processes this function started, by handle)
     try:
         os.remove(rdzv)
     except OSError:
