@@ -210,18 +210,17 @@ int mix_family(const wbx_ctx* c) {
   return (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips)) ? 1 : 0;
 }
 
-// stereo sessions with resampled or integer-PCM clips or with tracks cut into several clips, blocks of 256 / 512 / 1024
-// frames: the instances with both channels of a frame in one lane (position and masked-row arithmetic once per frame;
-// measured equal or better on every such workload, tools/ab_cl2.sh — fp32 sessions at unity speed with one clip per
-// track keep the U = 4 instance, 4-8 % ahead there)
+// stereo sessions with integer-PCM clips or with tracks cut into several clips, blocks of 256 / 512 / 1024 frames: the
+// instances with both channels of a frame in one lane (position and masked-row arithmetic once per frame, one set of record
+// scalars for both channels).  Measured (tools/ab_cl2.sh, tools/ab_masked.sh, tools/ab_blocks.sh; slab-allocated sessions):
+// integer PCM +2-10 %, sessions cut into clips +5-11 % (2 x at 256 frames, where the other instances have no masked
+// rows), fp32 sessions of one clip per track 3-8 % slower (they fetch 1.06 x their bytes instead of 1.02 x) — those keep
+// one channel per wave.
 bool mix_two_channels_per_lane(const wbx_ctx* c) {
   const uint32_t F = c->cfg.block_frames;
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
-  if (!(c->has_window_clips || c->has_integer_clips || c->has_cut_tracks) || c->cfg.channels != 2u || std::getenv("WBX_NO_CL2"))
-    return false;
-  // 256-frame blocks: the one-wave workgroups are 8 % behind the two-blocks-per-workgroup instance on fp32 sessions of one
-  // clip per track (tools/ab_blocks.sh) and twice as fast as soon as tracks are cut into clips — which is what decides
-  return F == 512u || F == 1024u || (F == 256u && (c->has_cut_tracks || c->has_integer_clips));
+  if (!(c->has_integer_clips || c->has_cut_tracks) || c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
+  return F == 512u || F == 1024u || F == 256u;
 }
 
 // Can the mix instance a render of this shape will launch take masked rows (partial-coverage records, ROW_PAIRs) in its
