@@ -506,13 +506,14 @@ def main():
         for name, wl, kw in (("c2", "c2", dict(n_tracks=256)), ("c4", "c4", dict(n_tracks=4096)),
                              ("c3_clips5.3", "c3", dict(n_tracks=4096, clip_blocks=5.3)),
                              ("i16r", "i16r", dict(n_tracks=4096))):
-            sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=10, warmup=2, ramp=24 if wl != "c2" else 60,
+            sub_steps = 20
+            sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=sub_steps, warmup=3, ramp=40 if wl != "c2" else 60,
                               mem_budget=40e9, **kw)
             d2 = WORKLOADS[wl]
             subs[name] = {"workload": f"{wl} — {d2[0]}" + (f", every track cut into clips of {kw['clip_blocks']} blocks"
                                                           if kw.get("clip_blocks") else ""),
-                          "value": 10 * K * F / sr["dt"], "unit": "frames/s", "steps": 10, "blocks_per_step": K,
-                          "tracks": sr["n_tracks"], "ms_per_step": 1e3 * sr["dt"] / 10,
+                          "value": sub_steps * K * F / sr["dt"], "unit": "frames/s", "steps": sub_steps, "blocks_per_step": K,
+                          "tracks": sr["n_tracks"], "ms_per_step": 1e3 * sr["dt"] / sub_steps,
                           "roofline": roofline_of(sr, traffic_table)}
         line["configs"] = subs
     if world == 1 and not args.no_cpu_baseline:

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <algorithm>
@@ -101,6 +102,7 @@ struct wbx_ctx {
   std::vector<ClipSlot> clips;
   std::vector<std::unique_ptr<ClipSlab>> slabs;   // clip storage (slab_mu: clips are built outside the editor lock)
   std::mutex slab_mu;
+  std::atomic<uint32_t> slab_seq{0};  // clips placed so far (seeds the gap in front of the next one)
   DevBuf<DSample> d_samples;
   bool samples_dirty = true;
 

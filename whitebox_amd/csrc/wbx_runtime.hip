@@ -572,7 +572,15 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
   {
     static const bool use_slabs = !(std::getenv("WBX_CLIP_ARENA") && std::getenv("WBX_CLIP_ARENA")[0] == '0');   // A/B aid
     constexpr size_t kSlab = (size_t)1 << 30, kGranule = (size_t)64 << 10;   // (8-GiB slabs, 2-MiB granules: no difference)
-    const size_t need = align_up(stride * channels, kGranule);
+    // A pseudo-random gap of 0..15 granules in front of every clip (at most an eighth of the clip): a session of equally
+    // long clips has one clip-to-clip stride, and some strides alias in the HBM address hash — the workgroups in flight
+    // read the same offset of many clips at once (c4 with 9.06-MiB clips: 0.82 instead of 0.73 ms per launch;
+    // tools/ab_arena.sh).  WBX_SLAB_JITTER=0: A/B aid.
+    static const bool jitter = !(std::getenv("WBX_SLAB_JITTER") && std::getenv("WBX_SLAB_JITTER")[0] == '0');
+    const size_t body = align_up(stride * channels, kGranule);
+    const uint32_t span = (uint32_t)std::min<size_t>(16, body / kGranule / 8 + 1);
+    const size_t gap = jitter ? (size_t)((((c->slab_seq.fetch_add(1u, std::memory_order_relaxed) + 1u) * 2654435761u) >> 8) % span) * kGranule : 0;
+    const size_t need = body + gap;
     if (use_slabs && need <= kSlab / 4) {   // (slab sizes grow 64 MiB, 256 MiB, 1 GiB, 1 GiB ...: small sessions stay small)
       std::lock_guard<std::mutex> g(c->slab_mu);
       ClipSlab* sl = nullptr;
@@ -589,7 +597,7 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
         sl = c->slabs.back().get();
       }
       s.slab = sl;
-      s.base = sl->mem + sl->used;
+      s.base = sl->mem + sl->used + gap;
       sl->used += need;
       sl->live++;
     } else {
