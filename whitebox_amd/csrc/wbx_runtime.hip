@@ -568,7 +568,7 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
     return fail(c, WBX_ERR_INVALID, "interleaved device buffer must be 16-byte aligned");
   (void)hipSetDevice(c->cfg.device);
   s = ClipSlot{};
-  const size_t stride = align_up((frames + kPad) * eb, 256);
+  const size_t stride = align_up((frames + kPad) * eb, 256);   // (varying the distance between a clip's channel rows: no effect)
   {
     static const bool use_slabs = !(std::getenv("WBX_CLIP_ARENA") && std::getenv("WBX_CLIP_ARENA")[0] == '0');   // A/B aid
     constexpr size_t kSlab = (size_t)1 << 30, kGranule = (size_t)64 << 10;   // (8-GiB slabs, 2-MiB granules: no difference)
