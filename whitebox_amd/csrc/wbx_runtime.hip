@@ -591,16 +591,22 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
         if (!fresh) return WBX_ERR_OOM;
         const size_t grown = c->slabs.size() >= 2 ? kSlab : ((size_t)64 << 20) << (2 * c->slabs.size());
         const size_t sz = std::max(grown, need);
-        WBX_HIP(c, hipMalloc((void**)&fresh->mem, sz));
-        fresh->size = sz;
-        c->slabs.push_back(std::move(fresh));
-        sl = c->slabs.back().get();
+        if (hipMalloc((void**)&fresh->mem, sz) == hipSuccess) {
+          fresh->size = sz;
+          c->slabs.push_back(std::move(fresh));
+          sl = c->slabs.back().get();
+        } else {
+          (void)hipGetLastError();   // a device too full for another slab: this clip gets an allocation of its own below
+        }
       }
-      s.slab = sl;
-      s.base = sl->mem + sl->used + gap;
-      sl->used += need;
-      sl->live++;
-    } else {
+      if (sl) {
+        s.slab = sl;
+        s.base = sl->mem + sl->used + gap;
+        sl->used += need;
+        sl->live++;
+      }
+    }
+    if (!s.slab) {
       WBX_HIP(c, hipMalloc(&s.alloc, stride * channels));
       s.base = s.alloc;
     }
