@@ -1346,3 +1346,29 @@ def test_clip_storage_slabs_grow_and_are_reused():
     for ch in range(2):
         assert np.array_equal(ctx.clip_download(9, ch, len(big[ch]), np.int16), big[ch])
     ctx.close()
+
+
+@pytest.mark.parametrize("kw,block,expect", [
+    (dict(), 512, "wbx::mix_kernel<4, true, 3, 0, 1, 1, 1, 256>"),                              # fp32 unity, one clip per track
+    (dict(src_rate=44100), 512, "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1, 256>"),                # fp32 resampled, one clip per track
+    (dict(src_rate=44100, seek=True), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),     # ... tracks cut into clips
+    (dict(fmt="i16"), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),                     # integer PCM at the session rate
+    (dict(fmt="i16", src_rate=44100), 512, "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 128>"),     # 16-bit only, resampled: the 16-bit family
+    (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"),     # resampled 24-bit: everything
+    (dict(src_rate=96000), 512, "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"),                # per-frame taps: everything
+    (dict(src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 0, 2, 1, 1, 256>"),                # 256-frame blocks, one clip per track
+    (dict(src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>"),      # ... cut: one wave = one block
+    (dict(fmt="i16", seek=True), 1024, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 256>"),         # 1024-frame blocks
+])
+def test_instance_selection(kw, block, expect):
+    """Which mix_kernel instance a session takes (wbx_runtime.hip: mix_family, mix_two_channels_per_lane, launch_mix) — and
+    that it renders the session like the oracle."""
+    spec = synth.make_session("sel", 40, n_blocks=8, block=block, seed=0x5E1EC7, **kw)
+    om, opk, _, _, _ = run_oracle(spec, 8)
+    eng = build_engine(spec, max_blocks=8)
+    eng.play()
+    eng.render(8)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert eng.ctx.kernel_name() == expect
+    assert np.array_equal(bits(m), bits(om)) and np.array_equal(pk, opk[:, :, :spec.channels])
+    eng.close()
