@@ -1359,6 +1359,8 @@ def test_clip_storage_slabs_grow_and_are_reused():
     (dict(src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 0, 2, 1, 1, 256>"),                # 256-frame blocks, one clip per track
     (dict(src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>"),      # ... cut: one wave = one block
     (dict(fmt="i16", seek=True), 1024, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 256>"),         # 1024-frame blocks
+    (dict(fmt="i16", src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 64>"),    # the 16-bit family at 256 ...
+    (dict(fmt="i16", src_rate=44100, seek=True), 1024, "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 256>"),  # ... and 1024 frames
 ])
 def test_instance_selection(kw, block, expect):
     """Which mix_kernel instance a session takes (wbx_runtime.hip: mix_family, mix_two_channels_per_lane, launch_mix) — and

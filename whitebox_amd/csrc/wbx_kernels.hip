@@ -1841,9 +1841,12 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   const bool stride_rows = family != 0;   // (the short-block instances: everything or the lean fp32 family)
-  // variant >= 1000, stereo 256-frame blocks (family 0): one wave = one block with both channels of a frame in a lane
-  if (variant >= 1000 && family == 0 && a.channels == 2u && S4 == 64u) {
-    WBX_MIX(2, true, 3, 0, 1, 1, 2, 64, grid, dim3(64))
+  // variant >= 1000, stereo 256-frame blocks (families 0 and 2): one wave = one block with both channels of a frame in a lane
+  if (variant >= 1000 && family != 1 && a.channels == 2u && S4 == 64u) {
+    if (family == 2)
+      WBX_MIX(2, true, 3, 2, 1, 1, 2, 64, grid, dim3(64))
+    else
+      WBX_MIX(2, true, 3, 0, 1, 1, 2, 64, grid, dim3(64))
     return name;
   }
   if (!full) {
@@ -1885,6 +1888,8 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   if (family == 2) {   // all-16-bit sessions at speeds up to 0.999 or 1: the lean 16-bit family
     if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
       WBX_MIX(2, true, 3, 2, 1, 1, 2, 128, grid, dim3(128))
+    else if (variant >= 1000 && a.channels == 2u && S4 == 256u)
+      WBX_MIX(2, true, 3, 2, 1, 1, 2, 256, dim3(n_blocks, a.n_groups, 1), dim3(256))
     else
       WBX_MIX(2, true, 4, 2, 1, 1, 1, 256, grid, block)
     return name;

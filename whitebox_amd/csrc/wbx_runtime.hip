@@ -231,12 +231,12 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
   const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
   bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
-  // (256-frame stereo blocks: the one-wave instance with both channels per lane, lean fp32 family only)
-  if (!full && c->cfg.channels == 2u && S4 == 64u && mix_family(c) == 0 && mix_two_channels_per_lane(c)) full = true;
+  // (256-frame stereo blocks: the one-wave instances with both channels per lane, the lean families only)
+  if (!full && c->cfg.channels == 2u && S4 == 64u && mix_family(c) != 1 && mix_two_channels_per_lane(c)) full = true;
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
   if (!full || c->force_g) return 0u;
-  if (mix_family(c) == 2) return (lanes % 256u == 0u) ? 3u : 0u;   // sessions of 16-bit PCM only: also their resampled rows
+  if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
   if (stride_clips) return 0u;
   if (!c->has_integer_clips) return 1u;
   return window_clips ? 0u : 2u;
