@@ -21,7 +21,8 @@
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
-const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s);   // -> the instance's name
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s, hipEvent_t t0 = nullptr,
+                       hipEvent_t t1 = nullptr);   // -> the instance's name
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);

@@ -18,6 +18,7 @@
 // explicitly rounded intrinsics (__fmul_rn, __dadd_rn, ...) and the file is built with
 // -ffp-contract=off so that nothing is fused: the reference build has no FMA.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -1829,12 +1830,14 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
-const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s) {
+// t0 / t1 (optional): events that take the kernel's own start and end times (hipExtLaunchKernelGGL: the time stamps of
+// its dispatch packet — no event packets of their own in the stream)
+const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const char* name = "";   // the instance as rocprofv3 prints it (wbx_kernel_name)
 #define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, T, GRID, BLOCK)                                                  \
   {                                                                                                      \
     name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ", " #T ">";              \
-    hipLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, a);                   \
+    hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, t0, t1, 0, a);    \
   }
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
   const uint32_t S4 = a.block_frames >> 2;

@@ -288,14 +288,16 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
         WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
         drain_events(c);
       }
-      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     }
+    // the timer's two events ride on the kernel's own dispatch packet (start / end time stamps of the kernel itself): no
+    // event packets between two mixes.  WBX_TIMER_PACKETS=1: the old way, an event record either side (A/B aid)
+    static const bool packets = std::getenv("WBX_TIMER_PACKETS") != nullptr;
+    if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
     c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : mix_two_channels_per_lane(c) ? 1023
                                           : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
-               mix_family(c), ms);
-    if (timed) {
-      WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
-    }
+               mix_family(c), ms, (timed && !packets) ? c->ev[c->ev_pending][0] : nullptr,
+               (timed && !packets) ? c->ev[c->ev_pending][1] : nullptr);
+    if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
   }
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
