@@ -116,6 +116,11 @@ wbx_status wbx_clip_upload(wbx_ctx* ctx, uint32_t clip, int format, uint32_t cha
 wbx_status wbx_clip_synth(wbx_ctx* ctx, uint32_t clip, int format, uint32_t channels, uint32_t sample_rate,
                           uint64_t frames, uint64_t seed, uint32_t key_track, float amp);
 wbx_status wbx_clip_free(wbx_ctx* ctx, uint32_t clip);
+/* Clip storage in numbers.  Clip audio lives in slabs (64 MiB, 256 MiB, then 1 GiB each) carved up in order; the extent of
+ * a freed or replaced clip is reused by the next clip that fits (first fit), a slab whose last clip went is empty again;
+ * slabs go back to the driver with the context.  bytes_reserved: what the pool holds from the driver; bytes_live: what
+ * its clips occupy.  Any pointer may be NULL. */
+wbx_status wbx_clip_pool_stats(wbx_ctx* ctx, uint32_t* n_slabs, uint64_t* bytes_reserved, uint64_t* bytes_live);
 
 /* Clip ingest: interleaved frames as a decoder delivers them (sf_readf_short/int/float, drmp3_read_pcm_frames_f32)
  * -> the same planar storage.  Replaces deinterleave_samples<T> + the allocation/padding of Sample::load_file

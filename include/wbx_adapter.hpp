@@ -141,27 +141,18 @@ struct Error : std::runtime_error {
 
 struct Engine;
 
-// engine/vu_meter.h:16-46 — the UI-side half is the reference's code shape (level is exchanged with 0 by update());
-// the audio-side push_samples runs on the GPU (running per-track maxima), Engine::fetch_levels() moves them in here.
+// The audio-side half of engine/vu_meter.h (push_samples, :20-30) runs on the GPU as running per-track maxima;
+// Engine::fetch_levels() moves them in here with the reference's CAS-max.  The UI-rate decay (VUMeter::update /
+// get_value) is not part of this path: the host keeps its own meter for that and feeds it take_level().
 struct VUMeter {
   std::atomic<float> level{0.0f};
-  float current_level = 0.0f;
-  void push_level(float new_level) {   // the CAS-max tail of VUMeter::push_samples, vu_meter.h:26-29
-    float old_level = level.load(std::memory_order_relaxed);
-    while (old_level < new_level &&
-           !level.compare_exchange_weak(old_level, new_level, std::memory_order_release, std::memory_order_relaxed))
-      ;
-  }
-  void update(float frame_rate, float speed) {   // vu_meter.h:32-40
-    float new_level = level.exchange(0.0f, std::memory_order_release);
-    if (new_level > current_level) {
-      current_level = new_level;
-    } else {
-      float update_rate = 1.0f - std::exp(-1.0f / (frame_rate * speed));
-      current_level += (new_level - current_level) * update_rate;
+  void push_level(float peak) {   // the CAS-max tail of VUMeter::push_samples, vu_meter.h:26-29
+    float seen = level.load(std::memory_order_relaxed);
+    while (seen < peak && !level.compare_exchange_weak(seen, peak, std::memory_order_release, std::memory_order_relaxed)) {
     }
   }
-  float get_value() const { return current_level; }
+  // the maximum since the last call; resets it (what the host's own VUMeter::update starts from)
+  float take_level() { return level.exchange(0.0f, std::memory_order_acq_rel); }
 };
 
 struct Track {   // track.h:110-139
@@ -278,7 +269,7 @@ struct Engine {
       process_status.store(st, std::memory_order_release);
     }
   }
-  // UI thread, once per frame before Track::level_meter[c].update(): the running per-track maxima the GPU kept since
+  // UI thread, once per frame before the host's meters decay (Track::level_meter[c].take_level()): the running per-track maxima the GPU kept since
   // the last call (VUMeter::push_samples, vu_meter.h:20-30) go into the tracks' meters
   void fetch_levels() {
     if (tracks.empty()) return;

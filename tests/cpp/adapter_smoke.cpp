@@ -68,11 +68,10 @@ int main() {
   if (g_engine.process_status.load() != WBX_OK) return 3;
   wbo_engine_destroy(o);
 
-  // meters: Track::level_meter[c] as the UI reads them (vu_meter.h:32-46)
+  // meters: the maxima since the last read, as the host's own VUMeter::update takes them (vu_meter.h:32-33)
   g_engine.fetch_levels();
-  for (auto& t : g_engine.tracks)
-    for (uint32_t c = 0; c < C; c++) t->level_meter[c].update(60.0f, 0.1f);
-  if (!(g_engine.tracks[0]->level_meter[0].get_value() > 0.0f) || !(g_engine.tracks[1]->level_meter[1].get_value() > 0.0f)) return 4;
+  if (!(g_engine.tracks[0]->level_meter[0].take_level() > 0.0f) || !(g_engine.tracks[1]->level_meter[1].take_level() > 0.0f)) return 4;
+  if (g_engine.tracks[0]->level_meter[0].take_level() != 0.0f) return 4;   // (read and reset)
   // the effect slot exists and stays empty
   wbx_plugin fx{nullptr, nullptr};
   if (g_engine.add_plugin_to_track(t0, &fx) != nullptr || t0->plugin_instance != nullptr) return 5;

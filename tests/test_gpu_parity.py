@@ -1215,6 +1215,51 @@ def test_set_audio_channel_config_on_a_live_engine():
     eng.close()
 
 
+@pytest.mark.parametrize("fmt,rates", [("f32", (44100, 48000, 96000)), ("i16", (44100, 48000, 44100)), ("i24", (44100, 48000, 22050))])
+def test_rate_change_in_mid_play(fmt, rates):
+    """set_audio_channel_config with a new device rate WITHOUT a stop: clips that are playing keep the playback speed their
+    sampler was reset with (Sampler::reset_state ran at the old rate, sampler.h:18-27), clips that start afterwards take
+    the new one — for a few blocks the session holds rows of both rates (e.g. 16-bit 44.1 kHz clips in a session switched
+    from 48 kHz to 44.1 kHz: resampled rows next to unity rows).  The instance / chunk-mode flags must cover both."""
+    n_tracks, K = 36, 3
+    beat_frames = 48000 * 60.0 / 120.0
+    total = 5 * K * 512
+    samples, clips, vols, pans = [], [], [], []
+    for t in range(n_tracks):
+        samples.append(synth.SampleSpec(seed_track=t, channels=2, rate=44100, frames=int(total * 2.3) + 400, fmt=fmt,
+                                        amp=0.02 if fmt == "f32" else 1.0))
+        v, p = synth.track_params(0x4A7E, t)
+        vols.append(float(v) - (0.0 if fmt == "f32" else 30.0))
+        pans.append(float(p))
+        L = 2.3 * 512
+        pos = -((t * 37) % 101) / 101.0 * L
+        while pos < total:
+            a = max(pos, 0.0)
+            clips.append(synth.ClipSpec(t, a / beat_frames, (pos + L) / beat_frames, start_offset=a * 0.9, sample=t))
+            pos += L
+    spec = synth.SessionSpec(name="ratechg", n_tracks=n_tracks, seed=0x4A7E, samples=samples, clips=clips, volumes_db=vols,
+                             pans=pans, mutes=[False] * n_tracks, sample_rate=rates[0])
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    eng = build_engine(spec, max_blocks=K, group_size=n_tracks)
+    eng.play()
+    for step, rate in enumerate((rates[0], rates[1], rates[1], rates[2], rates[2])):
+        e.e.contents.sample_rate = rate
+        eng.set_audio_channel_config(0, 2, 512, rate)
+        eng.render(K)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        rows = []
+        for b in range(K):
+            om, _ = e.process()
+            rows += oracle_rows(e, b)
+            assert np.array_equal(pk[b], e.peaks()[:, :2]), (step, b)
+            assert np.array_equal(bits(m[b]), bits(om)), (step, b, rms(m[b], om))
+        assert plan_rows(eng.fetch_plan()) == rows, step
+    e.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("alt", ["0", "1"])
 def test_alternating_mix_streams_keep_every_render_intact(monkeypatch, alt):
     """WBX_MIX_ALT=1: batch renders of layer 2 alternate between two streams so that consecutive mixes overlap; peaks

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""tools/ab.py — A/B and sweep runs of bench.py inside ONE gpurun call (same box, same thermal state).
+
+    python tools/ab.py PRESET [-r REPEATS] [-o OUT.jsonl]
+    python tools/ab.py run "<label>;<ENV=1 ENV2=2>;<bench args>" ...      ad-hoc cases
+
+Every case is one `python bench.py <args> --no-cpu-baseline --no-configs` (+ `--latency-blocks 0` unless the case
+measures the callback path) with the given environment; cases are interleaved REPEATS times (A B A B, not A A B B) so
+that drift of the box hits both sides.  One summary line per run; `-o` appends the raw bench lines (with the label).
+
+The presets are the experiments DESIGN-experiments.md refers to (one shell script each until round 3).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STD = "--steps 20 --warmup 3 --ramp-steps 40"
+
+
+def case(label, env="", args="", lat=False):
+    return {"label": label, "env": env, "args": args, "lat": lat}
+
+
+def presets(other_lib=None):
+    P = {}
+    # round 3: the reference's summation order at full width — one workgroup walks all N rows of its block in track order;
+    # parallelism comes from the K blocks of a launch instead of from track groups
+    P["exact"] = [case(f"{w} exact K={k}", "", f"--workload {w} --group-size 4096 --blocks {k} --steps {max(4, 5120 // k)} "
+                       f"--warmup 2 --ramp-steps {max(4, 10240 // k)}")
+                  for w in ("c3", "c4") for k in (256, 512, 768, 1024, 1536, 2048)] + \
+                 [case(f"{w} groups128 K=256", "", f"--workload {w} {STD}") for w in ("c3", "c4")]
+    P["exact_variants"] = [case(f"{w} exact K={k} variant={v}", f"WBX_MIX_VARIANT={v}",
+                                f"--workload {w} --group-size 4096 --blocks {k} --steps {max(4, 5120 // k)} --warmup 2 "
+                                f"--ramp-steps {max(4, 10240 // k)}")
+                           for w in ("c3", "c4") for k in (1024, 2048) for v in (24, 43, 82, 1000)]
+    P["variants"] = [case(f"c3 variant={v}", f"WBX_MIX_VARIANT={v}", STD) for v in (24, 43, 82)]
+    P["c2_groups"] = [case(f"c2 group={g} variant={v}", f"WBX_MIX_VARIANT={v}",
+                           f"--workload c2 --group-size {g} --steps 20 --warmup 3 --ramp-steps 60")
+                      for g in (128, 64, 32) for v in (43, 24)]
+    P["alt"] = [case(f"{w} alt={a}", f"WBX_MIX_ALT={a}", f"--workload {w} {STD}") for w in ("c3", "c4") for a in (1, 0)]
+    P["arena"] = [case(f"{w} {'per-clip allocations' if a else 'slabs'}", "WBX_CLIP_ARENA=0" if a else "",
+                       f"--workload {w} {STD}") for w in ("c3", "c4") for a in (0, 1)]
+    P["blocks"] = [case(f"F={f} {w} L={l} {v or 'default'}", v,
+                        f"--workload {w} --block-frames {f} {'--clip-blocks %s' % l if l else ''} {STD}")
+                   for f in (256, 1024) for w in ("c3", "i16") for l in (0, 5.3) for v in ("", "WBX_NO_CL2=1")]
+    P["blocks_per_step"] = [case(f"K={k}", "", f"--blocks {k} --steps {5120 // k} --warmup 3 --ramp-steps {10240 // k}")
+                            for k in (256, 512, 1024)]
+    P["cl2"] = [case(f"{w} {'one channel/wave' if v else 'default'}", "WBX_NO_CL2=1" if v else "", f"--workload {w} {STD}")
+                for w in ("c3", "c4", "i16", "mixfmt") for v in (0, 1)]
+    P["lanes"] = [case(f"lanes={n} L={l}", f"WBX_PLAN_LANES={n}", f"--clip-blocks {l} --steps 10 --warmup 2 --ramp-steps 30")
+                  for n in (64, 32, 16, 8) for l in (5.3, 20)]
+    P["latency"] = [case(f"masked={m} no_uniform={nu}", f"WBX_MASKED_ROWS={m}" + (" WBX_NO_UNIFORM=1" if nu else ""),
+                         "--steps 2 --warmup 1 --ramp-steps 2 --latency-blocks 400", lat=True)
+                    for m in (1, 0) for nu in (0, 1)]
+    P["latency_groups"] = [case(f"group={g}", "", f"--group-size {g} --steps 2 --warmup 1 --ramp-steps 2 --latency-blocks 400",
+                                lat=True) for g in (128, 64, 32, 16, 8)]
+    P["lean16"] = [case(f"i16r L={l} {v or 'default'}", v, f"--workload i16r {'--clip-blocks %s' % l if l else ''} {STD}")
+                   for l in (0, 5.3) for v in ("", "WBX_NO_CL2=1", "WBX_NO_LEAN16=1")]
+    P["masked"] = [case(f"{w} L={l} {'pre-render' if m else 'hot loop'}", "WBX_MASKED_ROWS=0" if m else "",
+                        f"--workload {w} {'--clip-blocks %s' % l if l else ''} {STD}")
+                   for w in ("c3", "i16") for l in (5.3, 20, 0) for m in (0, 1)]
+    P["planprio"] = [case(f"L={l} plan_prio={p}", f"WBX_PLAN_PRIO={p}", f"--clip-blocks {l} --steps 10 --warmup 2 --ramp-steps 30")
+                     for l in (5.3, 20) for p in ("hi", "lo")]
+    P["ramp"] = [case(f"ramp={r}", "", f"--steps 20 --warmup 3 --ramp-steps {r}") for r in (40, 150, 400)]
+    P["timer"] = [case(f"{w} {v or 'default (dispatch packet)'}", v, f"--workload {w} {STD}")
+                  for w in ("c2", "c3") for v in ("", "WBX_TIMER_PACKETS=1", "WBX_KERNEL_TIMER=0")]
+    P["uniform"] = [case(f"{w} no_uniform={nu}", "WBX_NO_UNIFORM=1" if nu else "", f"--workload {w} {STD}")
+                    for w in ("c3", "i16r") for nu in (0, 1)]
+    P["formats"] = [case(w, "", f"--workload {w} {STD}") for w in ("i16r", "i24r", "mixr", "mixfmt", "i16", "d96")]
+    P["cuts"] = [case(f"{w} L={l}", "", f"--workload {w} {'--clip-blocks %s' % l if l else ''} {STD}")
+                 for w in ("c3", "i16", "i16r", "i24r", "mixr") for l in (0, 5.3, 20)]
+    if other_lib:   # head-to-head of two builds of libwbx.so
+        P["lib"] = [case(f"{w} {'other' if o else 'this'}", f"WBX_LIB={other_lib}" if o else "", f"--workload {w} {STD}")
+                    for w in ("c3", "c4", "i16r", "c2") for o in (0, 1)]
+    return P
+
+
+def run_case(c, out):
+    env = dict(os.environ)
+    for kv in c["env"].split():
+        k, v = kv.split("=", 1)
+        env[k] = v
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + c["args"].split() + ["--no-cpu-baseline", "--no-configs"]
+    if not c["lat"]:
+        cmd += ["--latency-blocks", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print(f"{c['label']:44s} FAILED rc={p.returncode} {p.stderr[-400:]!r}", flush=True)
+        return
+    d = json.loads(lines[-1])
+    r = d["roofline"]
+    msg = (f"{c['label']:44s} {d['value']:.4g} frames/s  step {d['ms_per_step']:.4f} ms  mix {r['kernel_ms_avg']:.4f} ms  "
+           f"frac {r['frac']:.3f}  frac_step {r.get('frac_step', 0.0):.3f}  {r['kernel']}")
+    if c["lat"] and d.get("latency_mode"):
+        msg += f"  latency {d['latency_mode']['ms_per_block']:.4f} ms/block"
+    if d.get("verify"):
+        msg += f"  verify rms {d['verify'].get('rms'):.2e}"
+    print(msg, flush=True)
+    if out:
+        d["ab_label"] = c["label"]
+        d["ab_env"] = c["env"]
+        out.write(json.dumps(d) + "\n")
+        out.flush()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("preset")
+    ap.add_argument("cases", nargs="*")
+    ap.add_argument("-r", "--repeats", type=int, default=2)
+    ap.add_argument("-o", "--out", default=None)
+    ap.add_argument("--other-lib", default=None)
+    a = ap.parse_args()
+    if a.preset == "run":
+        cs = []
+        for spec in a.cases:
+            label, env, args = (spec.split(";") + ["", ""])[:3]
+            cs.append(case(label.strip(), env.strip(), args.strip(), lat="--latency-blocks" in args))
+    else:
+        P = presets(a.other_lib)
+        if a.preset not in P:
+            raise SystemExit(f"unknown preset {a.preset}; have: {' '.join(sorted(P))} run")
+        cs = P[a.preset]
+    out = open(a.out, "a") if a.out else None
+    for _ in range(a.repeats):
+        for c in cs:
+            run_case(c, out)
+
+
+if __name__ == "__main__":
+    main()

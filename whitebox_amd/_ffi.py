@@ -66,6 +66,7 @@ SYMBOLS = {
     "wbx_clip_upload": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _pp]),
     "wbx_clip_synth": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, C.c_uint64, _u32, _f]),
     "wbx_clip_free": (C.c_int, [_vp, _u32]),
+    "wbx_clip_pool_stats": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "wbx_clip_upload_interleaved": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _vp]),
     "wbx_clip_ingest_device": (C.c_int, [_vp, _u32, C.c_int, _u32, _u32, C.c_uint64, _vp]),
     "wbx_clip_download": (C.c_int, [_vp, _u32, _u32, _vp]),

@@ -28,6 +28,7 @@ void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
+void launch_levels_take(uint32_t* levels, uint32_t* dst, uint32_t n, hipStream_t s);
 void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
                          hipStream_t s);
 void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s);
@@ -50,13 +51,18 @@ constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run pla
 // driver with the context.  Clips above 256 MiB get an allocation of their own.
 struct ClipSlab {
   char* mem = nullptr;
-  size_t size = 0, used = 0;
-  uint32_t live = 0;        // clips inside
+  size_t size = 0, used = 0;   // [0, used): handed out in order (bump); [used, size): untouched
+  uint32_t live = 0;           // clips inside
+  size_t live_bytes = 0;
+  // extents below `used` that released clips gave back, sorted by offset, neighbours merged: first-fit for the next clip
+  // that fits (replacing a clip again and again, or add / delete cycles beside a long-lived clip, stay inside the slab)
+  std::vector<std::pair<size_t, size_t>> holes;   // (offset, bytes)
 };
 
 struct ClipSlot {
   void* alloc = nullptr;    // an allocation of its own (hipFree), or
   ClipSlab* slab = nullptr; // the slab it lives in
+  size_t slab_off = 0, slab_len = 0;   // ... and its extent there (the gap in front of the clip included)
   void* base = nullptr;     // first channel row; all channels in one piece
   size_t stride = 0;        // bytes between channel rows
   DSample d{};

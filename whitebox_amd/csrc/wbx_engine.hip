@@ -45,8 +45,16 @@ struct wbx_engine {
 
   DevBuf<DClip> d_clips;
   DevBuf<uint32_t> d_clip_first;
+  // [max_tracks], allocated once by the first render.  Invariant: the slots from state_tracks on are all-zero (a track
+  // added later starts from cleared state without any device work: no allocation, no copy, no synchronisation on the
+  // audio thread).  permute_tracks_locked keeps it.
   DevBuf<DTrackState> d_state;
-  DevBuf<float> d_levels;
+  DevBuf<float> d_levels;               // [max_tracks][2] running maxima, same invariant
+  // wbx_engine_levels (UI thread): the take kernel runs on a stream of its own into this pinned block; the editor lock
+  // is held only while the take is ENQUEUED behind the renders in flight, never across the wait for it
+  hipStream_t levels_stream = nullptr;
+  hipEvent_t levels_ev = nullptr;
+  uint32_t* h_levels = nullptr;         // [max_tracks][2]
 };
 
 namespace {
@@ -95,6 +103,12 @@ extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out)
   e->hs.dst_rate = cfg->sample_rate;
   c->owner = e;
   c->sample_in_use = sample_in_use_cb;
+  if (hipStreamCreateWithFlags(&e->levels_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->levels_ev, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_levels, (size_t)cfg->max_tracks * 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    wbx_engine_destroy(e);
+    return WBX_ERR_OOM;
+  }
   *out = e;
   return WBX_OK;
 }
@@ -106,6 +120,12 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
     (void)hipStreamSynchronize(e->ctx->plan_stream);
     (void)sync_main(e->ctx);
   }
+  if (e->levels_stream) {
+    (void)hipStreamSynchronize(e->levels_stream);
+    (void)hipStreamDestroy(e->levels_stream);
+  }
+  if (e->levels_ev) (void)hipEventDestroy(e->levels_ev);
+  if (e->h_levels) (void)hipHostFree(e->h_levels);
   e->d_clips.release();
   e->d_clip_first.release();
   e->d_state.release();
@@ -170,12 +190,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   }
   if (e->d_levels.p) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
   // the destination rate enters every clip's playback speed: which clips the hot loop streams directly is re-derived
-  e->hs.dst_rate = sample_rate;
-  e->hs.any_slow_clip = e->hs.any_window_clip = e->hs.any_stride_clip = e->hs.any_crawl_clip = false;
-  e->hs.any_win16_clip = e->hs.any_other_window_clip = false;
-  e->hs.window_speed = 0.0;
-  for (auto& t : e->hs.tracks)
-    for (auto& hc : t->clips) e->hs.note_clip(hc.d);
+  e->hs.set_dst_rate_locked(sample_rate);
   return WBX_OK;
 }
 
@@ -668,18 +683,17 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, e->first.data(), e->first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
 
-  // -- per-track device state for tracks added since the last render
+  // -- per-track device state: allocated once at max_tracks capacity; tracks added since the last render find their
+  //    slots cleared already (wbx_engine::d_state)
   if (e->state_tracks < N) {
-    DevBuf<DTrackState> grown;
-    WBX_EHIP(e, grown.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
-    WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-    WBX_EHIP(e, sync_main(c));
-    WBX_EHIP(e, hipMemset(grown.p, 0, grown.cap * sizeof(DTrackState)));
-    if (e->state_tracks) WBX_EHIP(e, hipMemcpy(grown.p, e->d_state.p, e->state_tracks * sizeof(DTrackState), hipMemcpyDeviceToDevice));
-    e->d_state.release();
-    e->d_state = grown;
-    WBX_EHIP(e, e->d_levels.ensure((size_t)c->cfg.max_tracks * 2));
-    if (e->state_tracks == 0) WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    if (e->d_state.cap < N) {
+      WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
+      WBX_EHIP(e, sync_main(c));
+      WBX_EHIP(e, e->d_state.ensure(std::max<size_t>(N, c->cfg.max_tracks)));
+      WBX_EHIP(e, e->d_levels.ensure((size_t)c->cfg.max_tracks * 2));
+      WBX_EHIP(e, hipMemset(e->d_state.p, 0, e->d_state.cap * sizeof(DTrackState)));
+      WBX_EHIP(e, hipMemset(e->d_levels.p, 0, e->d_levels.cap * sizeof(float)));
+    }
     e->state_tracks = N;
   }
 
@@ -873,17 +887,33 @@ extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, doub
   return WBX_OK;
 }
 
+// VUMeter::level of every track: the maximum since the last call, reset by the call (VUMeter::update's
+// `level.exchange(0.0f)`, vu_meter.h:33).  UI thread.  Tracks that have not been through a render yet (just added, or
+// the audio callback is not running) read 0.  The reference's meters are lock-free atomics; here the editor lock is held
+// only while the take is enqueued behind the renders issued so far (two stream calls), never across the device wait —
+// the audio thread's next block is not held up by a meter read.
 extern "C" wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks) {
   if (!e || !levels) return WBX_ERR_INVALID;
-  LockGuard g(e->hs.editor_lock);
-  if (n_tracks > e->state_tracks) return WBX_ERR_INVALID;
   wbx_ctx* c = e->ctx;
-  const size_t n = (size_t)n_tracks * c->cfg.channels;
-  WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
-  WBX_EHIP(e, join_alt(c));   // a mix on the alternate stream may still be raising the levels
-  WBX_EHIP(e, hipMemcpyAsync(levels, e->d_levels.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  WBX_EHIP(e, hipMemsetAsync(e->d_levels.p, 0, n * sizeof(float), c->stream));   // VUMeter::update exchanges with 0 (vu_meter.h:33)
-  WBX_EHIP(e, sync_main(c));
+  (void)hipSetDevice(c->cfg.device);
+  uint32_t have = 0, C = 0;
+  {
+    LockGuard g(e->hs.editor_lock);
+    C = c->cfg.channels;
+    have = std::min(n_tracks, e->state_tracks);
+    if (have) {
+      // every render issued before this call is covered: the take is ordered after the mixes in flight
+      WBX_EHIP(e, join_alt(c));
+      WBX_EHIP(e, hipEventRecord(e->levels_ev, c->stream));
+      WBX_EHIP(e, hipStreamWaitEvent(e->levels_stream, e->levels_ev, 0));
+      launch_levels_take(reinterpret_cast<uint32_t*>(e->d_levels.p), e->h_levels, have * C, e->levels_stream);
+    }
+  }
+  if (have) {
+    WBX_EHIP(e, hipStreamSynchronize(e->levels_stream));
+    std::memcpy(levels, e->h_levels, (size_t)have * C * sizeof(float));
+  }
+  if (n_tracks > have) std::memset(levels + (size_t)have * C, 0, (size_t)(n_tracks - have) * C * sizeof(float));
   return WBX_OK;
 }
 

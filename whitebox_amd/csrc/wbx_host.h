@@ -146,6 +146,7 @@ struct HostSession {
   // the one playback speed of all resampled clips seen so far (44.1 kHz clips in a 48 kHz session ...), for the mix
   // kernel's hoisted position products: 0 = none yet, < 0 = several / outside the narrow-window range
   double window_speed = 0.0;
+  bool rate_flags_sticky = false;       // the flags above still cover the row kinds of an earlier destination rate
   size_t total_clips = 0;
   size_t cut_tracks = 0;                // tracks that hold more than one clip (clip boundaries inside blocks are the rule there)
   uint32_t next_clip_uid = 0;
@@ -234,6 +235,37 @@ struct HostSession {
     if ((ps > 0.999 || smp.format != FMT_F32) && ps != 1.0) any_stride_clip = true;
     // BlockWalker::stream / plan_steady_run leave the shared-template path when (count - offset) >= speed * 2^32
     if (!(ps * 4294967040.0 > (double)smp.count)) any_crawl_clip = true;
+  }
+
+  void rederive_clip_flags() {
+    any_slow_clip = any_window_clip = any_stride_clip = any_crawl_clip = false;
+    any_win16_clip = any_other_window_clip = false;
+    window_speed = 0.0;
+    for (auto& t : tracks)
+      for (auto& hc : t->clips) note_clip(hc.d);
+  }
+
+  // A new destination rate (Engine::set_audio_channel_config on a live engine).  The flags above are what the mix
+  // kernel's instance and chunk modes are chosen from — a promise about every row the sequencer can emit.  Clips that are
+  // PLAYING keep the playback speed their sampler was reset with (Sampler::reset_state ran with the old rate, sampler.h:
+  // 18-27; DTrackState holds it), so while the transport runs the promise must cover the old rate's row kinds as well:
+  // the old flags stay OR-ed in and no single resampling ratio is assumed, until a stop re-triggers every track.
+  void set_dst_rate_locked(uint32_t rate) {
+    const bool changed = rate != dst_rate;
+    const bool o_slow = any_slow_clip, o_win = any_window_clip, o_stride = any_stride_clip, o_crawl = any_crawl_clip;
+    const bool o_w16 = any_win16_clip, o_other = any_other_window_clip;
+    dst_rate = rate;
+    rederive_clip_flags();
+    if (changed && (playing.load(std::memory_order_relaxed) || rate_flags_sticky)) {
+      any_slow_clip |= o_slow;
+      any_window_clip |= o_win;
+      any_stride_clip |= o_stride;
+      any_crawl_clip |= o_crawl;
+      any_win16_clip |= o_w16;
+      any_other_window_clip |= o_other;
+      if (any_window_clip) window_speed = -1.0;
+      rate_flags_sticky = true;
+    }
   }
 
   // Track::find_next_clip over the host copy (track.cpp:182-213)
@@ -387,6 +419,10 @@ struct HostSession {
     playhead = playhead_start;
     for (auto& t : tracks) t->patch.flags |= PATCH_STOP;
     patches_pending = true;
+    if (rate_flags_sticky) {   // every sampler restarts at the current rate from here on (set_dst_rate_locked)
+      rate_flags_sticky = false;
+      rederive_clip_flags();
+    }
   }
 
   bool sample_referenced(uint32_t sample) const {

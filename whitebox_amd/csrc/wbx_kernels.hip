@@ -534,10 +534,12 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   constexpr uint32_t kPS = (CL == 2 && kWaves == 4u) ? 8u : 4u;   // peak slots per record: one per (wave, channel of the wave)
   __shared__ uint32_t s_pk[SB * kRecs * kPS];   // FULL: one slot per (record, wave[, channel]), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[kPS];         // FULL: sub-block * C + channel a slot holds (unused slots: none)
-  __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? kSt : 1];   // EXP: the chunk's plan rows
+  __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? 2 * kSt : 1];   // EXP: the plan rows of this chunk and (prefetched) of the next
+  __shared__ uint32_t s_ord[EXP ? kSt : 1];       // EXP: the routing-order entries of the next chunk (prefetched)
   __shared__ uint16_t s_map[EXP ? 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
   __shared__ uint16_t s_off[EXP ? kSt + 1 : 1];   // EXP: local track -> its first staged row
   __shared__ uint32_t s_wpairs[3];                // EXP: pairs in waves 0 and 1, staged rows of the chunk
+  __shared__ int s_shape;                         // the row shapes the chunk holds (OR over its records)
 
   // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
   // of a group read adjacent pieces of the same clip rows (they share the cache line at the seam), so give every
@@ -1363,26 +1365,57 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     }
   };
 
-  for (uint32_t chunk0 = 0; chunk0 < grp.count; chunk0 += kSt) {
-    const uint32_t cn = (grp.count - chunk0) < kSt ? (grp.count - chunk0) : kSt;   // tracks of this chunk
-    uint32_t cn2 = cn;                                                                  // staged rows of this chunk
+  // A group is walked in chunks of up to kSt tracks.  A LONG walk — one workgroup adding ALL tracks of its block in track
+  // order, the reference's own summation order (engine.cpp:1600-1617) — passes dozens of chunk seams, each a phase
+  // without clip loads in flight (rows -> templates -> LDS, then the pipeline fills again).  Three things keep the seams
+  // short and apart: the rows and routing entries of the NEXT chunk are fetched while this one is staged (a seam then
+  // costs one round trip for the templates, not three dependent ones), the template loads of a chunk are all issued
+  // before the first is waited for, and the first chunk of a long walk is shortened by a per-workgroup phase so that
+  // the workgroups sharing a CU do not reach their seams together.
+  uint32_t first_cn = kSt;
+  if (EXP && a.stagger && grp.count > 2u * kSt) first_cn = kSt - (kSt / 4u) * (((blockIdx.x >> 8) ^ (blockIdx.x >> 3)) & 3u);
+  uint32_t chunk0 = 0u;
+  for (uint32_t chunk_i = 0u; chunk0 < grp.count; chunk_i++) {
+    const uint32_t left = grp.count - chunk0, want = chunk_i == 0u ? first_cn : kSt;
+    const uint32_t cn = left < want ? left : want;   // tracks of this chunk
+    uint32_t cn2 = cn;                                // staged rows of this chunk
     __syncthreads();
+    if (tid == 0u) s_shape = 0;
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
     // A record = the template its 16-B plan row points at, with the row's position patched in when the template
     // is shared by a run of blocks; silent rows become all-zero records (kind 0).
-    if (EXP && a.masked_rows) {
-      // Rows may be ROW_PAIRs (a clip boundary inside the block: two single-segment templates).  Pass 1, one lane per
-      // track: fetch the 16-B plan row, count a pair as two staged rows, wave-ballot prefix sum -> the track's first
-      // staged row.  Pass 2 copies the records as before, through the staged-row -> (track, record) map.
+    if constexpr (EXP) {
+      // Rows may be ROW_PAIRs (a clip boundary inside the block: two single-segment templates; only with
+      // MixArgs::masked_rows).  Pass 1, one lane per track: the 16-B plan row (fetched by the previous chunk's staging,
+      // except for the first chunk), a pair counts as two staged rows, wave-ballot prefix sum -> the track's first
+      // staged row; the loads for the next chunk's rows and the routing entries of the one after it are issued here and
+      // land in LDS at the end of the staging.  Pass 2 copies the records through the staged-row -> (track, record) map.
+      DRow* rows_cur = s_rows + (chunk_i & 1u) * kSt;
+      DRow* rows_nxt = s_rows + ((chunk_i & 1u) ^ 1u) * kSt;
+      const uint32_t n0 = chunk0 + cn, nleft = grp.count - n0, ncn = nleft < kSt ? nleft : kSt;       // the next chunk
+      const uint32_t m0 = n0 + ncn, mleft = grp.count - m0, mcn = mleft < kSt ? mleft : kSt;         // the one after it
       uint32_t before = 0u;
       bool is_pair = false;
+      DRow nrow;
+      nrow.pos = 0.0;
+      nrow.tmpl = 0xFFFFFFFFu;
+      nrow.flags = ROW_SILENT;
+      uint32_t nord = 0u;
       if (tid < kSt) {
-        DRow row;
-        row.pos = 0.0;
-        row.tmpl = 0xFFFFFFFFu;
-        row.flags = ROW_SILENT;
-        if (tid < cn) row = a.rows[(size_t)bx * N + a.order[grp.first + chunk0 + tid]];
-        *reinterpret_cast<uint4*>(&s_rows[tid]) = *reinterpret_cast<const uint4*>(&row);
+        DRow row = nrow;
+        uint32_t o1 = 0u;
+        if (chunk_i == 0u) {
+          uint32_t o0 = 0u;
+          if (tid < cn) o0 = a.order[grp.first + tid];
+          if (tid < ncn) o1 = a.order[grp.first + n0 + tid];
+          if (tid < cn) row = a.rows[(size_t)bx * N + o0];
+        } else {
+          row = rows_cur[tid];
+          o1 = s_ord[tid];
+        }
+        if (tid < ncn) nrow = a.rows[(size_t)bx * N + o1];
+        if (tid < mcn) nord = a.order[grp.first + m0 + tid];
+        if (chunk_i == 0u) *reinterpret_cast<uint4*>(&rows_cur[tid]) = *reinterpret_cast<const uint4*>(&row);
         is_pair = (row.flags & (ROW_PAIR | ROW_SILENT)) == ROW_PAIR;
         const unsigned long long bal = __ballot(is_pair);
         before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -1402,23 +1435,50 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         s_wpairs[2] = total;
       }
       __syncthreads();
-      cn2 = s_wpairs[2];
-      for (uint32_t i = tid; i < kRecs * 4u; i += kT) {
-        const uint32_t rec = i >> 2, q = i & 3u;
-        uint4 w = {0u, 0u, 0u, 0u};
-        if (rec < cn2) {
-          const uint32_t mp = s_map[rec];
-          const DRow row = s_rows[mp & 0x7FFFu];
-          if (!(row.flags & ROW_SILENT)) {
-            w = reinterpret_cast<const uint4*>(a.tmpl + row.tmpl + (mp >> 15))[q];
-            if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
-              const uint2 pb = *reinterpret_cast<const uint2*>(&row.pos);
-              w.x = pb.x;
-              w.y = pb.y;
+      cn2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_wpairs[2]);
+      // the template quads of all staged rows: every load is issued before the first one is waited for (one round trip
+      // per chunk; a lane holds up to kQ quads for a moment)
+      constexpr uint32_t kQ = (kRecs * 4u + kT - 1u) / kT;
+      const uint32_t nq = (cn2 * 4u + kT - 1u) / kT;   // iterations that reach a staged row (wave-uniform)
+      uint4 wq[kQ];
+      uint32_t tq = tid;   // (opaque: the per-iteration indices below are cheap to recompute, hoisted out of the chunk loop
+      asm volatile("" : "+v"(tq));   //  they would sit in registers — spilled ones — through the whole pipeline)
+#pragma unroll
+      for (uint32_t it = 0; it < kQ; it++) {
+        wq[it] = uint4{0u, 0u, 0u, 0u};
+        if (it < nq) {
+          const uint32_t i = tq + it * kT, rec = i >> 2, q = i & 3u;
+          const bool in = rec < cn2;
+          const uint32_t mp = s_map[in ? rec : 0u];
+          const DRow row = rows_cur[mp & 0x7FFFu];
+          const bool live = in && !(row.flags & ROW_SILENT);
+          // (a lane without a live record reads template 0: the load stays unconditional, its result is dropped)
+          wq[it] = reinterpret_cast<const uint4*>(a.tmpl + (live ? row.tmpl + (mp >> 15) : 0u))[q];
+        }
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < kQ; it++) {
+        const uint32_t i = tq + it * kT, rec = i >> 2, q = i & 3u;
+        if (i < kRecs * 4u) {
+          uint4 w = {0u, 0u, 0u, 0u};
+          if (it < nq && rec < cn2) {
+            const uint32_t mp = s_map[rec];
+            const DRow row = rows_cur[mp & 0x7FFFu];
+            if (!(row.flags & ROW_SILENT)) {
+              w = wq[it];
+              if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
+                const uint2 pb = *reinterpret_cast<const uint2*>(&row.pos);
+                w.x = pb.x;
+                w.y = pb.y;
+              }
             }
           }
+          reinterpret_cast<uint4*>(s_tb)[i] = w;
         }
-        reinterpret_cast<uint4*>(s_tb)[i] = w;
+      }
+      if (tid < kSt) {   // (arrived with the templates: loads return in order)
+        *reinterpret_cast<uint4*>(&rows_nxt[tid]) = *reinterpret_cast<const uint4*>(&nrow);
+        s_ord[tid] = nord;
       }
     } else {
     for (uint32_t i = tid; i < SB * kRecs * 4u; i += kT) {
@@ -1464,13 +1524,14 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
                : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
       if ((k == KIND_WINDOW || k == KIND_WINDOW_I16) && !(s_tb[i].speed >= kNarrowSpeed)) shape |= 16;   // needs the general tap selection
     }
-    const int has_f32 = __syncthreads_or(shape & 3), has_win = __syncthreads_or(shape & 2);
-    const int has_i16 = __syncthreads_or(shape & 4), has_i32 = __syncthreads_or(shape & 8);
-    const int has_wide = __syncthreads_or(shape & 16);
+    if (shape) atomicOr(&s_shape, shape);
+    __syncthreads();
+    const int shapes = __builtin_amdgcn_readfirstlane(s_shape);
+    const int has_f32 = shapes & 3, has_win = shapes & 2, has_i16 = shapes & 4, has_i32 = shapes & 8, has_wide = shapes & 16;
     // (G instances only: sessions without such clips run the instance that does not carry these modes)
-    const int has_stride = G ? __syncthreads_or(shape & 64) : 0;    // per-frame taps
-    const int has_win16 = W16 ? __syncthreads_or(shape & 32) : 0;   // 16-bit PCM window rows
-    const int has_win32 = G ? __syncthreads_or(shape & 128) : 0;    // 24/32-bit PCM window rows
+    const int has_stride = G ? (shapes & 64) : 0;    // per-frame taps
+    const int has_win16 = W16 ? (shapes & 32) : 0;   // 16-bit PCM window rows
+    const int has_win32 = G ? (shapes & 128) : 0;    // 24/32-bit PCM window rows
     int mode;
     if (LEAN16) {
       if (has_win16)
@@ -1565,9 +1626,9 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       if (FULL && CW == 2) {
         pk = s_pk[(sb * kRecs + rec) * kPS + ch];
       } else if (FULL) {
-        // (EXP with masked rows: the track's staged row, or the two of its pair — one peak over both stream calls)
-        const uint32_t r0 = (EXP && a.masked_rows) ? s_off[rec] : rec;
-        const uint32_t r1 = (EXP && a.masked_rows) ? s_off[rec + 1u] : rec + 1u;
+        // (EXP: the track's staged row, or the two of its pair — one peak over both stream calls)
+        const uint32_t r0 = EXP ? s_off[rec] : rec;
+        const uint32_t r1 = EXP ? s_off[rec + 1u] : rec + 1u;
         for (uint32_t rr = r0; rr < r1; rr++) {
           const uint32_t* slots = &s_pk[(sb * kRecs + rr) * kPS];
 #pragma unroll
@@ -1584,6 +1645,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       // VUMeter::level keeps the maximum until the UI reads it (vu_meter.h:26-29)
       if (a.levels && pk != 0u) atomicMax(a.levels + (size_t)track * C + ch, pk);
     }
+    chunk0 += cn;
   }
 
   if (active && bvalid) {
@@ -1790,6 +1852,15 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* master, void*
   }
 }
 
+// VUMeter::update's read of the running maxima (vu_meter.h:33: `level.exchange(0.0f)`): every level is exchanged with
+// 0 and handed to the host (dst: pinned, device-mapped memory).  Runs on a stream of its own beside whatever mix is in
+// flight — the mix kernel raises the same words with atomicMax, so a maximum that arrives after the exchange is seen by
+// the next read, exactly like the reference's std::atomic<float>.
+__global__ __launch_bounds__(256) void levels_take_kernel(uint32_t* levels, uint32_t* dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) dst[i] = atomicExch(levels + i, 0u);
+}
+
 // synthetic clip generator — same integer hash as whitebox_amd/synth.py (bench/test input only)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ull;
@@ -1950,6 +2021,10 @@ void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t 
   const size_t total = (size_t)n_blocks * F * C;
   hipLaunchKernelGGL(convert_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, master, dst, n_blocks, F, C,
                      fmt);
+}
+
+void launch_levels_take(uint32_t* levels, uint32_t* dst, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(levels_take_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, levels, dst, n);
 }
 
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s) {

@@ -278,6 +278,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
+  static const bool stagger = !(std::getenv("WBX_STAGGER") && std::getenv("WBX_STAGGER")[0] == '0');   // (A/B aid)
+  m.stagger = stagger ? 1u : 0u;
   m.uniform_speed = std::getenv("WBX_NO_UNIFORM") ? 0.0 : c->uniform_speed;   // (A/B aid)
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(m.peaks, 0, (size_t)K * N * C * sizeof(float), ms));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
@@ -549,7 +551,29 @@ void clip_release(wbx_ctx* c, ClipSlot& s) {
   if (s.alloc) (void)hipFree(s.alloc);
   if (s.slab) {
     std::lock_guard<std::mutex> g(c->slab_mu);
-    if (s.slab->live && --s.slab->live == 0) s.slab->used = 0;   // the slab's space is free again
+    ClipSlab& sl = *s.slab;
+    sl.live_bytes -= std::min(sl.live_bytes, s.slab_len);
+    if (sl.live && --sl.live == 0) {   // the whole slab is free again
+      sl.used = 0;
+      sl.holes.clear();
+    } else if (s.slab_off + s.slab_len == sl.used) {   // the newest extent: the bump pointer steps back (over a hole that ends there, too)
+      sl.used = s.slab_off;
+      if (!sl.holes.empty() && sl.holes.back().first + sl.holes.back().second == sl.used) {
+        sl.used = sl.holes.back().first;
+        sl.holes.pop_back();
+      }
+    } else {                           // a hole, merged with its neighbours
+      auto it = std::lower_bound(sl.holes.begin(), sl.holes.end(), std::make_pair(s.slab_off, (size_t)0));
+      it = sl.holes.insert(it, std::make_pair(s.slab_off, s.slab_len));
+      if (it + 1 != sl.holes.end() && it->first + it->second == (it + 1)->first) {
+        it->second += (it + 1)->second;
+        it = sl.holes.erase(it + 1) - 1;
+      }
+      if (it != sl.holes.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+        (it - 1)->second += it->second;
+        sl.holes.erase(it);
+      }
+    }
   }
   if (s.mip) (void)hipFree(s.mip);
   s = ClipSlot{};
@@ -586,8 +610,23 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
     if (use_slabs && need <= kSlab / 4) {   // (slab sizes grow 64 MiB, 256 MiB, 1 GiB, 1 GiB ...: small sessions stay small)
       std::lock_guard<std::mutex> g(c->slab_mu);
       ClipSlab* sl = nullptr;
-      for (auto it = c->slabs.rbegin(); it != c->slabs.rend() && !sl; ++it)   // the newest slab first
-        if ((*it)->size - (*it)->used >= need) sl = it->get();
+      size_t at = 0;
+      bool in_hole = false;
+      for (auto it = c->slabs.rbegin(); it != c->slabs.rend() && !sl; ++it) {   // the newest slab first: a hole that fits, else its tail
+        for (auto h = (*it)->holes.begin(); h != (*it)->holes.end() && !sl; ++h)
+          if (h->second >= need) {
+            sl = it->get();
+            at = h->first;
+            in_hole = true;
+            if (h->second == need) {
+              sl->holes.erase(h);
+            } else {
+              h->first += need;
+              h->second -= need;
+            }
+          }
+        if (!sl && (*it)->size - (*it)->used >= need) sl = it->get();
+      }
       if (!sl) {
         std::unique_ptr<ClipSlab> fresh(new (std::nothrow) ClipSlab());
         if (!fresh) return WBX_ERR_OOM;
@@ -602,10 +641,16 @@ wbx_status clip_build(wbx_ctx* c, ClipSlot& s, int format, uint32_t channels, ui
         }
       }
       if (sl) {
+        if (!in_hole) {
+          at = sl->used;
+          sl->used += need;
+        }
         s.slab = sl;
-        s.base = sl->mem + sl->used + gap;
-        sl->used += need;
+        s.slab_off = at;
+        s.slab_len = need;
+        s.base = sl->mem + at + gap;
         sl->live++;
+        sl->live_bytes += need;
       }
     }
     if (!s.slab) {
@@ -863,6 +908,27 @@ extern "C" wbx_status wbx_clip_free(wbx_ctx* c, uint32_t clip) {
   WBX_HIP(c, sync_main(c));
   clip_release(c, c->clips[clip]);
   c->samples_dirty = true;
+  return WBX_OK;
+}
+
+// clip storage in numbers: slabs allocated, bytes reserved from the driver (slabs + clips with an allocation of their
+// own), bytes held by live clips
+extern "C" wbx_status wbx_clip_pool_stats(wbx_ctx* c, uint32_t* n_slabs, uint64_t* bytes_reserved, uint64_t* bytes_live) {
+  if (!c) return WBX_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->slab_mu);
+  uint64_t reserved = 0, live = 0;
+  for (auto& sl : c->slabs) {
+    reserved += sl->size;
+    live += sl->live_bytes;
+  }
+  for (auto& s : c->clips)
+    if (s.alloc) {
+      reserved += s.stride * s.d.channels;
+      live += s.stride * s.d.channels;
+    }
+  if (n_slabs) *n_slabs = (uint32_t)c->slabs.size();
+  if (bytes_reserved) *bytes_reserved = reserved;
+  if (bytes_live) *bytes_live = live;
   return WBX_OK;
 }
 
