@@ -41,6 +41,8 @@ WORKLOADS = {
     "c2": ("configs[1]: 256 stereo tracks, per-track gain+pan, 512-frame blocks", 48000, 0, "f32"),
     "c3": ("configs[2]: 4096 stereo tracks, gain+pan + linear clip resample 44.1k->48k, 512-frame blocks", 44100, 0, "f32"),
     "c4": ("configs[3]: 4096 stereo tracks into 64 sub-buses + master sum, 512-frame blocks", 48000, 64, "f32"),
+    "u4096": ("config 4's input side: 4096 stereo tracks at the session rate straight into the master (no buses), 512-frame blocks",
+              48000, 0, "f32"),
     "i16": ("next-2 (SURVEY 8f): 4096 stereo 16-bit PCM tracks, gain+pan, unity rate, 512-frame blocks", 48000, 0, "i16"),
     "d96": ("4096 stereo 96 kHz tracks played in the 48 kHz session (playback speed 2, per-frame taps), 512-frame blocks",
             96000, 0, "f32"),
@@ -53,7 +55,7 @@ WORKLOADS = {
     "mixr": ("4096 stereo tracks, alternating 16-bit 44.1 kHz clips (resampled) and 24-bit 48 kHz clips, 512-frame blocks",
              48000, 0, "mixr"),
 }
-SEEDS = {"c2": 2, "c3": 3, "c4": 4, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8, "mixfmt": 9, "mixr": 10}
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "u4096": 11, "i16": 5, "d96": 6, "i16r": 7, "i24r": 8, "mixfmt": 9, "mixr": 10}
 # bytes per stored sample (the mixed workloads: mean over their tracks, rate ratio folded in for mixr)
 FMT_BYTES = {"f32": 4, "i16": 2, "i24": 4, "i32": 4, "mix3": 10.0 / 3.0, "mixr": (2 * 0.91875 + 4) / 2}
 
@@ -66,6 +68,41 @@ def algorithmic_bytes_per_block(n_tracks: int, src_rate: int, channels: int = 2,
     return F * (n_tracks * channels * FMT_BYTES[fmt] * r + channels * 4) + n_tracks * channels * 4 + n_tracks * 32
 
 
+def track_layout(workload, n_tracks, rank, world, session_blocks, clip_blocks=0.0):
+    """The synthetic session, one entry per local track: what both the device engine and the oracle are built from.
+    -> (amp, [(global_track, format, src_rate, volume_dB, pan, bus, [(min_beat, max_beat, start_offset), ...]), ...])"""
+    from whitebox_amd import synth
+    _, src_rate, n_buses, fmt = WORKLOADS[workload]
+    seed = 0x5EED0000 + SEEDS[workload]
+    total_tracks = n_tracks * world
+    amp = synth.default_amp(total_tracks)
+    beat_frames = SR * 60.0 / 120.0
+    per_bus = max(1, n_tracks // n_buses) if n_buses else 0
+    out = []
+    for t in range(n_tracks):
+        gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
+        tfmt = ("f32", "i16", "i24")[gt % 3] if fmt == "mix3" else ("i16", "i24")[gt % 2] if fmt == "mixr" else fmt
+        trate = 44100 if (fmt == "mixr" and gt % 2 == 0) else src_rate
+        v, p = synth.track_params(seed, gt)
+        if tfmt != "f32":
+            v = v - 20.0 * math.log10(0.25 / amp)     # integer clips are full scale: the session level goes into the faders
+        bus = min(t // per_bus, n_buses - 1) if n_buses else -1
+        clips = []
+        if clip_blocks <= 0.0:
+            clips.append((0.0, (session_blocks + 1) * F / beat_frames, 0.0))
+        else:
+            # side measurement: the track is cut into back-to-back clips of clip_blocks blocks (each reading on from
+            # where the previous one stopped), staggered per track
+            L = clip_blocks * F
+            pos = -((t * 37) % 512) / 512.0 * L
+            while pos < (session_blocks + 1) * F:
+                a, b = max(pos, 0.0), pos + L
+                clips.append((a / beat_frames, b / beat_frames, a * (src_rate / SR)))
+                pos = b
+        out.append((gt, tfmt, trate, float(v), float(p), bus, clips))
+    return seed, amp, out
+
+
 def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, world, group_size, clip_blocks=0.0):
     from whitebox_amd.engine import Engine
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
@@ -73,42 +110,69 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
     eng.set_bpm(120.0)
     if n_buses:
         eng.set_buses(n_buses)
-    seed = 0x5EED0000 + SEEDS[workload]
-    total_tracks = n_tracks * world
-    amp = synth.default_amp(total_tracks)
+    seed, amp, tracks = track_layout(workload, n_tracks, rank, world, session_blocks, clip_blocks)
     frames = int(math.ceil((session_blocks + 2) * F * (src_rate / SR))) + 64
-    beat_frames = SR * 60.0 / 120.0
-    per_bus = max(1, n_tracks // n_buses) if n_buses else 0
-    for t in range(n_tracks):
-        gt = rank * n_tracks + t                      # global track index keys the generator and the parameters
-        tfmt = ("f32", "i16", "i24")[gt % 3] if fmt == "mix3" else ("i16", "i24")[gt % 2] if fmt == "mixr" else fmt
-        trate = 44100 if (fmt == "mixr" and gt % 2 == 0) else src_rate
+    for (gt, tfmt, trate, v, p, bus, clips) in tracks:
         sid = eng.add_sample_synth(tfmt, 2, trate, frames, seed, gt, amp)
         tr = eng.add_track(f"t{gt}")
-        v, p = synth.track_params(seed, gt)
-        if tfmt != "f32":
-            v = v - 20.0 * math.log10(0.25 / amp)     # integer clips are full scale: the session level goes into the faders
-        tr.set_volume(float(v))
-        tr.set_pan(float(p))
+        tr.set_volume(v)
+        tr.set_pan(p)
         if n_buses:
-            tr.set_bus(min(t // per_bus, n_buses - 1))
-        if clip_blocks <= 0.0:
-            eng.add_audio_clip(tr, "clip", 0.0, (session_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
-        else:
-            # side measurement: the track is cut into back-to-back clips of clip_blocks blocks (each reading on from
-            # where the previous one stopped), staggered per track: a clip boundary inside a block sends that
-            # track-block through the pre-render pass
-            L = clip_blocks * F
-            pos = -((t * 37) % 512) / 512.0 * L
-            while pos < (session_blocks + 1) * F:
-                a, b = max(pos, 0.0), pos + L
-                eng.add_audio_clip(tr, "clip", a / beat_frames, b / beat_frames, a * (src_rate / SR), sid, 1.0, 1.0)
-                pos = b
+            tr.set_bus(bus)
+        for (a, b, off) in clips:
+            eng.add_audio_clip(tr, "clip", a, b, off, sid, 1.0, 1.0)
     return eng, seed, amp
 
 
 def rank_device(rank):
     return int(os.environ.get("LOCAL_RANK", rank))
+
+
+def build_oracle_session(workload, n_tracks, world, sample_blocks, clip_blocks=0.0, session_blocks=None):
+    """The same session (all `world` shards of it, in global track order) in the CPU oracle, with clip audio for the
+    first sample_blocks (+2) blocks only — identical to the head of the resident device session, whose generator is
+    keyed by (track, channel, frame).  TEST INFRASTRUCTURE: used by the verify step and the cpu_baseline leg only."""
+    import oracle_ffi as O
+    from whitebox_amd import synth
+    _, src_rate, n_buses, fmt = WORKLOADS[workload]
+    L = O.lib()
+    L.wbo_synth_f32.argtypes = [O.c_f32p, C.c_size_t, C.c_uint64, C.c_float, C.c_size_t]
+    e = O.OracleEngine(2, F, SR)
+    e.set_bpm(120.0)
+    if n_buses:
+        e.set_buses(n_buses * world)
+    keep = []
+    idx = 0
+    for rank in range(world):
+        seed, amp, tracks = track_layout(workload, n_tracks, rank, world, session_blocks or sample_blocks, clip_blocks)
+        amp32 = np.float32(amp)
+        for (gt, tfmt, trate, v, p, bus, clips) in tracks:
+            frames = int(math.ceil((sample_blocks + 2) * F * (trate / SR))) + 64
+            chans = []
+            for c in range(2):
+                if tfmt == "f32":
+                    a = np.empty(frames + 16, np.float32)
+                    L.wbo_synth_f32(a.ctypes.data_as(O.c_f32p), frames, int(synth.clip_key(seed, gt, c)), amp32, 16)
+                elif tfmt == "i16":
+                    a = np.concatenate([synth.clip_channel_i16(seed, gt, c, frames), np.zeros(16, np.int16)])
+                else:
+                    a = np.concatenate([synth.clip_channel_i32(seed, gt, c, frames, 24 if tfmt == "i24" else 32),
+                                        np.zeros(16, np.int32)])
+                chans.append(a)
+            keep.append(chans)
+            sid = e.add_sample(tfmt, 2, trate, frames, chans)
+            e.add_track()
+            e.set_volume(idx, v)
+            e.set_pan(idx, p)
+            if n_buses:
+                e.set_bus(idx, rank * n_buses + bus)
+            horizon = (sample_blocks + 1) * F / (SR * 60.0 / 120.0)
+            for (a, b, off) in clips:
+                if a <= horizon:
+                    e.add_audio_clip(idx, a, b, off, sid, 1.0, 1.0)
+            idx += 1
+    e._keep_clips = keep
+    return e
 
 
 def cpu_baseline(workload, n_tracks, budget_s=12.0):
@@ -118,38 +182,11 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
     from whitebox_amd import synth
     _, src_rate, n_buses, fmt = WORKLOADS[workload]
     L = O.lib()
-    L.wbo_synth_f32.argtypes = [O.c_f32p, C.c_size_t, C.c_uint64, C.c_float, C.c_size_t]
     sample_blocks = 24
+    e = build_oracle_session(workload, n_tracks, 1, sample_blocks)
+    keep = e._keep_clips
     seed = 0x5EED0000 + SEEDS[workload]
     amp = np.float32(synth.default_amp(n_tracks))
-    frames = int(math.ceil((sample_blocks + 2) * F * (src_rate / SR))) + 64
-    e = O.OracleEngine(2, F, SR)
-    e.set_bpm(120.0)
-    if n_buses:
-        e.set_buses(n_buses)
-    beat_frames = SR * 60.0 / 120.0
-    per_bus = max(1, n_tracks // n_buses) if n_buses else 0
-    keep = []
-    for t in range(n_tracks):
-        chans = []
-        for c in range(2):
-            if fmt == "f32":
-                a = np.empty(frames + 16, np.float32)
-                L.wbo_synth_f32(a.ctypes.data_as(O.c_f32p), frames, int(synth.clip_key(seed, t, c)), amp, 16)
-            else:
-                a = np.concatenate([synth.clip_channel_i16(seed, t, c, frames), np.zeros(16, np.int16)])
-            chans.append(a)
-        keep.append(chans)
-        sid = e.add_sample(fmt, 2, src_rate, frames, chans)
-        e.add_track()
-        v, p = synth.track_params(seed, t)
-        if fmt != "f32":
-            v = v - 20.0 * math.log10(0.25 / float(amp))
-        e.set_volume(t, v)
-        e.set_pan(t, p)
-        if n_buses:
-            e.set_bus(t, min(t // per_bus, n_buses - 1))
-        e.add_audio_clip(t, 0.0, (sample_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
     out = [np.zeros(F, np.float32) for _ in range(2)]
     ptrs = O.planar_ptrs(out)
     blocks_done, elapsed, passes = 0, 0.0, 0
@@ -181,21 +218,19 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
     split over one thread per physical core, each thread mixing its own shard (NOT the reference's threading —
     its engine is single-threaded by design; the final cross-shard sum of 2x512 floats is not timed)."""
     import threading
-    from whitebox_amd import synth
+    _, _, tracks = track_layout(workload, n_tracks, 0, 1, sample_blocks)
     P = max(1, min((os.cpu_count() or 2) // 2, n_tracks // 16))
     beat_frames = SR * 60.0 / 120.0
-    frames = len(keep[0][0]) - 16
     engines = []
     for p in range(P):
         t0, t1 = p * n_tracks // P, (p + 1) * n_tracks // P
         e = O.OracleEngine(2, F, SR)
         e.set_bpm(120.0)
         for i, t in enumerate(range(t0, t1)):
-            sid = e.add_sample(fmt, 2, src_rate, frames, keep[t])
+            (gt, tfmt, trate, v, pan, bus, clips) = tracks[t]
+            frames = len(keep[t][0]) - 16
+            sid = e.add_sample(tfmt, 2, trate, frames, keep[t])
             e.add_track()
-            v, pan = synth.track_params(seed, t)
-            if fmt != "f32":
-                v = v - 20.0 * math.log10(0.25 / float(amp))
             e.set_volume(i, v)
             e.set_pan(i, pan)
             e.add_audio_clip(i, 0.0, (sample_blocks + 1) * F / beat_frames, 0.0, sid, 1.0, 1.0)
@@ -227,6 +262,52 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
+def verify_head(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks, chain=False, n_check=8):
+    """What did the timed loop compute?  After it, the transport is rewound (Engine::stop + play), one more step of K
+    blocks is rendered exactly like the timed ones, and its first `n_check` blocks are compared with the CPU oracle
+    built from the same seeds: the device sequencer's stream-call log and the per-track peaks bit for bit, the master
+    bit for bit when the render adds in the reference's order, within 1e-6 RMS otherwise.  Outside the timed region;
+    the oracle only checks (bench.py's timed path never touches it)."""
+    import oracle_ffi as O
+    n_check = min(n_check, K)
+    got = host_master.array[:n_check * 2 * F].reshape(n_check, 2, F).copy()
+    res = {"blocks": n_check, "tracks": n_tracks * world}
+    L = eng.L
+    ng, longest, ref = C.c_uint32(), C.c_uint32(), C.c_int()
+    L.wbx_render_order(eng.ctx.h, K, C.byref(ng), C.byref(longest), C.byref(ref))
+    res["summation"] = (f"{ng.value} workgroup-level group(s) per block, longest {longest.value} tracks: "
+                        + ("the reference's order" if ref.value else "grouped order"))
+    e = build_oracle_session(workload, n_tracks, world, n_check, clip_blocks, session_blocks)
+    e.enable_seglog()
+    e.play()
+    om, opk, orows = [], [], []
+    for b in range(n_check):
+        m, _ = e.process()
+        om.append(m)
+        opk.append(e.peaks())
+        orows += [(b, t, ds, min(ln, 0xFFFF), O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g))
+                  for (t, ds, ln, off, spd, g, smp) in e.seglog()]
+    e.close()
+    om, opk = np.stack(om), np.stack(opk)
+    d = got.astype(np.float64) - om.astype(np.float64)
+    res["rms"] = float(np.sqrt(np.mean(d * d)))
+    res["max_abs"] = float(np.abs(d).max())
+    res["master_bit_exact"] = bool(np.array_equal(got.view(np.uint32), om.view(np.uint32)))
+    # peaks and plan rows: this rank's tracks (the other ranks' never leave their GPU)
+    first = rank * n_tracks
+    _, pk, _ = eng.ctx.fetch(peaks=True)
+    res["peaks_equal"] = bool(np.array_equal(pk[:n_check], opk[:, first:first + n_tracks, :2]))
+    plan = eng.fetch_plan(max_records=n_check * n_tracks * 4)
+    rows = [(b, t + first, bo, ns, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g))
+            for (b, t, bo, ns, na, smp, off, spd, g, fl) in plan if b < n_check]
+    want = [r for r in orows if first <= r[1] < first + n_tracks]
+    res["plan_rows_equal"] = rows == want
+    res["plan_rows"] = len(want)
+    res["ok"] = bool(res["peaks_equal"] and res["plan_rows_equal"]
+                     and (res["master_bit_exact"] if (ref.value and (world == 1 or chain)) else res["rms"] <= 1e-6))
+    return res
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -236,27 +317,33 @@ def free_port():
     return p
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` run plainly: start the N ranks (one process per GPU) and pass rank 0's line through."""
+def self_launch(n, rank_cmd=None, poll_s=0.05, grace_s=5.0):
+    """`python bench.py --gpus N` run plainly: start the N ranks (one process per GPU) and pass rank 0's line through.
+    A rank that fails ends the launch: the others (which would sit in the RCCL rendezvous) are terminated — killed if
+    they ignore that for `grace_s` seconds — the rendezvous file is removed, and the first failing exit code is returned.
+    `rank_cmd`: the command of one rank (tests pass a stub; default: this script with the same arguments)."""
     import subprocess
-    import whitebox_amd as W
-    have = W.lib().wbx_device_count()
-    if have < n:
-        raise SystemExit(f"bench.py --gpus {n} needs {n} gfx950 devices on this node, {have} visible "
-                         "(one process per GPU; --force-dist-path runs the multi-GPU code path on one)")
+    if rank_cmd is None:
+        import whitebox_amd as W
+        have = W.lib().wbx_device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n} needs {n} gfx950 devices on this node, {have} visible "
+                             "(one process per GPU; --force-dist-path runs the multi-GPU code path on one)")
+        rank_cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     port = free_port()
     rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wbx_rdzv_{port}_{os.getpid()}")
+    nonce = f"{os.getpid()}:{port}:{time.time_ns()}"        # names this launch: a stale file of an earlier one is ignored
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), WBX_RDZV=rdzv)
+                   MASTER_PORT=str(port), WBX_RDZV=rdzv, WBX_RDZV_NONCE=nonce)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes here
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    # wait for all ranks; a rank that fails takes the others with it (they would sit in the RCCL rendezvous for ever)
+        procs.append(subprocess.Popen(list(rank_cmd), env=env))
     rc = 0
     alive = list(procs)
+    deadline = None
     while alive:
-        time.sleep(0.05)
+        time.sleep(poll_s)
         for p in list(alive):
             r = p.poll()
             if r is None:
@@ -264,17 +351,24 @@ def self_launch(n):
             alive.remove(p)
             if r != 0 and rc == 0:
                 rc = r
+                print(f"bench.py: rank {procs.index(p)} exited with {r}: ending the other ranks", file=sys.stderr, flush=True)
                 for q in alive:
                     q.terminate()        # (the processes this function started, by handle)
-    try:
-        os.remove(rdzv)
-    except OSError:
-        pass
-    raise SystemExit(rc)
+                deadline = time.time() + grace_s
+        if deadline is not None and alive and time.time() > deadline:
+            for q in alive:
+                q.kill()
+            deadline = None
+    for path in (rdzv, ):
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return rc
 
 
 def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, warmup, ramp, clip_blocks=0.0,
-                 use_dist=False, dist_mode=0, mem_budget=96e9, latency_blocks=0):
+                 use_dist=False, dist_mode=0, mem_budget=96e9, latency_blocks=0, verify=True):
     """Build the session in HBM, run warmup + ramp untimed steps straight into `steps` timed ones, return the measurements."""
     from whitebox_amd.dist import Dist, PinnedBuffer
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
@@ -312,6 +406,8 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     L = W.lib()
     state = {"done": 0}
 
+    result_rank = dist.result_rank if dist is not None else 0   # who holds the summed master (chain mode: the last rank)
+
     def step():
         if state["done"] + K > session_blocks:     # end of the resident session: rewind (Engine::stop + play)
             eng.stop()
@@ -319,7 +415,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
             state["done"] = 0
         eng.render(K)
         if dist is not None:
-            dist.exchange(host_master.ptr if rank == 0 else None)   # asynchronous, beside the next renders
+            dist.exchange(host_master.ptr if rank == result_rank else None)   # asynchronous, beside the next renders
         # keep the submitting thread at most 12 steps ahead of the device: far deeper, the HIP runtime stalls a
         # launch until its queue has drained (tens of ms) and the device then idles
         L.wbx_pace(eng.ctx.h, 12)
@@ -362,9 +458,31 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     if dist is not None:
         dt = dist.max(dt)                              # MAX over ranks
 
-    master_peak = float(np.abs(host_master.array).max()) if rank == 0 else 0.0
+    master_peak = float(np.abs(host_master.array).max()) if rank == result_rank else 0.0
+    # what did the timed loop compute?  rewind, one more step like the timed ones, its head against the CPU oracle
+    ver = None
+    if verify:
+        eng.stop()
+        eng.play()
+        state["done"] = 0
+        step()
+        drain()
+        if rank == result_rank:
+            ver = verify_head(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks,
+                              chain=dist is not None and dist_mode == 2)
+    exch = None
     if dist is not None:
+        exch = dist.info()
+        if world > 1:   # what the result rank found travels to rank 0, which prints the line
+            got = dist.allgather(json.dumps({"verify": ver, "master_peak": master_peak}).encode(), 2048)
+            if rank == 0:
+                back = json.loads(got[result_rank].decode())
+                ver, master_peak = back["verify"], back["master_peak"]
         dist.shutdown()
+    dev = eng.ctx.device_info()
+    ng, longest, ref_order = eng.ctx.render_order(K)
+    summation = (f"{ng} workgroup-level group(s) per block, longest {longest} tracks: "
+                 + ("the reference's sequential order" if ref_order else "grouped order (within 1e-6 RMS)"))
     eng.close()
     host_master.close()
 
@@ -393,14 +511,20 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,
             "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "alg": alg, "achieved": achieved,
             "desc": desc, "kernel_name": kernel_name, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
-            "clip_blocks": clip_blocks, "workload": workload}
+            "clip_blocks": clip_blocks, "workload": workload, "verify": ver, "device": dev, "exchange": exch, "summation": summation,
+            "session_blocks": session_blocks}
 
 
 def roofline_of(r, traffic_table):
     key = f"{r['workload']}_K{r['K']}_N{r['n_tracks']}" + (f"_L{r['clip_blocks']}" if r["clip_blocks"] else "")
     traffic = traffic_table.get(key, {}).get("hbm_bytes_per_launch")
+    step_ms = 1e3 * r["dt"] / r["steps"]
     return {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": r["achieved"] / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": r["achieved"] / HBM_PEAK_GBS,
+            # the same bytes over the whole step (sequencer, launch gaps, sum and master write-out included): what the
+            # job sustains end to end, next to what the dominant kernel reaches while it runs
+            "frac_step": r["alg"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": step_ms,
+            "traffic": traffic,
             # NOT this run's counters: the PMC passes of the same command, committed under profiles/ (tools/pmc_run.sh)
             "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command)" if traffic else None,
             "kernel": r["kernel_name"],
@@ -411,17 +535,30 @@ def roofline_of(r, traffic_table):
             "algorithmic_bytes_per_launch": r["alg"]}
 
 
+def config_entry(name, wl, sr, K, traffic_table, extra=""):
+    d2 = WORKLOADS[wl]
+    ent = {"workload": f"{wl} — {d2[0]}" + extra,
+           "value": sr["steps"] * K * F / sr["dt"], "unit": "frames/s", "steps": sr["steps"], "blocks_per_step": K,
+           "tracks": sr["n_tracks"], "ms_per_step": 1e3 * sr["dt"] / sr["steps"], "seconds": sr["dt"],
+           "roofline": roofline_of(sr, traffic_table)}
+    if sr.get("verify"):
+        ent["verify"] = sr["verify"]
+    return ent
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ramp-steps", type=int, default=40, help="further untimed steps straight before the timed ones: "
-                    "the device needs ~20 ms of continuous load to reach its sustained clocks, and drops them again "
-                    "in any idle gap")
+    ap.add_argument("--ramp-steps", type=int, default=None, help="further untimed steps straight before the timed ones "
+                    "(default: 10240 blocks' worth, at least 6): the device needs ~20 ms of continuous load to reach "
+                    "its sustained clocks, and drops them again in any idle gap")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
-    ap.add_argument("--blocks", type=int, default=256, help="512-frame blocks per step (one device pass)")
+    ap.add_argument("--blocks", type=int, default=1024, help="512-frame blocks per step (one device pass).  Renders of "
+                    ">= 1024 blocks add every block's tracks in the reference's strictly sequential order (bit-exact "
+                    "master); shorter ones in groups of 128 (within 1e-6 RMS)")
     ap.add_argument("--group-size", type=int, default=0)
     ap.add_argument("--clip-blocks", type=float, default=0.0, help="side measurement: cut every track into back-to-back "
                     "clips of this many blocks (0: one clip per track, the BASELINE.json configs)")
@@ -434,16 +571,23 @@ def main():
     ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="run the multi-GPU code path (RCCL exchange + clamp on root) even with one rank")
-    ap.add_argument("--dist-mode", default="reduce", choices=["reduce", "ordered"],
-                    help="exchange: one ncclReduce, or gather + fixed-order add on the root (bit-reproducible)")
+    ap.add_argument("--dist-mode", default="reduce", choices=["reduce", "ordered", "chain"],
+                    help="exchange: one ncclReduce; gather + fixed-order add on the root (bit-reproducible); or a chain — "
+                    "rank g continues rank g-1's running master (the reference's sequential order across GPUs: bit-exact)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: BASELINE configs[4]'s 32768 tracks split over "
+                    "the N ranks (default: weak scaling, 4096 tracks per GPU)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other single-GPU configurations "
-                    "(c2, c4, c3 cut into clips, i16r) that fill the line's `configs` object")
+                    "(c2, c4, c3 cut into clips, i16r, the sustained run) that fill the line's `configs` object")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the rendered head against the CPU oracle "
+                    "(after the timed loop, outside the timed region)")
+    ap.add_argument("--sustain-blocks", type=int, default=512000, help="blocks of the sustained-clock run in `configs` "
+                    "(2 000 steps of 256 blocks' worth: >= 1.5 s of uninterrupted load)")
     args = ap.parse_args()
     global F
     F = args.block_frames
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)                      # does not return
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
@@ -456,18 +600,27 @@ def main():
                          "the mix path has no CPU implementation")
 
     n_tracks = args.tracks or (256 if args.workload == "c2" else 4096)
+    if args.strong:
+        if 32768 % world:
+            raise SystemExit("--strong: 32768 tracks do not split evenly over this many ranks")
+        n_tracks = 32768 // world
     K = args.blocks
+    ramp = args.ramp_steps if args.ramp_steps is not None else max(6, 10240 // K)
     use_dist = world > 1 or args.force_dist_path
+    dist_mode = {"reduce": 0, "ordered": 1, "chain": 2}[args.dist_mode]
     r = run_workload(W, synth, args, args.workload, rank, world, n_tracks=n_tracks, K=K, steps=args.steps,
-                     warmup=args.warmup, ramp=args.ramp_steps, clip_blocks=args.clip_blocks, use_dist=use_dist,
-                     dist_mode=1 if args.dist_mode == "ordered" else 0, latency_blocks=args.latency_blocks)
+                     warmup=args.warmup, ramp=ramp, clip_blocks=args.clip_blocks, use_dist=use_dist,
+                     dist_mode=dist_mode, latency_blocks=args.latency_blocks, verify=not args.no_verify)
+    # every rank says what it ran on (stderr: stdout carries rank 0's one JSON line)
+    print(json.dumps({"rank": rank, "world": world, "device": r["device"], "tracks": n_tracks, "exchange": r["exchange"],
+                      "mix_ms_avg": r["mix_ms"], "seconds": r["dt"]}), file=sys.stderr, flush=True)
     if rank != 0:
         return
 
     dt = r["dt"]
     master_frames = args.steps * K * F
     total_tracks = n_tracks * world
-    value = (total_tracks / 4096.0) * master_frames / dt if n_tracks == 4096 else master_frames / dt * world
+    value = (total_tracks / 4096.0) * master_frames / dt
     traffic_table = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -476,16 +629,18 @@ def main():
         except Exception:
             traffic_table = {}
     desc, src_rate, n_buses, fmt = WORKLOADS[args.workload]
+    ver = r["verify"]
     line = {
         "metric": "stereo fp32 frames/sec mixed (4096 tracks @ 512-frame blocks)",
         "value": value, "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": args.ramp_steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": ramp,
         "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32" if fmt == "f32" else f"f32 (clips stored as {fmt})", "data": "synthetic",
         "config": {"workload": f"{args.workload} — {desc}", "tracks_per_gpu": n_tracks, "total_tracks": total_tracks,
                    "blocks_per_step": K, "block_frames": F, "dst_rate": SR, "src_rate": src_rate, "clip_format": fmt,
-                   "sub_buses": n_buses, "group_size": args.group_size or (64 if n_buses else 128),
+                   "sub_buses": n_buses, "group_size": args.group_size or "library default",
+                   "summation": r["summation"],
                    "clip_blocks": args.clip_blocks or None,
                    "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}",
                    "exchange": (f"libwbx wbx_dist_exchange over RCCL, mode {args.dist_mode}" if use_dist else None)},
@@ -496,29 +651,47 @@ def main():
         "master_peak": r["master_peak"],
         "roofline": roofline_of(r, traffic_table),
     }
+    if ver is not None:
+        line["verify"] = ver
+    if use_dist and r["exchange"]:
+        # what the exchange saw: RCCL's world size, which device every rank ran on, the exchange's own time
+        line.update({"rccl_world": r["exchange"]["world"], "devices": r["exchange"]["devices"], "tracks_per_gpu": n_tracks,
+                     "exchange_ms_avg": r["exchange"]["exchange_ms_avg"]})
     if r["lat"] is not None:
         line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"]}
 
     # the other single-GPU configurations of BASELINE.json (configs[1], configs[3]), the headline session cut into
-    # clips and the 16-bit resampled session: short runs, each with its own roofline from its own HIP-event kernel times
+    # clips, the 16-bit resampled session, the round-2 operating point (256-block renders, grouped order) and a
+    # sustained run: each with its own roofline from its own HIP-event kernel times, each checked against the oracle
+    failed = [] if (ver is None or ver["ok"]) else ["headline"]
     if world == 1 and not use_dist and not args.no_configs and args.workload == "c3" and not args.clip_blocks and F == 512:
         subs = {}
         for name, wl, kw in (("c2", "c2", dict(n_tracks=256)), ("c4", "c4", dict(n_tracks=4096)),
                              ("c3_clips5.3", "c3", dict(n_tracks=4096, clip_blocks=5.3)),
                              ("i16r", "i16r", dict(n_tracks=4096))):
-            sub_steps = 20
-            sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=sub_steps, warmup=3, ramp=40 if wl != "c2" else 60,
-                              mem_budget=40e9, **kw)
-            d2 = WORKLOADS[wl]
-            subs[name] = {"workload": f"{wl} — {d2[0]}" + (f", every track cut into clips of {kw['clip_blocks']} blocks"
-                                                          if kw.get("clip_blocks") else ""),
-                          "value": sub_steps * K * F / sr["dt"], "unit": "frames/s", "steps": sub_steps, "blocks_per_step": K,
-                          "tracks": sr["n_tracks"], "ms_per_step": 1e3 * sr["dt"] / sub_steps,
-                          "roofline": roofline_of(sr, traffic_table)}
+            sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=20, warmup=3, ramp=ramp * (3 if wl == "c2" else 1),
+                              mem_budget=40e9, verify=not args.no_verify, **kw)
+            subs[name] = config_entry(name, wl, sr, K, traffic_table,
+                                      f", every track cut into clips of {kw['clip_blocks']} blocks" if kw.get("clip_blocks") else "")
+        # renders of 256 blocks: the grouped summation order (within 1e-6 RMS), the operating point of rounds 1-2
+        sr = run_workload(W, synth, args, "c3", 0, 1, n_tracks=4096, K=256, steps=20, warmup=3, ramp=40, mem_budget=40e9,
+                          verify=not args.no_verify)
+        subs["c3_K256_grouped"] = config_entry("c3_K256_grouped", "c3", sr, 256, traffic_table, ", 256-block renders (128-track groups)")
+        # sustained clocks: the headline configuration for >= 1.5 s of consecutive steps
+        s_steps = max(20, -(-args.sustain_blocks // K))
+        sr = run_workload(W, synth, args, "c3", 0, 1, n_tracks=4096, K=K, steps=s_steps, warmup=3, ramp=ramp, verify=False)
+        subs["c3_sustained"] = config_entry("c3_sustained", "c3", sr, K, traffic_table,
+                                            f", {s_steps} consecutive steps = {s_steps * K} blocks")
+        for name, ent in subs.items():
+            if ent.get("verify") and not ent["verify"]["ok"]:
+                failed.append(name)
         line["configs"] = subs
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n_tracks, args.cpu_seconds)
     print(json.dumps(line), flush=True)
+    if failed:
+        print(f"bench.py: the rendered head differs from the CPU oracle in: {', '.join(failed)}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -73,10 +73,14 @@ typedef struct wbx_config {
   uint32_t block_frames;   /* F, Engine::audio_buffer_size (reference default 512, src/config.cpp:146); multiple of 4 */
   uint32_t channels;       /* C, output channels: 1 or 2 (reference: 2, src/config.cpp:224) */
   uint32_t sample_rate;    /* destination rate, Engine::audio_sample_rate */
-  uint32_t group_size;     /* tracks summed in index order by one workgroup (0 = default: 128; when max_blocks == 1,
-                              the audio-callback configuration: 64, and 32 for sessions of more than 64 tracks).  The
-                              master is the in-order sum of the group sums; group_size >= N reproduces
-                              the reference's strictly sequential order bit-for-bit. */
+  uint32_t group_size;     /* tracks summed in index order by one workgroup; the master is the in-order sum of the group
+                              sums, so group_size >= N reproduces the reference's strictly sequential order (engine.cpp:
+                              1600-1617) bit for bit.  0 = the library picks: renders of >= 1024 blocks walk ALL tracks of a
+                              block (of a bus) in one workgroup — the reference's order, bit-exact master, at the full rate
+                              (the blocks of the render supply the parallelism); shorter renders take groups of 128 (when
+                              max_blocks == 1, the audio-callback configuration: 64, and 32 for sessions of more than 64
+                              tracks), within 1e-6 RMS of the reference's order at mix-bus levels (DESIGN.md "Summation
+                              order" states the levels). */
   uint32_t max_segments;   /* extra (beyond one per track-block) segment slots per launch; 0 = default */
   void* stream;            /* hipStream_t to launch on, or NULL: the ctx creates its own */
 } wbx_config;
@@ -150,6 +154,13 @@ wbx_status wbx_clip_mipmap_device(wbx_ctx* ctx, uint32_t clip, uint32_t level, c
  * track_bus[t] in [0, n_buses) or -1 (straight to master).  NULL / n_buses 0 = reference behaviour. */
 wbx_status wbx_set_routing(wbx_ctx* ctx, uint32_t n_tracks, const int32_t* track_bus, uint32_t n_buses);
 
+/* How a render of n_blocks blocks is summed, with the routing as it stands (after the last render / wbx_set_routing):
+ * workgroup-level groups per block, the longest of them, and whether that IS the reference's order (every member list —
+ * all tracks, or the tracks of each bus — added sequentially by one workgroup: engine.cpp:1600-1617, bit-exact master). */
+wbx_status wbx_render_order(wbx_ctx* ctx, uint32_t n_blocks, uint32_t* n_groups, uint32_t* longest_group, int* reference_order);
+/* PCI bus id ("0000:05:00.0") and marketing / arch name of the ctx's device (multi-GPU hosts log which rank got which). */
+wbx_status wbx_device_info(wbx_ctx* ctx, char* pci_bus_id, size_t n_pci, char* name, size_t n_name);
+
 /* Mix K blocks of n_tracks tracks.  segs[] holds the Sampler::stream calls grouped by (block, track):
  * those of (b, t) are segs[seg_offsets[b*n_tracks+t] .. seg_offsets[b*n_tracks+t+1]).  gains[(b*n_tracks+t)*2+c]
  * = fl(volume*pan_coeffs[c]) (0 when muted), the factor of track.cpp:728-731.  Asynchronous. */
@@ -163,6 +174,13 @@ wbx_status wbx_submit(wbx_ctx* ctx, uint32_t n_blocks, uint32_t n_tracks, const 
  *  buses            : [K][n_buses][C][F] bus sums */
 wbx_status wbx_fetch(wbx_ctx* ctx, float* const* master_planar, float* peaks, float* buses);
 wbx_status wbx_fetch_interleaved(wbx_ctx* ctx, int out_format, void* dst);  /* K*F*C interleaved samples */
+/* Let later submits / renders leave their master as interleaved samples of a device format (WBX_OUT_*; 0 = planar fp32
+ * again): the conversion of core/audio_format_conv.cpp:5-91 becomes the epilogue of the sum kernel — no separate
+ * conversion launch, no planar master in between.  The master target (the ctx's own buffer or wbx_set_master_target's,
+ * then at least K*F*C samples of the format) holds [K*F][C] samples, packed 24-bit as the reference writes it (see
+ * WBX_OUT_I24).  wbx_fetch_interleaved of the same format is then a plain copy; wbx_fetch's planar master is not
+ * available.  Not with a multi-GPU exchange (partial masters stay planar fp32). */
+wbx_status wbx_set_master_format(wbx_ctx* ctx, int out_format);
 wbx_status wbx_sync(wbx_ctx* ctx);
 /* Order `stream` (a hipStream_t; NULL = the ctx stream) after every kernel that writes the results of the last
  * submit / render (master, bus sums, peaks).  The sum of a render runs on a stream of its own beside the next mix:
@@ -184,6 +202,13 @@ wbx_status wbx_set_clamp(wbx_ctx* ctx, int clamp_on_submit); /* 0: leave the mas
 /* Write the master of later submits/renders into a caller-owned DEVICE buffer of at least
  * max_blocks*C*F floats (e.g. the send buffer of the RCCL reduce); NULL restores the ctx-owned one. */
 wbx_status wbx_set_master_target(wbx_ctx* ctx, void* device_buffer);
+/* Start the master of later submits / renders from a running sum instead of the cleared buffer: `device_buffer`
+ * ([max_blocks][C][F] floats, device memory or pinned device-mapped host memory, 16-byte aligned) holds the UN-clamped
+ * master of the engine that owns the tracks BEFORE this one's in the session's track order; the first group in summation
+ * order continues from it, so that a session split over several engines (several GPUs: WBX_DIST_CHAIN does exactly this
+ * over RCCL; or one GPU, to go beyond max_tracks) is added in the reference's strictly sequential order
+ * (engine.cpp:1600-1617) across the split.  NULL restores the cleared start.  Not with sub-buses. */
+wbx_status wbx_set_master_init(wbx_ctx* ctx, const void* device_buffer);
 
 /* ---- multi-GPU: tracks sharded over one process per GPU, ONE exchange per render ---------------
  * The reference has no distributed code; this is the path's only exchange step: every rank mixes its own contiguous
@@ -198,18 +223,32 @@ wbx_status wbx_set_master_target(wbx_ctx* ctx, void* device_buffer);
  * to two further renders may be issued while an exchange is in flight; nothing in the loop blocks the host.
  * WBX_DIST_REDUCE: one ncclReduce(sum) — RCCL's summation order is implementation-defined (inside the 1e-6 RMS budget).
  * WBX_DIST_ORDERED: ncclGather + a fixed-order add on the root, (((0 + p0) + p1) + ...) in rank = track order:
- * bit-reproducible on any topology (SURVEY §7 hard part 8). */
+ * bit-reproducible on any topology (SURVEY §7 hard part 8).  Both add SHARD sums, which is not the reference's
+ * track-after-track association: at 32768 tracks the difference leaves the 1e-6 RMS budget once the master runs at
+ * mix-bus level (profiles/r03_level_probe.txt).
+ * WBX_DIST_CHAIN: the reference's order across GPUs — rank g receives the running un-clamped master of rank g-1, its mix
+ * continues that sum with its own tracks, rank g+1 gets the result; the LAST rank clamps and holds the result
+ * (wbx_dist_result_rank; its wbx_dist_exchange takes `dst`).  With renders of >= 1024 blocks (whole-list walks) the
+ * master is bit-identical to a single engine over all tracks.  The ranks form a pipeline over consecutive renders: same
+ * throughput, a render's latency grows with the world size.  Not with sub-buses.
+ * wbx_dist_init fails with WBX_ERR_FAILED when the collective start-up does not complete within
+ * WBX_DIST_INIT_TIMEOUT_S seconds (environment, default 60, 0 = wait for ever). */
 #define WBX_DIST_ID_BYTES 128
 typedef struct wbx_dist_id {
   char bytes[WBX_DIST_ID_BYTES];
 } wbx_dist_id;
-enum { WBX_DIST_REDUCE = 0, WBX_DIST_ORDERED = 1 };
+enum { WBX_DIST_REDUCE = 0, WBX_DIST_ORDERED = 1, WBX_DIST_CHAIN = 2 };
 void wbx_shard_tracks(uint32_t n_tracks, uint32_t world, uint32_t rank, uint32_t* first, uint32_t* count);
 wbx_status wbx_dist_new_id(wbx_dist_id* out);
 wbx_status wbx_dist_init(wbx_ctx* ctx, const wbx_dist_id* id, uint32_t rank, uint32_t world, int mode);
 wbx_status wbx_dist_info(wbx_ctx* ctx, uint32_t* rank, uint32_t* world, int* mode);
-/* dst (rank 0): [K][C][F] floats, device memory or pinned device-mapped host memory, 16-byte aligned */
+wbx_status wbx_dist_result_rank(wbx_ctx* ctx, uint32_t* rank);   /* 0 (reduce / ordered) or world - 1 (chain) */
+/* dst (the result rank only): [K][C][F] floats, device memory or pinned device-mapped host memory, 16-byte aligned */
 wbx_status wbx_dist_exchange(wbx_ctx* ctx, void* dst);
+/* average ms one exchange took on its own stream, over the exchanges completed so far (after wbx_dist_sync) */
+wbx_status wbx_dist_exchange_time(wbx_ctx* ctx, double* ms_avg, uint64_t* n_exchanges);
+/* every rank hands in `bytes` (<= 4096) bytes of host memory and gets all ranks' bytes in rank order; also a barrier */
+wbx_status wbx_dist_allgather(wbx_ctx* ctx, const void* send, void* recv, size_t bytes);
 wbx_status wbx_dist_sync(wbx_ctx* ctx);                  /* host waits for the renders and exchanges issued so far */
 wbx_status wbx_dist_barrier(wbx_ctx* ctx);               /* all ranks */
 wbx_status wbx_dist_max(wbx_ctx* ctx, double* value);    /* max over all ranks, in place (also a barrier) */
@@ -340,6 +379,11 @@ wbx_status wbx_engine_stop(wbx_engine* e);                                      
 
 /* Engine::process (engine.cpp:1576-1654): one block into out_planar[c][0..F). */
 wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar);
+/* Engine::process and the audio back end's conversion to the device's sample format in one call (the call site
+ * audio_io_pulseaudio.cpp:419-461: process(), then output_buffer.interleave_samples_to(buffer, 0, n, format) ->
+ * core/audio_format_conv.cpp:5-91): dst receives the block as F*C interleaved samples of `out_format` (WBX_OUT_*), the
+ * conversion running as the epilogue of the sum kernel — one launch fewer than process + wbx_fetch_interleaved. */
+wbx_status wbx_engine_process_interleaved(wbx_engine* e, int out_format, void* dst);
 /* K consecutive blocks in one device pass (render-ahead / offline): sequencing, mixing, summing and
  * clamping all on the device.  Asynchronous; results via wbx_fetch(wbx_engine_ctx(e), ...). */
 wbx_status wbx_engine_render(wbx_engine* e, uint32_t n_blocks);

@@ -269,6 +269,18 @@ struct Engine {
       process_status.store(st, std::memory_order_release);
     }
   }
+  // process() and the back end's output_buffer.interleave_samples_to(dst, 0, audio_buffer_size, format)
+  // (audio_io_pulseaudio.cpp:419-461, audio_buffer.h:143-160) in one call: the device-format conversion of
+  // core/audio_format_conv.cpp runs on the GPU as the last step of the block.  Never throws (see process()).
+  void process_interleaved(void* dst, AudioFormat format) noexcept {
+    const wbx_status st = wbx_engine_process_interleaved(h, static_cast<int>(format), dst);
+    if (st != WBX_OK) {
+      const size_t eb = format == AudioFormat::I16 ? 2 : format == AudioFormat::I24 ? 3 : 4;
+      std::memset(dst, 0, (size_t)audio_buffer_size * num_output_channels * eb);
+      process_error = wbx_engine_last_error(h);
+      process_status.store(st, std::memory_order_release);
+    }
+  }
   // UI thread, once per frame before the host's meters decay (Track::level_meter[c].take_level()): the running per-track maxima the GPU kept since
   // the last call (VUMeter::push_samples, vu_meter.h:20-30) go into the tracks' meters
   void fetch_levels() {

@@ -1044,7 +1044,19 @@ static void track_process(wbo_engine* e, wbo_track* t, float* const* out, double
  * bus order, then the clamp. */
 void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out) { wbo_engine_process_ex(e, out, bus_out, 1); }
 
+static void engine_process_impl(wbo_engine* e, float* const* out, float* bus_out, int clamp, int keep_out);
+
 void wbo_engine_process_ex(wbo_engine* e, float* const* out, float* bus_out, int clamp) {
+  engine_process_impl(e, out, bus_out, clamp, 0);
+}
+
+/* NOT in the reference: Engine::process WITHOUT the output_buffer.clear() of engine.cpp:1598 — `out` holds the running,
+ * un-clamped sum of the tracks that precede this engine's in a session split over several engines, and the track loop
+ * (engine.cpp:1600-1617) continues it.  The checker for the product's wbx_set_master_init / WBX_DIST_CHAIN: a chain of
+ * such calls over the shards is, addition for addition, one Engine::process over all tracks. */
+void wbo_engine_process_from(wbo_engine* e, float* const* out, int clamp) { engine_process_impl(e, out, NULL, clamp, 1); }
+
+static void engine_process_impl(wbo_engine* e, float* const* out, float* bus_out, int clamp, int keep_out) {
   const uint32_t F = e->buffer_size, C = e->out_channels;
   double sample_rate = (double)e->sample_rate;
   double buffer_duration = (double)F / sample_rate;                /* :1578 */
@@ -1058,7 +1070,7 @@ void wbo_engine_process_ex(wbo_engine* e, float* const* out, float* bus_out, int
     e->tracks[i].n_events = 0;
   e->n_seglog = 0;
 
-  wbo_clear(out, C, F);                                            /* :1598 */
+  if (!keep_out) wbo_clear(out, C, F);                             /* :1598 */
   if (e->n_buses)
     memset(e->busbuf, 0, (size_t)e->n_buses * C * F * sizeof(float));
 

@@ -203,6 +203,9 @@ void wbo_engine_process(wbo_engine* e, float* const* out, float* bus_out);
 /* same, with the final clamp optional (clamp = 0: the un-clamped sum, what one shard of a multi-GPU
  * session contributes before the cross-GPU reduce) */
 void wbo_engine_process_ex(wbo_engine* e, float* const* out, float* bus_out, int clamp);
+/* NOT in the reference: the same without clearing `out` first (engine.cpp:1598) — `out` holds the running un-clamped
+ * sum of the tracks before this engine's; checker for wbx_set_master_init / WBX_DIST_CHAIN.  No sub-buses. */
+void wbo_engine_process_from(wbo_engine* e, float* const* out, int clamp);
 
 /* synthetic input generator (integer hash; input generation only, same bits as whitebox_amd/synth.py) */
 void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pad);

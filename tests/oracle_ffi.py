@@ -320,6 +320,14 @@ class OracleEngine:
                                      int(clamp))
         return np.stack(out), bus
 
+    def process_from(self, running: np.ndarray, clamp=False) -> np.ndarray:
+        """Engine::process continuing `running` ([C][F], the un-clamped sum of the tracks before this engine's) instead of
+        the cleared output buffer — the checker for wbx_set_master_init / WBX_DIST_CHAIN."""
+        out = [np.ascontiguousarray(running[c], dtype=np.float32).copy() for c in range(self.C)]
+        self.L.wbo_engine_process_from.argtypes = [C.POINTER(_Engine), c_f32pp, C.c_int]
+        self.L.wbo_engine_process_from(self.e, planar_ptrs(out), int(clamp))
+        return np.stack(out)
+
     def enable_seglog(self, on=True): self.L.wbo_engine_enable_seglog(self.e, int(on))
 
     def seglog(self):

@@ -231,6 +231,76 @@ def _worker_pipelined(rank, world, port, n_tracks, mode, q):
     dist.destroy_process_group()
 
 
+def _worker_chain(rank, world, port, n_tracks, amp, q):
+    """WBX_DIST_CHAIN's protocol with gloo send / recv: five renders of two blocks; rank g receives rank g-1's running,
+    un-clamped master for render i, continues it with its own tracks (the oracle's Engine::process without the output
+    clear = what the mix kernel does with MixArgs::init), hands it to rank g+1; the LAST rank clamps and holds the
+    result.  Receives land in a ring of three incoming buffers and sends leave from a ring of three partial buffers, as
+    in wbx_dist.hip; every rank issues recv(i) / render(i) / send(i) in that order, so the ranks form a pipeline."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_ffi as O
+    from whitebox_amd.dist import shard_tracks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = _session(n_tracks, amp)
+    for s in spec.samples:
+        s.frames *= 4
+    first, count = shard_tracks(n_tracks, world, rank)
+    e = O.build_oracle_engine(_shard_spec(spec, first, count))
+    e.play()
+    NS, K, steps = 3, 2, 5
+    incoming = [torch.zeros(K, 2, 512) for _ in range(NS)]
+    partial = [torch.zeros(K, 2, 512) for _ in range(NS)]
+    sends, results = {}, []
+    clamp = _clamp_with_oracle(O)
+    for i in range(steps):
+        slot = i % NS
+        if rank > 0:
+            dist.recv(incoming[slot], src=rank - 1)
+        else:
+            incoming[slot].zero_()
+        run = incoming[slot].numpy()
+        out = np.stack([e.process_from(run[b]) for b in range(K)])
+        if slot in sends:                                      # the slot's previous send must be out before it is refilled
+            sends.pop(slot).wait()
+        partial[slot].copy_(torch.from_numpy(out))
+        if rank + 1 < world:
+            sends[slot] = dist.isend(partial[slot], dst=rank + 1)
+        else:
+            final = partial[slot].numpy().copy()
+            clamp(final)
+            results.append(final)
+    for w in sends.values():
+        w.wait()
+    e.close()
+    if rank == world - 1:
+        q.put(np.concatenate(results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tracks,amp", [(2, 23, 0.6), (3, 20, None), (3, 22, 0.6)])
+def test_chain_mode_is_the_reference_order_across_ranks(world, n_tracks, amp):
+    """Bit-identical to ONE engine over all tracks — hot sessions included, where the sum of shard sums is not."""
+    import oracle_ffi as O
+    got = _run(world, _worker_chain, (n_tracks, amp))
+    spec = _session(n_tracks, amp)
+    for s in spec.samples:
+        s.frames *= 4
+    e = O.build_oracle_engine(spec)
+    e.play()
+    want = np.stack([e.process()[0] for _ in range(10)])
+    e.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if amp:
+        assert (np.abs(want) == 1.0).any()
+
+
 @pytest.mark.parametrize("world,n_tracks,mode", [(2, 23, "reduce"), (3, 20, "reduce"), (3, 20, "ordered")])
 def test_pipelined_exchange_ring_of_three(world, n_tracks, mode):
     import oracle_ffi as O

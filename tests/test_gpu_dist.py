@@ -13,7 +13,7 @@ import pytest
 import oracle_ffi as O
 import whitebox_amd as W
 from whitebox_amd import synth
-from whitebox_amd.dist import ORDERED, REDUCE, Dist, PinnedBuffer
+from whitebox_amd.dist import CHAIN, ORDERED, REDUCE, Dist, PinnedBuffer
 from whitebox_amd.engine import build_engine
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def oracle_master(spec, n_blocks, clamp=True):
     return m
 
 
-@pytest.mark.parametrize("mode", [REDUCE, ORDERED])
+@pytest.mark.parametrize("mode", [REDUCE, ORDERED, CHAIN])
 @pytest.mark.parametrize("K", [4, 16])          # short renders sum in-stream, long ones on the sum stream
 def test_world1_exchange_through_rccl_equals_the_oracle(mode, K):
     steps = 5
@@ -97,7 +97,7 @@ def test_bench_multi_gpu_launch_paths():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "2"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and f"needs {have + 1} gfx950 devices" in r.stderr, r.stderr[-500:]
-    for mode in ("reduce", "ordered"):
+    for mode in ("reduce", "ordered", "chain"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--blocks", "64", "--steps", "6",
                             "--warmup", "1", "--ramp-steps", "4", "--force-dist-path", "--dist-mode", mode,
                             "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
@@ -108,3 +108,26 @@ def test_bench_multi_gpu_launch_paths():
         line = json.loads(lines[0])
         assert line["n_gpus"] == 1 and line["value"] > 0 and "wbx_dist_exchange" in line["config"]["exchange"]
         assert 0.0 < line["master_peak"] <= 1.0
+        # what the exchange saw, and the head of the run against the oracle
+        assert line["rccl_world"] == 1 and len(line["devices"]) == 1 and line["devices"][0].count(":") == 2
+        assert line["exchange_ms_avg"] > 0.0 and line["tracks_per_gpu"] == 256
+        assert line["verify"]["ok"] and line["verify"]["peaks_equal"] and line["verify"]["plan_rows_equal"]
+
+
+def test_dist_info_and_allgather_at_world_1():
+    spec = synth.make_session("dist3", 4, n_blocks=2, seed=0xD153)
+    eng = build_engine(spec, max_blocks=2)
+    d = Dist(eng.ctx, 0, 1, CHAIN)
+    assert d.result_rank == 0 and d.allgather(b"hello", 16) == [b"hello"]
+    out = PinnedBuffer(2 * 2 * 512)
+    eng.play()
+    eng.render(2)
+    d.exchange(out.ptr)
+    d.sync()
+    info = d.info()
+    assert info["world"] == 1 and info["mode"] == "chain" and info["exchanges"] == 1 and info["exchange_ms_avg"] > 0.0
+    assert info["devices"] == [eng.ctx.device_info()["pci"]]
+    assert np.array_equal(bits(out.array.reshape(2, 2, 512)), bits(oracle_master(spec, 2)))
+    d.shutdown()
+    out.close()
+    eng.close()

@@ -159,6 +159,168 @@ def test_config3_exact_order_mode():
     check_against_oracle(spec, 2, group_size=1024, expect_exact=True)
 
 
+def test_config3_4096_whole_list_walk_is_bit_exact(monkeypatch):
+    """BASELINE config 3 at full width in the reference's own summation order: one workgroup walks all 4096 tracks of
+    its block (32 staged chunks: prefetched rows, staggered first chunk).  That is what the library picks for renders of
+    >= 1024 blocks; WBX_EXACT_MIN_BLOCKS lowers the threshold so that the oracle only has to render 4 blocks.  Master,
+    peaks, stream-call log and transport bit for bit."""
+    monkeypatch.setenv("WBX_EXACT_MIN_BLOCKS", "4")
+    spec = synth.make_session("c3", 4096, src_rate=44100, n_blocks=4, seed=0x5EED0003)
+    check_against_oracle(spec, 4, expect_exact=True)
+    spec = synth.make_session("c3s", 4096, src_rate=44100, seek=True, n_blocks=5, seed=0x5EED0013)   # clip boundaries in the walk
+    check_against_oracle(spec, 5, expect_exact=True)
+
+
+def test_render_of_1024_blocks_takes_the_reference_order():
+    """The default for a long render, at BASELINE config 3's full size and the benchmark's render length: wbx_render_order
+    reports the reference's order, the launched instance is the two-channels-per-lane one, and the head of the render —
+    the first 4 blocks — is bit-identical to the oracle (the bench's own --verify does the same after its timed loop)."""
+    K, N = 1024, 4096
+    long_spec = synth.make_session("c3", N, src_rate=44100, n_blocks=K, seed=0x5EED0003)
+    eng = build_engine(long_spec, max_blocks=K, device_synth=True)
+    eng.play()
+    eng.render(K)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    assert eng.ctx.render_order(K) == (1, N, True) and eng.ctx.render_order(256)[2] is False
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"
+    om, opk, _, _, _ = run_oracle(synth.make_session("c3", N, src_rate=44100, n_blocks=4, seed=0x5EED0003), 4)
+    assert np.array_equal(bits(m[:4]), bits(om)) and np.array_equal(pk[:4], opk[..., :2])
+    assert np.abs(m[4:]).max() > 0.05 and np.isfinite(m).all()
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the 1e-6 RMS gate where it is tight: sessions at mix-bus level (tools/level_probe.py, profiles/r03_level_probe.txt)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw,mult", [("c3", dict(src_rate=44100), 1.0), ("c3", dict(src_rate=44100), 2.0),
+                                          ("c4", dict(n_buses=64), 1.0), ("c4", dict(n_buses=64), 2.0)])
+def test_grouped_order_at_mix_bus_levels(name, kw, mult):
+    """Short renders add 128-track groups in order and then the group sums.  The association error scales with the level
+    of the running sum: the synthetic default amp = 0.25/sqrt(N) (master peak 0.4) is a friendly level.  Here the master
+    runs around full scale (amp = 1/sqrt(N): rms 0.44, 3 % of the samples on the clamp) and far beyond (2/sqrt(N): a
+    quarter of them clamped) — N = 4096 stays inside north_star's 1e-6 RMS either way (measured 4.9e-7 / 7.0e-7); config
+    4's bus layout (64-track buses = one group each) is the reference's order and stays bit-exact."""
+    N, K = 4096, 4
+    spec = synth.make_session(name, N, n_blocks=K, seed=0x5EED0003, amp=float(np.float32(mult / np.sqrt(N))), **kw)
+    om, opk, _, _, _ = run_oracle(spec, K)
+    eng = build_engine(spec, max_blocks=K)
+    eng.play()
+    eng.render(K)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    eng.close()
+    assert np.array_equal(pk, opk[..., :2])
+    d = m.astype(np.float64) - om.astype(np.float64)
+    r, mx = float(np.sqrt(np.mean(d * d))), float(np.abs(d).max())
+    print(f"{name} amp={mult}/sqrt(N): master rms {np.sqrt(np.mean(om.astype(np.float64) ** 2)):.3f}, "
+          f"clamped {np.mean(np.abs(om) >= 1.0):.3f}, rms vs oracle {r:.3e}, max abs {mx:.3e}")
+    if name == "c4":
+        assert np.array_equal(bits(m), bits(om))
+    else:
+        assert r <= RMS_TOL, r
+
+
+@pytest.mark.parametrize("mult", [0.25, 1.0])
+def test_config5_chain_of_8_engines_is_bit_exact(mult):
+    """BASELINE config 5 in the reference's order ACROSS the shards: engine g continues the running, un-clamped master of
+    engine g-1 (wbx_set_master_init — what WBX_DIST_CHAIN does between GPUs with ncclSend / ncclRecv), every shard walks
+    its 4096 tracks in one workgroup per block, the last engine clamps.  Bit-identical to the single-engine oracle over
+    all 32768 tracks — also at mix-bus level (amp = 1/sqrt(N)), where adding shard SUMS leaves the 1e-6 RMS budget
+    (1.5e-6: profiles/r03_level_probe.txt)."""
+    from test_dist_gloo import _shard_spec
+    from whitebox_amd.dist import PinnedBuffer, shard_tracks
+    n_tracks, world, K = 32768, 8, 2
+    spec = synth.make_session("c5", n_tracks, n_blocks=K, seed=0x5EED0006, amp=float(np.float32(mult / np.sqrt(n_tracks))))
+    om, opk, _, _, _ = run_oracle(spec, K)
+    running = PinnedBuffer(K * 2 * 512)
+    shard_sums = np.zeros_like(om)
+    for rank in range(world):
+        first, count = shard_tracks(n_tracks, world, rank)
+        eng = build_engine(_shard_spec(spec, first, count), max_blocks=K, group_size=count)
+        eng.ctx.set_clamp(rank == world - 1)                   # engine.cpp:1627-1636 follows the LAST addition
+        eng.ctx.set_master_target(running.ptr)
+        eng.ctx.set_master_init(running.ptr if rank else None)
+        eng.play()
+        eng.render(K)
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk, opk[:, first:first + count, :2])
+        eng.close()
+    got = running.array.reshape(K, 2, 512).copy()
+    running.close()
+    assert np.array_equal(bits(got), bits(om)), rms(got, om)
+
+
+def test_master_init_continues_a_running_sum():
+    """wbx_set_master_init on a small session split 23 + 17 + 9 tracks over three engines, clip boundaries inside the
+    blocks, block by block (Engine::process) and as one render; sub-buses refuse."""
+    from test_dist_gloo import _shard_spec
+    from whitebox_amd.dist import PinnedBuffer
+    K = 5
+    spec = synth.make_session("split", 49, seek=True, src_rate=44100, n_blocks=K, seed=0x51C, amp=0.3)
+    om, _, _, _, _ = run_oracle(spec, K)
+    running = PinnedBuffer(K * 2 * 512)
+    first = 0
+    for i, count in enumerate((23, 17, 9)):
+        eng = build_engine(_shard_spec(spec, first, count), max_blocks=K, group_size=count)
+        eng.ctx.set_clamp(i == 2)
+        eng.ctx.set_master_target(running.ptr)
+        eng.ctx.set_master_init(running.ptr if i else None)
+        eng.play()
+        eng.render(K)
+        eng.ctx.sync()
+        eng.close()
+        first += count
+    assert np.array_equal(bits(running.array.reshape(K, 2, 512)), bits(om))
+    assert (np.abs(om) == 1.0).any()                          # the session really clamps, and only after the last shard
+    eng = build_engine(synth.make_session("b", 8, n_buses=2, n_blocks=1), max_blocks=1)
+    eng.ctx.set_master_init(running.ptr)
+    eng.play()
+    with pytest.raises(W.WbxError):
+        eng.render(1)
+    eng.close()
+    running.close()
+
+
+def test_levels_of_tracks_added_since_the_last_render_read_zero():
+    """wbx_engine_levels for more tracks than have been through a render (a track was just added, the audio callback is
+    not running): zeros for those, no error — the UI's per-frame meter read must not fail."""
+    spec = synth.make_session("lv", 6, n_blocks=2, seed=0x1E7)
+    eng = build_engine(spec, max_blocks=2, spare_tracks=2)
+    assert not eng.levels().any()                              # nothing rendered yet
+    eng.play()
+    eng.render(2)
+    eng.add_track("late")
+    eng.add_track("later")
+    lv = eng.levels()
+    assert lv.shape == (8, 2) and (lv[:6] > 0).all() and not lv[6:].any()
+    assert not eng.levels().any()                              # read and reset (VUMeter::update, vu_meter.h:33)
+    eng.render(2)                                              # the new tracks get their (cleared) device state: no stall, no error
+    assert (eng.levels()[:6] > 0).all()
+    eng.close()
+
+
+def test_clip_storage_reuses_the_extent_of_a_replaced_clip():
+    """Replacing a clip again and again beside a long-lived one stays inside the slab (first fit over the released
+    extents): the pool does not grow."""
+    ctx = W.MixContext(8, max_blocks=1)
+    rng = np.random.default_rng(11)
+    keep = [rng.standard_normal(1_000_000).astype(np.float32)]
+    ctx.clip_upload(0, "f32", 48000, keep)
+
+    def stats():
+        import ctypes as CT
+        n, res, live = CT.c_uint32(), CT.c_uint64(), CT.c_uint64()
+        assert ctx.L.wbx_clip_pool_stats(ctx.h, CT.byref(n), CT.byref(res), CT.byref(live)) == 0
+        return n.value, res.value, live.value
+    for i in range(40):                                        # 40 x 16 MB through a 64-MiB slab
+        data = [rng.standard_normal(4_000_000 - 1000 * i).astype(np.float32)]
+        ctx.clip_upload(1, "f32", 48000, data)
+        assert np.array_equal(ctx.clip_download(1, 0, len(data[0]), np.float32), data[0])
+    n, res, live = stats()
+    assert n == 1 and res == 64 << 20 and live < 24 << 20
+    assert np.array_equal(ctx.clip_download(0, 0, len(keep[0]), np.float32), keep[0])
+    ctx.close()
+
+
 def test_config4_4096_into_64_buses():
     """BASELINE config 4 at full size: bus = track/64, group_size 64 -> every bus is summed in the
     oracle's order and the master in bus order: bit-exact, bus sums included."""
@@ -661,6 +823,56 @@ def test_interleaved_output_formats():
             getattr(L, "wbo_f32_to_interleaved_" + fmt)(a.ctypes.data, O.planar_ptrs(src), 0, 512, 2)
             exp.append(a)
         assert np.array_equal(got.view(np.uint8), np.concatenate(exp).view(np.uint8)), fmt
+    eng.close()
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_device_format_as_the_sum_kernel_epilogue(channels):
+    """wbx_engine_process_interleaved (the audio callback: Engine::process + interleave_samples_to in one call) and
+    wbx_set_master_format (render-ahead): the conversion of audio_format_conv.cpp as the epilogue of the sum kernel — all
+    five formats, stereo and mono out, a hot session (the clamp precedes the conversion), buses; bytes equal to the
+    reference's converters over the oracle's master."""
+    K = 3
+    spec = synth.make_session("convf", 24, n_blocks=K, amp=0.3, seed=0x73, n_buses=3, src_rate=44100)
+    spec.channels = channels
+    om, _, _, _, _ = run_oracle(spec, K)
+    assert (np.abs(om) == 1.0).any()
+    L = O.lib()
+
+    def expected(fmt, dt, b):
+        a = np.zeros(512 * channels * (3 if fmt == "i24" else 1), dt)
+        src = [np.ascontiguousarray(om[b][c]) for c in range(channels)]
+        getattr(L, "wbo_f32_to_interleaved_" + fmt)(a.ctypes.data, O.planar_ptrs(src), 0, 512, channels)
+        return a
+    formats = (("i16", np.int16), ("i24", np.uint8), ("i24_x8", np.int32), ("i32", np.int32), ("f32", np.float32))
+    eng = build_engine(spec, max_blocks=1)
+    for fmt, dt in formats:
+        eng.play()
+        for b in range(K):
+            got = eng.process_interleaved(fmt)
+            assert np.array_equal(got.view(np.uint8), expected(fmt, dt, b).view(np.uint8)), (fmt, b)
+        eng.stop()
+    out = W.AudioBuffer(512, channels)                         # ... and the planar call is what it was
+    eng.play()
+    eng.process(None, out, 48000.0)
+    assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om[0]))
+    eng.close()
+    eng = build_engine(spec, max_blocks=K)
+    for fmt, dt in formats:
+        eng.ctx.set_master_format(fmt)
+        eng.play()
+        eng.render(K)
+        got = eng.ctx.fetch_interleaved(fmt)
+        exp = np.concatenate([expected(fmt, dt, b) for b in range(K)])
+        assert np.array_equal(got.view(np.uint8), exp.view(np.uint8)), fmt
+        with pytest.raises(W.WbxError):
+            eng.ctx.fetch()                                    # no planar master after such a render
+        eng.stop()
+    eng.ctx.set_master_format(None)
+    eng.play()
+    eng.render(K)
+    m, _, _ = eng.ctx.fetch()
+    assert np.array_equal(bits(m), bits(om))
     eng.close()
 
 

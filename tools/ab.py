@@ -36,6 +36,16 @@ def presets(other_lib=None):
                                 f"--workload {w} --group-size 4096 --blocks {k} --steps {max(4, 5120 // k)} --warmup 2 "
                                 f"--ramp-steps {max(4, 10240 // k)}")
                            for w in ("c3", "c4") for k in (1024, 2048) for v in (24, 43, 82, 1000)]
+    # whole-list walks (the library's choice for renders of >= 1024 blocks) against 128-track groups at the same render length
+    P["exact_vs_grouped"] = [case(f"{w}{' L=%s' % l if l else ''} K=1024 {'grouped' if g else 'whole lists'}",
+                                  "WBX_EXACT_MIN_BLOCKS=0" if g else "",
+                                  f"--workload {w} {'--clip-blocks %s' % l if l else ''} --blocks 1024 --steps 6 --warmup 2 --ramp-steps 10")
+                             for (w, l) in (("c3", 0), ("c4", 0), ("c2", 0), ("u4096", 0), ("i16", 0), ("i16r", 0), ("i24r", 0),
+                                            ("mixr", 0), ("mixfmt", 0), ("d96", 0), ("c3", 5.3), ("i16", 5.3))
+                             for g in (0, 1)]
+    P["exact_k"] = [case(f"{w}{' L=%s' % l if l else ''} K={k} whole lists", "",
+                         f"--workload {w} {'--clip-blocks %s' % l if l else ''} --blocks {k} --steps {6144 // k} --warmup 2 --ramp-steps {10240 // k}")
+                    for (w, l) in (("i16r", 0), ("i16", 0), ("c3", 5.3), ("i24r", 0)) for k in (1024, 1536, 2048)]
     P["variants"] = [case(f"c3 variant={v}", f"WBX_MIX_VARIANT={v}", STD) for v in (24, 43, 82)]
     P["c2_groups"] = [case(f"c2 group={g} variant={v}", f"WBX_MIX_VARIANT={v}",
                            f"--workload c2 --group-size {g} --steps 20 --warmup 3 --ramp-steps 60")
@@ -84,6 +94,10 @@ def run_case(c, out):
         k, v = kv.split("=", 1)
         env[k] = v
     cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + c["args"].split() + ["--no-cpu-baseline", "--no-configs"]
+    if "--verify" in cmd:
+        cmd.remove("--verify")      # (a case may ask for the oracle check of the rendered head; sweeps skip it)
+    else:
+        cmd.append("--no-verify")
     if not c["lat"]:
         cmd += ["--latency-blocks", "0"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True)

@@ -75,10 +75,13 @@ SYMBOLS = {
     "wbx_clip_build_mipmaps": (C.c_int, [_vp, _u32, C.c_int]),
     "wbx_clip_fetch_mipmap": (C.c_int, [_vp, _u32, _u32, _vp]),
     "wbx_clip_mipmap_device": (C.c_int, [_vp, _u32, _u32, _pp, C.POINTER(C.c_uint64)]),
+    "wbx_render_order": (C.c_int, [_vp, _u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int)]),
+    "wbx_device_info": (C.c_int, [_vp, C.c_char_p, _sz, C.c_char_p, _sz]),
     "wbx_set_routing": (C.c_int, [_vp, _u32, C.POINTER(_i32), _u32]),
     "wbx_submit": (C.c_int, [_vp, _u32, _u32, C.POINTER(Segment), C.POINTER(_u32), C.POINTER(_f)]),
     "wbx_fetch": (C.c_int, [_vp, _fpp, C.POINTER(_f), C.POINTER(_f)]),
     "wbx_fetch_interleaved": (C.c_int, [_vp, C.c_int, _vp]),
+    "wbx_set_master_format": (C.c_int, [_vp, C.c_int]),
     "wbx_sync": (C.c_int, [_vp]),
     "wbx_master_ready": (C.c_int, [_vp, _vp]),
     "wbx_partial_master": (C.c_int, [_vp, _pp, C.POINTER(_sz)]),
@@ -86,11 +89,15 @@ SYMBOLS = {
     "wbx_finalize_master_into": (C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp]),
     "wbx_set_clamp": (C.c_int, [_vp, C.c_int]),
     "wbx_set_master_target": (C.c_int, [_vp, _vp]),
+    "wbx_set_master_init": (C.c_int, [_vp, _vp]),
     "wbx_shard_tracks": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "wbx_dist_new_id": (C.c_int, [_vp]),
     "wbx_dist_init": (C.c_int, [_vp, _vp, _u32, _u32, C.c_int]),
     "wbx_dist_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int)]),
+    "wbx_dist_result_rank": (C.c_int, [_vp, C.POINTER(_u32)]),
     "wbx_dist_exchange": (C.c_int, [_vp, _vp]),
+    "wbx_dist_exchange_time": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(C.c_uint64)]),
+    "wbx_dist_allgather": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wbx_dist_sync": (C.c_int, [_vp]),
     "wbx_dist_barrier": (C.c_int, [_vp]),
     "wbx_dist_max": (C.c_int, [_vp, C.POINTER(_d)]),
@@ -141,6 +148,7 @@ SYMBOLS = {
     "wbx_engine_play": (C.c_int, [_vp]),
     "wbx_engine_stop": (C.c_int, [_vp]),
     "wbx_engine_process": (C.c_int, [_vp, _fpp]),
+    "wbx_engine_process_interleaved": (C.c_int, [_vp, C.c_int, _vp]),
     "wbx_engine_render": (C.c_int, [_vp, _u32]),
     "wbx_engine_transport": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int)]),
     "wbx_engine_levels": (C.c_int, [_vp, C.POINTER(_f), _u32]),

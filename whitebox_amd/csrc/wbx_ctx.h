@@ -117,7 +117,13 @@ struct wbx_ctx {
   uint32_t routing_tracks = 0, n_buses = 0;
   std::vector<int32_t> track_bus;
   std::vector<uint32_t> order;
-  std::vector<DGroup> groups;
+  std::vector<DGroup> groups;         // member lists cut into pieces of group_size tracks (one workgroup per piece and block)
+  std::vector<DGroup> groups_exact;   // the member lists whole: the reference's summation order (build_routing)
+  bool buses_alias_exact = false;     // buses_alias_partials of groups_exact
+  bool whole_lists_now = false;       // the render being issued takes groups_exact (render_walks_whole_lists)
+  uint32_t longest_list = 0;          // tracks in the longest member list
+  uint32_t exact_min_blocks = 1024;   // renders of at least this many blocks do, when the library picks the grouping
+                                      // (WBX_EXACT_MIN_BLOCKS; 0 = never)
   DevBuf<uint32_t> d_order;
   DevBuf<DGroup> d_groups;
   bool routing_dirty = true;
@@ -182,6 +188,9 @@ struct wbx_ctx {
   bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
   bool clamp = true;
   float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
+  int master_format = 0;              // wbx_set_master_format: 0 planar fp32, else WBX_OUT_* interleaved (sum kernel epilogue)
+  int last_master_format = 0;         // ... of the last render
+  const float* master_init = nullptr; // wbx_set_master_init: the running sum the first group starts from, or null: zero
 
   // kernel timing (mix kernel)
   hipEvent_t ev[kEventRing][3]{};       // before the mix, after the mix, after the sum
@@ -275,12 +284,15 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
+bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K);
 int mix_family(const wbx_ctx* c);
 bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 
 // wbx_dist.hip
 float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);
+const float* dist_mix_init(wbx_ctx* c, uint32_t K, hipStream_t mix_stream, wbx_status* st);
+hipError_t dist_mix_issued(wbx_ctx* c, hipStream_t mix_stream);
 void dist_destroy(wbx_ctx* c);
 
 }  // namespace wbx

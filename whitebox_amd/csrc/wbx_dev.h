@@ -197,14 +197,13 @@ struct MixArgs {
   const uint32_t* order;        // [N] track permutation (routing order)
   const DGroup* groups;         // [NG]
   float* partial;               // [K][NG][C][F]
+  const float* init;            // [K][C][F] or null: what the first group's sum starts from (wbx_set_master_init)
   float* peaks;                 // [K][N][C]
   uint32_t* levels;             // [N][C] running maxima (VUMeter::level) as uint images, or null
   uint32_t n_tracks, n_groups, block_frames, channels;
   uint32_t tiles;               // ceil(C*F/4 / 256)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
   uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
-  uint32_t stagger;             // long walks (a group of more than two staged chunks): shorten the first chunk by a
-                                // per-workgroup phase (tuning knob WBX_STAGGER=0 turns it off; results are identical)
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
 };
@@ -213,6 +212,8 @@ struct SumArgs {
   const float* partial;         // [K][NG][C][F]
   const DGroup* groups;
   float* master;                // [K][C][F]
+  void* out_il;                 // or: interleaved device-format samples [K*F][C] (packed 24-bit: [K][F*C*3] bytes), then
+  uint32_t out_format;          // master is unused; WBX_OUT_* (3 i16, 5 packed i24, 6 i24 in 32, 7 i32, 9 f32)
   float* buses;                 // [K][NB][C][F] or null
   uint32_t n_groups, n_buses, block_frames, channels;
   uint32_t clamp;

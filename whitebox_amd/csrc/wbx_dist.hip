@@ -13,13 +13,25 @@
 //   * the root's clamp writes the final master straight into the caller's destination (device memory or pinned,
 //     device-mapped host memory — plain kernel stores, no copy engine).
 //
-// Two modes: WBX_DIST_REDUCE — one ncclReduce(sum) (RCCL's summation order is implementation-defined, inside the
-// 1e-6 RMS budget); WBX_DIST_ORDERED — ncclGather of the N partials to the root and a fixed-order add
-// ((((0 + p0) + p1) + ...) + pN-1, rank order = track order) in a kernel: bit-reproducible whatever the topology.
+// Three modes: WBX_DIST_REDUCE — one ncclReduce(sum) (RCCL's summation order is implementation-defined);
+// WBX_DIST_ORDERED — ncclGather of the N partials to the root and a fixed-order add ((((0 + p0) + p1) + ...) + pN-1,
+// rank order = track order) in a kernel: bit-reproducible whatever the topology.  Both add SHARD sums: the association of
+// the fp32 additions differs from the reference's track-after-track order, and at 32768 tracks that difference leaves
+// the 1e-6 RMS budget once the master runs at mix-bus level (profiles/r03_level_probe.txt: 4.4e-7 at the synthetic
+// level amp = 0.25/sqrt(N), 1.5e-6 at 1/sqrt(N)).  WBX_DIST_CHAIN — the reference's order across GPUs: rank g receives
+// the running, un-clamped master of rank g-1 (ncclRecv), its mix kernel CONTINUES that sum with its own tracks
+// (MixArgs::init) and rank g+1 gets the result (ncclSend); the last rank clamps.  With whole-list walks inside every shard
+// (renders of >= 1024 blocks) the master is bit-identical to the single-engine reference at any level.  The ranks work
+// as a pipeline — rank g on render i while rank g-1 is on render i+1 — so the throughput is a render per mix time as in
+// the other modes; only the latency of one render grows with the world size.
 //
 // RCCL is loaded on first use (dlopen of librccl.so.1): a single-GPU host never maps it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <thread>
 
 #include "wbx_ctx.h"
 
@@ -37,6 +49,9 @@ struct Rccl {
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -64,6 +79,9 @@ Rccl* rccl() {
   r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
   r.Gather = reinterpret_cast<decltype(r.Gather)>(sym("ncclGather"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+  r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+  r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
   return &r;
 }
@@ -73,6 +91,8 @@ Rccl* rccl() {
 namespace wbx {
 
 constexpr int kDistRing = 3;
+constexpr int kDistTimers = 32;
+constexpr size_t kGatherBytes = 4096;   // wbx_dist_allgather: bytes per rank
 
 struct DistState {
   ncclComm_t comm = nullptr;
@@ -88,7 +108,29 @@ struct DistState {
   int slot = -1;                           // ring slot of the last render
   bool exchanged = true;                   // the last render's exchange has been issued
   double* scalar = nullptr;                // device scratch of wbx_dist_max / _barrier
+  // chain mode, rank > 0: the running master of rank - 1, one buffer per ring slot
+  float* chain_in[kDistRing] = {};
+  hipEvent_t in_ready[kDistRing] = {};     // the receive has landed (the mix waits for it)
+  hipEvent_t in_free[kDistRing] = {};      // the mix that read the buffer has been issued ... and finished (its stream)
+  bool in_used[kDistRing] = {};
+  // the exchange's own time on its stream (from "the partial is there" to "the result / the send is out")
+  hipEvent_t t0[kDistTimers] = {}, t1[kDistTimers] = {};
+  int t_pending = 0;
+  double ex_ms_total = 0.0;
+  uint64_t ex_n = 0;
+  char* gather = nullptr;                  // wbx_dist_allgather scratch: [world + 1][kGatherBytes]
 };
+
+static void drain_exchange_timers(DistState* d) {
+  for (int i = 0; i < d->t_pending; i++) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, d->t0[i], d->t1[i]) == hipSuccess) {
+      d->ex_ms_total += ms;
+      d->ex_n++;
+    }
+  }
+  d->t_pending = 0;
+}
 
 // called by launch_mix_sum: where this render's partial master goes; `sum_stream` (the stream its sum kernel runs on)
 // is made to wait until the slot's previous exchange has read it
@@ -101,6 +143,45 @@ float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err) {
   return d->master[d->slot];
 }
 
+// called by launch_mix_sum after dist_begin_render and before the mix launch: what this render's sum starts from.  Chain
+// mode, rank > 0: the receive of rank - 1's running master for this render is enqueued on the exchange stream and the mix
+// stream is made to wait for it.
+const float* dist_mix_init(wbx_ctx* c, uint32_t K, hipStream_t mix_stream, wbx_status* st) {
+  *st = WBX_OK;
+  DistState* d = c->dist;
+  if (!d || d->mode != WBX_DIST_CHAIN || d->rank == 0) return c->master_init;
+  if (c->n_buses) {
+    *st = fail(c, WBX_ERR_UNSUPPORTED, "WBX_DIST_CHAIN: a running master cannot be continued through sub-buses");
+    return nullptr;
+  }
+  const size_t n = (size_t)K * c->cfg.channels * c->cfg.block_frames;
+  const int slot = d->slot;
+  hipError_t e = hipSuccess;
+  if (d->in_used[slot]) e = hipStreamWaitEvent(d->comm_stream, d->in_free[slot], 0);   // its last reader, three renders ago
+  if (e == hipSuccess) {
+    const ncclResult_t nr = rccl()->Recv(d->chain_in[slot], n, ncclFloat, (int)d->rank - 1, d->comm, d->comm_stream);
+    if (nr != ncclSuccess) {
+      *st = fail(c, WBX_ERR_DEVICE, (std::string("ncclRecv: ") + rccl()->GetErrorString(nr)).c_str());
+      return nullptr;
+    }
+    e = hipEventRecord(d->in_ready[slot], d->comm_stream);
+  }
+  if (e == hipSuccess) e = hipStreamWaitEvent(mix_stream, d->in_ready[slot], 0);
+  if (e != hipSuccess) {
+    *st = fail(c, WBX_ERR_DEVICE, "WBX_DIST_CHAIN receive", e);
+    return nullptr;
+  }
+  return d->chain_in[slot];
+}
+
+// ... and right after the mix launch: the incoming buffer is free again when that mix is over
+hipError_t dist_mix_issued(wbx_ctx* c, hipStream_t mix_stream) {
+  DistState* d = c->dist;
+  if (!d || d->mode != WBX_DIST_CHAIN || d->rank == 0) return hipSuccess;
+  d->in_used[d->slot] = true;
+  return hipEventRecord(d->in_free[d->slot], mix_stream);
+}
+
 void dist_destroy(wbx_ctx* c) {
   DistState* d = c->dist;
   if (!d) return;
@@ -109,7 +190,15 @@ void dist_destroy(wbx_ctx* c) {
   for (int i = 0; i < kDistRing; i++) {
     if (d->master[i]) (void)hipFree(d->master[i]);
     if (d->slot_free[i]) (void)hipEventDestroy(d->slot_free[i]);
+    if (d->chain_in[i]) (void)hipFree(d->chain_in[i]);
+    if (d->in_ready[i]) (void)hipEventDestroy(d->in_ready[i]);
+    if (d->in_free[i]) (void)hipEventDestroy(d->in_free[i]);
   }
+  for (int i = 0; i < kDistTimers; i++) {
+    if (d->t0[i]) (void)hipEventDestroy(d->t0[i]);
+    if (d->t1[i]) (void)hipEventDestroy(d->t1[i]);
+  }
+  if (d->gather) (void)hipFree(d->gather);
   if (d->gathered) (void)hipFree(d->gathered);
   if (d->scalar) (void)hipFree(d->scalar);
   if (d->sum_ev) (void)hipEventDestroy(d->sum_ev);
@@ -147,7 +236,8 @@ extern "C" wbx_status wbx_dist_new_id(wbx_dist_id* out) {
 }
 
 extern "C" wbx_status wbx_dist_init(wbx_ctx* c, const wbx_dist_id* id, uint32_t rank, uint32_t world, int mode) {
-  if (!c || !id || world == 0 || rank >= world || (mode != WBX_DIST_REDUCE && mode != WBX_DIST_ORDERED)) return WBX_ERR_INVALID;
+  if (!c || !id || world == 0 || rank >= world || (mode != WBX_DIST_REDUCE && mode != WBX_DIST_ORDERED && mode != WBX_DIST_CHAIN))
+    return WBX_ERR_INVALID;
   if (c->dist) return fail(c, WBX_ERR_INVALID, "wbx_dist_init: already initialised");
   Rccl* r = rccl();
   if (!r->err.empty()) return fail(c, WBX_ERR_UNSUPPORTED, r->err.c_str());
@@ -172,13 +262,65 @@ extern "C" wbx_status wbx_dist_init(wbx_ctx* c, const wbx_dist_id* id, uint32_t 
   if (e == hipSuccess && mode == WBX_DIST_ORDERED && rank == 0) e = hipMalloc((void**)&d->gathered, n * world * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&d->scalar, 2 * sizeof(double));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->sum_ev, hipEventDisableTiming);
+  for (int i = 0; i < kDistRing && e == hipSuccess && mode == WBX_DIST_CHAIN && rank > 0; i++) {
+    e = hipMalloc((void**)&d->chain_in[i], n * sizeof(float));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->in_ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->in_free[i], hipEventDisableTiming);
+  }
+  for (int i = 0; i < kDistTimers && e == hipSuccess; i++) {
+    e = hipEventCreate(&d->t0[i]);
+    if (e == hipSuccess) e = hipEventCreate(&d->t1[i]);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&d->gather, (size_t)(world + 1) * kGatherBytes);
   if (e != hipSuccess) {
     dist_destroy(c);
     return fail(c, WBX_ERR_DEVICE, "wbx_dist_init", e);
   }
   ncclUniqueId nid;
   std::memcpy(&nid, id->bytes, sizeof(nid));
-  const ncclResult_t nr = r->CommInitRank(&d->comm, (int)world, nid, (int)rank);   // collective: blocks until every rank has called
+  // ncclCommInitRank is collective: it blocks until every rank has called it with the same id — for ever, when a peer
+  // died on the way or read a stale id.  It runs on a helper thread; this one waits WBX_DIST_INIT_TIMEOUT_S seconds
+  // (default 60, 0 = no limit) and then fails with a message instead of hanging the launch.  (The helper stays blocked
+  // in RCCL; the process is expected to exit.)
+  struct InitJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto job = std::make_shared<InitJob>();
+  const int dev = c->cfg.device;
+  std::thread([job, r, world, nid, rank, dev]() {
+    (void)hipSetDevice(dev);
+    ncclComm_t cm = nullptr;
+    const ncclResult_t res = r->CommInitRank(&cm, (int)world, nid, (int)rank);
+    std::lock_guard<std::mutex> g(job->m);
+    job->res = res;
+    job->comm = cm;
+    job->done = true;
+    job->cv.notify_all();
+  }).detach();
+  double limit = 60.0;
+  if (const char* t = std::getenv("WBX_DIST_INIT_TIMEOUT_S")) limit = std::atof(t);
+  {
+    std::unique_lock<std::mutex> lk(job->m);
+    if (limit > 0.0) {
+      if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; })) {
+        lk.unlock();
+        d->comm = nullptr;
+        dist_destroy(c);
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "ncclCommInitRank (rank %u of %u) did not complete within %.0f s: a peer rank is missing, "
+                      "died before the rendezvous, or was handed another communicator id", rank, world, limit);
+        return fail(c, WBX_ERR_FAILED, msg);
+      }
+    } else {
+      job->cv.wait(lk, [&] { return job->done; });
+    }
+  }
+  const ncclResult_t nr = job->res;
+  d->comm = job->comm;
   if (nr != ncclSuccess) {
     d->comm = nullptr;
     dist_destroy(c);
@@ -215,7 +357,9 @@ extern "C" wbx_status wbx_dist_exchange(wbx_ctx* c, void* dst) {
   DistState* d = c->dist;
   if (!d) return fail(c, WBX_ERR_INVALID, "wbx_dist_exchange: wbx_dist_init has not been called");
   if (d->slot < 0 || d->exchanged) return fail(c, WBX_ERR_FAILED, "wbx_dist_exchange: no render since the last exchange");
-  if (d->rank == 0 && (!dst || ((uintptr_t)dst & 15u))) return fail(c, WBX_ERR_INVALID, "wbx_dist_exchange: the root needs a 16-byte aligned destination");
+  const uint32_t result_rank = d->mode == WBX_DIST_CHAIN ? d->world - 1u : 0u;
+  if (d->rank == result_rank && (!dst || ((uintptr_t)dst & 15u)))
+    return fail(c, WBX_ERR_INVALID, "wbx_dist_exchange: the rank that holds the result needs a 16-byte aligned destination");
   (void)hipSetDevice(c->cfg.device);
   Rccl* r = rccl();
   const size_t n = (size_t)c->last_K * c->cfg.channels * c->cfg.block_frames;
@@ -228,7 +372,19 @@ extern "C" wbx_status wbx_dist_exchange(wbx_ctx* c, void* dst) {
     WBX_HIP(c, hipEventRecord(d->sum_ev, c->stream));
     WBX_HIP(c, hipStreamWaitEvent(d->comm_stream, d->sum_ev, 0));
   }
-  if (d->mode == WBX_DIST_ORDERED) {
+  if (d->t_pending == kDistTimers) {
+    WBX_HIP(c, hipEventSynchronize(d->t1[kDistTimers - 1]));
+    drain_exchange_timers(d);
+  }
+  WBX_HIP(c, hipEventRecord(d->t0[d->t_pending], d->comm_stream));
+  if (d->mode == WBX_DIST_CHAIN) {
+    // the partial of this rank already continues rank - 1's running master (dist_mix_init): hand it on, or — last rank —
+    // clamp it into the destination (engine.cpp:1627-1636 follows the LAST addition)
+    if (d->rank + 1u < d->world)
+      WBX_NCCL(c, r->Send(buf, n, ncclFloat, (int)d->rank + 1, d->comm, d->comm_stream));
+    else
+      launch_clamp_into(buf, (float*)dst, n, 1, d->comm_stream);
+  } else if (d->mode == WBX_DIST_ORDERED) {
     WBX_NCCL(c, r->Gather(buf, d->gathered, n, ncclFloat, 0, d->comm, d->comm_stream));
     if (d->rank == 0) launch_ordered_add(d->gathered, (float*)dst, n, d->world, 1, d->comm_stream);
   } else {
@@ -236,6 +392,7 @@ extern "C" wbx_status wbx_dist_exchange(wbx_ctx* c, void* dst) {
     if (d->rank == 0) launch_clamp_into(buf, (float*)dst, n, 1, d->comm_stream);
   }
   WBX_HIP(c, hipGetLastError());
+  WBX_HIP(c, hipEventRecord(d->t1[d->t_pending++], d->comm_stream));
   WBX_HIP(c, hipEventRecord(d->slot_free[d->slot], d->comm_stream));
   d->slot_used[d->slot] = true;
   d->exchanged = true;
@@ -250,6 +407,41 @@ extern "C" wbx_status wbx_dist_sync(wbx_ctx* c) {
   WBX_HIP(c, sync_main(c));
   WBX_HIP(c, hipStreamSynchronize(c->dist->comm_stream));
   drain_events(c);
+  drain_exchange_timers(c->dist);
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_dist_result_rank(wbx_ctx* c, uint32_t* rank) {
+  if (!c || !rank) return WBX_ERR_INVALID;
+  *rank = (c->dist && c->dist->mode == WBX_DIST_CHAIN) ? c->dist->world - 1u : 0u;
+  return WBX_OK;
+}
+
+// average time of one exchange on its stream, over the exchanges waited for so far (wbx_dist_sync)
+extern "C" wbx_status wbx_dist_exchange_time(wbx_ctx* c, double* ms_avg, uint64_t* n) {
+  if (!c) return WBX_ERR_INVALID;
+  DistState* d = c->dist;
+  if (ms_avg) *ms_avg = (d && d->ex_n) ? d->ex_ms_total / (double)d->ex_n : 0.0;
+  if (n) *n = d ? d->ex_n : 0u;
+  return WBX_OK;
+}
+
+// every rank contributes `bytes` (<= 4096) bytes of host memory, every rank gets all of them in rank order (what a
+// host needs to agree on at start-up: which device a rank runs on, its track range ...); also a barrier
+extern "C" wbx_status wbx_dist_allgather(wbx_ctx* c, const void* send, void* recv, size_t bytes) {
+  if (!c || !send || !recv || bytes == 0 || bytes > kGatherBytes) return WBX_ERR_INVALID;
+  DistState* d = c->dist;
+  if (!d) return fail(c, WBX_ERR_INVALID, "wbx_dist_allgather: wbx_dist_init has not been called");
+  if (d->world == 1) {
+    std::memcpy(recv, send, bytes);
+    return WBX_OK;
+  }
+  (void)hipSetDevice(c->cfg.device);
+  char* mine = d->gather + (size_t)d->world * kGatherBytes;
+  WBX_HIP(c, hipMemcpyAsync(mine, send, bytes, hipMemcpyHostToDevice, d->comm_stream));
+  WBX_NCCL(c, rccl()->AllGather(mine, d->gather, bytes, ncclChar, d->comm, d->comm_stream));
+  WBX_HIP(c, hipMemcpyAsync(recv, d->gather, bytes * d->world, hipMemcpyDeviceToHost, d->comm_stream));
+  WBX_HIP(c, hipStreamSynchronize(d->comm_stream));
   return WBX_OK;
 }
 

@@ -641,8 +641,12 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     hipError_t me = hipSuccess;
     float* master = begin_master(c, s, &me);
     WBX_EHIP(e, me);
-    WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * sizeof(float), s));
+    {   // (all-zero bytes are silence in every output format; packed 24-bit counts its 3 bytes per sample)
+      const size_t eb = c->master_format == WBX_OUT_I16 ? 2 : c->master_format == WBX_OUT_I24 ? 3 : 4;
+      WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * eb, s));
+    }
     c->last_master = master;
+    c->last_master_format = c->master_format;
     c->last_master_on_host = false;
     c->last_K = K;
     c->last_N = 0;
@@ -772,6 +776,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
+  c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance below)
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
@@ -830,15 +835,45 @@ extern "C" wbx_status wbx_engine_render(wbx_engine* e, uint32_t K) {
   return render_locked(e, K);
 }
 
+namespace {
+wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format, void* out_il);
+}
+
 extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar) {   // engine.cpp:1576-1654
   if (!e || !out_planar) return WBX_ERR_INVALID;
+  return process_block(e, out_planar, 0, nullptr);
+}
+
+// Engine::process + the back end's conversion to the device format (audio_io_pulseaudio.cpp:419-461:
+// output_buffer.interleave_samples_to(buffer, 0, n, output_sample_format) -> core/audio_format_conv.cpp:5-91) in one
+// call: the conversion is the epilogue of the sum kernel, the block arrives interleaved — no planar round trip, no extra
+// launch.  dst: F * C samples of the format (packed 24-bit: the reference's bytes, see WBX_OUT_I24).
+extern "C" wbx_status wbx_engine_process_interleaved(wbx_engine* e, int out_format, void* dst) {
+  if (!e || !dst) return WBX_ERR_INVALID;
+  if (out_format != WBX_OUT_I16 && out_format != WBX_OUT_I24 && out_format != WBX_OUT_I24_X8 && out_format != WBX_OUT_I32 &&
+      out_format != WBX_OUT_F32)
+    return efail(e, WBX_ERR_UNSUPPORTED, "interleaved output format");
+  return process_block(e, nullptr, out_format, dst);
+}
+
+namespace {
+
+wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format, void* out_il) {
   wbx_ctx* c = e->ctx;
   LockGuard g(e->hs.editor_lock);   // held for the whole block, like editor_lock in Engine::process (engine.cpp:1587-1651)
   if (c->master_target || c->dist) {   // the caller redirected the master: leave it there and fetch the ordinary way
+    if (out_format) return efail(e, WBX_ERR_UNSUPPORTED, "wbx_engine_process_interleaved: not with a redirected master / a multi-GPU exchange");
     wbx_status st = render_locked(e, 1);
     if (st != WBX_OK) return st;
     return cfail(e, wbx_fetch(c, out_planar, nullptr, nullptr));
   }
+  const int saved_format = c->master_format;
+  c->master_format = out_format;
+  struct Restore {
+    wbx_ctx* c;
+    int f;
+    ~Restore() { c->master_format = f; }
+  } restore{c, saved_format};
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   if (!e->h_block) WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
   if (!e->h_status) WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -872,11 +907,19 @@ extern "C" wbx_status wbx_engine_process(wbx_engine* e, float* const* out_planar
   WBX_EHIP(e, sync_main(c));
   for (int i = 0; i < kRing; i++) e->patch_valid[i] = e->gains_valid[i] = false;   // every plan that read them is over
   drain_events(c);
-  for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
+  if (out_format == 0) {
+    for (uint32_t ch = 0; ch < C; ch++) std::memcpy(out_planar[ch], e->h_block + (size_t)ch * F, F * sizeof(float));
+  } else if (out_format == WBX_OUT_I24) {   // (the reference's writer leaves the other 3*F*(C-1) bytes of the block untouched)
+    std::memcpy(out_il, e->h_block, (size_t)F * 3);
+  } else {
+    std::memcpy(out_il, e->h_block, (size_t)F * C * (out_format == WBX_OUT_I16 ? 2 : 4));
+  }
   c->last_master_on_host = true;   // set after launch_mix_sum cleared it: the master of this block is e->h_block
   if (e->hs.n_tracks() == 0) return WBX_OK;
   return cfail(e, plan_status_to_error(c, e->h_status[1]));
 }
+
+}  // namespace
 
 extern "C" wbx_status wbx_engine_transport(wbx_engine* e, double* playhead, double* sample_position, int* playing) {
   if (!e) return WBX_ERR_INVALID;

@@ -578,6 +578,14 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   Row acc;
 #pragma unroll
   for (int ch = 0; ch < CL; ch++) acc.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+  // MixArgs::init: the running sum of the tracks BEFORE this engine's in the session's track order (another engine's
+  // un-clamped master: the previous shard of a multi-GPU chain) — the first group in summation order starts from it instead
+  // of the cleared buffer, so the additions continue exactly where that engine stopped
+  if (a.init && g == 0u && active && bvalid) {
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++)
+      acc.c[ch] = *reinterpret_cast<const f4*>(a.init + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0);
+  }
 
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
@@ -1367,18 +1375,18 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 
   // A group is walked in chunks of up to kSt tracks.  A LONG walk — one workgroup adding ALL tracks of its block in track
   // order, the reference's own summation order (engine.cpp:1600-1617) — passes dozens of chunk seams, each a phase
-  // without clip loads in flight (rows -> templates -> LDS, then the pipeline fills again).  Three things keep the seams
-  // short and apart: the rows and routing entries of the NEXT chunk are fetched while this one is staged (a seam then
-  // costs one round trip for the templates, not three dependent ones), the template loads of a chunk are all issued
-  // before the first is waited for, and the first chunk of a long walk is shortened by a per-workgroup phase so that
-  // the workgroups sharing a CU do not reach their seams together.
-  uint32_t first_cn = kSt;
-  if (EXP && a.stagger && grp.count > 2u * kSt) first_cn = kSt - (kSt / 4u) * (((blockIdx.x >> 8) ^ (blockIdx.x >> 3)) & 3u);
-  uint32_t chunk0 = 0u;
+  // without clip loads in flight (rows -> templates -> LDS, then the pipeline fills again).  Two things keep the seams
+  // short: the rows and routing entries of the NEXT chunk are fetched while this one is staged (a seam then costs one
+  // round trip for the templates, not three dependent ones), and the template loads of a chunk are all issued before the
+  // first is waited for.  (Measured, tools/ab.py seams: a walk with NO staging at its seams at all would be 3-4 % faster
+  // on fp32 sessions, 10 % on 16-bit resampled ones; shortening the first chunk by a per-workgroup phase so that the
+  // workgroups of a CU meet their seams apart: no effect.)
+  uint32_t chunk0 = 0u, cn2 = 0u;
+  int mode = MODE_U;
   for (uint32_t chunk_i = 0u; chunk0 < grp.count; chunk_i++) {
-    const uint32_t left = grp.count - chunk0, want = chunk_i == 0u ? first_cn : kSt;
-    const uint32_t cn = left < want ? left : want;   // tracks of this chunk
-    uint32_t cn2 = cn;                                // staged rows of this chunk
+    const uint32_t left = grp.count - chunk0;
+    const uint32_t cn = left < kSt ? left : kSt;     // tracks of this chunk
+    cn2 = cn;                                         // staged rows of this chunk
     __syncthreads();
     if (tid == 0u) s_shape = 0;
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
@@ -1532,7 +1540,6 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     const int has_stride = G ? (shapes & 64) : 0;    // per-frame taps
     const int has_win16 = W16 ? (shapes & 32) : 0;   // 16-bit PCM window rows
     const int has_win32 = G ? (shapes & 128) : 0;    // 24/32-bit PCM window rows
-    int mode;
     if (LEAN16) {
       if (has_win16)
         mode = (!has_f32 && !has_i32) ? (has_wide ? MODE_WI : us > 0.0 ? MODE_WINU : MODE_WIN) : MODE_MIXED;
@@ -1662,9 +1669,25 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 // with bus u = in-order sum of its groups (AudioBuffer::mix order, audio_buffer.h:73-82), then the
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
+// float -> int32 as the reference's x86 build converts (cvttss2si / cvttsd2si): truncation toward zero, and the
+// "integer indefinite" 0x80000000 for NaN and for anything outside [-2^31, 2^31) — the GPU's own conversion saturates
+// and maps NaN to 0, which differs whenever the master is left un-clamped or holds NaN.
+__device__ __forceinline__ int x86_cvtt_f32(float t) { return (t >= -2147483648.0f && t < 2147483648.0f) ? (int)t : (int)0x80000000; }
+__device__ __forceinline__ int x86_cvtt_f64(double t) { return (t >= -2147483648.0 && t < 2147483648.0) ? (int)t : (int)0x80000000; }
+
+// One sample of the master in an interleaved device format (core/audio_format_conv.cpp:5-20 i16, :45-60 i24 in 32-bit
+// containers, :62-77 i32): asymmetric scales, truncation toward zero, the x86 conversion results.
+__device__ __forceinline__ int to_i16(float v) { return x86_cvtt_f32(v > 0.0f ? __fmul_rn(v, 32767.0f) : __fmul_rn(v, 32768.0f)); }
+__device__ __forceinline__ int to_i24(float v) { return v > 0.0f ? x86_cvtt_f32(__fmul_rn(v, 8388607.0f)) : x86_cvtt_f32(__fmul_rn(v, 8388608.0f)); }
+__device__ __forceinline__ int to_i32(float v) { return x86_cvtt_f64(v > 0.0f ? __dmul_rn((double)v, 2147483647.0) : __dmul_rn((double)v, 2147483648.0)); }
+
 // PF = group partials in flight per lane: 16 for batch renders (the kernel runs beside the next mix and must stay small),
 // 32 for the one-block callback, whose sum is a chain of dependent HBM round trips — 128 groups are four of them, not eight
-template <int PF, bool BUSES>
+// IL: the master leaves as INTERLEAVED device-format samples (SumArgs::out_format: what the audio back end hands the
+// device, audio_io_pulseaudio.cpp:419-461 -> AudioBuffer::interleave_samples_to -> core/audio_format_conv.cpp) instead
+// of planar fp32 — the conversion is the epilogue of the sum, no separate launch and no planar round trip.  A lane then
+// owns 4 frames of EVERY channel (grid.y covers F/4 slots).
+template <int PF, bool BUSES, bool IL = false>
 __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {
     const uint32_t queued = a.status_src[2];
@@ -1674,11 +1697,12 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t F = a.block_frames, C = a.channels;
   const uint32_t slot = blockIdx.y * 64u + threadIdx.x;
-  if (slot >= (C * F) >> 2) return;
-  const size_t e0 = (size_t)slot * 4u;
+  if (slot >= ((IL ? F : C * F) >> 2)) return;
   const size_t stride = (size_t)C * F;
-  const float* p = a.partial + (size_t)b * a.n_groups * stride + e0;
 
+  // the master of elements e0 .. e0+3 of the block ([C][F] order): groups in order, buses in order, clamp
+  auto sum_at = [&](size_t e0) {
+  const float* p = a.partial + (size_t)b * a.n_groups * stride + e0;
   f4 master = {0.0f, 0.0f, 0.0f, 0.0f};
   f4 busacc = {0.0f, 0.0f, 0.0f, 0.0f};
   int cur = -1;
@@ -1750,7 +1774,61 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
     master.z = master.z > 1.0f ? 1.0f : (master.z < -1.0f ? -1.0f : master.z);
     master.w = master.w > 1.0f ? 1.0f : (master.w < -1.0f ? -1.0f : master.w);
   }
-  *reinterpret_cast<f4*>(a.master + (size_t)b * stride + e0) = master;
+  return master;
+  };
+
+  if constexpr (!IL) {
+    const size_t e0 = (size_t)slot * 4u;
+    *reinterpret_cast<f4*>(a.master + (size_t)b * stride + e0) = sum_at(e0);
+  } else {
+    const uint32_t j0 = slot * 4u;
+    f4 m[2];
+    m[0] = sum_at(j0);
+    m[1] = C > 1u ? sum_at((size_t)F + j0) : m[0];
+    const float s[2][4] = {{m[0].x, m[0].y, m[0].z, m[0].w}, {m[1].x, m[1].y, m[1].z, m[1].w}};
+    const size_t f0 = (size_t)b * F + j0;   // first frame of the lane in the whole render
+    // (stereo: the lane's 4 frames x 2 channels leave as one or two 16-byte stores — the destination is usually pinned host
+    //  memory, where narrow stores waste the PCIe write path)
+    uint32_t w[8];   // the 8 interleaved samples of a stereo lane as 32-bit words (i16: packed in pairs into w[0..3])
+    const uint32_t fmt = a.out_format;
+    if (fmt == 5u) {   // packed 24-bit: the reference's writer has no channel term in its destination index (audio_format_conv.cpp:
+      // 22-43), so a block's region of F*C*3 bytes holds the LAST channel's samples in its first 3*F bytes; the rest is
+      // never written.  12 bytes per lane: three dword stores.
+      const int q0 = to_i24(s[1][0]), q1 = to_i24(s[1][1]), q2 = to_i24(s[1][2]), q3 = to_i24(s[1][3]);   // (s[1] = the last channel, also for mono)
+      uint32_t* o = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.out_il) + (size_t)b * F * C * 3u + (size_t)j0 * 3u);
+      o[0] = ((uint32_t)q0 & 0xFFFFFFu) | ((uint32_t)q1 << 24);
+      o[1] = (((uint32_t)q1 >> 8) & 0xFFFFu) | ((uint32_t)q2 << 16);
+      o[2] = (((uint32_t)q2 >> 16) & 0xFFu) | ((uint32_t)q3 << 8);
+      return;
+    }
+    auto conv = [&](float v) -> uint32_t {
+      return fmt == 3u ? (uint32_t)(uint16_t)(int16_t)to_i16(v) : fmt == 6u ? (uint32_t)(to_i24(v) & 0xFFFFFF)
+             : fmt == 7u ? (uint32_t)to_i32(v) : __float_as_uint(v);
+    };
+    if (C == 2u) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        w[2 * k] = conv(s[0][k]);
+        w[2 * k + 1] = conv(s[1][k]);
+      }
+      if (fmt == 3u) {
+        uint4 o = {w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
+        *reinterpret_cast<uint4*>(reinterpret_cast<int16_t*>(a.out_il) + f0 * 2u) = o;
+      } else {
+        uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.out_il) + f0 * 2u);
+        o[0] = uint4{w[0], w[1], w[2], w[3]};
+        o[1] = uint4{w[4], w[5], w[6], w[7]};
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = conv(s[0][k]);
+      if (fmt == 3u) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<int16_t*>(a.out_il) + f0) = uint2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.out_il) + f0) = uint4{w[0], w[1], w[2], w[3]};
+      }
+    }
+  }
 }
 
 // buses with no member groups stay zero: cleared before the launch by the runtime.
@@ -1784,12 +1862,6 @@ __global__ __launch_bounds__(256) void clamp_into_kernel(const float* __restrict
     }
   }
 }
-
-// float -> int32 as the reference's x86 build converts (cvttss2si / cvttsd2si): truncation toward zero, and the
-// "integer indefinite" 0x80000000 for NaN and for anything outside [-2^31, 2^31) — the GPU's own conversion saturates
-// and maps NaN to 0, which differs whenever the master is left un-clamped or holds NaN.
-__device__ __forceinline__ int x86_cvtt_f32(float t) { return (t >= -2147483648.0f && t < 2147483648.0f) ? (int)t : (int)0x80000000; }
-__device__ __forceinline__ int x86_cvtt_f64(double t) { return (t >= -2147483648.0 && t < 2147483648.0) ? (int)t : (int)0x80000000; }
 
 // multi-GPU, ordered mode: the partial masters of all ranks lie behind one another in `g` ([world][n]); the master is
 // their sum in RANK order starting from the cleared output buffer — (((0 + p0) + p1) + ...) — like the reference adds
@@ -1825,7 +1897,7 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* master, void*
     if (i >= (size_t)n_blocks * F) return;
     const uint32_t b = (uint32_t)(i / F), j = (uint32_t)(i % F);
     const float v = master[((size_t)b * C + (C - 1u)) * F + j];
-    const int q = v > 0.0f ? x86_cvtt_f32(__fmul_rn(v, 8388607.0f)) : x86_cvtt_f32(__fmul_rn(v, 8388608.0f));
+    const int q = to_i24(v);
     uint8_t* o = (uint8_t*)dst + i * 3u;
     o[0] = (uint8_t)q;
     o[1] = (uint8_t)(q >> 8);
@@ -1996,6 +2068,14 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
 }
 
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
+  if (a.out_il) {   // interleaved device-format output: a lane owns 4 frames of every channel
+    const uint32_t tiles = ((a.block_frames >> 2) + 63u) / 64u;
+    if (a.n_buses != 0u)
+      hipLaunchKernelGGL((sum_kernel<16, true, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((sum_kernel<16, false, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+    return;
+  }
   const uint32_t tiles = (((a.channels * a.block_frames) >> 2) + 63u) / 64u;
   if (a.n_buses != 0u)
     hipLaunchKernelGGL((sum_kernel<16, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);

@@ -53,20 +53,33 @@ void drain_events(wbx_ctx* c) {
   c->ev_pending = 0;
 }
 
-// default routing: identity order, groups of group_size, everything straight into the master
+// Routing tables.  `order`: the direct tracks in index order, then the members of bus 0, bus 1, ... — the order the sums
+// run in.  Two group sets over it: `groups` cuts every member list into workgroup-sized pieces of group_size tracks
+// (the master is the in-order sum of the piece sums), `groups_exact` keeps every member list whole — one workgroup walks
+// all direct tracks of its block in track order, which IS the reference's summation (engine.cpp:1600-1617,
+// audio_buffer.h:73-82: bit-exact master).  Which set a render takes: render_walks_whole_lists().
 void build_routing(wbx_ctx* c, uint32_t n_tracks) {
   uint32_t G = c->cfg.group_size;
   if (c->auto_group && c->cfg.max_blocks == 1 && n_tracks > 64u) G = kStage / 4;   // the callback configuration, large session
   c->order.clear();
   c->groups.clear();
+  c->groups_exact.clear();
   auto emit = [&](const std::vector<uint32_t>& members, int32_t bus) {
+    const uint32_t base = (uint32_t)c->order.size();
+    for (uint32_t t : members) c->order.push_back(t);
     for (size_t i = 0; i < members.size(); i += G) {
       DGroup g{};
-      g.first = (uint32_t)c->order.size();
+      g.first = base + (uint32_t)i;
       g.count = (uint32_t)std::min<size_t>(G, members.size() - i);
       g.bus = bus;
-      for (uint32_t k = 0; k < g.count; k++) c->order.push_back(members[i + k]);
       c->groups.push_back(g);
+    }
+    if (!members.empty()) {
+      DGroup g{};
+      g.first = base;
+      g.count = (uint32_t)members.size();
+      g.bus = bus;
+      c->groups_exact.push_back(g);
     }
   };
   std::vector<uint32_t> direct;
@@ -84,9 +97,24 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
   c->routing_dirty = true;
   // every bus exactly one group and nothing routed straight to the master: group g's partial sum IS bus g's sum, so
   // the bus output can alias the partial buffer instead of being written a second time by the sum kernel
-  c->buses_alias_partials = c->n_buses > 0 && c->groups.size() == c->n_buses;
-  for (size_t g = 0; g < c->groups.size() && c->buses_alias_partials; g++)
-    if (c->groups[g].bus != (int32_t)g) c->buses_alias_partials = false;
+  auto aliases = [&](const std::vector<DGroup>& gs) {
+    if (c->n_buses == 0 || gs.size() != c->n_buses) return false;
+    for (size_t g = 0; g < gs.size(); g++)
+      if (gs[g].bus != (int32_t)g) return false;
+    return true;
+  };
+  c->buses_alias_partials = aliases(c->groups);
+  c->buses_alias_exact = aliases(c->groups_exact);
+  c->longest_list = 0;
+  for (auto& g : c->groups_exact) c->longest_list = std::max(c->longest_list, g.count);
+}
+
+// Does a render of K blocks take `groups_exact` (one workgroup per member list and block)?  Only when the library
+// picks the grouping (wbx_config.group_size == 0) and the render is long enough to fill the device with one workgroup
+// per block: the parallelism that track groups give a short render comes from the K blocks of a long one.  Measured on
+// c3 (profiles/): from about a thousand blocks per render on, whole-list walks run at the grouped order's rate.
+bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
+  return c->auto_group && c->exact_min_blocks != 0u && K >= c->exact_min_blocks;
 }
 
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
@@ -98,13 +126,16 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
     WBX_HIP(c, join_sum(c));                          // a sum beside the main stream may still read d_groups
     WBX_HIP(c, sync_main(c));
     WBX_HIP(c, c->d_order.ensure(std::max<size_t>(1, c->order.size())));
-    WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size())));
+    WBX_HIP(c, c->d_groups.ensure(std::max<size_t>(1, c->groups.size() + c->groups_exact.size())));   // [groups | groups_exact]
     if (!c->order.empty())
       WBX_HIP(c, hipMemcpyAsync(c->d_order.p, c->order.data(), c->order.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
                                 c->stream));
     if (!c->groups.empty())
       WBX_HIP(c, hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(DGroup),
                                 hipMemcpyHostToDevice, c->stream));
+    if (!c->groups_exact.empty())
+      WBX_HIP(c, hipMemcpyAsync(c->d_groups.p + c->groups.size(), c->groups_exact.data(),
+                                c->groups_exact.size() * sizeof(DGroup), hipMemcpyHostToDevice, c->stream));
     WBX_HIP(c, sync_main(c));   // host vectors may change right after
     c->routing_dirty = false;
   }
@@ -219,8 +250,12 @@ int mix_family(const wbx_ctx* c) {
 bool mix_two_channels_per_lane(const wbx_ctx* c) {
   const uint32_t F = c->cfg.block_frames;
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
-  if (!(c->has_integer_clips || c->has_cut_tracks) || c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
-  return F == 512u || F == 1024u || F == 256u;
+  if (c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
+  if (!(F == 512u || F == 1024u || F == 256u)) return false;
+  // a render whose workgroups walk whole member lists of many staged chunks: the half-size workgroups of these instances
+  // put six of them on a CU, and the walk runs 15 % faster than through the four-wave ones (c3, 1024 blocks: 2.94 vs 3.43 ms)
+  if (c->whole_lists_now && c->longest_list > 2u * kStage) return true;
+  return c->has_integer_clips || c->has_cut_tracks;
 }
 
 // Can the mix instance a render of this shape will launch take masked rows (partial-coverage records, ROW_PAIRs) in its
@@ -258,7 +293,12 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.zero_page = c->d_zero.p;
   m.pool = PB(c).pool.p;
   m.order = c->d_order.p;
-  m.groups = c->d_groups.p;
+  // the group set of this render: workgroup-sized pieces, or the whole member lists (the reference's summation order)
+  const bool whole = c->whole_lists_now;
+  const DGroup* d_groups = c->d_groups.p + (whole ? c->groups.size() : 0);
+  const uint32_t n_groups = (uint32_t)(whole ? c->groups_exact.size() : c->groups.size());
+  const bool buses_alias = whole ? c->buses_alias_exact : c->buses_alias_partials;
+  m.groups = d_groups;
   const int pp = (int)(c->render_seq % kRing);
   // this partial buffer was last read by the sum of kRing renders ago; the engine path has already made the PLAN
   // stream wait for that sum (the mix waits for the plan), which keeps the barrier off the main stream
@@ -271,16 +311,29 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.peaks = c->d_peaks[pk].p;
   c->last_peaks = m.peaks;
   m.levels = c->levels_target;
+  // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
+  // hand-overs cost more than the few microseconds of overlap they could buy
+  const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
+  hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
+  // where this render's master goes (the ctx's own buffer, the caller's target, or the multi-GPU ring slot) and what its
+  // sum starts from (zero; wbx_set_master_init's running sum; chain mode: the previous rank's, received for this render)
+  float* master_dst = nullptr;
+  {
+    hipError_t me = hipSuccess;
+    master_dst = begin_master(c, ss, &me);
+    WBX_HIP(c, me);
+    wbx_status ist = WBX_OK;
+    m.init = c->dist ? dist_mix_init(c, K, ms, &ist) : c->master_init;
+    if (ist != WBX_OK) return ist;
+    if (m.init && c->n_buses) return fail(c, WBX_ERR_UNSUPPORTED, "a running master (wbx_set_master_init) cannot be continued through sub-buses");
+  }
   m.n_tracks = N;
-  m.n_groups = (uint32_t)c->groups.size();
+  m.n_groups = n_groups;
   m.block_frames = F;
   m.channels = C;
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
-  static const bool stagger = !(std::getenv("WBX_STAGGER") && std::getenv("WBX_STAGGER")[0] == '0');   // (A/B aid)
-  m.stagger = stagger ? 1u : 0u;
-  m.uniform_speed = std::getenv("WBX_NO_UNIFORM") ? 0.0 : c->uniform_speed;   // (A/B aid)
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(m.peaks, 0, (size_t)K * N * C * sizeof(float), ms));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
@@ -300,28 +353,27 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
                mix_family(c), ms, (timed && !packets) ? c->ev[c->ev_pending][0] : nullptr,
                (timed && !packets) ? c->ev[c->ev_pending][1] : nullptr);
     if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
+    if (c->dist) WBX_HIP(c, dist_mix_issued(c, ms));
   }
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
   WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));
   if (ms != c->stream) c->alt_pending = pp;
-  // short renders (the one-block callback path above all) keep everything on the main stream: the cross-stream
-  // hand-overs cost more than the few microseconds of overlap they could buy
-  const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
-  hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
   SumArgs s{};
   s.partial = c->d_partial2[pp].p;
-  s.groups = c->d_groups.p;
-  {
-    hipError_t me = hipSuccess;
-    s.master = begin_master(c, ss, &me);   // the ctx's own buffer, the caller's target, or the multi-GPU ring slot
-    WBX_HIP(c, me);
+  s.groups = d_groups;
+  s.master = master_dst;
+  if (c->master_format) {   // the device format is the sum's epilogue: interleaved samples instead of planar fp32
+    if (c->dist) return fail(c, WBX_ERR_UNSUPPORTED, "wbx_set_master_format: a multi-GPU partial master stays planar fp32");
+    s.out_il = master_dst;
+    s.out_format = (uint32_t)c->master_format;
   }
+  c->last_master_format = c->master_format;
   c->last_master = s.master;
   c->last_master_on_host = false;
-  s.buses = (c->n_buses && !c->buses_alias_partials) ? c->d_buses.p : nullptr;
-  c->last_buses = c->n_buses ? (c->buses_alias_partials ? c->d_partial2[pp].p : c->d_buses.p) : nullptr;
+  s.buses = (c->n_buses && !buses_alias) ? c->d_buses.p : nullptr;
+  c->last_buses = c->n_buses ? (buses_alias ? c->d_partial2[pp].p : c->d_buses.p) : nullptr;
   s.n_groups = m.n_groups;
   s.n_buses = c->n_buses;
   s.block_frames = F;
@@ -330,7 +382,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
   s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
-  if (c->n_buses && !c->buses_alias_partials && !c->buses_clean) {
+  if (c->n_buses && !buses_alias && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
     WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), ms));
@@ -415,6 +467,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   c->auto_group = c->cfg.group_size == 0;
   if (c->cfg.group_size == 0) c->cfg.group_size = c->cfg.max_blocks == 1 ? kStage / 2 : kStage;
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
+  if (const char* u = std::getenv("WBX_EXACT_MIN_BLOCKS")) c->exact_min_blocks = (uint32_t)std::atoi(u);   // 0: never
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
   if (const char* u = std::getenv("WBX_KERNEL_TIMER")) c->profiling = std::atoi(u) != 0;   // 0: no HIP-event kernel timer
   if (cfg->stream) {
@@ -946,9 +999,62 @@ extern "C" wbx_status wbx_set_routing(wbx_ctx* c, uint32_t n_tracks, const int32
   return WBX_OK;
 }
 
+// how a render of n_blocks blocks is summed, with the routing as it stands (the last render's, or wbx_set_routing's)
+extern "C" wbx_status wbx_render_order(wbx_ctx* c, uint32_t n_blocks, uint32_t* n_groups, uint32_t* longest_group,
+                                       int* reference_order) {
+  if (!c || n_blocks == 0) return WBX_ERR_INVALID;
+  const bool whole = render_walks_whole_lists(c, n_blocks);
+  const std::vector<DGroup>& gs = whole ? c->groups_exact : c->groups;
+  uint32_t longest = 0;
+  for (auto& g : gs) longest = std::max(longest, g.count);
+  if (n_groups) *n_groups = (uint32_t)gs.size();
+  if (longest_group) *longest_group = longest;
+  if (reference_order) *reference_order = (whole || gs.size() == c->groups_exact.size()) ? 1 : 0;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_device_info(wbx_ctx* c, char* pci_bus_id, size_t n_pci, char* name, size_t n_name) {
+  if (!c) return WBX_ERR_INVALID;
+  if (pci_bus_id && n_pci) {
+    pci_bus_id[0] = 0;
+    WBX_HIP(c, hipDeviceGetPCIBusId(pci_bus_id, (int)n_pci, c->cfg.device));
+  }
+  if (name && n_name) {
+    hipDeviceProp_t p;
+    WBX_HIP(c, hipGetDeviceProperties(&p, c->cfg.device));
+    std::snprintf(name, n_name, "%s (%s)", p.name, p.gcnArchName);
+  }
+  return WBX_OK;
+}
+
 extern "C" wbx_status wbx_set_clamp(wbx_ctx* c, int on) {
   if (!c) return WBX_ERR_INVALID;
   c->clamp = on != 0;
+  return WBX_OK;
+}
+
+static size_t out_format_bytes(int fmt) {
+  switch (fmt) {
+    case WBX_OUT_I16: return 2;
+    case WBX_OUT_I24: return 3;
+    case WBX_OUT_I24_X8:
+    case WBX_OUT_I32:
+    case WBX_OUT_F32: return 4;
+    default: return 0;
+  }
+}
+
+extern "C" wbx_status wbx_set_master_format(wbx_ctx* c, int out_format) {
+  if (!c) return WBX_ERR_INVALID;
+  if (out_format != 0 && out_format_bytes(out_format) == 0) return fail(c, WBX_ERR_UNSUPPORTED, "interleaved output format");
+  c->master_format = out_format;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_set_master_init(wbx_ctx* c, const void* device_buffer) {
+  if (!c) return WBX_ERR_INVALID;
+  if ((uintptr_t)device_buffer & 15u) return fail(c, WBX_ERR_INVALID, "wbx_set_master_init: the buffer must be 16-byte aligned");
+  c->master_init = (const float*)device_buffer;
   return WBX_OK;
 }
 
@@ -1058,6 +1164,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  c->whole_lists_now = render_walks_whole_lists(c, K);
   (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
   c->masked_rows = 0u;   // host-sequenced plans send every partial row through the pre-render pass
   c->uniform_speed = 0.0;   // ... and make no promise about their playback speeds
@@ -1102,6 +1209,8 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
   WBX_HIP(c, join_sum(c));
   const uint32_t K = c->last_K, N = c->last_N, C = c->cfg.channels, F = c->cfg.block_frames;
+  if (master_planar && c->last_master_format)
+    return fail(c, WBX_ERR_INVALID, "the last render left its master in a device format (wbx_set_master_format): wbx_fetch_interleaved");
   if (master_planar) {
     // device [K][C][F] -> host planar[c][b*F + j]
     for (uint32_t ch = 0; ch < C; ch++)
@@ -1140,6 +1249,23 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
     default: return fail(c, WBX_ERR_UNSUPPORTED, "interleaved output format");
   }
   const uint32_t K = c->last_K, C = c->cfg.channels, F = c->cfg.block_frames;
+  if (c->last_master_format) {   // the sum kernel already wrote this format (wbx_set_master_format): a copy
+    if (c->last_master_format != out_format) return fail(c, WBX_ERR_INVALID, "the last render's master is in another device format");
+    if (c->last_master_on_host) {
+      WBX_HIP(c, sync_main(c));
+      if (out_format == WBX_OUT_I24)
+        for (uint32_t b = 0; b < K; b++) std::memcpy((char*)dst + (size_t)b * F * C * 3, (const char*)c->last_master + (size_t)b * F * C * 3, (size_t)F * 3);
+      else
+        std::memcpy(dst, c->last_master, (size_t)K * F * C * eb);
+      return WBX_OK;
+    }
+    if (out_format == WBX_OUT_I24)
+      WBX_HIP(c, hipMemcpy2DAsync(dst, (size_t)F * C * 3, c->last_master, (size_t)F * C * 3, (size_t)F * 3, K, hipMemcpyDeviceToHost, c->stream));
+    else
+      WBX_HIP(c, hipMemcpyAsync(dst, c->last_master, (size_t)K * F * C * eb, hipMemcpyDeviceToHost, c->stream));
+    WBX_HIP(c, sync_main(c));
+    return WBX_OK;
+  }
   if (out_format == WBX_OUT_I24) {
     // convert_f32_to_interleaved_i24 (audio_format_conv.cpp:22-43) writes byte 3*i.. of EVERY channel's sample i — the
     // destination index has no channel term — so per converted block the last channel's packed samples fill bytes

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _ffi
 
-REDUCE, ORDERED = 0, 1
+REDUCE, ORDERED, CHAIN = 0, 1, 2
 
 
 def shard_tracks(n_tracks: int, world: int, rank: int) -> Tuple[int, int]:
@@ -36,32 +36,56 @@ def rendezvous_path() -> str:
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wbx_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
 
 
+def launch_nonce() -> bytes:
+    """16 bytes that name THIS launch, the same on all of its ranks and different from any earlier launch's: what keeps a
+    reader from taking a stale rendezvous file (a crashed launch that used the same port and parent pid) for rank 0's.
+    bench.py's launcher passes WBX_RDZV_NONCE; under torchrun the run id plus the agent's pid and start time serve."""
+    import hashlib
+    tag = os.environ.get("WBX_RDZV_NONCE")
+    if not tag:
+        ppid = os.getppid()
+        try:
+            started = open(f"/proc/{ppid}/stat").read().rsplit(")", 1)[1].split()[19]   # the parent's start time (clock ticks)
+        except Exception:
+            started = "?"
+        tag = f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}:{os.environ.get('MASTER_PORT', '0')}:{ppid}:{started}"
+    return hashlib.sha256(tag.encode()).digest()[:16]
+
+
 def exchange_id(rank: int, world: int, timeout_s: float = 120.0) -> C.Array:
     """Rank 0 makes the communicator id (wbx_dist_new_id) and publishes it through the rendezvous file; the other
-    ranks wait for it.  128 bytes, written atomically (rename)."""
+    ranks wait for it.  The file holds the launch nonce followed by the 128 id bytes; rank 0 removes whatever lies at
+    the path first, creates its file exclusively (O_EXCL, mode 0600) under a private name and renames it into place;
+    readers ignore a file whose nonce is not this launch's."""
     buf = (C.c_char * 128)()
     path = rendezvous_path()
+    nonce = launch_nonce()
     if rank == 0:
         st = _ffi.lib().wbx_dist_new_id(buf)
         if st != 0:
             raise _ffi.WbxError(st, "wbx_dist_new_id", "RCCL could not be loaded" if st == -3 else "")
         if world > 1:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as f:
-                f.write(bytes(buf))
+            fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            with os.fdopen(fd, "wb") as f:
+                f.write(nonce + bytes(buf))
             os.replace(tmp, path)
         return buf
     t0 = time.time()
     while True:
         try:
             data = open(path, "rb").read()
-            if len(data) == 128:
-                C.memmove(buf, data, 128)
+            if len(data) == 144 and data[:16] == nonce:
+                C.memmove(buf, data[16:], 128)
                 return buf
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout_s:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout_s:.0f} s")
+            raise TimeoutError(f"rank {rank}: no communicator id of this launch at {path} after {timeout_s:.0f} s")
         time.sleep(0.02)
 
 
@@ -104,6 +128,33 @@ class Dist:
     def _check(self, st, where):
         if st != 0:
             raise _ffi.WbxError(st, where, self.L.wbx_last_error(self.ctx.h).decode())
+
+    @property
+    def result_rank(self) -> int:
+        """the rank whose wbx_dist_exchange takes the destination: 0, or the last one in chain mode"""
+        r = C.c_uint32()
+        self._check(self.L.wbx_dist_result_rank(self.ctx.h, C.byref(r)), "wbx_dist_result_rank")
+        return r.value
+
+    def allgather(self, payload: bytes, width: int = 64) -> list:
+        """every rank's `payload` (padded to `width` bytes), in rank order"""
+        send = (C.c_char * width)(*payload[:width].ljust(width, b"\0"))
+        recv = (C.c_char * (width * self.world))()
+        self._check(self.L.wbx_dist_allgather(self.ctx.h, send, recv, width), "wbx_dist_allgather")
+        raw = bytes(recv)
+        return [raw[i * width:(i + 1) * width].rstrip(b"\0") for i in range(self.world)]
+
+    def info(self) -> dict:
+        """What the exchange saw: RCCL's world size, the device of every rank (PCI bus ids, rank order), the mode, the
+        average time of one exchange on its stream (call after sync)."""
+        rank, world, mode = C.c_uint32(), C.c_uint32(), C.c_int()
+        self._check(self.L.wbx_dist_info(self.ctx.h, C.byref(rank), C.byref(world), C.byref(mode)), "wbx_dist_info")
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.wbx_dist_exchange_time(self.ctx.h, C.byref(ms), C.byref(n)), "wbx_dist_exchange_time")
+        pci = self.ctx.device_info()["pci"].encode()
+        devices = [d.decode() for d in self.allgather(pci, 32)]
+        return {"rank": rank.value, "world": world.value, "mode": ("reduce", "ordered", "chain")[mode.value],
+                "devices": devices, "exchange_ms_avg": ms.value, "exchanges": n.value, "result_rank": self.result_rank}
 
     def exchange(self, dst_ptr: Optional[int]):
         self._check(self.L.wbx_dist_exchange(self.ctx.h, dst_ptr), "wbx_dist_exchange")

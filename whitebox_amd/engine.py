@@ -187,6 +187,11 @@ class MixContext:
         _check(self.L.wbx_fetch_interleaved(self.h, _ffi.OUT_FMT[fmt], out.ctypes.data), "wbx_fetch_interleaved", self.h)
         return out
 
+    def set_master_format(self, fmt: Optional[str]):
+        """Later renders leave their master as interleaved samples of `fmt` ("i16", "i24", "i24_x8", "i32", "f32"; None:
+        planar fp32 again) — the conversion runs as the sum kernel's epilogue."""
+        _check(self.L.wbx_set_master_format(self.h, _ffi.OUT_FMT[fmt] if fmt else 0), "wbx_set_master_format", self.h)
+
     def sync(self):
         _check(self.L.wbx_sync(self.h), "wbx_sync", self.h)
 
@@ -196,6 +201,21 @@ class MixContext:
 
     def set_master_target(self, device_ptr: Optional[int]):
         _check(self.L.wbx_set_master_target(self.h, device_ptr), "wbx_set_master_target", self.h)
+
+    def set_master_init(self, device_ptr: Optional[int]):
+        """Later renders continue the running (un-clamped) sum in `device_ptr` instead of starting from zero."""
+        _check(self.L.wbx_set_master_init(self.h, device_ptr), "wbx_set_master_init", self.h)
+
+    def render_order(self, n_blocks: int):
+        """(groups per block, longest group, is it the reference's order) for a render of n_blocks blocks"""
+        ng, lg, ref = C.c_uint32(), C.c_uint32(), C.c_int()
+        _check(self.L.wbx_render_order(self.h, n_blocks, C.byref(ng), C.byref(lg), C.byref(ref)), "wbx_render_order", self.h)
+        return ng.value, lg.value, bool(ref.value)
+
+    def device_info(self):
+        pci, name = C.create_string_buffer(32), C.create_string_buffer(128)
+        _check(self.L.wbx_device_info(self.h, pci, 32, name, 128), "wbx_device_info", self.h)
+        return {"pci": pci.value.decode(), "name": name.value.decode()}
 
     def partial_master(self):
         p, n = C.c_void_p(), C.c_size_t()
@@ -422,6 +442,15 @@ class Engine:
             _check(st, "Engine::process", self.h, True)
         self.ctx.last = (1, len(self.tracks))
 
+    def process_interleaved(self, fmt: str) -> np.ndarray:
+        """Engine::process + the back end's interleave_samples_to(format) in one call: the block as F*C interleaved samples."""
+        dt = {"i16": np.int16, "i24": np.uint8, "i24_x8": np.int32, "i32": np.int32, "f32": np.float32}[fmt]
+        out = np.zeros(self.audio_buffer_size * self.num_output_channels * (3 if fmt == "i24" else 1), dtype=dt)
+        _check(self.L.wbx_engine_process_interleaved(self.h, _ffi.OUT_FMT[fmt], out.ctypes.data), "Engine::process_interleaved",
+               self.h, True)
+        self.ctx.last = (1, len(self.tracks))
+        return out
+
     def render(self, n_blocks: int):
         """K consecutive blocks in one device pass; fetch with self.ctx.fetch()."""
         _check(self.L.wbx_engine_render(self.h, n_blocks), "wbx_engine_render", self.h, True)
@@ -438,19 +467,25 @@ class Engine:
         _check(self.L.wbx_engine_levels(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), n), "wbx_engine_levels", self.h, True)
         return out
 
-    def fetch_plan(self):
+    def fetch_plan(self, max_records: Optional[int] = None):
+        """The Sampler::stream calls of the last render, ordered by (block, track, call); `max_records` keeps the first
+        ones only (the head of a long render)."""
         n = C.c_size_t()
-        self.L.wbx_engine_fetch_plan(self.h, None, 0, C.byref(n))
+        if max_records is None:
+            self.L.wbx_engine_fetch_plan(self.h, None, 0, C.byref(n))
+        else:
+            n.value = max_records
         arr = (_ffi.PlanRecord * max(1, n.value))()
         _check(self.L.wbx_engine_fetch_plan(self.h, arr, n.value, C.byref(n)), "wbx_engine_fetch_plan", self.h, True)
+        got = n.value if max_records is None else min(n.value, max_records)
         return [(r.block, r.track, r.buffer_offset, r.num_samples, r.num_actual, r.sample, r.sample_offset,
-                 r.playback_speed, r.gain, r.flags) for r in arr[:n.value]]
+                 r.playback_speed, r.gain, r.flags) for r in arr[:got]]
 
 
 def build_engine(spec, max_blocks: int = 8, group_size: int = 0, device: int = 0, device_synth: bool = False,
-                 interleaved_ingest: bool = False) -> Engine:
+                 interleaved_ingest: bool = False, spare_tracks: int = 0) -> Engine:
     """Build a product Engine from a synth.SessionSpec through the reference-shaped API."""
-    eng = Engine(max(spec.n_tracks, 1), spec.block, spec.sample_rate, spec.channels, max_blocks=max_blocks,
+    eng = Engine(max(spec.n_tracks, 1) + spare_tracks, spec.block, spec.sample_rate, spec.channels, max_blocks=max_blocks,
                  group_size=group_size, device=device)
     eng.set_bpm(spec.bpm)
     if spec.playhead_start:
