@@ -283,7 +283,7 @@ def test_master_init_continues_a_running_sum():
 def test_levels_of_tracks_added_since_the_last_render_read_zero():
     """wbx_engine_levels for more tracks than have been through a render (a track was just added, the audio callback is
     not running): zeros for those, no error — the UI's per-frame meter read must not fail."""
-    spec = synth.make_session("lv", 6, n_blocks=2, seed=0x1E7)
+    spec = synth.make_session("lv", 6, n_blocks=5, seed=0x1E7)
     eng = build_engine(spec, max_blocks=2, spare_tracks=2)
     assert not eng.levels().any()                              # nothing rendered yet
     eng.play()
