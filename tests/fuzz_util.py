@@ -42,18 +42,23 @@ def random_session(seed):
 
 
 
-def random_masked_session(seed, integer_unity=False, lean16=False):
+def random_masked_session(seed, integer_unity=False, lean16=False, everything=False):
     """Sessions the masked-row path of the mix kernel takes: fp32 clips only, 44.1 / 48 kHz sources, stretch speeds on the
     unity and 5-sample-window paths, stereo 512-frame (or mono / stereo 1024-frame) blocks — with everything a clip list
     can do to a block: touching clips, gaps, clips shorter than a block (three and more stream calls: those still go to
     the pre-render pass), clips that outlast their audio, random start offsets and gains, mutes, sub-buses, more tracks
     than one staged chunk.  `integer_unity`: the second kind of session that path takes — clips of every storage format
     (16 / 24 / 32-bit PCM, fp32; some sessions one format only), all recorded at the session rate and played at speed 1.
-    `lean16`: the third kind — 16-bit PCM only, 44.1 / 48 kHz sources, the same stretch speeds as the fp32 sessions."""
-    rng = np.random.default_rng((0x16B0000 if lean16 else 0x1C70000 if integer_unity else 0xA5C0) + seed)
+    `lean16`: the third kind — 16-bit PCM only, 44.1 / 48 kHz sources, the same stretch speeds as the fp32 sessions.
+    `everything`: what the everything family of the mix kernel takes — every storage format (some sessions 24-bit only,
+    or 16- and 24-bit), 44.1 / 48 / 96 kHz sources, stretch speeds below and above 1 (window rows of every format,
+    per-frame-tap rows), always at least one clip that forces that family."""
+    rng = np.random.default_rng((0xE7E0000 if everything else 0x16B0000 if lean16 else 0x1C70000 if integer_unity else 0xA5C0) + seed)
     fmts = ["i16"] if lean16 else ["f32"]
     if integer_unity:
         fmts = [["i16"], ["i24"], ["i32"], ["i16", "i24", "i32", "f32"], ["i16", "f32"]][int(rng.integers(0, 5))]
+    if everything:
+        fmts = [["i24"], ["i16", "i24"], ["i16", "i24", "i32", "f32"], ["f32"], ["i32", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
     block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2)][int(rng.integers(0, 5))]
     n_blocks = int(rng.integers(2, 7))
@@ -64,17 +69,22 @@ def random_masked_session(seed, integer_unity=False, lean16=False):
     samples, clips = [], []
     for t in range(n_tracks):
         samples.append(synth.SampleSpec(seed_track=t, channels=int(rng.integers(1, 3)),
-                                        rate=sr if integer_unity else int(rng.choice([44100, 48000])),
+                                        rate=sr if integer_unity else int(rng.choice([44100, 48000, 96000] if everything else [44100, 48000])),
                                         frames=int(rng.integers(600, 9000)), fmt=str(rng.choice(fmts)), amp=0.05))
         pos = -0.2 * total_beats * rng.random() if rng.random() < 0.3 else total_beats * rng.random() * 0.3
         for _ in range(int(rng.integers(0, 6))):
             length = total_beats * (0.02 + 0.45 * rng.random())
             speed = 1.0 if integer_unity else float(rng.choice([1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 0.3, 0.67]))
+            if everything:
+                speed = float(rng.choice([1.0, 1.0, 0.5, 0.8, 0.999, 0.3, 1.25, 2.0, 1.0005]))
             clips.append(synth.ClipSpec(track=t, min_beat=float(pos), max_beat=float(pos + length),
                                         start_offset=float(rng.integers(0, 400)), speed=speed, gain=float(rng.choice([1.0, 0.5, 1.3]))))
             pos += length + (0.0 if rng.random() < 0.5 else total_beats * 0.1 * rng.random())   # touching or a gap
+    if everything and fmts == ["f32"]:   # an fp32-only session takes the everything family through a per-frame-tap clip
+        samples[0].rate = 96000
+        clips.append(synth.ClipSpec(track=0, min_beat=total_beats * 0.9, max_beat=total_beats * 0.97, start_offset=3.0, speed=1.0))
     n_buses = int(rng.choice([0, 0, 3]))
-    return synth.SessionSpec(name=f"{'sfuzz' if lean16 else 'ifuzz' if integer_unity else 'mfuzz'}{seed}", n_tracks=n_tracks, seed=0xF0330000 + seed, samples=samples, clips=clips,
+    return synth.SessionSpec(name=f"{'efuzz' if everything else 'sfuzz' if lean16 else 'ifuzz' if integer_unity else 'mfuzz'}{seed}", n_tracks=n_tracks, seed=0xF0330000 + seed, samples=samples, clips=clips,
                              volumes_db=[float(rng.uniform(-30, 3)) for _ in range(n_tracks)],
                              pans=[float(rng.uniform(-1, 1)) for _ in range(n_tracks)],
                              mutes=[bool(rng.random() < 0.1) for _ in range(n_tracks)],

@@ -608,6 +608,28 @@ def _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels=2, gaps=T
     return spec
 
 
+@pytest.mark.parametrize("fmts,rates", [(("i24",), (44100, 48000)), (("i16", "i24"), (44100, 48000)), (("f32", "i32"), (96000, 44100)),
+                                        (("i16", "i24", "f32"), (44100, 96000, 48000))])
+def test_clip_boundaries_in_the_hot_loop_every_format(fmts, rates):
+    """... and for the sessions the everything family serves: resampled 24 / 32-bit PCM, 16-bit resampled beside other
+    formats, 96 kHz clips (per-frame taps) — no pre-render queue entry for a block with one or two stream calls."""
+    n_blocks = 7
+    spec = _boundary_session(40, n_blocks, 512, 1.3)
+    for i, smp in enumerate(spec.samples):
+        smp.fmt = fmts[i % len(fmts)]
+        smp.rate = rates[(i // 2) % len(rates)]
+        smp.amp = 0.02 if smp.fmt == "f32" else 1.0
+        smp.frames = int(smp.frames * 2.2)
+    spec.volumes_db = [v - (0.0 if spec.samples[2 * t].fmt == "f32" else 30.0) for t, v in enumerate(spec.volumes_db)]
+    check_against_oracle(spec, n_blocks, group_size=40, expect_exact=True)
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=40)
+    eng.play()
+    eng.render(n_blocks)
+    eng.ctx.fetch()
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"
+    eng.close()
+
+
 @pytest.mark.parametrize("masked", ["1", "0"])
 @pytest.mark.parametrize("clip_blocks,block,channels,n_tracks,group", [(1.3, 512, 2, 40, 0), (0.7, 512, 2, 40, 16), (2.45, 1024, 2, 24, 0),
                                                                        (3.1, 1024, 1, 24, 5), (1.9, 512, 2, 300, 200)])
@@ -1555,6 +1577,15 @@ def test_random_masked_row_sessions_16bit_resampled(seed):
     (mix_kernel<.., FAM = 2, ..>) with partial KIND_WINDOW_I16 / KIND_UNITY_I16 records in MODE_WI / MODE_WIN / MODE_WINU /
     MODE_I16, the chunks that hold a pre-rendered fp32 row in its one-row-at-a-time mode."""
     check_masked_session(*FZ.random_masked_session(seed, lean16=True), seed)
+
+
+# WBX_FUZZ7_FROM / WBX_FUZZ7_TO widen the seed range for a soak run (default: seeds 0..59)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ7_FROM", "0")), int(os.environ.get("WBX_FUZZ7_TO", "60"))))
+def test_random_masked_row_sessions_everything_family(seed):
+    """Sessions the everything family (mix_kernel<.., FAM = 1, ..>) serves — resampled 24 / 32-bit PCM, 16-bit resampled
+    next to other formats, clips played faster than recorded: their clip boundaries are masked rows of the hot loop too
+    (partial KIND_WINDOW / KIND_WINDOW_I16 / KIND_STRIDE / KIND_UNITY_* records in MODE_W / WN / WI / WIN / MW / MWN / G)."""
+    check_masked_session(*FZ.random_masked_session(seed, everything=True), seed)
 
 
 def check_masked_session(spec, n_blocks, seed):

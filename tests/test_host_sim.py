@@ -52,7 +52,7 @@ def check_session(spec, n_blocks, batch, masked=False):
     sim.close()
 
 
-@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("masked", [0, 1, 4])
 @pytest.mark.parametrize("seed", range(0, 160))
 def test_host_sequencer_random_sessions_batched(seed, masked):
     """the 160 fuzz sessions of the GPU suite, all blocks in one plan (steady runs, templates, overflow pool); `masked`:
@@ -61,7 +61,7 @@ def test_host_sequencer_random_sessions_batched(seed, masked):
     check_session(spec, n_blocks, batch=True, masked=masked)
 
 
-@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("masked", [0, 1, 4])
 @pytest.mark.parametrize("seed", range(0, 40))
 def test_host_sequencer_random_sessions_block_by_block(seed, masked):
     """the second generator's sessions one block per plan (the audio-callback shape)"""
@@ -111,6 +111,14 @@ def test_clip_boundaries_stay_out_of_the_pre_render_queue():
 
 
 @pytest.mark.parametrize("seed", range(0, 80))
+def test_host_sequencer_everything_family_sessions(seed):
+    """the generator for the everything family (every storage format, speeds below and above 1), planned at level 4:
+    every one- or two-call block a masked row / ROW_PAIR"""
+    spec, n_blocks = FZ.random_masked_session(seed, everything=True)
+    check_session(spec, n_blocks, batch=bool(seed & 1), masked=4)
+
+
+@pytest.mark.parametrize("seed", range(40))
 def test_host_sequencer_masked_row_sessions(seed):
     """the third generator: sessions the masked-row path takes (fp32, unity / window speeds, 512- and 1024-frame blocks)"""
     spec, n_blocks = FZ.random_masked_session(seed)

@@ -1,0 +1,61 @@
+#!/bin/bash
+# Profile bundle of a round (one gpurun call): gpu tests, the default bench line (headline + configs), the other
+# workloads, the multi-GPU code path on one rank, rocprofv3 --kernel-trace --stats and separate --pmc passes for the
+# configurations the bench line's `configs` object names (c3, c4, c3 cut into clips, i16r) and for the grouped order at
+# 256-block renders.  Counters are never combined with trace domains other than --kernel-trace.
+# usage (on the GPU box): tools/profile_round.sh [tag]      -> gpurun_out/<tag>/ ; then tools/refresh_profiles.sh <tag> <round>
+set -u
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?" >> $O/bench_default.err
+B="--no-cpu-baseline --no-configs"
+for W in c4 c2 u4096 i16 i16r i24r d96 mixfmt mixr; do
+  timeout 300 python bench.py --workload $W $B > $O/bench_$W.json 2>> $O/bench_default.err
+done
+for W in c3 i16 i16r; do for L in 5.3 20; do
+  timeout 300 python bench.py --workload $W --clip-blocks $L $B > $O/bench_${W}_L$L.json 2>> $O/bench_default.err
+done; done
+# the grouped order (renders of 256 blocks: 128-track groups) for the same workloads
+for W in c3 c4 c2 i16 i16r i24r mixr; do
+  timeout 300 python bench.py --workload $W --blocks 256 $B > $O/bench_${W}_K256.json 2>> $O/bench_default.err
+done
+timeout 300 python bench.py --clip-blocks 5.3 --blocks 256 $B > $O/bench_c3_L5.3_K256.json 2>> $O/bench_default.err
+for M in reduce ordered chain; do
+  timeout 300 python bench.py --force-dist-path --dist-mode $M $B > $O/bench_dist1_$M.json 2>> $O/bench_default.err
+done
+timeout 300 python tools/longrun_probe.py > $O/longrun_probe.txt 2>&1
+cd /tmp
+kt() {   # name, bench args...
+  n=$1; shift
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$n -o $n -- python $R/bench.py $B --no-verify --latency-blocks 0 "$@" > $O/kt_${n}_bench.json 2> $O/kt_$n.err
+}
+kt c3
+kt c4 --workload c4
+kt c2 --workload c2
+kt c3_L5.3 --clip-blocks 5.3
+kt i16r --workload i16r
+kt c3_K256 --blocks 256
+pmc() {  # name, bench args...
+  n=$1; shift
+  mkdir -p $O/pmc_$n
+  for grp in "FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" "WRITE_SIZE TCC_HIT TCC_MISS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT" \
+             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    g=$(echo $grp | cut -d' ' -f1)
+    timeout 300 rocprofv3 --kernel-trace --kernel-include-regex "mix_kernel" --pmc $grp --output-format csv -d $O/pmc_$n/$g -o $n -- \
+      python $R/bench.py --steps 3 --warmup 1 --ramp-steps 3 $B --no-verify --latency-blocks 0 "$@" > $O/pmc_$n/$g.log 2>&1
+  done
+}
+pmc c3
+pmc c4 --workload c4
+pmc c3_L5.3 --clip-blocks 5.3
+pmc i16r --workload i16r
+pmc c3_K256 --blocks 256
+cd $R
+find $O -name "*.csv" -size +8M -delete
+find $O -name "*.db" -delete
+ls -R $O | head -60

@@ -174,6 +174,8 @@ struct wbx_ctx {
   bool partial_wait_done = false;     // the caller already ordered this render after the sum of two renders ago
   bool sum_overlap = true;            // WBX_SUM_OVERLAP=0: sum on the main stream
   DevBuf<uint8_t> d_conv;
+  DevBuf<unsigned long long> d_dbg;   // diagnostic (WBX_DBG_CLOCK=1): per-workgroup start / end times of the last mix
+  size_t dbg_wgs = 0;
   std::vector<DTrackBlock> h_tb;      // layer-1 staging
   std::vector<DRow> h_rows;
   std::vector<DSeg> h_pool;

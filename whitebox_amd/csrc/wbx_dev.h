@@ -204,7 +204,9 @@ struct MixArgs {
   uint32_t tiles;               // ceil(C*F/4 / 256)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
   uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
-  uint32_t scatter;             // EXPERIMENT (WBX_SCATTER=1): block order bit-reversed
+  uint32_t lds_pad;             // launch parameter, not read by the kernel: bytes of LDS reserved on top of the kernel's own, to
+                                // cap the workgroups a CU holds (launch_mix_sum: whole-list walks spread evenly over the CUs)
+  unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][2] start / end wall-clock ticks, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
 };

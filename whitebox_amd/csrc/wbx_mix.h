@@ -248,11 +248,9 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
   // of a group read adjacent pieces of the same clip rows (they share the cache line at the seam), so give every
   // XCD a contiguous run of blocks: id x -> block (x % 8) * K/8 + x / 8.
+  const unsigned long long dbg_t0 = a.dbg_clock ? wall_clock64() : 0ull;
   uint32_t bx = blockIdx.x;
   if ((gridDim.x & 7u) == 0u) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  // EXPERIMENT (MixArgs::scatter, power-of-two grids): consecutive workgroup ids render blocks far apart (bit reversal) —
-  // what the adjacency of concurrently running blocks is worth
-  if (a.scatter && (gridDim.x & (gridDim.x - 1u)) == 0u) bx = __brev(blockIdx.x) >> (__clz(gridDim.x) + 1);
   const uint32_t g = blockIdx.y, tile = blockIdx.z;
   const uint32_t tid = threadIdx.x;
   const DGroup grp = a.groups[g];
@@ -564,8 +562,13 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   // valid for unity rows (fx = 0, first tap = the sample itself).  fmt is wave-uniform.
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
   typedef int i1u __attribute__((aligned(2)));
-  auto load_stride = [&](const void* const (&src_c)[CL], double pos, double speed, uint32_t fmt, PreG& p) {
-    const double jd[4] = {j0d, jd1, jd2, jd3};
+  auto load_stride = [&](const void* const (&src_c)[CL], double pos, double speed, uint32_t fmt, bool part, uint32_t d, uint32_t n,
+                         PreG& p) {
+    double jd[4] = {j0d, jd1, jd2, jd3};
+    if (part) {   // a stream call that covers [d, d + n) of the block: the frame inside the call, clamped into it
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) jd[k] = (double)call_frame(k, d, n);
+    }
     float f4x[4];
     int ix[4];
 #pragma unroll
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         r.kind = t.kind & KIND_MASK;
       }
       if constexpr (MODE == MODE_G) {
-        load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), pre[u]);
+        load_stride(r.src, r.pos, r.speed, (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format), EXP && r.partial, r.d, r.n, pre[u]);
       } else if constexpr (MODE == MODE_W || MODE == MODE_WN || MODE == MODE_WNU) {
         double prod0;
         const bool part = EXP && r.partial;
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         load_window(r.src, r.pos, prod0, pre[u]);
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         double prod0;
-        if (EXP && LEAN16 && r.partial)    // the lane's first frame inside the stream call (partial 16-bit window rows: family 2 only)
+        if (EXP && (LEAN16 || G) && r.partial)    // the lane's first frame inside the stream call (partial 16-bit window rows)
           prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
         else if (MODE == MODE_WINU)   // one-ratio chunk: the hoisted product for the resampled rows, j * 1.0 for the unity ones
           prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16 ? up0 : j0d;
@@ -808,9 +811,11 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         typedef float f1a2 __attribute__((aligned(2)));
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
-        const double x0 = __dadd_rn(r.pos, __dmul_rn(j0d, r.speed));                      // sampler.cpp:50, frame j0
+        // (EXP: a partial stream call starts at the lane's first frame INSIDE the call, clamped into it)
+        const uint32_t cf0 = (EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0;
+        const double x0 = __dadd_rn(r.pos, __dmul_rn((EXP && r.partial) ? (double)(int32_t)cf0 : j0d, r.speed));   // sampler.cpp:50
         const bool win = k == KIND_WINDOW || k == KIND_WINDOW_I16;
-        const int ix0 = win ? (int)x0 : (int)((uint32_t)r.pos + j0);                      // :51 / :107
+        const int ix0 = win ? (int)x0 : (int)((uint32_t)r.pos + cf0);                     // :51 / :107
         if (active) {
 #pragma unroll
           for (int ch = 0; ch < CL; ch++) {
@@ -883,7 +888,42 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         const uint32_t ff = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
 #pragma unroll
         for (int ch = 0; ch < CL; ch++) m.c[ch] = row_stride(pre[u].v[ch], pre[u].b[ch], pre[u].fx, kk, ff, cg, gc[ch]);
+        if (EXP && r.partial) {   // frames outside the stream call contribute an exact +0.0
+#pragma unroll
+          for (int ch = 0; ch < CL; ch++) {
+            m.c[ch].x = and_mask(m.c[ch].x, frame_mask(0u, r.d, r.n));
+            m.c[ch].y = and_mask(m.c[ch].y, frame_mask(1u, r.d, r.n));
+            m.c[ch].z = and_mask(m.c[ch].z, frame_mask(2u, r.d, r.n));
+            m.c[ch].w = and_mask(m.c[ch].w, frame_mask(3u, r.d, r.n));
+          }
+        }
       } else {
+      // G: a partial row read through window-shaped loads, whatever its kind and storage format — its loaded samples
+      // normalised to fp32 (the linear path's normalisers sampler.cpp:9-14 for window rows, the unity path's with their
+      // clamp :109-144 for unity rows), then the general masked arithmetic.  `packed16`: the 16-bit samples arrived packed
+      // (v.x, v.y = samples 0..3, w4 = sample 4 in its low half)
+      auto partial_any = [&](const Pre& p, int k, uint32_t fmt, bool packed16) {
+        const bool unity = k == KIND_UNITY || k == KIND_UNITY_I16 || k == KIND_UNITY_I32;
+        Pre f = p;
+        if (packed16) {
+          f = unpack16(p, unity);
+        } else if (fmt != FMT_F32) {
+#pragma unroll
+          for (int ch = 0; ch < CL; ch++) {
+            if (unity) {
+              f.w[ch].v = norm_i32(p.w[ch].v, fmt);
+            } else {
+              const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;
+              f.w[ch].v.x = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.x));
+              f.w[ch].v.y = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.y));
+              f.w[ch].v.z = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.z));
+              f.w[ch].v.w = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].v.w));
+              f.w[ch].w4 = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].w4));
+            }
+          }
+        }
+        return row_window_masked(f, r.pos, r.speed, unity, r.d, r.n, cg, gc);
+      };
       // per channel: the rows whose arithmetic has nothing to share between the channels of a frame
       auto each_of = [&](const auto& pu, auto f) {
 #pragma unroll
@@ -902,6 +942,8 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else if (G && (fmt != FMT_F32 || k == KIND_UNITY_I32)) {   // 24 / 32-bit PCM (G instances only)
+            if constexpr (G) m = partial_any(pre[u], k, fmt, false);
           } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
             if (k == KIND_WINDOW)
               m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
@@ -924,7 +966,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         const bool win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16;
         constexpr std::integral_constant<bool, MODE != MODE_WI> narrow{};
-        if (EXP && LEAN16 && r.partial) {   // a stream call that covers part of the block (wave-uniform)
+        if (EXP && (LEAN16 || G) && r.partial) {   // a stream call that covers part of the block (wave-uniform)
           if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -944,7 +986,20 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_MWN> narrow{};
-        if (k == KIND_WINDOW_I16) {
+        if (EXP && r.partial) {   // a stream call that covers part of the block
+          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+#pragma unroll
+            for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else {
+            Pre q = pre[u];
+            const bool p16 = k == KIND_WINDOW_I16 || k == KIND_UNITY_I16;
+            if (p16) {
+#pragma unroll
+              for (int ch = 0; ch < CL; ch++) q.w[ch].w4 = pre[u].w[ch].v.z;   // the fifth sample of a 16-bit window: low half of the third dword
+            }
+            m = partial_any(q, k, fmt, p16);
+          }
+        } else if (k == KIND_WINDOW_I16) {
           Pre q = pre[u];
 #pragma unroll
           for (int ch = 0; ch < CL; ch++) q.w[ch].w4 = pre[u].w[ch].v.z;   // the fifth sample of a 16-bit window is the low half of the load's third dword
@@ -1362,6 +1417,11 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     chunk0 += cn;
   }
 
+  if (a.dbg_clock && tid == 0u) {   // (diagnostic, WBX_DBG_CLOCK=1: when did this workgroup start and end — 100 MHz wall clock)
+    const uint32_t wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    a.dbg_clock[2u * wg] = dbg_t0;
+    a.dbg_clock[2u * wg + 1u] = wall_clock64();
+  }
   if (active && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
@@ -1377,7 +1437,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 #define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, T, GRID, BLOCK)                                                   \
   {                                                                                                            \
     name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ", " #T ">";          \
-    hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, t0, t1, 0, a);      \
+    hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, a.lds_pad, s, t0, t1, 0, a); \
   }
 
 // the instances of one family (wbx_mix_fam<N>.hip); `variant`: 10 * U + W, or >= 1000 for both channels of a frame per lane

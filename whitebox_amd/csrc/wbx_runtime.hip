@@ -270,7 +270,8 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   if (!full && c->cfg.channels == 2u && S4 == 64u && mix_family(c) != 1 && mix_two_channels_per_lane(c)) full = true;
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
-  if (!full || c->force_g) return 0u;
+  if (!full) return 0u;
+  if (mix_family(c) == 1) return 4u;   // the everything family: every row kind it streams, also as a masked row
   if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
   if (stride_clips) return 0u;
   if (!c->has_integer_clips) return 1u;
@@ -334,8 +335,16 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
-  static const bool scatter = std::getenv("WBX_SCATTER") != nullptr;   // (experiment)
-  m.scatter = scatter ? 1u : 0u;
+  m.lds_pad = std::getenv("WBX_LDS_PAD") ? (uint32_t)std::atoi(std::getenv("WBX_LDS_PAD")) : 0u;   // (experiment)
+  {
+    static const bool dbg = std::getenv("WBX_DBG_CLOCK") != nullptr;   // diagnostic: per-workgroup start / end times of the mix
+    m.dbg_clock = nullptr;
+    if (dbg) {
+      c->dbg_wgs = (size_t)K * n_groups * m.tiles;
+      WBX_HIP(c, c->d_dbg.ensure(2 * c->dbg_wgs));
+      m.dbg_clock = c->d_dbg.p;
+    }
+  }
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(m.peaks, 0, (size_t)K * N * C * sizeof(float), ms));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
@@ -588,6 +597,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   for (auto& P : c->d_peaks) P.release();
   c->d_gains.release();
   c->d_conv.release();
+  c->d_dbg.release();
   c->d_zero.release();
   for (int i = 0; i < kEventRing; i++) {
     if (c->ev[i][0]) (void)hipEventDestroy(c->ev[i][0]);
@@ -1026,6 +1036,16 @@ extern "C" wbx_status wbx_device_info(wbx_ctx* c, char* pci_bus_id, size_t n_pci
     WBX_HIP(c, hipGetDeviceProperties(&p, c->cfg.device));
     std::snprintf(name, n_name, "%s (%s)", p.name, p.gcnArchName);
   }
+  return WBX_OK;
+}
+
+// diagnostic (not in wbx.h; WBX_DBG_CLOCK=1): start / end wall-clock ticks (100 MHz) of every workgroup of the last mix
+extern "C" wbx_status wbx_debug_wg_clocks(wbx_ctx* c, unsigned long long* out, size_t cap, size_t* n_wgs) {
+  if (!c || !n_wgs) return WBX_ERR_INVALID;
+  *n_wgs = c->dbg_wgs;
+  if (!out || !c->d_dbg.p) return WBX_OK;
+  WBX_HIP(c, sync_main(c));
+  WBX_HIP(c, hipMemcpy(out, c->d_dbg.p, std::min(cap, 2 * c->dbg_wgs) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return WBX_OK;
 }
 

@@ -424,11 +424,18 @@ __host__ __device__ inline uint32_t alloc_template(const PlanArgs& a, TrackCache
 // What the hot loop can render of ONE stream call that covers only part of the block (PlanArgs::masked_rows = level):
 // source positions below 2^31; fp32 at unity speed or at a speed the 5-sample window holds (level >= 1), integer PCM at
 // unity speed (level 2: sessions whose integer clips all play at the session rate), 16-bit PCM also at a speed the window
-// holds (level 3: sessions of 16-bit clips only, the lean 16-bit family of mix_kernel).  KIND_GENERIC: it cannot.
+// holds (level 3: sessions of 16-bit clips only, the lean 16-bit family of mix_kernel), every format at every streamable
+// speed (level 4: the everything family).  KIND_GENERIC: it cannot.
 __host__ __device__ inline uint8_t masked_kind(const DSeg& s, uint32_t block_frames, uint32_t level) {
   if (s.len == 0) return KIND_SILENT;
   if (!(s.pos >= 0.0 && s.pos < 2147483000.0)) return KIND_GENERIC;
   if ((uint32_t)s.dst_start + s.len > block_frames) return KIND_GENERIC;
+  if (level >= 4u) {   // the everything family: any storage format at any speed the hot loop streams, as classify() names it
+    if (!(s.speed > 0.0 && s.speed <= 4096.0) || !(s.pos + (double)s.len * s.speed < 2147483000.0)) return KIND_GENERIC;
+    if (s.speed == 1.0) return s.format == FMT_F32 ? KIND_UNITY : s.format == FMT_I16 ? KIND_UNITY_I16 : KIND_UNITY_I32;
+    if (s.speed > 0.999) return KIND_STRIDE;
+    return s.format == FMT_I16 ? KIND_WINDOW_I16 : KIND_WINDOW;
+  }
   if (s.format != FMT_F32) {
     if (level >= 3u && s.format == FMT_I16 && s.speed > 0.0 && s.speed <= 0.999) return KIND_WINDOW_I16;
     if (level < 2u || s.speed != 1.0) return KIND_GENERIC;
