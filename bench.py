@@ -6,8 +6,9 @@
       environment), or run plainly — bench.py then starts the N ranks itself.
 
 A "step" is one device pass of the hot path (clip sequencer + per-track render/gain/pan/resample +
-peaks + group/bus/master sum + clamp) over one batch of `--blocks` consecutive 512-frame blocks of a
-synthetic session that is already resident in HBM.  The default workload is BASELINE.json configs[2]
+peaks + group/bus/master sum + clamp) over one batch of `--blocks` consecutive 512-frame blocks (default 2048: the
+tracks of every block are added in the reference's strictly sequential order) of a synthetic session that is already
+resident in HBM.  After the timed loop the head of one more step is checked against the CPU oracle (`verify`).  The default workload is BASELINE.json configs[2]
 ("4096 stereo tracks, gain+pan + linear clip resample (44.1->48 kHz), 1 MI355X") — the configuration the
 metric "…4096 tracks @ 512-frame blocks" is quoted on.  With N GPUs every rank mixes its own 4096 tracks
 (weak scaling = configs[4]: 32768 tracks sharded 8-way) and the un-clamped partial masters are reduced
@@ -556,9 +557,10 @@ def main():
                     "its sustained clocks, and drops them again in any idle gap")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (default 4096; 256 for c2)")
-    ap.add_argument("--blocks", type=int, default=1024, help="512-frame blocks per step (one device pass).  Renders of "
+    ap.add_argument("--blocks", type=int, default=2048, help="512-frame blocks per step (one device pass).  Renders of "
                     ">= 1024 blocks add every block's tracks in the reference's strictly sequential order (bit-exact "
-                    "master); shorter ones in groups of 128 (within 1e-6 RMS)")
+                    "master: 128-track workgroups, each continuing the running sum of the one before it — at full rate "
+                    "from about 1536 blocks on); shorter ones in groups of 128 (within 1e-6 RMS)")
     ap.add_argument("--group-size", type=int, default=0)
     ap.add_argument("--clip-blocks", type=float, default=0.0, help="side measurement: cut every track into back-to-back "
                     "clips of this many blocks (0: one clip per track, the BASELINE.json configs)")

@@ -69,7 +69,7 @@ enum { WBX_OUT_I16 = 3, WBX_OUT_I24 = 5, WBX_OUT_I24_X8 = 6, WBX_OUT_I32 = 7, WB
 typedef struct wbx_config {
   int32_t device;          /* HIP device ordinal */
   uint32_t max_tracks;     /* N upper bound */
-  uint32_t max_blocks;     /* K upper bound per submit/render (1..2048) */
+  uint32_t max_blocks;     /* K upper bound per submit/render (1..4096) */
   uint32_t block_frames;   /* F, Engine::audio_buffer_size (reference default 512, src/config.cpp:146); multiple of 4 */
   uint32_t channels;       /* C, output channels: 1 or 2 (reference: 2, src/config.cpp:224) */
   uint32_t sample_rate;    /* destination rate, Engine::audio_sample_rate */

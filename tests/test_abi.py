@@ -56,7 +56,7 @@ def test_no_cpu_fallback_without_a_device():
 
 
 @pytest.mark.parametrize("field,value", [("channels", 3), ("channels", 0), ("block_frames", 510), ("block_frames", 0),
-                                         ("max_tracks", 0), ("max_blocks", 0), ("max_blocks", 4096), ("sample_rate", 0)])
+                                         ("max_tracks", 0), ("max_blocks", 0), ("max_blocks", 8192), ("sample_rate", 0)])
 def test_config_validation(field, value):
     L = W.lib()
     cfg = _ffi.Config(0, 8, 1, 512, 2, 48000, 0, 0, None)

@@ -159,34 +159,44 @@ def test_config3_exact_order_mode():
     check_against_oracle(spec, 2, group_size=1024, expect_exact=True)
 
 
-def test_config3_4096_whole_list_walk_is_bit_exact(monkeypatch):
-    """BASELINE config 3 at full width in the reference's own summation order: one workgroup walks all 4096 tracks of
-    its block (32 staged chunks: prefetched rows, staggered first chunk).  That is what the library picks for renders of
-    >= 1024 blocks; WBX_EXACT_MIN_BLOCKS lowers the threshold so that the oracle only has to render 4 blocks.  Master,
-    peaks, stream-call log and transport bit for bit."""
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_config3_4096_whole_list_walk_is_bit_exact(monkeypatch, chain):
+    """BASELINE config 3 at full width in the reference's own summation order, both ways the library has it: chained
+    128-track pieces (each workgroup continues the running sum of the piece before it: what renders of >= 1024 blocks
+    take) and, WBX_CHAIN=0, one workgroup walking all 4096 tracks of its block (32 staged chunks).  WBX_EXACT_MIN_BLOCKS
+    lowers the threshold so that the oracle only has to render 4 blocks.  Master, peaks, stream-call log and transport bit
+    for bit."""
     monkeypatch.setenv("WBX_EXACT_MIN_BLOCKS", "4")
+    monkeypatch.setenv("WBX_CHAIN", chain)
     spec = synth.make_session("c3", 4096, src_rate=44100, n_blocks=4, seed=0x5EED0003)
     check_against_oracle(spec, 4, expect_exact=True)
     spec = synth.make_session("c3s", 4096, src_rate=44100, seek=True, n_blocks=5, seed=0x5EED0013)   # clip boundaries in the walk
     check_against_oracle(spec, 5, expect_exact=True)
 
 
-def test_render_of_1024_blocks_takes_the_reference_order():
-    """The default for a long render, at BASELINE config 3's full size and the benchmark's render length: wbx_render_order
-    reports the reference's order, the launched instance is the two-channels-per-lane one, and the head of the render —
-    the first 4 blocks — is bit-identical to the oracle (the bench's own --verify does the same after its timed loop)."""
+def test_render_of_1024_blocks_takes_the_reference_order(monkeypatch):
+    """The default for a long render, at BASELINE config 3's full size and a benchmark-sized render: wbx_render_order
+    reports the reference's order (32 chained pieces of 128 tracks; WBX_CHAIN=0: one walk of 4096 tracks per workgroup),
+    the head of the render — the first 4 blocks — is bit-identical to the oracle (the bench's own --verify does the same
+    after its timed loop), and the two ways of adding in that order agree on every one of the 1024 blocks."""
     K, N = 1024, 4096
     long_spec = synth.make_session("c3", N, src_rate=44100, n_blocks=K, seed=0x5EED0003)
-    eng = build_engine(long_spec, max_blocks=K, device_synth=True)
-    eng.play()
-    eng.render(K)
-    m, pk, _ = eng.ctx.fetch(peaks=True)
-    assert eng.ctx.render_order(K) == (1, N, True) and eng.ctx.render_order(256)[2] is False
-    assert eng.ctx.kernel_name() == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"
     om, opk, _, _, _ = run_oracle(synth.make_session("c3", N, src_rate=44100, n_blocks=4, seed=0x5EED0003), 4)
-    assert np.array_equal(bits(m[:4]), bits(om)) and np.array_equal(pk[:4], opk[..., :2])
-    assert np.abs(m[4:]).max() > 0.05 and np.isfinite(m).all()
-    eng.close()
+    got = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("WBX_CHAIN", chain)
+        eng = build_engine(long_spec, max_blocks=K, device_synth=True)
+        eng.play()
+        eng.render(K)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert eng.ctx.render_order(K) == ((32, 128, True) if chain == "1" else (1, N, True)) and eng.ctx.render_order(256)[2] is False
+        assert eng.ctx.kernel_name() == ("wbx::mix_kernel<2, true, 4, 0, 1, 1, 1, 256>" if chain == "1"
+                                         else "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>")
+        assert np.array_equal(bits(m[:4]), bits(om)) and np.array_equal(pk[:4], opk[..., :2])
+        assert np.abs(m[4:]).max() > 0.05 and np.isfinite(m).all()
+        got[chain] = (m, pk)
+        eng.close()
+    assert np.array_equal(bits(got["1"][0]), bits(got["0"][0])) and np.array_equal(got["1"][1], got["0"][1])
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -43,11 +43,14 @@ def presets(other_lib=None):
                              for (w, l) in (("c3", 0), ("c4", 0), ("c2", 0), ("u4096", 0), ("i16", 0), ("i16r", 0), ("i24r", 0),
                                             ("mixr", 0), ("mixfmt", 0), ("d96", 0), ("c3", 5.3), ("i16", 5.3))
                              for g in (0, 1)]
-    # whole-list walks: workgroups per CU capped by reserving LDS (160 KiB / n each), so that K = 256 n workgroups land n per CU
-    P["ldspad"] = [case(f"{w}{' L=%s' % l if l else ''} K={k} pad={pad}", f"WBX_LDS_PAD={pad}" if pad else "",
-                        f"--workload {w} {'--clip-blocks %s' % l if l else ''} --blocks {k} --steps {6144 // k} --warmup 2 --ramp-steps {10240 // k}")
-                   for (w, l) in (("c3", 0), ("i16", 0), ("i16r", 0), ("c3", 5.3), ("u4096", 0))
-                   for (k, pad) in ((1024, 0), (1024, 13800), (1280, 0), (1280, 5800), (768, 26000), (1536, 0))]
+    # the reference's order three ways at several render lengths: chained pieces (default), whole-list walks (WBX_CHAIN=0),
+    # and the grouped order beside them (WBX_EXACT_MIN_BLOCKS=0)
+    P["chain"] = [case(f"{w}{' L=%s' % l if l else ''} K={k} {lab}", env,
+                       f"--workload {w} {'--clip-blocks %s' % l if l else ''} --blocks {k} --steps {max(3, 6144 // k)} --warmup 2 --ramp-steps {max(3, 10240 // k)}")
+                  for (w, l) in (("c3", 0), ("i16", 0), ("i16r", 0), ("c3", 5.3), ("u4096", 0), ("c2", 0))
+                  for k in (1024, 1536, 2048, 4096)
+                  for (lab, env) in (("chained", ""), ("whole lists", "WBX_CHAIN=0"), ("grouped", "WBX_EXACT_MIN_BLOCKS=0"))
+                  if not (k == 4096 and lab == "whole lists")]
     P["exact_k"] = [case(f"{w}{' L=%s' % l if l else ''} K={k} whole lists", "",
                          f"--workload {w} {'--clip-blocks %s' % l if l else ''} --blocks {k} --steps {6144 // k} --warmup 2 --ramp-steps {10240 // k}")
                     for (w, l) in (("i16r", 0), ("i16", 0), ("c3", 5.3), ("i24r", 0)) for k in (1024, 1536, 2048)]

@@ -122,6 +122,9 @@ struct wbx_ctx {
   bool buses_alias_exact = false;     // buses_alias_partials of groups_exact
   bool whole_lists_now = false;       // the render being issued takes groups_exact (render_walks_whole_lists)
   uint32_t longest_list = 0;          // tracks in the longest member list
+  mutable bool chain_broken = false;  // a chained render reported a failed hand-over (plan_status_to_error)
+  bool chain_now = false;             // ... as chained workgroup-sized pieces (render_chains_groups)
+  DevBuf<uint32_t> d_chain;           // chained renders: the "running sum is out" words
   uint32_t exact_min_blocks = 1024;   // renders of at least this many blocks do, when the library picks the grouping
                                       // (WBX_EXACT_MIN_BLOCKS; 0 = never)
   DevBuf<uint32_t> d_order;
@@ -287,6 +290,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
 bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K);
+bool render_chains_groups(const wbx_ctx* c, uint32_t K);
 int mix_family(const wbx_ctx* c);
 bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);

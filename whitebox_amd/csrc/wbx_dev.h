@@ -143,8 +143,11 @@ struct DBlockTime {       // per-block transport scalars computed by the host ex
 struct DGroup {           // tracks order[first .. first+count) are summed in order by one workgroup
   uint32_t first, count;
   int32_t bus;            // -1: straight into the master
-  uint32_t _pad;
+  uint32_t flags;         // GROUP_*: its place in the member list (all direct tracks / the tracks of one bus) it is a piece of
 };
+// Chained renders (MixArgs::chain): the pieces of a member list are ONE sum — piece i starts from the running sum piece
+// i-1 left (GROUP_CHAIN_IN) and hands its own on (GROUP_CHAIN_OUT); only a list's last piece holds a sum the sum kernel adds
+enum : uint32_t { GROUP_CHAIN_IN = 1, GROUP_CHAIN_OUT = 2 };
 
 struct PlanArgs {
   const DClip* clips;
@@ -204,9 +207,12 @@ struct MixArgs {
   uint32_t tiles;               // ceil(C*F/4 / 256)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
   uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
-  uint32_t lds_pad;             // launch parameter, not read by the kernel: bytes of LDS reserved on top of the kernel's own, to
-                                // cap the workgroups a CU holds (launch_mix_sum: whole-list walks spread evenly over the CUs)
-  unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][2] start / end wall-clock ticks, or null
+  uint32_t* chain;              // chained render: [workgroup columns][n_groups] "this piece's running sum is out" words, zeroed
+                                // before the launch; null: every group starts from zero (or MixArgs::init) and the sum
+                                // kernel adds the group sums
+  uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
+                                // device's in-order workgroup dispatch is not what it is documented to be)
+  unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][4] start / end wall-clock ticks, HW_ID, XCC_ID, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
 };
@@ -220,6 +226,7 @@ struct SumArgs {
   float* buses;                 // [K][NB][C][F] or null
   uint32_t n_groups, n_buses, block_frames, channels;
   uint32_t clamp;
+  uint32_t chain;               // chained render: groups flagged GROUP_CHAIN_OUT hold intermediate running sums — skip them
   uint32_t* status_src;         // optional: the plan's 4 counters, copied to status_dst (pinned host memory) so that
   uint32_t* status_dst;         // the one-block callback path learns the plan status without another launch
   uint32_t zero_status;         // ... and cleared for the next plan that uses this buffer (no memset launch per block),

@@ -725,7 +725,14 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   if (st != WBX_OK) return cfail(e, st);
 
   // -- rows for the track-blocks the hot loop cannot stream directly, and the plan's templates
-  st = ensure_gen_capacity(c, hs.gen_rows_hint(K));
+  c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance)
+  c->chain_now = render_chains_groups(c, K);
+  c->has_window_clips = hs.any_window_clip;
+  c->has_stride_clips = hs.any_stride_clip;
+  c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
+  c->has_cut_tracks = hs.cut_tracks != 0;
+  c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
+  st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration));
   if (st != WBX_OK) return cfail(e, st);
   st = ensure_template_capacity(c, hs.template_hint(K));
   if (st != WBX_OK) return cfail(e, st);
@@ -777,6 +784,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance below)
+  c->chain_now = render_chains_groups(c, K);
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
@@ -1009,5 +1017,9 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   *n_out = n;
   if (pc[1] & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow");
   if (pc[1] & 16u) return efail(e, WBX_ERR_OVERFLOW, "plan template array full");
+  if (pc[1] & 96u) {
+    c->chain_broken = true;
+    return efail(e, WBX_ERR_DEVICE, "a chained workgroup lost its predecessor's running sum (wait gave up / another XCD): this render is invalid");
+  }
   return WBX_OK;
 }

@@ -148,6 +148,8 @@ struct HostSession {
   double window_speed = 0.0;
   bool rate_flags_sticky = false;       // the flags above still cover the row kinds of an earlier destination rate
   size_t total_clips = 0;
+  size_t short_clips = 0;               // clips shorter than one block (gen_rows_hint), valid for block length short_clips_key
+  double short_clips_key = -1.0;
   size_t cut_tracks = 0;                // tracks that hold more than one clip (clip boundaries inside blocks are the rule there)
   uint32_t next_clip_uid = 0;
   uint64_t edit_seq = 0;                // locked edits completed so far (UI thread, under the lock)
@@ -208,6 +210,7 @@ struct HostSession {
   }
 
   void recount_clips() {
+    short_clips_key = -1.0;   // (the count of clips shorter than a block is taken again by the next render)
     total_clips = 0;
     cut_tracks = 0;
     for (auto& tr : tracks) {
@@ -509,9 +512,27 @@ struct HostSession {
   // plan storage a render of K blocks may need: pre-render rows (track-blocks with a clip start / end inside them,
   // all blocks of fast-forward clips) and templates (one per block with events + one per steady run + one per run of
   // a finished clip; every block when a crawling clip is present)
-  size_t gen_rows_hint(uint32_t K) const {
+  // track-blocks of a render that can hold a clip start / end (every block for fast-forward clips)
+  size_t boundary_blocks_hint(uint32_t K) const {
     const size_t all = (size_t)K * n_tracks();
     return any_slow_clip ? all : std::min(all, 4 * total_clips + 2 * (size_t)n_tracks() + 64);
+  }
+  // pre-render rows a render may queue.  Without masked rows: every boundary block.  With them (the hot loop takes blocks
+  // of one or two stream calls itself) only a block with THREE or more calls is queued, and that takes a clip shorter than
+  // a block: two rows per such clip (it can straddle a block seam) + slack for the wrap-around quirks of track.cpp:359-361.
+  // — A session of millions of clips used to reserve a scratch row for every boundary block (4 KiB each: 35 GB per plan
+  // buffer for c3 cut into 5.3-block clips at 2048 blocks) that the masked-row path never touches.
+  size_t gen_rows_hint(uint32_t K, uint32_t masked_level = 0, double block_beats = 0.0) {
+    const size_t all = (size_t)K * n_tracks();
+    if (!masked_level || any_slow_clip || !(block_beats > 0.0)) return boundary_blocks_hint(K);
+    if (short_clips_key != block_beats) {
+      short_clips = 0;
+      for (auto& tr : tracks)
+        for (auto& c : tr->clips)
+          if (c.d.max_time - c.d.min_time < block_beats) short_clips++;
+      short_clips_key = block_beats;
+    }
+    return std::min(all, 2 * short_clips + (size_t)n_tracks() + 64);
   }
   // (a ROW_PAIR block takes two templates; every track may strand part of a reservation of `reserve` templates)
   // tracks per wave of the plan kernel: a session cut into many clips meets a clip boundary every few blocks on every
@@ -528,7 +549,7 @@ struct HostSession {
   size_t template_hint(uint32_t K) const {
     const size_t all = (size_t)K * n_tracks(), stranded = (size_t)(template_reserve(K) + 1u) * n_tracks();
     if (any_crawl_clip) return 2 * all + stranded;
-    return std::min(2 * all, 2 * gen_rows_hint(K) + 3 * (size_t)n_tracks() + 64) + stranded;
+    return std::min(2 * all, 2 * boundary_blocks_hint(K) + 3 * (size_t)n_tracks() + 64) + stranded;
   }
 
   // the transport advance of Engine::process for K blocks (engine.cpp:1578-1585, :1619-1623), the arithmetic the plan

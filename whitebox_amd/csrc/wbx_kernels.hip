@@ -348,8 +348,9 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   int cur = -1;
   if constexpr (!BUSES) {
     // no sub-buses (the reference's own topology): every group goes straight into the master, in order — nothing but
-    // the loads, PF of them in flight, and the adds
-    for (uint32_t g0 = 0; g0 < a.n_groups; g0 += PF) {
+    // the loads, PF of them in flight, and the adds.  (Chained render: the pieces before the last hold intermediate
+    // running sums; the last one holds THE sum.)
+    for (uint32_t g0 = a.chain ? a.n_groups - 1u : 0u; g0 < a.n_groups; g0 += PF) {
       f4 v[PF];
 #pragma unroll
       for (int i = 0; i < PF; i++) {
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
       if (g0 + i >= a.n_groups) break;
+      if (a.chain && (a.groups[g0 + i].flags & GROUP_CHAIN_OUT)) continue;   // an intermediate running sum of a chained list
       const int bus = a.groups[g0 + i].bus;
       if (bus != cur) {
         if (cur >= 0) {

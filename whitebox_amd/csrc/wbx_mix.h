@@ -292,6 +292,24 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       acc.c[ch] = *reinterpret_cast<const f4*>(a.init + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0);
   }
 
+  // Chained render (MixArgs::chain): this group is a piece of a longer member list and CONTINUES the running sum of the
+  // piece before it — the reference's strictly sequential order (engine.cpp:1600-1617) at the parallelism and the dynamic
+  // workgroup scheduling of the grouped order.  Workgroup (x, g) is dispatched after (x, g-1) (lower linear id, in-order
+  // dispatch), so the predecessor is running or done; its "sum is out" word is read here, early — the staging of this
+  // group's records hides the round trip — and waited for right before the first row is added.
+  // Coherence: workgroups are handed to the 8 XCDs round-robin by linear id and the grid's x extent is a multiple of 8
+  // (the host chains only then), so (x, g-1) and (x, g) sit behind the SAME L2: the running sum is written with plain
+  // stores (the vector L1 writes through), the word after they are acknowledged, and both are read past the L1 (agent-scope
+  // loads, sc1: the L1 is bypassed, the XCD's own L2 answers).  Workgroup scope would poll a stale L1 line for ever; going
+  // through memory (system scope) cost 40 % of the kernel time.  The word carries the writer's XCC id: a
+  // successor on another XCD — the one thing this rests on — is reported (status bit 6), never silently wrong.
+  const bool chain_in = a.chain != nullptr && (grp.flags & GROUP_CHAIN_IN) != 0u;
+  const bool chain_out = a.chain != nullptr && (grp.flags & GROUP_CHAIN_OUT) != 0u;
+  uint32_t* chain_word = a.chain ? a.chain + ((size_t)(blockIdx.x * a.tiles + tile) * a.n_groups + g) : nullptr;
+  const uint32_t my_xcc = a.chain ? ((uint32_t)__builtin_amdgcn_s_getreg(63508) & 0xFu) + 1u : 0u;   // HW_REG_XCC_ID + 1
+  uint32_t chain_seen = 0u;
+  if (chain_in && tid == 0u) chain_seen = __hip_atomic_load(chain_word - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
   // frame positions j0+e as doubles, once per lane (the fp64 operand of sampler.cpp:50)
   const double jd1 = j0d + 1.0, jd2 = j0d + 2.0, jd3 = j0d + 3.0;
   // The usual session has ONE resampling ratio (44.1 kHz clips in a 48 kHz session): the products fl(j * speed) of
@@ -1345,6 +1363,31 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     }
     __syncthreads();
 
+    if (chain_in && chunk_i == 0u) {
+      if (tid == 0u) {
+        uint32_t spins = 0u;
+        while (chain_seen == 0u && spins < 400000u) {   // (bounded: ~0.2 s; a give-up is reported, never a hang)
+          __builtin_amdgcn_s_sleep(8);
+          chain_seen = __hip_atomic_load(chain_word - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          spins++;
+        }
+        if (chain_seen == 0u && a.chain_status) atomicOr(a.chain_status, 32u);
+        if (chain_seen != 0u && chain_seen != my_xcc && a.chain_status) atomicOr(a.chain_status, 64u);
+      }
+      __syncthreads();
+      if (active && bvalid) {
+#pragma unroll
+        for (int ch = 0; ch < CL; ch++) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(
+              a.partial + (((size_t)b * a.n_groups + (g - 1u)) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0);
+          acc.c[ch].x = __uint_as_float(__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (sc1: past the L1)
+          acc.c[ch].y = __uint_as_float(__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          acc.c[ch].z = __uint_as_float(__hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          acc.c[ch].w = __uint_as_float(__hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+      }
+    }
+
     switch (mode) {
       case MODE_U: pipeline(std::integral_constant<int, MODE_U>{}, cn2); break;
       case MODE_W:
@@ -1419,15 +1462,22 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 
   if (a.dbg_clock && tid == 0u) {   // (diagnostic, WBX_DBG_CLOCK=1: when did this workgroup start and end — 100 MHz wall clock)
     const uint32_t wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    a.dbg_clock[2u * wg] = dbg_t0;
-    a.dbg_clock[2u * wg + 1u] = wall_clock64();
+    a.dbg_clock[4u * wg] = dbg_t0;
+    a.dbg_clock[4u * wg + 1u] = wall_clock64();
+    a.dbg_clock[4u * wg + 2u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID: cu / sh / se of this wave
+    a.dbg_clock[4u * wg + 3u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
   }
   if (active && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
       float* out = a.partial + (((size_t)b * a.n_groups + g) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;
-      *reinterpret_cast<f4*>(out) = acc.c[ch];
+      *reinterpret_cast<f4*>(out) = acc.c[ch];   // (chained: the running sum for the next piece — the L1 writes through to the XCD's L2)
     }
+  }
+  if (chain_out) {
+    __builtin_amdgcn_s_waitcnt(0);   // every store of this wave has been acknowledged ...
+    __syncthreads();                 // ... of every wave of the workgroup
+    if (tid == 0u) __hip_atomic_store(chain_word, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1437,7 +1487,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 #define WBX_MIX(U, FULL, W, FAM, SB, CW, CL, T, GRID, BLOCK)                                                   \
   {                                                                                                            \
     name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ", " #T ">";          \
-    hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, a.lds_pad, s, t0, t1, 0, a); \
+    hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, t0, t1, 0, a);      \
   }
 
 // the instances of one family (wbx_mix_fam<N>.hip); `variant`: 10 * U + W, or >= 1000 for both channels of a frame per lane

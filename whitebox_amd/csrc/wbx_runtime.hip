@@ -72,6 +72,7 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
       g.first = base + (uint32_t)i;
       g.count = (uint32_t)std::min<size_t>(G, members.size() - i);
       g.bus = bus;
+      g.flags = (i ? GROUP_CHAIN_IN : 0u) | (i + G < members.size() ? GROUP_CHAIN_OUT : 0u);   // its place in the list (chained renders)
       c->groups.push_back(g);
     }
     if (!members.empty()) {
@@ -115,6 +116,18 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 // c3 (profiles/): from about a thousand blocks per render on, whole-list walks run at the grouped order's rate.
 bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
   return c->auto_group && c->exact_min_blocks != 0u && K >= c->exact_min_blocks;
+}
+
+// ... and of those, which chain the workgroup-sized pieces instead of walking a list in one workgroup: the same order of
+// additions, but scheduled like the grouped order (many short workgroups, dispatched dynamically) — a static assignment of
+// one long walk per workgroup ends when its slowest shader engine does (profiles/r03_wg_clocks.txt: 25-40 % behind the mean).
+// WBX_CHAIN=0: walk the lists whole.
+bool render_chains_groups(const wbx_ctx* c, uint32_t K) {
+  const char* e = std::getenv("WBX_CHAIN");
+  const bool off = (e && e[0] == '0') || c->chain_broken;   // (a reported hand-over failure: whole-list walks from then on)
+  // (K a multiple of 32: every instance's grid then has an x extent that is a multiple of 8, which keeps the pieces of a
+  //  block on one XCD — what the chain's L2-level hand-over rests on; other lengths walk the lists whole)
+  return render_walks_whole_lists(c, K) && !off && c->longest_list > c->cfg.group_size && (K % 32u) == 0u;
 }
 
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks) {
@@ -254,7 +267,7 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
   if (!(F == 512u || F == 1024u || F == 256u)) return false;
   // a render whose workgroups walk whole member lists of many staged chunks: the half-size workgroups of these instances
   // put six of them on a CU, and the walk runs 15 % faster than through the four-wave ones (c3, 1024 blocks: 2.94 vs 3.43 ms)
-  if (c->whole_lists_now && c->longest_list > 2u * kStage) return true;
+  if (c->whole_lists_now && !c->chain_now && c->longest_list > 2u * kStage) return true;
   return c->has_integer_clips || c->has_cut_tracks;
 }
 
@@ -295,7 +308,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.pool = PB(c).pool.p;
   m.order = c->d_order.p;
   // the group set of this render: workgroup-sized pieces, or the whole member lists (the reference's summation order)
-  const bool whole = c->whole_lists_now;
+  const bool chained = c->whole_lists_now && render_chains_groups(c, K);
+  const bool whole = c->whole_lists_now && !chained;
   const DGroup* d_groups = c->d_groups.p + (whole ? c->groups.size() : 0);
   const uint32_t n_groups = (uint32_t)(whole ? c->groups_exact.size() : c->groups.size());
   const bool buses_alias = whole ? c->buses_alias_exact : c->buses_alias_partials;
@@ -335,13 +349,21 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
-  m.lds_pad = std::getenv("WBX_LDS_PAD") ? (uint32_t)std::atoi(std::getenv("WBX_LDS_PAD")) : 0u;   // (experiment)
+  m.chain = nullptr;
+  m.chain_status = nullptr;
+  if (chained) {   // one "sum is out" word per (workgroup column, group), cleared in front of the mix
+    const size_t words = (size_t)K * m.tiles * n_groups;
+    WBX_HIP(c, c->d_chain.ensure(words));
+    WBX_HIP(c, hipMemsetAsync(c->d_chain.p, 0, words * sizeof(uint32_t), ms));
+    m.chain = c->d_chain.p;
+    m.chain_status = PB(c).counters + 1;
+  }
   {
     static const bool dbg = std::getenv("WBX_DBG_CLOCK") != nullptr;   // diagnostic: per-workgroup start / end times of the mix
     m.dbg_clock = nullptr;
     if (dbg) {
       c->dbg_wgs = (size_t)K * n_groups * m.tiles;
-      WBX_HIP(c, c->d_dbg.ensure(2 * c->dbg_wgs));
+      WBX_HIP(c, c->d_dbg.ensure(4 * c->dbg_wgs));
       m.dbg_clock = c->d_dbg.p;
     }
   }
@@ -390,6 +412,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.block_frames = F;
   s.channels = C;
   s.clamp = c->clamp ? 1u : 0u;
+  s.chain = chained ? 1u : 0u;
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
   s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
@@ -458,7 +481,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!cfg || !out) return WBX_ERR_INVALID;
   *out = nullptr;
   if (cfg->channels < 1 || cfg->channels > 2 || cfg->block_frames < 4 || (cfg->block_frames & 3u) ||
-      cfg->block_frames > 32768 || cfg->max_tracks == 0 || cfg->max_blocks == 0 || cfg->max_blocks > 2048 ||
+      cfg->block_frames > 32768 || cfg->max_tracks == 0 || cfg->max_blocks == 0 || cfg->max_blocks > 4096 ||
       cfg->sample_rate == 0)
     return WBX_ERR_INVALID;
   int n = 0;
@@ -597,6 +620,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   for (auto& P : c->d_peaks) P.release();
   c->d_gains.release();
   c->d_conv.release();
+  c->d_chain.release();
   c->d_dbg.release();
   c->d_zero.release();
   for (int i = 0; i < kEventRing; i++) {
@@ -1015,13 +1039,15 @@ extern "C" wbx_status wbx_set_routing(wbx_ctx* c, uint32_t n_tracks, const int32
 extern "C" wbx_status wbx_render_order(wbx_ctx* c, uint32_t n_blocks, uint32_t* n_groups, uint32_t* longest_group,
                                        int* reference_order) {
   if (!c || n_blocks == 0) return WBX_ERR_INVALID;
-  const bool whole = render_walks_whole_lists(c, n_blocks);
+  const bool chained = render_chains_groups(c, n_blocks);
+  const bool whole = render_walks_whole_lists(c, n_blocks) && !chained;
   const std::vector<DGroup>& gs = whole ? c->groups_exact : c->groups;
   uint32_t longest = 0;
   for (auto& g : gs) longest = std::max(longest, g.count);
   if (n_groups) *n_groups = (uint32_t)gs.size();
   if (longest_group) *longest_group = longest;
-  if (reference_order) *reference_order = (whole || gs.size() == c->groups_exact.size()) ? 1 : 0;
+  // (chained: the pieces are workgroup-sized, the additions are one sequence per member list all the same)
+  if (reference_order) *reference_order = (whole || chained || gs.size() == c->groups_exact.size()) ? 1 : 0;
   return WBX_OK;
 }
 
@@ -1045,7 +1071,7 @@ extern "C" wbx_status wbx_debug_wg_clocks(wbx_ctx* c, unsigned long long* out, s
   *n_wgs = c->dbg_wgs;
   if (!out || !c->d_dbg.p) return WBX_OK;
   WBX_HIP(c, sync_main(c));
-  WBX_HIP(c, hipMemcpy(out, c->d_dbg.p, std::min(cap, 2 * c->dbg_wgs) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  WBX_HIP(c, hipMemcpy(out, c->d_dbg.p, std::min(cap, 4 * c->dbg_wgs) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return WBX_OK;
 }
 
@@ -1187,6 +1213,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   c->whole_lists_now = render_walks_whole_lists(c, K);
+  c->chain_now = render_chains_groups(c, K);
   (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
   c->masked_rows = 0u;   // host-sequenced plans send every partial row through the pre-render pass
   c->uniform_speed = 0.0;   // ... and make no promise about their playback speeds
@@ -1223,6 +1250,16 @@ wbx_status wbx::plan_status_to_error(wbx_ctx* c, uint32_t bits) {
   if (bits & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
   if (bits & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
   if (bits & 16u) return fail(c, WBX_ERR_OVERFLOW, "plan template array full");
+  if (bits & 96u) {
+    // the chained hand-over rests on in-order workgroup dispatch and on a block's pieces sharing an XCD; a render that saw
+    // either fail says so — its results are invalid — and the context walks whole lists from here on (same order of
+    // additions, no hand-over between workgroups)
+    c->chain_broken = true;
+    return fail(c, WBX_ERR_DEVICE, (bits & 32u) ? "a chained workgroup gave up waiting for its predecessor's running sum: this render is invalid, "
+                                                    "later renders walk whole lists"
+                                                  : "a chained workgroup ran on another XCD than its predecessor: this render is invalid, later "
+                                                    "renders walk whole lists");
+  }
   return WBX_OK;
 }
 
