@@ -28,7 +28,7 @@ timeout 300 python bench.py --clip-blocks 5.3 --blocks 256 $B > $O/bench_c3_L5.3
 for M in reduce ordered chain; do
   timeout 300 python bench.py --force-dist-path --dist-mode $M $B > $O/bench_dist1_$M.json 2>> $O/bench_default.err
 done
-timeout 300 python tools/longrun_probe.py > $O/longrun_probe.txt 2>&1
+timeout 300 python tools/longrun_probe.py c3 2048 4 > $O/longrun_probe.txt 2>&1
 cd /tmp
 kt() {   # name, bench args...
   n=$1; shift

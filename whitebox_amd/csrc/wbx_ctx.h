@@ -124,6 +124,7 @@ struct wbx_ctx {
   uint32_t longest_list = 0;          // tracks in the longest member list
   mutable bool chain_broken = false;  // a chained render reported a failed hand-over (plan_status_to_error)
   bool chain_now = false;             // ... as chained workgroup-sized pieces (render_chains_groups)
+  uint32_t chain_epoch = 0;
   DevBuf<uint32_t> d_chain;           // chained renders: the "running sum is out" words
   uint32_t exact_min_blocks = 1024;   // renders of at least this many blocks do, when the library picks the grouping
                                       // (WBX_EXACT_MIN_BLOCKS; 0 = never)
@@ -139,6 +140,7 @@ struct wbx_ctx {
     uint32_t tmpl_cap = 0;
     DevBuf<DSeg> pool;
     uint32_t pool_chunks = 0;
+    DevBuf<DBlockTime> times;         // [K] per-block transport records of a batch render (PlanArgs::times)
     uint32_t* counters = nullptr;     // [0] pool chunks allocated, [1] status bits, [2] generic records queued,
                                       // [3] templates allocated
     bool counters_zero = true;        // cleared already (at creation, or by the sum kernel of a callback block)
@@ -193,6 +195,8 @@ struct wbx_ctx {
   bool last_master_on_host = false;   // the engine's pinned staging block, which is host memory)
   bool clamp = true;
   float* master_target = nullptr;     // caller-owned device buffer, or null: d_master
+  bool master_target_on_host = false; // ... it is pinned host memory: batch renders stage the master in d_stage and copy it out
+  DevBuf<float> d_stage[kRing];       // (see launch_mix_sum: a sum that stores 8 MB over PCIe itself holds up the next mix)
   int master_format = 0;              // wbx_set_master_format: 0 planar fp32, else WBX_OUT_* interleaved (sum kernel epilogue)
   int last_master_format = 0;         // ... of the last render
   const float* master_init = nullptr; // wbx_set_master_init: the running sum the first group starts from, or null: zero

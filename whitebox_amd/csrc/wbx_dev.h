@@ -171,6 +171,8 @@ struct PlanArgs {
   uint32_t n_tracks, n_blocks, block_frames, channels;
   double sample_rate;
   double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
+  DBlockTime* times;            // batch renders: the K per-block transport records in device memory (times_kernel fills them in
+                                // front of the plan); null: every workgroup computes them into its LDS (short renders: one launch less)
   uint32_t playing;
   uint32_t clips_changed;       // the clip lists were edited since the previous plan: re-read the current clip's gain
   uint32_t masked_rows;         // the mix instance of this render takes partial-coverage rows (one segment, or a
@@ -207,15 +209,18 @@ struct MixArgs {
   uint32_t tiles;               // ceil(C*F/4 / 256)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
   uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
-  uint32_t* chain;              // chained render: [workgroup columns][n_groups] "this piece's running sum is out" words, zeroed
-                                // before the launch; null: every group starts from zero (or MixArgs::init) and the sum
-                                // kernel adds the group sums
+  uint32_t* chain;              // chained render: [workgroup columns][n_groups] "this piece's running sum is out" words
+                                // ((chain_epoch << 4) | XCC id + 1 once out: never cleared between renders); null: every
+                                // group starts from zero (or MixArgs::init) and the sum kernel adds the group sums
+  uint32_t chain_epoch;         // this render's tag, 1 .. 2^28-1 (words are zeroed on allocation and when the tag wraps)
   uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
                                 // device's in-order workgroup dispatch is not what it is documented to be)
   unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][4] start / end wall-clock ticks, HW_ID, XCC_ID, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
 };
+
+constexpr uint32_t kSumGridBlocks = 512;   // blocks in flight of one sum launch (x its tiles = waves)
 
 struct SumArgs {
   const float* partial;         // [K][NG][C][F]
@@ -225,6 +230,7 @@ struct SumArgs {
   uint32_t out_format;          // master is unused; WBX_OUT_* (3 i16, 5 packed i24, 6 i24 in 32, 7 i32, 9 f32)
   float* buses;                 // [K][NB][C][F] or null
   uint32_t n_groups, n_buses, block_frames, channels;
+  uint32_t n_blocks;            // K (filled in by launch_sum; the grid's x covers min(K, kSumGridBlocks) and walks the rest)
   uint32_t clamp;
   uint32_t chain;               // chained render: groups flagged GROUP_CHAIN_OUT hold intermediate running sums — skip them
   uint32_t* status_src;         // optional: the plan's 4 counters, copied to status_dst (pinned host memory) so that

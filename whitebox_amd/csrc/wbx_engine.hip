@@ -797,6 +797,15 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.playhead = hs.playhead;
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;
+  a.times = nullptr;
+  if (plan_beside && !c->has_cut_tracks) {
+    // Batch render of a session whose tracks are single clips (a steady run per track, a handful of look-ups): the transport
+    // records live in device memory and the sequencer takes the register-capped instance — nothing in LDS, a wave no larger
+    // than a mix wave, so it runs BESIDE the previous mix instead of in the drain at its end.  Sessions cut into clips
+    // search the records all the time: theirs stay in LDS (device-memory latency tripled their plan) with the roomy instance.
+    WBX_EHIP(e, B.times.ensure(K));
+    a.times = B.times.p;
+  }
   launch_plan(a, ps);
   if (!e->in_process) {
     if (patch_slot >= 0) {

@@ -17,6 +17,8 @@
 // HBM-bound integer/fp32 streaming: no MFMA (≈3 flop per 4 B).  Parity-critical arithmetic uses the
 // explicitly rounded intrinsics (__fmul_rn, __dadd_rn, ...) and the file is built with
 // -ffp-contract=off so that nothing is fused: the reference build has no FMA.
+#include <cstdlib>
+
 #include "wbx_mix.h"
 #include "wbx_seq.h"
 
@@ -25,17 +27,34 @@ namespace wbx {
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) {
+__device__ __forceinline__ void plan_body(const PlanArgs& a) {
   // The K per-block transport records are the same for every track: one lane computes them into LDS with
   // exactly the arithmetic of Engine::process (engine.cpp:1578-1585 per block, :1619-1623 between blocks).
+  // Batch renders read them from device memory instead (PlanArgs::times, written once by times_kernel): K records in the LDS of
+  // every workgroup — 64 KiB for 2048 blocks — keep the sequencer's workgroups off any CU that holds four mix workgroups.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  DBlockTime* s_times = reinterpret_cast<DBlockTime*>(s_raw);
-  if (threadIdx.x == 0) block_times(a, s_times);
-  __syncthreads();
+  const DBlockTime* s_times = a.times;
+  if (!s_times) {
+    if (threadIdx.x == 0) block_times(a, reinterpret_cast<DBlockTime*>(s_raw));
+    __syncthreads();
+    s_times = reinterpret_cast<const DBlockTime*>(s_raw);
+  }
   if (threadIdx.x >= a.lanes) return;
   const uint32_t t = blockIdx.x * a.lanes + threadIdx.x;
   if (t >= a.n_tracks) return;
   plan_track(a, t, s_times);   // wbx_seq.h: the same source runs on the host in the CPU-side tests
+}
+
+__global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) { plan_body(a); }
+
+// The sequencer of a batch render runs BESIDE the previous render's mix.  At most 128 VGPRs (four waves per SIMD): a wave
+// then fits the hole ONE retiring mix wave leaves.  With the 243 the unbounded instance takes it needs two holes on one
+// SIMD at once, which a running mix never offers — the high-priority plan sat out the whole mix, ran in the drain at its
+// end, and the next mix waited for it.  The spills (scratch) make it slower alone; beside a mix it is hidden.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void plan_kernel_beside(PlanArgs a) { plan_body(a); }
+
+__global__ __launch_bounds__(64) void times_kernel(PlanArgs a) {
+  if (threadIdx.x == 0) block_times(a, a.times);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,11 +353,14 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
     a.status_dst[threadIdx.x] = a.status_src[threadIdx.x];
     if (a.zero_status && queued == 0u) a.status_src[threadIdx.x] = 0u;
   }
-  const uint32_t b = blockIdx.x;
   const uint32_t F = a.block_frames, C = a.channels;
   const uint32_t slot = blockIdx.y * 64u + threadIdx.x;
   if (slot >= ((IL ? F : C * F) >> 2)) return;
   const size_t stride = (size_t)C * F;
+  // a wave walks blocks blockIdx.x, + gridDim.x, ...: the launch stays a few waves per CU however long the render is, so the
+  // NEXT render's mix (other stream) finds free wave slots at once — a sum that fills every slot of the chip with waves
+  // waiting on their PCIe stores holds that mix back for its whole duration
+  for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
 
   // the master of elements e0 .. e0+3 of the block ([C][F] order): groups in order, buses in order, clamp
   auto sum_at = [&](size_t e0) {
@@ -441,7 +463,7 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
       o[0] = ((uint32_t)q0 & 0xFFFFFFu) | ((uint32_t)q1 << 24);
       o[1] = (((uint32_t)q1 >> 8) & 0xFFFFu) | ((uint32_t)q2 << 16);
       o[2] = (((uint32_t)q2 >> 16) & 0xFFu) | ((uint32_t)q3 << 8);
-      return;
+      continue;
     }
     auto conv = [&](float v) -> uint32_t {
       return fmt == 3u ? (uint32_t)(uint16_t)(int16_t)to_i16(v) : fmt == 6u ? (uint32_t)(to_i24(v) & 0xFFFFFF)
@@ -471,6 +493,7 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
       }
     }
   }
+  }   // blocks of this wave
 }
 
 // buses with no member groups stay zero: cleared before the launch by the runtime.
@@ -605,7 +628,12 @@ __global__ __launch_bounds__(256) void synth_kernel(void* dst, uint64_t frames, 
 // ------------------------------------------------------------------------------------------------
 void launch_plan(const PlanArgs& a, hipStream_t s) {
   const uint32_t nb = (a.n_tracks + a.lanes - 1u) / a.lanes;
-  hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.n_blocks * sizeof(DBlockTime), s, a);
+  if (a.times) hipLaunchKernelGGL(times_kernel, dim3(1), dim3(64), 0, s, a);
+  static const bool roomy = [] { const char* v = std::getenv("WBX_PLAN_BESIDE"); return v && v[0] == '0'; }();   // A/B aid
+  if (a.times && !roomy)
+    hipLaunchKernelGGL(plan_kernel_beside, dim3(nb), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.times ? 0 : a.n_blocks * sizeof(DBlockTime), s, a);
 }
 
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
@@ -631,22 +659,26 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   return launch_mix_fam0(a, n_blocks, variant, s, t0, t1);
 }
 
-void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s) {
+void launch_sum(const SumArgs& a0, uint32_t n_blocks, hipStream_t s) {
+  SumArgs a = a0;
+  a.n_blocks = n_blocks;
+  // at most ~2048 waves (8 per CU) whatever the render length: see the kernel's block loop
+  const uint32_t gx = n_blocks < kSumGridBlocks ? n_blocks : kSumGridBlocks;
   if (a.out_il) {   // interleaved device-format output: a lane owns 4 frames of every channel
     const uint32_t tiles = ((a.block_frames >> 2) + 63u) / 64u;
     if (a.n_buses != 0u)
-      hipLaunchKernelGGL((sum_kernel<16, true, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+      hipLaunchKernelGGL((sum_kernel<16, true, true>), dim3(gx, tiles), dim3(64), 0, s, a);
     else
-      hipLaunchKernelGGL((sum_kernel<16, false, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+      hipLaunchKernelGGL((sum_kernel<16, false, true>), dim3(gx, tiles), dim3(64), 0, s, a);
     return;
   }
   const uint32_t tiles = (((a.channels * a.block_frames) >> 2) + 63u) / 64u;
   if (a.n_buses != 0u)
-    hipLaunchKernelGGL((sum_kernel<16, true>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((sum_kernel<16, true>), dim3(gx, tiles), dim3(64), 0, s, a);
   else if (n_blocks < 8u && a.n_groups > 16u)
-    hipLaunchKernelGGL((sum_kernel<32, false>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((sum_kernel<32, false>), dim3(gx, tiles), dim3(64), 0, s, a);
   else
-    hipLaunchKernelGGL((sum_kernel<16, false>), dim3(n_blocks, tiles), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((sum_kernel<16, false>), dim3(gx, tiles), dim3(64), 0, s, a);
 }
 
 void launch_clamp(float* buf, size_t n, hipStream_t s) {

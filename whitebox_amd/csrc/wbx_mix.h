@@ -307,6 +307,9 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   const bool chain_out = a.chain != nullptr && (grp.flags & GROUP_CHAIN_OUT) != 0u;
   uint32_t* chain_word = a.chain ? a.chain + ((size_t)(blockIdx.x * a.tiles + tile) * a.n_groups + g) : nullptr;
   const uint32_t my_xcc = a.chain ? ((uint32_t)__builtin_amdgcn_s_getreg(63508) & 0xFu) + 1u : 0u;   // HW_REG_XCC_ID + 1
+  // a word reads (epoch << 4) | XCC id + 1 once its piece is out; the epoch is the render's, so the words are never cleared
+  // between renders (a memset in front of every mix sat behind the previous render's sum and cost its whole duration)
+  const uint32_t chain_tag = a.chain_epoch << 4;
   uint32_t chain_seen = 0u;
   if (chain_in && tid == 0u) chain_seen = __hip_atomic_load(chain_word - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -1366,13 +1369,14 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     if (chain_in && chunk_i == 0u) {
       if (tid == 0u) {
         uint32_t spins = 0u;
-        while (chain_seen == 0u && spins < 400000u) {   // (bounded: ~0.2 s; a give-up is reported, never a hang)
+        while ((chain_seen & ~0xFu) != chain_tag && spins < 400000u) {   // (bounded: ~0.2 s; a give-up is reported, never a hang)
           __builtin_amdgcn_s_sleep(8);
           chain_seen = __hip_atomic_load(chain_word - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           spins++;
         }
-        if (chain_seen == 0u && a.chain_status) atomicOr(a.chain_status, 32u);
-        if (chain_seen != 0u && chain_seen != my_xcc && a.chain_status) atomicOr(a.chain_status, 64u);
+        const bool chain_ok = (chain_seen & ~0xFu) == chain_tag;
+        if (!chain_ok && a.chain_status) atomicOr(a.chain_status, 32u);
+        if (chain_ok && (chain_seen & 0xFu) != my_xcc && a.chain_status) atomicOr(a.chain_status, 64u);
       }
       __syncthreads();
       if (active && bvalid) {
@@ -1477,7 +1481,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   if (chain_out) {
     __builtin_amdgcn_s_waitcnt(0);   // every store of this wave has been acknowledged ...
     __syncthreads();                 // ... of every wave of the workgroup
-    if (tid == 0u) __hip_atomic_store(chain_word, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0u) __hip_atomic_store(chain_word, chain_tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -351,10 +351,16 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.masked_rows = c->masked_rows ? 1u : 0u;
   m.chain = nullptr;
   m.chain_status = nullptr;
-  if (chained) {   // one "sum is out" word per (workgroup column, group), cleared in front of the mix
-    const size_t words = (size_t)K * m.tiles * n_groups;
+  if (chained) {   // one "sum is out" word per (workgroup column, group), tagged with this render's epoch: no clearing
+    const size_t words = (size_t)K * m.tiles * n_groups;   // between renders (a memset here waits out the previous sum)
+    const size_t had = c->d_chain.cap;
     WBX_HIP(c, c->d_chain.ensure(words));
-    WBX_HIP(c, hipMemsetAsync(c->d_chain.p, 0, words * sizeof(uint32_t), ms));
+    c->chain_epoch = (c->chain_epoch + 1u) & 0x0FFFFFFFu;
+    if (c->d_chain.cap != had || c->chain_epoch == 0u) {   // fresh storage, or the tag wrapped: start over from zeroed words
+      WBX_HIP(c, hipMemsetAsync(c->d_chain.p, 0, c->d_chain.cap * sizeof(uint32_t), ms));
+      if (c->chain_epoch == 0u) c->chain_epoch = 1u;
+    }
+    m.chain_epoch = c->chain_epoch;
     m.chain = c->d_chain.p;
     m.chain_status = PB(c).counters + 1;
   }
@@ -393,6 +399,25 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
   WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));
   if (ms != c->stream) c->alt_pending = pp;
+  // A master bound for pinned host memory leaves a batch render through a device staging buffer and the copy engine.  Stored
+  // by the sum kernel itself, its megabytes of posted writes fill the GPU's upstream queue in a few microseconds and drain at
+  // the PCIe rate; the command processor's own reads of host memory (the next dispatch packet, its signals) wait behind
+  // them, and the next mix started only when the sum had ended — 0.15 ms per 2048-block render.  (One-block callbacks keep
+  // the direct stores: 4 KB, and no second operation in the latency path.  Packed 24-bit too: its writer leaves part of
+  // the target untouched, which a whole-buffer copy would not.)
+  float* const master_home = master_dst;
+  size_t stage_bytes = 0;
+  if (sum_beside && !c->dist && c->master_target && c->master_target_on_host && c->master_format != 5) {
+    static const bool direct = [] { const char* v = std::getenv("WBX_HOST_MASTER_DIRECT"); return v && v[0] == '1'; }();   // A/B aid
+    // (from 4 MB: below, the copy's fixed cost on the sum stream outweighs the hold-up — a 256-track session rendering 256
+    //  blocks at a time lost a quarter of its rate to it, and gains a quarter at 2048)
+    const size_t bytes = (size_t)K * F * C * (c->master_format == 3 ? 2u : 4u);
+    if (!direct && bytes >= (4u << 20)) {
+      stage_bytes = bytes;
+      WBX_HIP(c, c->d_stage[pp].ensure((stage_bytes + 3u) / 4u));
+      master_dst = c->d_stage[pp].p;
+    }
+  }
   SumArgs s{};
   s.partial = c->d_partial2[pp].p;
   s.groups = d_groups;
@@ -403,7 +428,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     s.out_format = (uint32_t)c->master_format;
   }
   c->last_master_format = c->master_format;
-  c->last_master = s.master;
+  c->last_master = master_home;
   c->last_master_on_host = false;
   s.buses = (c->n_buses && !buses_alias) ? c->d_buses.p : nullptr;
   c->last_buses = c->n_buses ? (buses_alias ? c->d_partial2[pp].p : c->d_buses.p) : nullptr;
@@ -425,6 +450,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   if (ss == c->stream && ms != c->stream) c->alt_pending = -1;            // (the main stream has just joined that mix)
   launch_sum(s, K, ss);
+  if (stage_bytes) WBX_HIP(c, hipMemcpyAsync(master_home, master_dst, stage_bytes, hipMemcpyDeviceToHost, ss));
   if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
     c->ev_pending++;
@@ -597,6 +623,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
     B.prows.release();
     B.tmpl.release();
     B.pool.release();
+    B.times.release();
     B.gen_list.release();
     B.rows.release();
     B.saved.release();
@@ -616,6 +643,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   }
   for (auto& P : c->d_partial2) P.release();
   c->d_master.release();
+  for (auto& st : c->d_stage) st.release();
   c->d_buses.release();
   for (auto& P : c->d_peaks) P.release();
   c->d_gains.release();
@@ -1109,6 +1137,12 @@ extern "C" wbx_status wbx_set_master_init(wbx_ctx* c, const void* device_buffer)
 extern "C" wbx_status wbx_set_master_target(wbx_ctx* c, void* device_buffer) {
   if (!c) return WBX_ERR_INVALID;
   c->master_target = (float*)device_buffer;
+  c->master_target_on_host = false;
+  if (device_buffer) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, device_buffer) == hipSuccess) c->master_target_on_host = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+  }
   return WBX_OK;
 }
 

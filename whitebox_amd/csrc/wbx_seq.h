@@ -704,14 +704,18 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
 // :1619-1623 between blocks).
 __host__ __device__ inline void block_times(const PlanArgs& a, DBlockTime* times) {
   double playhead = a.playhead, sample_position = a.sample_position;
+  // the reference evaluates these three per block from the same operands: same bits every time, so once (a division per
+  // block made this loop — one lane, K dependent steps — the longest part of a batch render's plan)
+  const double buffer_duration = (double)a.block_frames / a.sample_rate;                                   // :1578
+  const double buffer_duration_in_beats = buffer_duration / a.beat_duration;                              // :1581
+  const double block_samples = beat_to_samples(buffer_duration_in_beats, a.sample_rate, a.beat_duration);   // :1620
+  const bool playing = a.playing != 0u;
   for (uint32_t i = 0; i < a.n_blocks; i++) {
-    const double buffer_duration = (double)a.block_frames / a.sample_rate;            // :1578
-    const double buffer_duration_in_beats = buffer_duration / a.beat_duration;       // :1581
     const double next_playhead_pos = playhead + buffer_duration_in_beats;            // :1582
     times[i] = DBlockTime{playhead, next_playhead_pos, sample_position, a.beat_duration};
-    if (a.playing) {
-      sample_position += beat_to_samples(buffer_duration_in_beats, a.sample_rate, a.beat_duration);   // :1620
-      playhead = next_playhead_pos;                                                                   // :1621
+    if (playing) {
+      sample_position += block_samples;                                              // :1620
+      playhead = next_playhead_pos;                                                  // :1621
     }
   }
 }
