@@ -171,8 +171,8 @@ struct PlanArgs {
   uint32_t n_tracks, n_blocks, block_frames, channels;
   double sample_rate;
   double playhead, sample_position, beat_duration;   // transport at the first block (engine.h:44-46)
-  DBlockTime* times;            // batch renders: the K per-block transport records in device memory (times_kernel fills them in
-                                // front of the plan); null: every workgroup computes them into its LDS (short renders: one launch less)
+  DBlockTime* times;            // batch renders: the K per-block transport records in device memory (the host computes them,
+                                // a copy in front of the plan); null: every workgroup computes them into its LDS (short renders: one launch less)
   uint32_t playing;
   uint32_t clips_changed;       // the clip lists were edited since the previous plan: re-read the current clip's gain
   uint32_t masked_rows;         // the mix instance of this render takes partial-coverage rows (one segment, or a

@@ -29,6 +29,15 @@ struct wbx_engine {
   bool gains_valid[kRing] = {};
   int gains_slot = -1;                  // the buffer plans currently read
   std::vector<float> gains_tmp;
+  // the per-block transport records of a batch render (PlanArgs::times): K dependent additions, done here on the host — it
+  // repeats that arithmetic anyway to keep its own transport — and copied in front of the plan by a kernel reading this pinned table; one lane of the GPU beside a
+  // running mix took 0.15-0.2 ms for 2048 blocks
+  static constexpr int kTimesRing = 8;
+  DBlockTime* h_times[kTimesRing] = {};
+  uint32_t times_cap[kTimesRing] = {};
+  hipEvent_t times_done[kTimesRing] = {};
+  bool times_valid[kTimesRing] = {};
+  uint32_t times_seq = 0;
   // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
   // and the plan status lands in — the callback path then needs no copy-engine transfer at all
   float* h_block = nullptr;             // [C][F]
@@ -135,6 +144,10 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
     if (e->patch_done[i]) (void)hipEventDestroy(e->patch_done[i]);
     if (e->h_gains[i]) (void)hipHostFree(e->h_gains[i]);
     if (e->gains_done[i]) (void)hipEventDestroy(e->gains_done[i]);
+  }
+  for (int i = 0; i < wbx_engine::kTimesRing; i++) {
+    if (e->h_times[i]) (void)hipHostFree(e->h_times[i]);
+    if (e->times_done[i]) (void)hipEventDestroy(e->times_done[i]);
   }
   if (e->h_block) (void)hipHostFree(e->h_block);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -805,6 +818,20 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     // search the records all the time: theirs stay in LDS (device-memory latency tripled their plan) with the roomy instance.
     WBX_EHIP(e, B.times.ensure(K));
     a.times = B.times.p;
+    const int ts = (int)(e->times_seq++ % wbx_engine::kTimesRing);
+    if (e->times_valid[ts]) WBX_EHIP(e, hipEventSynchronize(e->times_done[ts]));   // its copy of 8 renders ago (long over)
+    if (e->times_cap[ts] < K) {
+      if (e->h_times[ts]) (void)hipHostFree(e->h_times[ts]);
+      e->h_times[ts] = nullptr;
+      e->times_cap[ts] = 0;
+      WBX_EHIP(e, hipHostMalloc((void**)&e->h_times[ts], (size_t)K * sizeof(DBlockTime), hipHostMallocDefault));
+      e->times_cap[ts] = K;
+    }
+    if (!e->times_done[ts]) WBX_EHIP(e, hipEventCreateWithFlags(&e->times_done[ts], hipEventDisableTiming));
+    block_times(a, e->h_times[ts]);   // wbx_seq.h: the source the device compiles
+    launch_times_copy(e->h_times[ts], B.times.p, K, ps);
+    WBX_EHIP(e, hipEventRecord(e->times_done[ts], ps));
+    e->times_valid[ts] = true;
   }
   launch_plan(a, ps);
   if (!e->in_process) {

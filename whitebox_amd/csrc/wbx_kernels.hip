@@ -30,7 +30,7 @@ namespace wbx {
 __device__ __forceinline__ void plan_body(const PlanArgs& a) {
   // The K per-block transport records are the same for every track: one lane computes them into LDS with
   // exactly the arithmetic of Engine::process (engine.cpp:1578-1585 per block, :1619-1623 between blocks).
-  // Batch renders read them from device memory instead (PlanArgs::times, written once by times_kernel): K records in the LDS of
+  // Batch renders read them from device memory instead (PlanArgs::times, computed by the host and copied in): K records in the LDS of
   // every workgroup — 64 KiB for 2048 blocks — keep the sequencer's workgroups off any CU that holds four mix workgroups.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const DBlockTime* s_times = a.times;
@@ -53,8 +53,12 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) { plan_body(a); }
 // end, and the next mix waited for it.  The spills (scratch) make it slower alone; beside a mix it is hidden.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void plan_kernel_beside(PlanArgs a) { plan_body(a); }
 
-__global__ __launch_bounds__(64) void times_kernel(PlanArgs a) {
-  if (threadIdx.x == 0) block_times(a, a.times);
+// the host's table of per-block transport records (pinned memory) -> device memory, in front of a batch render's plan.  A
+// kernel of our own, not hipMemcpyAsync: the runtime's host-to-device path made the submitting thread wait for the stream
+// (measured: the renders of a 256-track session then ran one after the other instead of overlapped)
+__global__ __launch_bounds__(256) void times_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,9 +630,14 @@ __global__ __launch_bounds__(256) void synth_kernel(void* dst, uint64_t frames, 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from wbx_runtime.hip)
 // ------------------------------------------------------------------------------------------------
+void launch_times_copy(const DBlockTime* host_pinned, DBlockTime* dev, uint32_t n_blocks, hipStream_t s) {
+  const uint32_t n16 = n_blocks * (uint32_t)(sizeof(DBlockTime) / 16u);
+  hipLaunchKernelGGL(times_copy_kernel, dim3((n16 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const uint4*>(host_pinned),
+                     reinterpret_cast<uint4*>(dev), n16);
+}
+
 void launch_plan(const PlanArgs& a, hipStream_t s) {
   const uint32_t nb = (a.n_tracks + a.lanes - 1u) / a.lanes;
-  if (a.times) hipLaunchKernelGGL(times_kernel, dim3(1), dim3(64), 0, s, a);
   static const bool roomy = [] { const char* v = std::getenv("WBX_PLAN_BESIDE"); return v && v[0] == '0'; }();   // A/B aid
   if (a.times && !roomy)
     hipLaunchKernelGGL(plan_kernel_beside, dim3(nb), dim3(64), 0, s, a);
