@@ -742,6 +742,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->chain_now = render_chains_groups(c, K);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
+  c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->has_cut_tracks = hs.cut_tracks != 0;
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
@@ -801,6 +802,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
+  c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->has_cut_tracks = hs.cut_tracks != 0;
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
@@ -857,6 +859,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->levels_target = reinterpret_cast<uint32_t*>(e->d_levels.p);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
+  c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->uniform_speed = hs.uniform_window_speed();
   const int mix_parity = (int)(c->render_seq % kRing);

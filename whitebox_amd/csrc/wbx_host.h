@@ -139,7 +139,8 @@ struct HostSession {
   bool clips_edited = false;            // a clip list changed since the previous plan (PlanArgs::clips_changed)
   bool any_slow_clip = false;           // a clip the mix kernel cannot stream directly (playback speed > 4096)
   bool any_window_clip = false;         // a clip that is linearly resampled (playback speed != 1)
-  bool any_stride_clip = false;         // per-frame taps: fp32 played faster than recorded, resampled integer PCM
+  bool any_stride_clip = false;         // needs the everything family: fp32 played faster than recorded, resampled integer PCM
+  bool any_taps_clip = false;           // ... of those, the ones the hot loop reads with per-frame taps (KIND_STRIDE: speed > 0.999)
   bool any_win16_clip = false;          // 16-bit PCM resampled at a speed up to 0.999 (the 5-sample-window path)
   bool any_other_window_clip = false;   // any other clip at a speed != 1
   bool any_crawl_clip = false;          // (count - offset) / speed may exceed 2^32: every block owns a plan template
@@ -236,12 +237,13 @@ struct HostSession {
         window_speed = ps;
     }
     if ((ps > 0.999 || smp.format != FMT_F32) && ps != 1.0) any_stride_clip = true;
+    if (ps > 0.999 && ps != 1.0) any_taps_clip = true;
     // BlockWalker::stream / plan_steady_run leave the shared-template path when (count - offset) >= speed * 2^32
     if (!(ps * 4294967040.0 > (double)smp.count)) any_crawl_clip = true;
   }
 
   void rederive_clip_flags() {
-    any_slow_clip = any_window_clip = any_stride_clip = any_crawl_clip = false;
+    any_slow_clip = any_window_clip = any_stride_clip = any_crawl_clip = any_taps_clip = false;
     any_win16_clip = any_other_window_clip = false;
     window_speed = 0.0;
     for (auto& t : tracks)
@@ -255,7 +257,7 @@ struct HostSession {
   // the old flags stay OR-ed in and no single resampling ratio is assumed, until a stop re-triggers every track.
   void set_dst_rate_locked(uint32_t rate) {
     const bool changed = rate != dst_rate;
-    const bool o_slow = any_slow_clip, o_win = any_window_clip, o_stride = any_stride_clip, o_crawl = any_crawl_clip;
+    const bool o_slow = any_slow_clip, o_win = any_window_clip, o_stride = any_stride_clip, o_crawl = any_crawl_clip, o_taps = any_taps_clip;
     const bool o_w16 = any_win16_clip, o_other = any_other_window_clip;
     dst_rate = rate;
     rederive_clip_flags();
@@ -263,6 +265,7 @@ struct HostSession {
       any_slow_clip |= o_slow;
       any_window_clip |= o_win;
       any_stride_clip |= o_stride;
+      any_taps_clip |= o_taps;
       any_crawl_clip |= o_crawl;
       any_win16_clip |= o_w16;
       any_other_window_clip |= o_other;

@@ -658,6 +658,7 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   const uint32_t S4 = a.block_frames >> 2;
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  if (family == 3) return launch_mix_fam3(a, n_blocks, variant, s, t0, t1);   // (falls back to family 1 for shapes it has no instance for)
   // stereo 256-frame blocks with both channels per lane (families 0 and 2): one wave = one block
   if (variant >= 1000 && family != 1 && a.channels == 2u && S4 == 64u)
     return family == 2 ? launch_mix_fam2(a, n_blocks, variant, s, t0, t1) : launch_mix_fam0(a, n_blocks, variant, s, t0, t1);

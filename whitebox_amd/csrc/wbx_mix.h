@@ -217,7 +217,10 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   //   1  everything: also per-frame taps, 16-bit / 24-bit / 32-bit window rows, windows of several formats in one chunk
   //   2  sessions whose clips are all 16-bit PCM at speeds up to 0.999 or exactly 1 (CD-rate files in a 48 kHz project): U,
   //      I16, MU, WI, WIN, WINU; a chunk that holds fp32 rows next to 16-bit window rows (a pre-rendered block) -> MIXED
-  constexpr bool G = FAM == 1;
+  //   3  family 1 without the per-frame taps (MODE_G): sessions with resampled integer PCM but no clip that needs them — what
+  //      that mode costs in registers is the room for both channels per lane
+  constexpr bool G = FAM == 1 || FAM == 3;
+  constexpr bool STRIDE = FAM == 1;   // per-frame taps (MODE_G)
   constexpr bool W16 = FAM >= 1;      // the 16-bit window modes
   constexpr bool LEAN16 = FAM == 2;
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
@@ -1320,7 +1323,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     const int shapes = __builtin_amdgcn_readfirstlane(s_shape);
     const int has_f32 = shapes & 3, has_win = shapes & 2, has_i16 = shapes & 4, has_i32 = shapes & 8, has_wide = shapes & 16;
     // (G instances only: sessions without such clips run the instance that does not carry these modes)
-    const int has_stride = G ? (shapes & 64) : 0;    // per-frame taps
+    const int has_stride = STRIDE ? (shapes & 64) : 0;    // per-frame taps
     const int has_win16 = W16 ? (shapes & 32) : 0;   // 16-bit PCM window rows
     const int has_win32 = G ? (shapes & 128) : 0;    // 24/32-bit PCM window rows
     if (LEAN16) {
@@ -1404,7 +1407,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         if constexpr (!LEAN16) pipeline(std::integral_constant<int, MODE_WNU>{}, cn2);
         break;
       case MODE_G:
-        if constexpr (G) pipeline(std::integral_constant<int, MODE_G>{}, cn2);
+        if constexpr (STRIDE) pipeline(std::integral_constant<int, MODE_G>{}, cn2);
         break;
       case MODE_WI:
         if constexpr (W16) pipeline(std::integral_constant<int, MODE_WI>{}, cn2);
@@ -1498,5 +1501,6 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
 const char* launch_mix_fam0(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
 const char* launch_mix_fam1(const MixArgs& a, uint32_t n_blocks, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
 const char* launch_mix_fam2(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
+const char* launch_mix_fam3(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
 
 }  // namespace wbx

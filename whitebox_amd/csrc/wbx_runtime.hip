@@ -251,7 +251,9 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
 int mix_family(const wbx_ctx* c) {
   if (c->force_g) return 1;
   if (c->has_lean16_clips && !c->has_non16_clips && !std::getenv("WBX_NO_LEAN16")) return 2;
-  return (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips)) ? 1 : 0;
+  if (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips))
+    return (c->has_taps_clips || std::getenv("WBX_NO_FAM3")) ? 1 : 3;   // (3 = 1 without the per-frame taps)
+  return 0;
 }
 
 // stereo sessions with integer-PCM clips or with tracks cut into several clips, blocks of 256 / 512 / 1024 frames: the
@@ -280,11 +282,11 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
   bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   // (256-frame stereo blocks: the one-wave instances with both channels per lane, the lean families only)
-  if (!full && c->cfg.channels == 2u && S4 == 64u && mix_family(c) != 1 && mix_two_channels_per_lane(c)) full = true;
+  if (!full && c->cfg.channels == 2u && S4 == 64u && (mix_family(c) == 0 || mix_family(c) == 2) && mix_two_channels_per_lane(c)) full = true;
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
   if (!full) return 0u;
-  if (mix_family(c) == 1) return 4u;   // the everything family: every row kind it streams, also as a masked row
+  if (mix_family(c) == 1 || mix_family(c) == 3) return 4u;   // the everything family: every row kind it streams, also as a masked row
   if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
   if (stride_clips) return 0u;
   if (!c->has_integer_clips) return 1u;
