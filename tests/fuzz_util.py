@@ -60,7 +60,7 @@ def random_masked_session(seed, integer_unity=False, lean16=False, everything=Fa
     if everything:
         fmts = [["i24"], ["i16", "i24"], ["i16", "i24", "i32", "f32"], ["f32"], ["i32", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
-    block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2)][int(rng.integers(0, 5))]
+    block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2), (128, 2), (512, 1), (256, 1)][int(rng.integers(0, 8))]
     n_blocks = int(rng.integers(2, 7))
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))

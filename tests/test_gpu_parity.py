@@ -660,6 +660,35 @@ def test_clip_boundaries_in_the_hot_loop(monkeypatch, masked, clip_blocks, block
         check_against_oracle(spec, n_blocks, group_size=group)
 
 
+@pytest.mark.parametrize("fmts,rates,family", [(("f32",), (44100, 48000), 0), (("i24", "i16"), (44100, 48000), 1), (("i16",), (44100,), 1)])
+@pytest.mark.parametrize("clip_blocks,block,channels,instance", [(1.3, 128, 2, "1, 2, 1, 64>"), (2.2, 256, 2, "1, 1, 1, 128>"),
+                                                                 (0.7, 512, 1, "1, 1, 1, 128>"), (1.7, 256, 1, "1, 1, 1, 64>")])
+def test_clip_boundaries_in_the_hot_loop_short_blocks(clip_blocks, block, channels, instance, fmts, rates, family):
+    """... and for blocks shorter than a 256-lane workgroup — 128-frame stereo, 256-frame stereo, 256 / 512-frame mono, the
+    buffer sizes of a low-latency device: a session cut into clips takes the one-block-per-workgroup instances (a wave, or
+    two), which stage the sequencer's masked rows like the full-size ones.  Families 0 and 1 hold them; the 16-bit-only
+    and the no-per-frame-taps families borrow family 1's."""
+    n_blocks = 9
+    spec = _boundary_session(40, n_blocks, block, clip_blocks, channels)
+    for i, smp in enumerate(spec.samples):
+        smp.fmt = fmts[i % len(fmts)]
+        smp.rate = rates[(i // 2) % len(rates)]
+        smp.amp = 0.02 if smp.fmt == "f32" else 1.0
+        smp.frames = int(smp.frames * 2.2)
+    spec.volumes_db = [v - (0.0 if spec.samples[2 * t].fmt == "f32" else 30.0) for t, v in enumerate(spec.volumes_db)]
+    check_against_oracle(spec, n_blocks, group_size=40, expect_exact=True)
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=40)
+    eng.play()
+    eng.render(n_blocks)
+    eng.ctx.fetch()
+    name = eng.ctx.kernel_name()
+    if block == 256 and channels == 2 and fmts in (("f32",), ("i16",)):   # (the lean families have their own one-wave instance for this shape)
+        assert name == f"wbx::mix_kernel<2, true, 3, {0 if fmts == ('f32',) else 2}, 1, 1, 2, 64>"
+    else:
+        assert name == f"wbx::mix_kernel<2, true, 3, {family}, 1, " + instance[3:], name
+    eng.close()
+
+
 @pytest.mark.parametrize("salt", ["denormals_and_zeros", "nonfinite"])
 def test_masked_rows_with_special_float_values(salt):
     """non-finite and denormal samples right at clip boundaries: a masked-out frame contributes an exact +0.0 whatever
@@ -1655,7 +1684,10 @@ def test_clip_storage_slabs_grow_and_are_reused():
     (dict(src_rate=44100, seek=True), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),     # ... tracks cut into clips
     (dict(fmt="i16"), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),                     # integer PCM at the session rate
     (dict(fmt="i16", src_rate=44100), 512, "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 128>"),     # 16-bit only, resampled: the 16-bit family
-    (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"),     # resampled 24-bit: everything
+    (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<2, true, 3, 3, 1, 1, 2, 128>"),     # resampled 24-bit: everything but per-frame taps
+    (dict(fmt="i24", src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 1, 1, 1, 1, 128>"),   # ... cut, 256 frames: a wave per channel
+    (dict(fmt="i24", src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 1, 2, 1, 1, 256>"),     # ... one clip per track: two blocks per workgroup
+    (dict(src_rate=44100, seek=True), 128, "wbx::mix_kernel<2, true, 3, 0, 1, 2, 1, 64>"),      # 128-frame blocks, cut: one wave = one block, a channel per half
     (dict(src_rate=96000), 512, "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"),                # per-frame taps: everything
     (dict(src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 0, 2, 1, 1, 256>"),                # 256-frame blocks, one clip per track
     (dict(src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>"),      # ... cut: one wave = one block

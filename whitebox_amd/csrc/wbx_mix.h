@@ -224,9 +224,9 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   constexpr bool W16 = FAM >= 1;      // the 16-bit window modes
   constexpr bool LEAN16 = FAM == 2;
   static_assert(SB == 1 || FULL, "sub-blocks need waves that stay inside one block");
-  static_assert(CW == 1 || (CW == 2 && SB == 4), "two channels per wave: 128-frame stereo blocks, one block per wave");
+  static_assert(CW == 1 || (CW == 2 && (SB == 4 || (SB == 1 && T == 64))), "two channels per wave: 128-frame stereo blocks, one block per wave");
   static_assert(CL == 1 || (CL == 2 && FULL && SB == 1 && CW == 1), "two channels per lane: stereo blocks of 4 * T frames");
-  static_assert(T == 256 / CL || (CL == 2 && (T == 64 || T == 256)), "lanes per workgroup");
+  static_assert(T == 256 / CL || (CL == 2 && (T == 64 || T == 256)) || (CL == 1 && SB == 1 && (T == 64 || T == 128)), "lanes per workgroup");
   constexpr uint32_t kT = (uint32_t)T;   // lanes per workgroup (CL = 2: one block of 4 * T frames — 256, 512 or 1024)
   // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS; one-wave workgroups: half, so
   // that twelve of them fit — 12.6 KiB each)
@@ -348,8 +348,18 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       r.speed = __longlong_as_double((long long)(((uint64_t)rl(7) << 32) | rl(6)));
       r.gain = __uint_as_float(rl(8));
       r.gc[0] = __uint_as_float(c ? rl(10) : rl(9));
-      r.kind = (rl(11) >> 8) & KIND_MASK;
+      const uint32_t q11 = rl(11);
+      r.kind = (q11 >> 8) & KIND_MASK;
       r.format = rl(13) & 0xFFu;
+      if (EXP) {   // (as below)
+        r.partial = ((q11 >> 15) & 1u) != 0u;
+        r.d = 0u;
+        r.n = F;
+        if (r.partial) {
+          r.d = q11 >> 16;
+          r.n = rl(12) & 0xFFFFu;
+        }
+      }
       return r;
     }
     const uint32_t cs = FULL ? c : 0u;   // (only used when FULL: the channel is wave-uniform)
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     return r;
   };
   const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);   // FULL: the wave's first frame
+  constexpr uint32_t kWF = CW == 2 ? 128u : 256u;   // ... and how many it covers (CW == 2: the 128 frames of the block, once per half-wave)
   // Masked rows (EXP).  Frame j0+e of the block is frame (j0+e-d) of the stream call; clamped into the call, so that
   // what the masked-out frames of a lane load stays inside the clip — they are zeroed afterwards.  For a whole-block
   // record (d = 0, n = F) this is j0+e itself.
@@ -963,12 +974,12 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         constexpr std::integral_constant<bool, MODE != MODE_W> narrow{};
         constexpr std::integral_constant<bool, MODE == MODE_WNU> uni{};
         if (EXP && r.partial) {   // a stream call that covers part of the block (wave-uniform)
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
+          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (G && (fmt != FMT_F32 || k == KIND_UNITY_I32)) {   // 24 / 32-bit PCM (G instances only)
             if constexpr (G) m = partial_any(pre[u], k, fmt, false);
-          } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of this wave's frames
+          } else if (r.d <= wave_base && r.d + r.n >= wave_base + kWF) {   // ... all of this wave's frames
             if (k == KIND_WINDOW)
               m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
@@ -991,10 +1002,10 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         const bool win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16;
         constexpr std::integral_constant<bool, MODE != MODE_WI> narrow{};
         if (EXP && (LEAN16 || G) && r.partial) {   // a stream call that covers part of the block (wave-uniform)
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-          } else if (r.d <= wave_base && r.d + r.n >= wave_base + 256u) {   // ... all of them
+          } else if (r.d <= wave_base && r.d + r.n >= wave_base + kWF) {   // ... all of them
             if (win)
               m = row_window16_shifted(narrow, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
@@ -1011,7 +1022,7 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_MWN> narrow{};
         if (EXP && r.partial) {   // a stream call that covers part of the block
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else {
@@ -1045,8 +1056,8 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
         const int k = MODE == MODE_U ? KIND_UNITY : MODE == MODE_I16 ? KIND_UNITY_I16 : MODE == MODE_I32 ? KIND_UNITY_I32
                                                   : __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (MODE == MODE_I32 || MODE == MODE_MU) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) : 0u;
-        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + 256u)) {   // a stream call that covers part of the block
-          if (r.d >= wave_base + 256u || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + kWF)) {   // a stream call that covers part of the block
+          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (k == KIND_UNITY_I16) {   // ... some: normalise the four loaded samples, then select and mask as for fp32
@@ -1443,7 +1454,12 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)bb * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
       if (FULL && CW == 2) {
-        pk = s_pk[(sb * kRecs + rec) * kPS + ch];
+        const uint32_t r0 = EXP ? s_off[rec] : rec;   // (EXP: the track's staged row, or the two of its pair)
+        const uint32_t r1 = EXP ? s_off[rec + 1u] : rec + 1u;
+        for (uint32_t rr = r0; rr < r1; rr++) {
+          const uint32_t v = s_pk[(sb * kRecs + rr) * kPS + ch];
+          pk = pk > v ? pk : v;
+        }
       } else if (FULL) {
         // (EXP: the track's staged row, or the two of its pair — one peak over both stream calls)
         const uint32_t r0 = EXP ? s_off[rec] : rec;

@@ -15,6 +15,22 @@ const char* launch_mix_fam0(const MixArgs& a, uint32_t n_blocks, int variant, hi
     WBX_MIX(2, true, 3, 0, 1, 1, 2, 64, grid, dim3(64))
     return name;
   }
+  if (!full && a.masked_rows) {
+    // short blocks of a session cut into clips: one block per workgroup (a wave, or two), the instances that take the
+    // sequencer's masked rows — clip boundaries stay in the hot loop instead of going through the pre-render pass
+    if (S4 == 32u && a.channels == 2u) {          // 128-frame stereo: one wave, a channel per half-wave
+      WBX_MIX(2, true, 3, 0, 1, 2, 1, 64, grid, dim3(64))
+      return name;
+    }
+    if (S4 % 64u == 0u && lanes == 128u) {        // 256-frame stereo (a wave per channel), 512-frame mono
+      WBX_MIX(2, true, 3, 0, 1, 1, 1, 128, grid, dim3(128))
+      return name;
+    }
+    if (S4 == 64u && lanes == 64u) {              // 256-frame mono
+      WBX_MIX(2, true, 3, 0, 1, 1, 1, 64, grid, dim3(64))
+      return name;
+    }
+  }
   if (!full) {
     // blocks shorter than a workgroup whose waves are still channel-uniform (256 frames; 512 mono): 2 or 4
     // consecutive blocks per workgroup, same code as the full instances

@@ -11,6 +11,22 @@ const char* launch_mix_fam1(const MixArgs& a, uint32_t n_blocks, hipStream_t s, 
   const uint32_t S4 = a.block_frames >> 2;
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  if (!full && a.masked_rows) {
+    // short blocks of a session cut into clips: one block per workgroup (a wave, or two), the instances that take the
+    // sequencer's masked rows — clip boundaries stay in the hot loop instead of going through the pre-render pass
+    if (S4 == 32u && a.channels == 2u) {          // 128-frame stereo: one wave, a channel per half-wave
+      WBX_MIX(2, true, 3, 1, 1, 2, 1, 64, grid, dim3(64))
+      return name;
+    }
+    if (S4 % 64u == 0u && lanes == 128u) {        // 256-frame stereo (a wave per channel), 512-frame mono
+      WBX_MIX(2, true, 3, 1, 1, 1, 1, 128, grid, dim3(128))
+      return name;
+    }
+    if (S4 == 64u && lanes == 64u) {              // 256-frame mono
+      WBX_MIX(2, true, 3, 1, 1, 1, 1, 64, grid, dim3(64))
+      return name;
+    }
+  }
   if (!full) {
     if (S4 == 32u && a.channels == 2u) {   // 128-frame stereo blocks: one block per wave, a channel per half-wave
       const dim3 g4((n_blocks + 3u) / 4u, a.n_groups, 1);

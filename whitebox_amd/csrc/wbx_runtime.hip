@@ -283,6 +283,12 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   // (256-frame stereo blocks: the one-wave instances with both channels per lane, the lean families only)
   if (!full && c->cfg.channels == 2u && S4 == 64u && (mix_family(c) == 0 || mix_family(c) == 2) && mix_two_channels_per_lane(c)) full = true;
+  // short blocks — 128-frame stereo, 256-frame stereo in the families without that one-wave instance, 256 / 512-frame mono:
+  // one-block-per-workgroup instances (a wave or two) exist for families 0 and 1; a session with tracks cut into clips takes
+  // them, the others keep the instances that put 2 or 4 blocks into a workgroup
+  if (!full && c->has_cut_tracks &&
+      ((c->cfg.channels == 2u && S4 == 32u) || (S4 % 64u == 0u && lanes == 128u) || (S4 == 64u && lanes == 64u)))
+    full = true;
   if (const char* e = std::getenv("WBX_MASKED_ROWS"))
     if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
   if (!full) return 0u;
