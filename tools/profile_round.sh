@@ -25,6 +25,16 @@ for W in c3 c4 c2 i16 i16r i24r mixr; do
   timeout 300 python bench.py --workload $W --blocks 256 $B > $O/bench_${W}_K256.json 2>> $O/bench_default.err
 done
 timeout 300 python bench.py --clip-blocks 5.3 --blocks 256 $B > $O/bench_c3_L5.3_K256.json 2>> $O/bench_default.err
+# short blocks (the buffer sizes of a low-latency device) cut into clips: boundaries in the hot loop, and through the pre-render pass
+for BF in 128 256; do
+  timeout 300 python bench.py --block-frames $BF --blocks 1024 --clip-blocks 5.3 $B > $O/bench_c3_F${BF}_L5.3.json 2>> $O/bench_default.err
+  WBX_MASKED_ROWS=0 timeout 300 python bench.py --block-frames $BF --blocks 1024 --clip-blocks 5.3 $B > $O/bench_c3_F${BF}_L5.3_prerender.json 2>> $O/bench_default.err
+  timeout 300 python bench.py --block-frames $BF --blocks 1024 $B > $O/bench_c3_F${BF}.json 2>> $O/bench_default.err
+done
+for W in i24r mixr; do
+  timeout 300 python bench.py --workload $W --clip-blocks 5.3 $B > $O/bench_${W}_L5.3.json 2>> $O/bench_default.err
+  WBX_NO_FAM3=1 timeout 300 python bench.py --workload $W $B > $O/bench_${W}_fam1.json 2>> $O/bench_default.err
+done
 for M in reduce ordered chain; do
   timeout 300 python bench.py --force-dist-path --dist-mode $M $B > $O/bench_dist1_$M.json 2>> $O/bench_default.err
 done
