@@ -107,7 +107,10 @@ def track_layout(workload, n_tracks, rank, world, session_blocks, clip_blocks=0.
 def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, rank, world, group_size, clip_blocks=0.0):
     from whitebox_amd.engine import Engine
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
-    eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank))
+    # (A/B aid WBX_MASKED_ROWS=0 sends every clip boundary through the pre-render pass: its segment pool must hold them)
+    pre_render = clip_blocks and os.environ.get("WBX_MASKED_ROWS") == "0"
+    eng = Engine(n_tracks, F, SR, 2, max_blocks=blocks, group_size=group_size, device=rank_device(rank),
+                 max_segments=4 * n_tracks * blocks if pre_render else 0)
     eng.set_bpm(120.0)
     if n_buses:
         eng.set_buses(n_buses)

@@ -75,9 +75,11 @@ typedef struct wbx_config {
   uint32_t sample_rate;    /* destination rate, Engine::audio_sample_rate */
   uint32_t group_size;     /* tracks summed in index order by one workgroup; the master is the in-order sum of the group
                               sums, so group_size >= N reproduces the reference's strictly sequential order (engine.cpp:
-                              1600-1617) bit for bit.  0 = the library picks: renders of >= 1024 blocks walk ALL tracks of a
-                              block (of a bus) in one workgroup — the reference's order, bit-exact master, at the full rate
-                              (the blocks of the render supply the parallelism); shorter renders take groups of 128 (when
+                              1600-1617) bit for bit.  0 = the library picks: renders of >= 1024 blocks add ALL tracks of a
+                              block (of a bus) in track order — the reference's order, bit-exact master, at the full rate:
+                              128-track workgroups that continue each other's running sum, the blocks of the render supply
+                              the parallelism (blocks shorter than 256 lanes count by the workgroup: 2048 blocks of 256
+                              frames, 4096 of 128 — wbx_render_order tells); shorter renders take groups of 128 (when
                               max_blocks == 1, the audio-callback configuration: 64, and 32 for sessions of more than 64
                               tracks), within 1e-6 RMS of the reference's order at mix-bus levels (DESIGN.md "Summation
                               order" states the levels). */

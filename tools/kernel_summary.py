@@ -14,6 +14,9 @@ def short(name):
     return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else None
 
 
+ORDER = ["times_copy_kernel", "plan_kernel", "plan_kernel_beside", "gen_kernel", "mix_kernel", "sum_kernel"]
+
+
 def one(trace, bench, title):
     d = json.loads([l for l in open(bench) if l.startswith("{")][-1])
     timed = d["steps"]
@@ -21,7 +24,7 @@ def one(trace, bench, title):
     per = {}
     for r in rows:
         k = short(r["Kernel_Name"])
-        if k and k.split("<")[0] in ("plan_kernel", "gen_kernel", "mix_kernel", "sum_kernel"):
+        if k and k.split("<")[0] in ORDER:
             per.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"# rocprofv3 --kernel-trace of `{title}` ({d['config']['workload'].split(' ')[0]}, K={d['config']['blocks_per_step']}): "
           f"{d['warmup']} warm-up + {d['ramp_steps']} ramp + {timed} timed steps")
@@ -30,7 +33,7 @@ def one(trace, bench, title):
           + (f", over all {d['roofline']['kernel_launches_all']} launches {1e3 * d['roofline']['kernel_ms_avg_all_launches']:.1f} us"
              if "kernel_ms_avg_all_launches" in d["roofline"] else ""))
     print("# kernel, launches, mean us (all), mean us (last %d = the timed steps), min us, max us" % timed)
-    for k in sorted(per, key=lambda k: ["plan", "gen_", "mix_", "sum_"].index(k[:4])):
+    for k in sorted(per, key=lambda k: ORDER.index(k.split("<")[0])):
         v = per[k]
         last = v[-timed:]
         print(f"{k:<34}{len(v):>6}{sum(v) / len(v):>11.1f}{sum(last) / len(last):>11.1f}{min(v):>11.1f}{max(v):>11.1f}")

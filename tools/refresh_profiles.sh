@@ -29,6 +29,9 @@ python tools/kernel_summary.py \
   $O/kt_c3_L5.3/c3_L5.3_kernel_trace.csv $O/kt_c3_L5.3_bench.json "$C --clip-blocks 5.3" \
   $O/kt_i16r/i16r_kernel_trace.csv $O/kt_i16r_bench.json "$C --workload i16r" \
   $O/kt_c3_K256/c3_K256_kernel_trace.csv $O/kt_c3_K256_bench.json "$C --blocks 256 (grouped order)" > profiles/${RN}_kernel_summary.txt
+for n in c3 c2 c4 c3_L5.3; do
+  python tools/timeline.py $O/kt_$n/${n}_kernel_trace.csv 16 > profiles/${RN}_timeline_$n.txt
+done
 KH=$(kof $O/kt_c3_bench.json)
 python tools/pmc_traffic.py $O/pmc_c3 c3 $KH 4096 mix_kernel > /dev/null
 python tools/pmc_traffic.py $O/pmc_c4 c4 $KH 4096 mix_kernel > /dev/null

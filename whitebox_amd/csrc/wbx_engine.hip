@@ -738,13 +738,13 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   if (st != WBX_OK) return cfail(e, st);
 
   // -- rows for the track-blocks the hot loop cannot stream directly, and the plan's templates
-  c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance)
-  c->chain_now = render_chains_groups(c, K);
   c->has_window_clips = hs.any_window_clip;
   c->has_stride_clips = hs.any_stride_clip;
   c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->has_cut_tracks = hs.cut_tracks != 0;
+  c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance; reads the flags above)
+  c->chain_now = render_chains_groups(c, K);
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration));
   if (st != WBX_OK) return cfail(e, st);

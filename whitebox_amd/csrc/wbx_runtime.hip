@@ -114,8 +114,24 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 // picks the grouping (wbx_config.group_size == 0) and the render is long enough to fill the device with one workgroup
 // per block: the parallelism that track groups give a short render comes from the K blocks of a long one.  Measured on
 // c3 (profiles/): from about a thousand blocks per render on, whole-list walks run at the grouped order's rate.
+// What counts is the number of workgroup COLUMNS, not of blocks: the instances for blocks shorter than a workgroup put 2 or 4
+// consecutive blocks into one, and a 1024-block render of 128-frame blocks through them is 256 columns — 256 chains, or 256
+// walks, on a device that holds a thousand workgroups (measured: 0.30 of the roofline instead of 0.60).
+static uint32_t blocks_per_workgroup(const wbx_ctx* c) {
+  const uint32_t C = c->cfg.channels, S4 = c->cfg.block_frames >> 2, lanes = C * S4;
+  if ((lanes % 256u == 0u) && (S4 % 64u == 0u)) return 1u;
+  const char* e = std::getenv("WBX_MASKED_ROWS");
+  const bool short_ok = (C == 2u && S4 == 32u) || (S4 % 64u == 0u && lanes == 128u) || (S4 == 64u && lanes == 64u);
+  if (short_ok && c->has_cut_tracks && !(e && e[0] == '0')) return 1u;   // the one-block-per-workgroup instances (masked rows)
+  const int fam = mix_family(c);
+  if (C == 2u && S4 == 64u && (fam == 0 || fam == 2) && (c->has_integer_clips || c->has_cut_tracks)) return 1u;   // one wave = one block
+  if (C == 2u && S4 == 32u) return 4u;
+  if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) return 256u / lanes;
+  return 1u;
+}
+
 bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
-  return c->auto_group && c->exact_min_blocks != 0u && K >= c->exact_min_blocks;
+  return c->auto_group && c->exact_min_blocks != 0u && K / blocks_per_workgroup(c) >= c->exact_min_blocks;
 }
 
 // ... and of those, which chain the workgroup-sized pieces instead of walking a list in one workgroup: the same order of
