@@ -587,7 +587,7 @@ def main():
                     "(c2, c4, c3 cut into clips, i16r, the sustained run) that fill the line's `configs` object")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the rendered head against the CPU oracle "
                     "(after the timed loop, outside the timed region)")
-    ap.add_argument("--sustain-blocks", type=int, default=512000, help="blocks of the sustained-clock run in `configs` "
+    ap.add_argument("--sustain-blocks", type=int, default=655360, help="blocks of the sustained-clock run in `configs` "
                     "(2 000 steps of 256 blocks' worth: >= 1.5 s of uninterrupted load)")
     args = ap.parse_args()
     global F
