@@ -890,6 +890,46 @@ def test_interleaved_output_formats():
     eng.close()
 
 
+def test_host_bound_master_of_a_long_render_leaves_through_the_staging_buffer():
+    """A master bound for pinned host memory (wbx_set_master_target) of 4 MB and more is summed into a device staging buffer
+    and copied out on the sum stream (the sum kernel's own PCIe stores held up the next mix); shorter renders keep the
+    direct stores.  Planar fp32 and interleaved device formats, several renders through the staging ring, the same bits as
+    the oracle either way."""
+    from whitebox_amd.dist import PinnedBuffer
+    K = 2048
+    spec = synth.make_session("stage", 8, n_blocks=2 * K, seed=0x57A6, src_rate=44100, amp=0.2)
+    om, _, _, _, _ = run_oracle(spec, 2 * K)
+    host = PinnedBuffer(K * 2 * 512)
+    eng = build_engine(spec, max_blocks=K)
+    eng.ctx.set_master_target(host.ptr)
+    eng.play()
+    for r in range(2):                                   # 8 MB per render: staged
+        eng.render(K)
+        eng.ctx.sync()
+        assert np.array_equal(bits(host.array.reshape(K, 2, 512)), bits(om[r * K:(r + 1) * K])), r
+    eng.stop()
+    eng.play()
+    eng.render(256)                                      # 1 MB: the sum kernel stores it itself
+    eng.ctx.sync()
+    assert np.array_equal(bits(host.array.reshape(K, 2, 512)[:256]), bits(om[:256]))
+    L = O.lib()
+    for fmt, dt, per in (("i16", np.int16, 2), ("f32", np.float32, 4)):   # 2048 x 512 x 2 samples: 4 MB / 8 MB, staged
+        eng.ctx.set_master_format(fmt)
+        eng.stop()
+        eng.play()
+        eng.render(K)
+        eng.ctx.sync()
+        exp = np.zeros(K * 512 * 2, dt)
+        for b in range(K):
+            src = [np.ascontiguousarray(om[b][c]) for c in range(2)]
+            getattr(L, "wbo_f32_to_interleaved_" + fmt)(exp[b * 1024:].ctypes.data, O.planar_ptrs(src), 0, 512, 2)
+        got = host.array.view(np.uint8)[:K * 1024 * per]
+        assert np.array_equal(got, exp.view(np.uint8)), fmt
+    eng.ctx.set_master_format(None)
+    eng.close()
+    host.close()
+
+
 @pytest.mark.parametrize("channels", [2, 1])
 def test_device_format_as_the_sum_kernel_epilogue(channels):
     """wbx_engine_process_interleaved (the audio callback: Engine::process + interleave_samples_to in one call) and
