@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256, 6) void gen_kernel(GenArgs a) {
   const uint32_t F = a.block_frames, C = a.channels, S4 = F >> 2;
   const size_t row_floats = (size_t)C * (F + 8);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  // (waves are independent — no LDS, no barrier: launched as one-wave workgroups, which find a slot beside a running mix
+  //  where a four-wave workgroup with scratch waits for the mix to drain)
+  const uint32_t wpb = blockDim.x >> 6;
+  const uint32_t wave = blockIdx.x * wpb + (threadIdx.x >> 6), n_waves = gridDim.x * wpb;
   // the queue entry and the record of the wave's NEXT row are fetched while the current one is rendered (queued
   // templates are distinct, so the rewrite at the end of a row cannot touch the one in flight)
   uint32_t idx_n = 0u, w_n = 0u;
@@ -649,7 +652,7 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
   // grid-stride over the queue: the grid only bounds the parallelism (a short render cannot queue many rows)
   const uint32_t wgs = (a.gen_cap + 3u) / 4u;   // one wave per queued record
   const uint32_t grid = wgs < max_grid ? (wgs ? wgs : 1u) : max_grid;
-  hipLaunchKernelGGL(gen_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gen_kernel, dim3(grid * 4u), dim3(64), 0, s, a);   // (max_grid counts four-wave units)
 }
 
 // which instance of the hot kernel a render takes: the family's translation unit holds the instances
