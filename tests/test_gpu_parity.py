@@ -639,7 +639,7 @@ def test_clip_boundaries_in_the_hot_loop_every_format(fmts, rates):
     # family 1 (everything) when a clip needs per-frame taps (played faster than 0.999 of the session rate), else family 3:
     # the same modes without them, both channels of a frame per lane
     taps = any(0.999 < spec.samples[c.sample].rate / float(spec.sample_rate) * c.speed != 1.0 for c in spec.clips)
-    assert eng.ctx.kernel_name() == ("wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>" if taps else "wbx::mix_kernel<2, true, 3, 3, 1, 1, 2, 128>")
+    assert eng.ctx.kernel_name() == ("wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>" if taps else "wbx::mix_kernel<1, true, 3, 3, 1, 1, 2, 128>")
     eng.close()
 
 
@@ -1724,7 +1724,7 @@ def test_clip_storage_slabs_grow_and_are_reused():
     (dict(src_rate=44100, seek=True), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),     # ... tracks cut into clips
     (dict(fmt="i16"), 512, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"),                     # integer PCM at the session rate
     (dict(fmt="i16", src_rate=44100), 512, "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 128>"),     # 16-bit only, resampled: the 16-bit family
-    (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<2, true, 3, 3, 1, 1, 2, 128>"),     # resampled 24-bit: everything but per-frame taps
+    (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<1, true, 3, 3, 1, 1, 2, 128>"),     # resampled 24-bit: everything but per-frame taps
     (dict(fmt="i24", src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 1, 1, 1, 1, 128>"),   # ... cut, 256 frames: a wave per channel
     (dict(fmt="i24", src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 1, 2, 1, 1, 256>"),     # ... one clip per track: two blocks per workgroup
     (dict(src_rate=44100, seek=True), 128, "wbx::mix_kernel<2, true, 3, 0, 1, 2, 1, 64>"),      # 128-frame blocks, cut: one wave = one block, a channel per half

@@ -13,6 +13,8 @@ const char* launch_mix_fam2(const MixArgs& a, uint32_t n_blocks, int variant, hi
     WBX_MIX(2, true, 3, 2, 1, 1, 2, 64, grid, dim3(64))
   else if (variant == 1042 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
     WBX_MIX(4, true, 2, 2, 1, 1, 2, 128, grid, dim3(128))
+  else if (variant == 1013 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
+    WBX_MIX(1, true, 3, 2, 1, 1, 2, 128, grid, dim3(128))
   else if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u)
     WBX_MIX(2, true, 3, 2, 1, 1, 2, 128, grid, dim3(128))
   else if (variant >= 1000 && a.channels == 2u && S4 == 256u)

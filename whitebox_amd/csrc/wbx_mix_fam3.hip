@@ -10,14 +10,13 @@ const char* launch_mix_fam3(const MixArgs& a, uint32_t n_blocks, int variant, hi
   const dim3 grid(n_blocks, a.n_groups, a.tiles);
   const uint32_t S4 = a.block_frames >> 2;
   if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u) {
-    if (variant == 1013)        // (tuning variants, WBX_MIX_VARIANT: one row per batch; twice the rows at two waves per SIMD)
-      WBX_MIX(1, true, 3, 3, 1, 1, 2, 128, grid, dim3(128))
-    else if (variant == 1042)
-      WBX_MIX(4, true, 2, 3, 1, 1, 2, 128, grid, dim3(128))
-    else if (variant == 1022)
-      WBX_MIX(2, true, 2, 3, 1, 1, 2, 128, grid, dim3(128))
-    else
+    // one row per pipeline batch: with two, this family's widest modes spill 84 B per lane at three waves per SIMD
+    // (measured, one box: i24r 0.650 -> 0.690 of the roofline, mixr 0.501 -> 0.530, cut into clips +2-3 %; two waves per SIMD
+    // without spills — <2,true,2,...> — 0.62 / 0.51, <4,true,2,...> 0.61 / 0.48).  WBX_MIX_VARIANT=1022: two rows per batch.
+    if (variant == 1022)
       WBX_MIX(2, true, 3, 3, 1, 1, 2, 128, grid, dim3(128))
+    else
+      WBX_MIX(1, true, 3, 3, 1, 1, 2, 128, grid, dim3(128))
     return name;
   }
   return launch_mix_fam1(a, n_blocks, s, t0, t1);   // every other block shape: the everything family holds all of this one's modes
