@@ -59,53 +59,53 @@ inline ResizeResult calc_resize_clip(double clip_min, double clip_max, double cl
   ResizeResult r{};
   r.speed = 1.0;
   if (!is_min) {   // right edge, :29-75
-    const double old_max = clip_max;
-    const double actual_min_length = resize_limit + min_length - clip_min;
-    double new_max = maxd(clip_max + relative_pos, 0.0);
-    if (new_max - clip_min < actual_min_length) new_max = clip_min + actual_min_length;
+    const double right0 = clip_max;
+    const double shortest = resize_limit + min_length - clip_min;
+    double right = maxd(clip_max + relative_pos, 0.0);
+    if (right - clip_min < shortest) right = clip_min + shortest;
     double so = clip_start_offset;
     if (shift) {
       so = samples_to_beat(so, sample_rate, beat_duration);
-      if (old_max < new_max)
-        so -= (new_max - old_max) * clip_speed;
+      if (right0 < right)
+        so -= (right - right0) * clip_speed;
       else
-        so += (old_max - new_max) * clip_speed;
+        so += (right0 - right) * clip_speed;
       so = maxd(so, 0.0);
       so = mind(so, sample_count);
       so = beat_to_samples_h(so, sample_rate, beat_duration);
     }
     if (stretch) {
-      const double old_length = sample_count / clip_speed;
-      const double num_samples = beat_to_samples_h(relative_pos, sample_rate, beat_duration);
-      r.speed = sample_count / (old_length + num_samples);
+      const double span_samples = sample_count / clip_speed;
+      const double delta_samples = beat_to_samples_h(relative_pos, sample_rate, beat_duration);
+      r.speed = sample_count / (span_samples + delta_samples);
     }
     r.min = clip_min;
-    r.max = new_max;
+    r.max = right;
     r.start_offset = so;
     return r;
   }
-  const double old_min = clip_min;   // left edge, :77-125
-  const double actual_min_length = clip_max - resize_limit + min_length;
-  double new_min = maxd(clip_min + relative_pos, 0.0);
-  if (clip_max - new_min < actual_min_length) new_min = clip_max - actual_min_length;
-  if (clamp_at_resize_pos && new_min < min_resize_pos) new_min = min_resize_pos;
+  const double left0 = clip_min;   // left edge, :77-125
+  const double shortest = clip_max - resize_limit + min_length;
+  double left = maxd(clip_min + relative_pos, 0.0);
+  if (clip_max - left < shortest) left = clip_max - shortest;
+  if (clamp_at_resize_pos && left < min_resize_pos) left = min_resize_pos;
   double so = clip_start_offset;
   if (!shift) {
     so = samples_to_beat(so, sample_rate, beat_duration);
-    if (old_min < new_min)
-      so -= old_min - new_min;
+    if (left0 < left)
+      so -= left0 - left;
     else
-      so += new_min - old_min;
-    if (so < 0.0) new_min = new_min - so;
+      so += left - left0;
+    if (so < 0.0) left = left - so;
     so = maxd(so, 0.0);
     so = beat_to_samples_h(so, sample_rate, beat_duration);
   }
   if (stretch) {
-    const double old_length = sample_count / clip_speed;
-    const double num_samples = beat_to_samples_h(old_min - new_min, sample_rate, beat_duration);
-    r.speed = sample_count / (old_length + num_samples);
+    const double span_samples = sample_count / clip_speed;
+    const double delta_samples = beat_to_samples_h(left0 - left, sample_rate, beat_duration);
+    r.speed = sample_count / (span_samples + delta_samples);
   }
-  r.min = new_min;
+  r.min = left;
   r.max = clip_max;
   r.start_offset = so;
   return r;
