@@ -129,7 +129,11 @@ def build_device_session(W, synth, workload, n_tracks, blocks, session_blocks, r
 
 
 def rank_device(rank):
-    return int(os.environ.get("LOCAL_RANK", rank))
+    dev = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("WBX_SHARE_DEVICE") == "1":
+        import whitebox_amd as W
+        dev %= max(1, W.lib().wbx_device_count())
+    return dev
 
 
 def build_oracle_session(workload, n_tracks, world, sample_blocks, clip_blocks=0.0, session_blocks=None):
@@ -330,7 +334,8 @@ def self_launch(n, rank_cmd=None, poll_s=0.05, grace_s=5.0):
     if rank_cmd is None:
         import whitebox_amd as W
         have = W.lib().wbx_device_count()
-        if have < n:
+        # (WBX_SHARE_DEVICE=1, an experiment aid: the ranks share the devices there are — RCCL decides whether it accepts that)
+        if have < n and os.environ.get("WBX_SHARE_DEVICE") != "1":
             raise SystemExit(f"bench.py --gpus {n} needs {n} gfx950 devices on this node, {have} visible "
                              "(one process per GPU; --force-dist-path runs the multi-GPU code path on one)")
         rank_cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
