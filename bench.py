@@ -347,6 +347,11 @@ def self_launch(n, rank_cmd=None, poll_s=0.05, grace_s=5.0):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), WBX_RDZV=rdzv, WBX_RDZV_NONCE=nonce)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes here
+        if os.environ.get("WBX_SHARE_DEVICE") == "1":
+            # experiment aid (one-GPU box): every rank claims a host of its own, so that RCCL accepts ranks that share a device
+            # and carries the exchange over its socket transport on the loopback interface — slow, but it is wbx_dist.hip
+            # running with world > 1 between processes
+            env.update(NCCL_HOSTID=f"wbx-rank-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
         procs.append(subprocess.Popen(list(rank_cmd), env=env))
     rc = 0
     alive = list(procs)

@@ -1,7 +1,8 @@
 """The multi-GPU exchange of libwbx (wbx_dist_*, whitebox_amd/csrc/wbx_dist.hip) on the GPU box: the same code
 path N ranks run — ring of three partial-master buffers, RCCL collective on its own stream, clamp on the root into
 pinned host memory — with a REAL RCCL communicator of world size 1, against the oracle and against the single-GPU
-default path.  (N > 1 ranks need N devices: the driver's scaling run; the CPU side covers the protocol with gloo.)"""
+default path, and world 2 / 4 between processes that SHARE the device (RCCL's socket transport: test_ranks_that_share_the_device_…).
+(N ranks on N devices: the driver's scaling run; the CPU side covers the protocol with gloo.)"""
 import json
 import os
 import subprocess
@@ -112,6 +113,39 @@ def test_bench_multi_gpu_launch_paths():
         assert line["rccl_world"] == 1 and len(line["devices"]) == 1 and line["devices"][0].count(":") == 2
         assert line["exchange_ms_avg"] > 0.0 and line["tracks_per_gpu"] == 256
         assert line["verify"]["ok"] and line["verify"]["peaks_equal"] and line["verify"]["plan_rows_equal"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_that_share_the_device_exchange_over_rccl(world):
+    """wbx_dist.hip with world > 1 between processes, on a box with ONE GPU: every rank claims a host of its own
+    (NCCL_HOSTID — bench.py sets it under WBX_SHARE_DEVICE=1), so RCCL accepts ranks that share the device and carries the
+    exchange over its socket transport on the loopback interface.  Slow — but it is the launcher, the rendezvous,
+    ncclCommInitRank across processes, ncclReduce / the gather + fixed-order add / the send-receive chain, and the
+    all-gather of the ranks' facts, for real; the bench's own check compares the head of what the ranks rendered together
+    (world x 1024 tracks) with the oracle: chain mode bit-exact — the reference's order across ranks."""
+    env = dict(os.environ, WBX_SHARE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    for mode in ("reduce", "ordered", "chain"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-mode", mode, "--tracks", "1024",
+                            "--blocks", "64", "--session-blocks", "256", "--steps", "4", "--warmup", "1", "--ramp-steps", "2",
+                            "--no-cpu-baseline", "--no-configs", "--latency-blocks", "0"]
+                           # (a render of 64 blocks adds 128-track groups; one group per rank = the reference's order inside a rank)
+                           + (["--group-size", "1024"] if mode == "chain" else []),
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (mode, r.stderr[-2500:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == world and line["rccl_world"] == world and len(line["devices"]) == world
+        assert line["config"]["total_tracks"] == 1024 * world and line["exchange_ms_avg"] > 0.0
+        v = line["verify"]
+        assert v["ok"] and v["tracks"] == 1024 * world and v["peaks_equal"] and v["plan_rows_equal"], v
+        if mode == "chain":
+            assert v["master_bit_exact"], v
+        ranks = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"rank"')]
+        assert sorted(x["rank"] for x in ranks) == list(range(world))       # every rank said what it ran on
+        assert all(x["exchange"]["world"] == world and x["exchange"]["mode"] == mode for x in ranks)
 
 
 def test_dist_info_and_allgather_at_world_1():
