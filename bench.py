@@ -609,6 +609,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a launch of {world} ranks")
+    if world > 1 and os.environ.get("WBX_SHARE_DEVICE") == "1":   # (also under another launcher, e.g. torch.distributed.run)
+        os.environ.setdefault("NCCL_HOSTID", f"wbx-rank-{rank}")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
     import whitebox_amd as W
     from whitebox_amd import synth
