@@ -30,8 +30,9 @@ struct wbx_engine {
   int gains_slot = -1;                  // the buffer plans currently read
   std::vector<float> gains_tmp;
   // the per-block transport records of a batch render (PlanArgs::times): K dependent additions, done here on the host — it
-  // repeats that arithmetic anyway to keep its own transport — and copied in front of the plan by a kernel reading this pinned table; one lane of the GPU beside a
-  // running mix took 0.15-0.2 ms for 2048 blocks
+  // repeats that arithmetic anyway to keep its own transport — and moved in front of the plan by a kernel that reads this
+  // pinned table (one lane of the GPU beside a running mix took 0.15-0.2 ms for 2048 blocks).  A ring of eight: the host
+  // runs at most that many renders ahead of the sequencer before it waits for a table's copy.
   static constexpr int kTimesRing = 8;
   DBlockTime* h_times[kTimesRing] = {};
   uint32_t times_cap[kTimesRing] = {};
