@@ -503,8 +503,10 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     # K = 1 latency mode, the drop-in's real operating point: the audio callback, Engine::process one block at a time,
     # on an engine configured the way a callback host configures it (max_blocks = 1: 64-track groups)
     lat = None
-    if rank == 0 and latency_blocks > 0 and dist is None:
-        eng, _, _ = build_device_session(W, synth, workload, n_tracks, 1, latency_blocks + 16, rank, world, args.group_size,
+    lat_small = {}
+
+    def callback_latency(tracks):
+        eng, _, _ = build_device_session(W, synth, workload, tracks, 1, latency_blocks + 16, rank, world, args.group_size,
                                          clip_blocks)
         out = W.AudioBuffer(F, 2)
         eng.play()
@@ -517,13 +519,22 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
         for _ in range(latency_blocks):
             if process(handle, ptrs) != 0:
                 raise RuntimeError("wbx_engine_process failed")
-        lat = (time.perf_counter() - t1) / latency_blocks
+        dt1 = (time.perf_counter() - t1) / latency_blocks
         eng.close()
+        return dt1
+
+    if rank == 0 and latency_blocks > 0 and dist is None:
+        lat = callback_latency(n_tracks)
+        # ... and for sessions of the size a DAW project usually has (up to 64 tracks: ONE group — the reference's order
+        # bit for bit, and the mix workgroup stores the master itself: two launches instead of three)
+        for small in (8, 64):
+            if small < n_tracks:
+                lat_small[str(small)] = 1e3 * callback_latency(small)
 
     alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
     achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
     return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,
-            "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "alg": alg, "achieved": achieved,
+            "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "lat_small": lat_small, "alg": alg, "achieved": achieved,
             "desc": desc, "kernel_name": kernel_name, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
             "clip_blocks": clip_blocks, "workload": workload, "verify": ver, "device": dev, "exchange": exch, "summation": summation,
             "session_blocks": session_blocks}
@@ -679,7 +690,9 @@ def main():
         line.update({"rccl_world": r["exchange"]["world"], "devices": r["exchange"]["devices"], "tracks_per_gpu": n_tracks,
                      "exchange_ms_avg": r["exchange"]["exchange_ms_avg"]})
     if r["lat"] is not None:
-        line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"]}
+        line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"],
+                                # the same call for sessions of 8 / 64 tracks (one group: the mix workgroup stores the master itself)
+                                "ms_per_block_small_sessions": r.get("lat_small") or None}
 
     # the other single-GPU configurations of BASELINE.json (configs[1], configs[3]), the headline session cut into
     # clips, the 16-bit resampled session, the round-2 operating point (256-block renders, grouped order) and a

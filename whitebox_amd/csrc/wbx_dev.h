@@ -212,6 +212,14 @@ struct MixArgs {
   uint32_t* chain;              // chained render: [workgroup columns][n_groups] "this piece's running sum is out" words
                                 // ((chain_epoch << 4) | XCC id + 1 once out: never cleared between renders); null: every
                                 // group starts from zero (or MixArgs::init) and the sum kernel adds the group sums
+  // One-block callbacks of sessions that are ONE group (up to 64 tracks, no sub-buses): the workgroup is the block's whole sum,
+  // so it clamps and stores the master itself (and hands the plan status to the host) — no sum kernel, one launch fewer
+  // in the latency path.  Null: the group sums go to `partial` for sum_kernel.
+  float* fused_master;          // [K][C][F], usually pinned host memory
+  uint32_t fused_clamp;
+  uint32_t* fused_status_src;   // as SumArgs::status_src / status_dst / zero_status
+  uint32_t* fused_status_dst;
+  uint32_t fused_zero_status;
   uint32_t chain_epoch;         // this render's tag, 1 .. 2^28-1 (words are zeroed on allocation and when the tag wraps)
   uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
                                 // device's in-order workgroup dispatch is not what it is documented to be)

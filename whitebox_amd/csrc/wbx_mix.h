@@ -1490,7 +1490,30 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     a.dbg_clock[4u * wg + 2u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID: cu / sh / se of this wave
     a.dbg_clock[4u * wg + 3u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
   }
-  if (active && bvalid) {
+  if (a.fused_master) {   // (wave-uniform) this workgroup's sum IS the block's: what sum_kernel would do with one group
+    if (a.fused_status_dst && blockIdx.x == 0u && tid < 4u) {
+      const uint32_t queued = a.fused_status_src[2];
+      a.fused_status_dst[tid] = a.fused_status_src[tid];
+      if (a.fused_zero_status && queued == 0u) a.fused_status_src[tid] = 0u;
+    }
+    if (active && bvalid) {
+#pragma unroll
+      for (int ch = 0; ch < CL; ch++) {
+        f4 m = acc.c[ch];
+        m.x = __fadd_rn(0.0f, m.x);   // the master starts from the cleared buffer (engine.cpp:1598): -0.0 becomes +0.0
+        m.y = __fadd_rn(0.0f, m.y);
+        m.z = __fadd_rn(0.0f, m.z);
+        m.w = __fadd_rn(0.0f, m.w);
+        if (a.fused_clamp) {          // engine.cpp:1627-1636: compare, don't min/max (NaN passes through unchanged)
+          m.x = m.x > 1.0f ? 1.0f : (m.x < -1.0f ? -1.0f : m.x);
+          m.y = m.y > 1.0f ? 1.0f : (m.y < -1.0f ? -1.0f : m.y);
+          m.z = m.z > 1.0f ? 1.0f : (m.z < -1.0f ? -1.0f : m.z);
+          m.w = m.w > 1.0f ? 1.0f : (m.w < -1.0f ? -1.0f : m.w);
+        }
+        *reinterpret_cast<f4*>(a.fused_master + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0) = m;
+      }
+    }
+  } else if (active && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
       float* out = a.partial + (((size_t)b * a.n_groups + g) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;

@@ -373,6 +373,22 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = ((C * F / 4) + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
+  // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
+  // master, nothing to continue): the mix workgroup clamps and stores the master itself — the sum kernel is not launched
+  bool fused = false;
+  {
+    static const bool off = [] { const char* v = std::getenv("WBX_FUSE_SUM"); return v && v[0] == '0'; }();   // A/B aid
+    fused = !off && K < kOverlapMinBlocks && n_groups == 1u && c->n_buses == 0u && m.tiles == 1u && !c->master_format && !c->dist &&
+            !m.init && !chained;
+    m.fused_master = nullptr;
+    if (fused) {
+      m.fused_master = master_dst;
+      m.fused_clamp = c->clamp ? 1u : 0u;
+      m.fused_status_src = c->status_dst ? PB(c).counters : nullptr;
+      m.fused_status_dst = c->status_dst;
+      m.fused_zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
+    }
+  }
   m.chain = nullptr;
   m.chain_status = nullptr;
   if (chained) {   // one "sum is out" word per (workgroup column, group), tagged with this render's epoch: no clearing
@@ -473,7 +489,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   }
   if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   if (ss == c->stream && ms != c->stream) c->alt_pending = -1;            // (the main stream has just joined that mix)
-  launch_sum(s, K, ss);
+  if (!fused) launch_sum(s, K, ss);
   if (stage_bytes) WBX_HIP(c, hipMemcpyAsync(master_home, master_dst, stage_bytes, hipMemcpyDeviceToHost, ss));
   if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
