@@ -14,7 +14,7 @@ def random_session(seed):
     rng = np.random.default_rng(seed)
     n_tracks = int(rng.integers(1, 28))
     block = int(rng.choice([64, 128, 256, 512]))
-    n_blocks = int(rng.integers(2, 7))
+    n_blocks = int(rng.integers(2, 13))   # (from 8 blocks on a render takes the batch instances, below the callback path's)
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))
     beat_frames = sr * 60.0 / bpm
@@ -61,7 +61,7 @@ def random_masked_session(seed, integer_unity=False, lean16=False, everything=Fa
         fmts = [["i24"], ["i16", "i24"], ["i16", "i24", "i32", "f32"], ["f32"], ["i32", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
     block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2), (128, 2), (512, 1), (256, 1)][int(rng.integers(0, 8))]
-    n_blocks = int(rng.integers(2, 7))
+    n_blocks = int(rng.integers(2, 13))   # (from 8 blocks on a render takes the batch instances, below the callback path's)
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))
     beat_frames = sr * 60.0 / bpm

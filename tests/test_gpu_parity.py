@@ -623,7 +623,7 @@ def _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels=2, gaps=T
 def test_clip_boundaries_in_the_hot_loop_every_format(fmts, rates):
     """... and for the sessions the everything family serves: resampled 24 / 32-bit PCM, 16-bit resampled beside other
     formats, 96 kHz clips (per-frame taps) — no pre-render queue entry for a block with one or two stream calls."""
-    n_blocks = 7
+    n_blocks = 9
     spec = _boundary_session(40, n_blocks, 512, 1.3)
     for i, smp in enumerate(spec.samples):
         smp.fmt = fmts[i % len(fmts)]
@@ -1157,20 +1157,30 @@ def test_kernel_timer_reports():
 def test_kernel_name_follows_the_session(monkeypatch):
     """wbx_kernel_name: resampled stereo 512-frame sessions take the instance with both channels of a frame in one lane
     (CL = 2), WBX_NO_CL2 the one-channel-per-wave instance; both give the same master bit for bit."""
-    spec = synth.make_session("r", 200, n_blocks=6, src_rate=44100, seek=True)   # (seek: clip boundaries inside blocks)
+    spec = synth.make_session("r", 200, n_blocks=8, src_rate=44100, seek=True)   # (seek: clip boundaries inside blocks)
     outs = {}
     for no_cl2 in (False, True):
         if no_cl2:
             monkeypatch.setenv("WBX_NO_CL2", "1")
-        eng = build_engine(spec, max_blocks=6)
+        eng = build_engine(spec, max_blocks=8)
         eng.play()
-        eng.render(6)
+        eng.render(8)
         m, pk, _ = eng.ctx.fetch(peaks=True)
         outs[no_cl2] = (m.copy(), pk.copy(), eng.ctx.kernel_name())
         eng.close()
     assert outs[False][2] == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"
     assert outs[True][2] == "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1, 256>"
     assert np.array_equal(outs[False][0], outs[True][0]) and np.array_equal(outs[False][1], outs[True][1])
+    # ... and a render of fewer than 8 blocks (the callback path: a handful of workgroups, each a chain of dependent rows)
+    # takes the wave-per-channel-half instance by itself: four waves share the chain instead of two
+    monkeypatch.delenv("WBX_NO_CL2")
+    eng = build_engine(spec, max_blocks=8)
+    eng.play()
+    eng.render(5)
+    m5, pk5, _ = eng.ctx.fetch(peaks=True)
+    assert eng.ctx.kernel_name() == "wbx::mix_kernel<2, true, 4, 0, 1, 1, 1, 256>"
+    assert np.array_equal(m5, outs[False][0][:5]) and np.array_equal(pk5, outs[False][1][:5])
+    eng.close()
 
 
 def test_cpp_host_through_the_adapter(tmp_path):

@@ -744,6 +744,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->has_cut_tracks = hs.cut_tracks != 0;
+  c->short_render_now = K < kOverlapMinBlocks;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance; reads the flags above)
   c->chain_now = render_chains_groups(c, K);
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
@@ -798,6 +799,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
   hs.clips_edited = false;
+  c->short_render_now = K < kOverlapMinBlocks;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance below)
   c->chain_now = render_chains_groups(c, K);
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them

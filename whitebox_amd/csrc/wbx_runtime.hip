@@ -283,6 +283,10 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
   if (c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
   if (!(F == 512u || F == 1024u || F == 256u)) return false;
+  // the callback path (a handful of workgroups, each a chain of dependent rows): a wave per channel half — four waves share
+  // the chain instead of two (measured, 4096 / 64 tracks: 16-bit resampled 53 -> 51 / 55 -> 49 us, cut into clips 63 -> 58 /
+  // 66 -> 58, 24-bit 55 -> 53 / 58 -> 53).  256-frame blocks keep the one-wave instances: only those take their masked rows.
+  if (c->short_render_now && F != 256u) return false;
   // a render whose workgroups walk whole member lists of many staged chunks: the half-size workgroups of these instances
   // put six of them on a CU, and the walk runs 15 % faster than through the four-wave ones (c3, 1024 blocks: 2.94 vs 3.43 ms)
   if (c->whole_lists_now && !c->chain_now && c->longest_list > 2u * kStage) return true;
@@ -1286,6 +1290,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   WBX_HIP(c, hipMemcpyAsync(PB(c).prows.p, c->h_rows.data(), c->h_rows.size() * sizeof(DRow), hipMemcpyHostToDevice, c->stream));
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
+  c->short_render_now = K < kOverlapMinBlocks;
   c->whole_lists_now = render_walks_whole_lists(c, K);
   c->chain_now = render_chains_groups(c, K);
   (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
