@@ -1391,6 +1391,18 @@ def test_random_sessions_match_oracle(seed):
     check_against_oracle(spec, n_blocks, expect_exact=True)
 
 
+@pytest.mark.parametrize("seed", [220, 270, 312, 426, 546])
+def test_bus_sums_of_the_first_long_render_after_a_routing_change(seed):
+    """Regression (found by the soak run once the random sessions drew renders of 8 blocks and more): sub-bus sums that
+    live in their own buffer are cleared once after a routing change — that memset used to run on the mix stream behind
+    the mix, while the sum of a render of >= 8 blocks runs beside on its own stream: it could wipe the bus sums the sum had
+    just written.  These seeds (3 sub-buses, random assignment, 8-12 blocks) hit it; the clear now precedes the sum on the
+    sum's stream."""
+    spec, n_blocks = FZ.random_session(seed)
+    assert spec.n_buses == 3 and n_blocks >= 8
+    check_against_oracle(spec, n_blocks, expect_exact=True)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ2_FROM", "0")), int(os.environ.get("WBX_FUZZ2_TO", "40"))))
 def test_random_sessions_grouped_and_callback(seed):
     """The same random sessions with small track groups (several chunks of records, ragged last group: plan rows,

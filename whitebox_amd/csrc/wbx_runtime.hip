@@ -485,13 +485,16 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
   s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
+  if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   if (c->n_buses && !buses_alias && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
-    // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4)
-    WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), ms));
+    // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4).
+    // On the SUM's stream, in front of the sum: cleared on the mix stream behind the mix, it raced with a sum that runs
+    // beside (renders of 8 blocks and more) and could wipe the bus sums of the first render after a routing change —
+    // found by the randomised sessions once they drew renders that long.
+    WBX_HIP(c, hipMemsetAsync(c->d_buses.p, 0, c->d_buses.cap * sizeof(float), ss));
     c->buses_clean = true;
   }
-  if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
   if (ss == c->stream && ms != c->stream) c->alt_pending = -1;            // (the main stream has just joined that mix)
   if (!fused) launch_sum(s, K, ss);
   if (stage_bytes) WBX_HIP(c, hipMemcpyAsync(master_home, master_dst, stage_bytes, hipMemcpyDeviceToHost, ss));
