@@ -1,5 +1,7 @@
 """Seeded random sessions and clip-edit scripts shared by the GPU parity tests (product engine vs oracle) and the
 CPU-side host tests (the product's host code + sequencer source vs oracle)."""
+import os
+
 import numpy as np
 
 import oracle_ffi as O
@@ -14,7 +16,8 @@ def random_session(seed):
     rng = np.random.default_rng(seed)
     n_tracks = int(rng.integers(1, 28))
     block = int(rng.choice([64, 128, 256, 512]))
-    n_blocks = int(rng.integers(2, 13))   # (from 8 blocks on a render takes the batch instances, below the callback path's)
+    # (from 8 blocks on a render takes the batch path and its instances, below the callback path's; WBX_FUZZ_MAX_BLOCKS: soak runs)
+    n_blocks = int(rng.integers(2, int(os.environ.get("WBX_FUZZ_MAX_BLOCKS", "12")) + 1))
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))
     beat_frames = sr * 60.0 / bpm
@@ -61,7 +64,8 @@ def random_masked_session(seed, integer_unity=False, lean16=False, everything=Fa
         fmts = [["i24"], ["i16", "i24"], ["i16", "i24", "i32", "f32"], ["f32"], ["i32", "f32"]][int(rng.integers(0, 5))]
     n_tracks = int(rng.choice([3, 17, 40, 130, 200]))
     block, channels = [(512, 2), (512, 2), (1024, 2), (1024, 1), (256, 2), (128, 2), (512, 1), (256, 1)][int(rng.integers(0, 8))]
-    n_blocks = int(rng.integers(2, 13))   # (from 8 blocks on a render takes the batch instances, below the callback path's)
+    # (from 8 blocks on a render takes the batch path and its instances, below the callback path's; WBX_FUZZ_MAX_BLOCKS: soak runs)
+    n_blocks = int(rng.integers(2, int(os.environ.get("WBX_FUZZ_MAX_BLOCKS", "12")) + 1))
     sr = 48000
     bpm = float(rng.choice([120.0, 97.0, 140.5]))
     beat_frames = sr * 60.0 / bpm
