@@ -1391,6 +1391,50 @@ def test_random_sessions_match_oracle(seed):
     check_against_oracle(spec, n_blocks, expect_exact=True)
 
 
+# WBX_FUZZ8_FROM / WBX_FUZZ8_TO widen the seed range for a soak run (default: seeds 0..23)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ8_FROM", "0")), int(os.environ.get("WBX_FUZZ8_TO", "24"))))
+def test_random_sessions_rendered_in_random_pieces(seed, monkeypatch):
+    """One engine, one transport, the session rendered in pieces of random length — batch renders of 8-24 blocks (plan and
+    sum on their own streams, rings of three), short ones of 1-7 (everything on the main stream, the callback path's
+    instances, one-group sessions without a sum launch) and single Engine::process calls, in random order: every piece
+    equals the oracle's blocks at that position (peaks, sub-bus sums and master bit for bit — fewer tracks than a group),
+    so nothing is lost or reordered when the path changes from one render to the next."""
+    rng = np.random.default_rng(0x91EC + seed)
+    kind = ["plain", "masked", "integer", "lean16", "everything"][seed % 5]
+    monkeypatch.setenv("WBX_FUZZ_MAX_BLOCKS", "64")   # (sessions of up to 64 blocks: clips all the way through)
+    if kind == "plain":
+        spec, total = FZ.random_session(seed)
+    else:
+        spec, total = FZ.random_masked_session(seed, integer_unity=kind == "integer", lean16=kind == "lean16", everything=kind == "everything")
+    total += 3                                          # (... and a few blocks past the end of the last clip)
+    if spec.n_tracks > 128:
+        pytest.skip("more tracks than one group: the grouped order is compared elsewhere")
+    om, opk, obus, _, otr = run_oracle(spec, total, want_buses=bool(spec.n_buses))
+    eng = build_engine(spec, max_blocks=24, group_size=max(spec.n_tracks, 1))
+    eng.play()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    done = 0
+    while done < total:
+        mode = int(rng.integers(0, 3))
+        k = 1 if mode == 0 else int(rng.integers(1, 8)) if mode == 1 else int(rng.integers(8, 25))
+        k = min(k, total - done)
+        if mode == 0:
+            eng.process(None, out, float(spec.sample_rate))
+            m = np.stack(out.channel_buffers)[None]
+            _, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        else:
+            eng.render(k)
+            m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        assert np.array_equal(bits(m), bits(om[done:done + k])), (done, k, mode)
+        assert np.array_equal(pk, opk[done:done + k, :, :spec.channels]), (done, k, mode)
+        if spec.n_buses:
+            assert np.array_equal(bits(bus), bits(obus[done:done + k])), (done, k, mode)
+        done += k
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(otr[0]), O.f64_bits(otr[1]))
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", [220, 270, 312, 426, 546])
 def test_bus_sums_of_the_first_long_render_after_a_routing_change(seed):
     """Regression (found by the soak run once the random sessions drew renders of 8 blocks and more): sub-bus sums that
