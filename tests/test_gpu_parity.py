@@ -1226,6 +1226,68 @@ def test_clip_edits_match_oracle_lists_and_audio(seed):
     eng.close()
 
 
+@pytest.mark.parametrize("n_tracks", [6, 200])
+def test_short_render_behind_a_batch_render_in_flight(n_tracks):
+    """Regression (found by the edit scripts once they stopped fetching every render): a render of 8+ blocks leaves its sum
+    pending on the sum stream; a short render issued right behind it — nobody fetched, nothing synchronised — sums on the
+    main stream (a one-group session's mix even stores the master itself) into the same master buffer, and the batch
+    render's late sum overwrote the head of its blocks.  The main stream now waits for the pending sum first.  Forty
+    rounds of (10 blocks unfetched, then 1-3 blocks fetched), both session sizes: one group / several groups + sum launch."""
+    rounds, K = 40, 10
+    spec = synth.make_session("inflight", n_tracks, n_blocks=rounds * (K + 3), seed=0x1F17, src_rate=44100, amp=0.05)
+    om, _, _, _, _ = run_oracle(spec, rounds * (K + 3))
+    eng = build_engine(spec, max_blocks=K, group_size=n_tracks)
+    eng.play()
+    done = 0
+    for r in range(rounds):
+        eng.render(K)                      # not fetched: its sum is still pending when the next render is issued
+        done += K
+        k = 1 + r % 3
+        eng.render(k)
+        m, _, _ = eng.ctx.fetch()
+        assert np.array_equal(bits(m), bits(om[done:done + k])), (r, k)
+        done += k
+    eng.close()
+
+
+# WBX_FUZZ9_FROM / WBX_FUZZ9_TO widen the seed range for a soak run (default: seeds 2024..2031)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ9_FROM", "2024")), int(os.environ.get("WBX_FUZZ9_TO", "2032"))))
+def test_clip_edits_between_renders_of_random_length(seed):
+    """The same edit scripts, but between two edits the engine renders 1-12 blocks in one call — from 8 blocks on the batch
+    path: the plan on its own stream two renders ahead of its consumer, the sum beside the next mix, the clip table
+    re-uploaded (and the device's live clip flags merged back) while earlier renders may still be in flight."""
+    spec = FZ.edit_session_spec(seed)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=12)
+    e.enable_seglog()
+    rng = np.random.default_rng(seed ^ 0xB10C)
+    trail = []          # (k, fetched) of the renders so far: what a failure message needs
+
+    def on_block(step, op):
+        k = int(rng.integers(1, 13))
+        oms, opks, rows = [], [], []
+        for b in range(k):
+            om, _ = e.process()
+            oms.append(om)
+            opks.append(e.peaks())
+            rows += oracle_rows(e, b)
+        eng.render(k)
+        fetched = not rng.integers(0, 10) < 3
+        trail.append((k, fetched))
+        if not fetched:
+            return          # nobody waits for this render: the next edit meets it in flight (its results are checked through
+                            # the state every later render continues from)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert plan_rows(eng.fetch_plan()) == rows, (seed, step, op, trail[-4:])
+        bad = [b for b in range(k) if not np.array_equal(bits(m[b]), bits(oms[b]))]
+        badpk = [b for b in range(k) if not np.array_equal(pk[b], opks[b][:, :spec.channels])]
+        assert not bad and not badpk, (seed, step, op, bad, badpk, trail[-4:], spec.block, spec.channels)
+
+    FZ.run_edit_script(seed, spec, e, eng, on_block, steps=16)
+    e.close()
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # integer PCM streamed directly by the hot loop (SURVEY §8(f) next-2)
 # ---------------------------------------------------------------------------------------------------

@@ -379,6 +379,11 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.masked_rows = c->masked_rows ? 1u : 0u;
   // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
   // master, nothing to continue): the mix workgroup clamps and stores the master itself — the sum kernel is not launched
+  // A short render's sum runs on the main stream (and a one-group session's mix stores the master itself): neither may
+  // overtake the sum of a batch render that is still pending on the sum stream — they write the same master (and bus)
+  // buffers, and the late one would overwrite the head of the short render's blocks.  (Found by the edit scripts once they
+  // stopped fetching every render: nobody had made the main stream wait, because a fetch in between always had.)
+  if (ss == c->stream) WBX_HIP(c, join_sum(c));
   bool fused = false;
   {
     static const bool off = [] { const char* v = std::getenv("WBX_FUSE_SUM"); return v && v[0] == '0'; }();   // A/B aid
@@ -486,6 +491,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.status_dst = c->status_dst;
   s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
   if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+
   if (c->n_buses && !buses_alias && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
     // buffer only needs clearing when the routing or the allocation changed (64 MB per render saved on config 4).
