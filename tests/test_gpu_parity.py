@@ -1497,6 +1497,84 @@ def test_random_sessions_rendered_in_random_pieces(seed, monkeypatch):
     eng.close()
 
 
+# WBX_FUZZ10_FROM / WBX_FUZZ10_TO widen the seed range for a soak run (default: seeds 0..23)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_FUZZ10_FROM", "0")), int(os.environ.get("WBX_FUZZ10_TO", "24"))))
+def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
+    """The pieces again, now with what a host does between them — volume / pan / mute messages, stop, seek, play, a tempo
+    change — and with a third of the renders never fetched, so that the next control or render meets them in flight (the
+    parameter, patch and transport tables are rings the device reads in place; the sums of batch renders run beside what
+    follows).  Every fetched piece equals the oracle's blocks at that position."""
+    rng = np.random.default_rng(0xC0A7 + seed)
+    monkeypatch.setenv("WBX_FUZZ_MAX_BLOCKS", "64")
+    kind = ["plain", "masked", "integer", "lean16", "everything"][seed % 5]
+    if kind == "plain":
+        spec, total = FZ.random_session(seed)
+    else:
+        spec, total = FZ.random_masked_session(seed, integer_unity=kind == "integer", lean16=kind == "lean16", everything=kind == "everything")
+    if spec.n_tracks > 128 or spec.n_tracks == 0:
+        pytest.skip("more tracks than one group: the grouped order is compared elsewhere")
+    total += 12
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=24, group_size=spec.n_tracks)
+    e.play()
+    eng.play()
+    done, trail = 0, []
+    while done < total:
+        r = rng.random()
+        if r < 0.35:                                      # a parameter message (applied from the next block on, track.cpp:618-643)
+            t, what = int(rng.integers(0, spec.n_tracks)), int(rng.integers(0, 3))
+            if what == 0:
+                v = float(rng.uniform(-30.0, 3.0))
+                e.set_volume(t, v)
+                eng.tracks[t].set_volume(v)
+            elif what == 1:
+                v = float(rng.uniform(-1.0, 1.0))
+                e.set_pan(t, v)
+                eng.tracks[t].set_pan(v)
+            else:
+                v = bool(rng.integers(0, 2))
+                e.set_mute(t, v)
+                eng.tracks[t].set_mute(v)
+            trail.append(("param", t, what))
+        elif r < 0.42:                                    # stop, seek, play
+            beat = float(rng.uniform(0.0, 0.3))
+            e.stop()
+            eng.stop()
+            e.set_playhead(beat)
+            eng.set_playhead_position(beat)
+            e.play()
+            eng.play()
+            trail.append(("seek", beat))
+        elif r < 0.46:
+            bpm = float(rng.choice([90.0, 120.0, 151.0]))
+            e.set_bpm(bpm)
+            eng.set_bpm(bpm)
+            trail.append(("bpm", bpm))
+        mode = int(rng.integers(0, 3))
+        k = 1 if mode == 0 else int(rng.integers(1, 8)) if mode == 1 else int(rng.integers(8, 25))
+        oms, opks, obus = [], [], []
+        for _ in range(k):
+            om, bu = e.process(want_buses=bool(spec.n_buses))
+            oms.append(om)
+            opks.append(e.peaks())
+            obus.append(bu)
+        eng.render(k)
+        fetched = rng.random() >= 0.33 or os.environ.get("WBX_FUZZ_ALWAYS_FETCH") == "1"   # (diagnosis aid)
+        trail.append((k, fetched))
+        done += k
+        if not fetched:
+            continue
+        m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        bad = [b for b in range(k) if not np.array_equal(bits(m[b]), bits(oms[b]))]
+        badpk = [b for b in range(k) if not np.array_equal(pk[b], opks[b][:, :spec.channels])]
+        badbus = [b for b in range(k) if spec.n_buses and not np.array_equal(bits(bus[b]), bits(obus[b]))]
+        assert not bad and not badpk and not badbus, (seed, bad, badpk, badbus, trail[-6:], spec.block, spec.channels, spec.n_tracks)
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
+    e.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", [220, 270, 312, 426, 546])
 def test_bus_sums_of_the_first_long_render_after_a_routing_change(seed):
     """Regression (found by the soak run once the random sessions drew renders of 8 blocks and more): sub-bus sums that

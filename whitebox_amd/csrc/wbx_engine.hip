@@ -64,6 +64,11 @@ struct wbx_engine {
   // is held only while the take is ENQUEUED behind the renders in flight, never across the wait for it
   hipStream_t levels_stream = nullptr;
   hipEvent_t levels_ev = nullptr;
+  // the sequencer of render n+1 continues from the per-track state render n's left: on one stream that is the stream's
+  // order; when the stream changes (short renders plan on the main stream, batch renders on the plan stream) the new one
+  // waits for this event, recorded at the old one's tail
+  hipStream_t last_plan_stream = nullptr;
+  hipEvent_t plan_handover = nullptr;
   uint32_t* h_levels = nullptr;         // [max_tracks][2]
 };
 
@@ -135,6 +140,7 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
     (void)hipStreamDestroy(e->levels_stream);
   }
   if (e->levels_ev) (void)hipEventDestroy(e->levels_ev);
+  if (e->plan_handover) (void)hipEventDestroy(e->plan_handover);
   if (e->h_levels) (void)hipHostFree(e->h_levels);
   e->d_clips.release();
   e->d_clip_first.release();
@@ -838,6 +844,15 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, hipEventRecord(e->times_done[ts], ps));
     e->times_valid[ts] = true;
   }
+  if (e->last_plan_stream && e->last_plan_stream != ps) {
+    // (found by the random-pieces test once it left renders unfetched: a batch render's plan, on the idle plan stream,
+    //  overtook the plan of a short render still queued on the main stream behind earlier mixes and read the state before
+    //  that one had written it)
+    if (!e->plan_handover) WBX_EHIP(e, hipEventCreateWithFlags(&e->plan_handover, hipEventDisableTiming));
+    WBX_EHIP(e, hipEventRecord(e->plan_handover, e->last_plan_stream));
+    WBX_EHIP(e, hipStreamWaitEvent(ps, e->plan_handover, 0));
+  }
+  e->last_plan_stream = ps;
   launch_plan(a, ps);
   if (!e->in_process) {
     if (patch_slot >= 0) {
