@@ -1511,13 +1511,17 @@ def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
         spec, total = FZ.random_session(seed)
     else:
         spec, total = FZ.random_masked_session(seed, integer_unity=kind == "integer", lean16=kind == "lean16", everything=kind == "everything")
-    if spec.n_tracks > 128 or spec.n_tracks == 0:
-        pytest.skip("more tracks than one group: the grouped order is compared elsewhere")
+    if spec.n_tracks == 0:
+        pytest.skip("no tracks")
     total += 12
+    # one workgroup walks all tracks (the reference's order: bit-exact) — or, every other seed, groups of 16 and a sum launch
+    # (several groups also in short renders; the master then within the RMS budget, peaks and sub-bus membership still exact)
+    exact = seed % 2 == 0 or spec.n_buses
     e = O.build_oracle_engine(spec)
-    eng = build_engine(spec, max_blocks=24, group_size=spec.n_tracks)
+    eng = build_engine(spec, max_blocks=24, group_size=spec.n_tracks if exact else 16)
     e.play()
     eng.play()
+    cb_out = W.AudioBuffer(spec.block, spec.channels)
     done, trail = 0, []
     while done < total:
         r = rng.random()
@@ -1558,14 +1562,23 @@ def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
             oms.append(om)
             opks.append(e.peaks())
             obus.append(bu)
-        eng.render(k)
-        fetched = rng.random() >= 0.33 or os.environ.get("WBX_FUZZ_ALWAYS_FETCH") == "1"   # (diagnosis aid)
-        trail.append((k, fetched))
         done += k
-        if not fetched:
-            continue
-        m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
-        bad = [b for b in range(k) if not np.array_equal(bits(m[b]), bits(oms[b]))]
+        if mode == 0 and rng.random() < 0.5:              # the audio callback itself (waits for its block), amid whatever is in flight
+            eng.process(None, cb_out, float(spec.sample_rate))
+            trail.append(("process",))
+            m = np.stack(cb_out.channel_buffers)[None]
+            _, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        else:
+            eng.render(k)
+            fetched = rng.random() >= 0.33 or os.environ.get("WBX_FUZZ_ALWAYS_FETCH") == "1"   # (diagnosis aid)
+            trail.append((k, fetched))
+            if not fetched:
+                continue
+            m, pk, bus = eng.ctx.fetch(peaks=True, buses=bool(spec.n_buses))
+        if exact:
+            bad = [b for b in range(k) if not np.array_equal(bits(m[b]), bits(oms[b]))]
+        else:
+            bad = [b for b in range(k) if rms(m[b], oms[b]) > RMS_TOL]
         badpk = [b for b in range(k) if not np.array_equal(pk[b], opks[b][:, :spec.channels])]
         badbus = [b for b in range(k) if spec.n_buses and not np.array_equal(bits(bus[b]), bits(obus[b]))]
         assert not bad and not badpk and not badbus, (seed, bad, badpk, badbus, trail[-6:], spec.block, spec.channels, spec.n_tracks)
