@@ -1522,11 +1522,11 @@ def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
     e.play()
     eng.play()
     cb_out = W.AudioBuffer(spec.block, spec.channels)
-    done, trail = 0, []
+    done, trail, nt = 0, [], spec.n_tracks
     while done < total:
         r = rng.random()
         if r < 0.35:                                      # a parameter message (applied from the next block on, track.cpp:618-643)
-            t, what = int(rng.integers(0, spec.n_tracks)), int(rng.integers(0, 3))
+            t, what = int(rng.integers(0, nt)), int(rng.integers(0, 3))
             if what == 0:
                 v = float(rng.uniform(-30.0, 3.0))
                 e.set_volume(t, v)
@@ -1554,6 +1554,22 @@ def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
             e.set_bpm(bpm)
             eng.set_bpm(bpm)
             trail.append(("bpm", bpm))
+        elif r < 0.50 and nt > 1:                          # the track list itself: the device state follows its Track
+            a, b = int(rng.integers(0, nt)), int(rng.integers(0, nt))
+            e.move_track(a, b)
+            eng.move_track(a, b)
+            trail.append(("move", a, b))
+        elif r < 0.53:
+            t = int(rng.integers(0, nt))
+            e.solo_track(t)
+            eng.solo_track(t)
+            trail.append(("solo", t))
+        elif r < 0.55 and nt > 2 and not spec.n_buses:
+            t = int(rng.integers(0, nt))
+            e.delete_track(t)
+            eng.delete_track(t)
+            nt -= 1
+            trail.append(("delete", t))
         mode = int(rng.integers(0, 3))
         k = 1 if mode == 0 else int(rng.integers(1, 8)) if mode == 1 else int(rng.integers(8, 25))
         oms, opks, obus = [], [], []
