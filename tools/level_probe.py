@@ -2,7 +2,7 @@
 """tools/level_probe.py — where the grouped summation order stands against the 1e-6 RMS budget as the session gets hotter.
 
 The reference adds tracks strictly sequentially (engine.cpp:1600-1617).  Renders shorter than 1024 blocks — and the
-one-block audio callback — add 128-track (64 / 32-track) groups in order and then the group sums: per-track values are
+one-block audio callback — add 128-track (64 / 32 / 16-track) groups in order and then the group sums: per-track values are
 identical, only the association of the fp32 additions differs, and that error scales with the level of the running sum.
 This prints, for N = 4096 (c3: 44.1 kHz clips; c4: 64 buses) and the 8-way sharded N = 32768 (c5), RMS and max-abs of
 (device master - oracle master) at session levels amp = m / sqrt(N), m = 0.25 (the synthetic default) ... 4, with the
@@ -54,7 +54,7 @@ def main():
             amp = float(np.float32(m / math.sqrt(N)))
             spec = synth.make_session(name, N, n_blocks=K, seed=0x5EED0003, amp=amp, **kw)
             om = oracle_master(spec, K)
-            for label, gs, mb in (("128 (render-ahead)", 0, K), ("32 (callback)", 0, 1), ("whole list", N, K)):
+            for label, gs, mb in (("128 (render-ahead)", 0, K), ("16 (callback)", 0, 1), ("whole list", N, K)):
                 if label != "128 (render-ahead)" and name == "c4":
                     continue
                 eng = build_engine(spec, max_blocks=mb, group_size=gs)

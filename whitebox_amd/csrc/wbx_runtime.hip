@@ -60,7 +60,9 @@ void drain_events(wbx_ctx* c) {
 // audio_buffer.h:73-82: bit-exact master).  Which set a render takes: render_walks_whole_lists().
 void build_routing(wbx_ctx* c, uint32_t n_tracks) {
   uint32_t G = c->cfg.group_size;
-  if (c->auto_group && c->cfg.max_blocks == 1 && n_tracks > 64u) G = kStage / 4;   // the callback configuration, large session
+  // the callback configuration, large session: more workgroups for the one block — 32-track groups, 16 from 1024 tracks on
+  // (4096 tracks: 256 workgroups, one per CU; 49.5 -> 47.0 us per block, tools/ab.py latency_groups)
+  if (c->auto_group && c->cfg.max_blocks == 1 && n_tracks > 64u) G = n_tracks > 1024u ? kStage / 8 : kStage / 4;
   c->order.clear();
   c->groups.clear();
   c->groups_exact.clear();
