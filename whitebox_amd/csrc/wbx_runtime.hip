@@ -576,7 +576,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
   // default 128: one staging round per workgroup; a context that can only render one block per call (the audio
-  // callback) takes 64, and 32 for sessions of more than 64 tracks (build_routing) — more workgroups for the one block,
+  // callback) takes 64, 32 for sessions of more than 64 tracks and 16 above 1024 (build_routing) — more workgroups for the one block,
   // whose mix is a latency chain per workgroup; the block's group sums are then added by sum_kernel<32> in four rounds
   // of loads.  Sessions of up to 64 tracks stay one group: the reference's summation order, bit for bit.
   c->auto_group = c->cfg.group_size == 0;
