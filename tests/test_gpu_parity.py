@@ -1564,6 +1564,11 @@ def test_random_pieces_with_controls_and_renders_in_flight(seed, monkeypatch):
             e.solo_track(t)
             eng.solo_track(t)
             trail.append(("solo", t))
+        elif r < 0.58 and spec.n_buses:                    # routing: a track moves to another sub-bus (or straight to the master)
+            t, b = int(rng.integers(0, nt)), int(rng.integers(-1, spec.n_buses))
+            e.set_bus(t, b)
+            eng.tracks[t].set_bus(b)
+            trail.append(("bus", t, b))
         elif r < 0.55 and nt > 2 and not spec.n_buses:
             t = int(rng.integers(0, nt))
             e.delete_track(t)
