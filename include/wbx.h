@@ -184,6 +184,14 @@ wbx_status wbx_fetch_interleaved(wbx_ctx* ctx, int out_format, void* dst);  /* K
  * available.  Not with a multi-GPU exchange (partial masters stay planar fp32). */
 wbx_status wbx_set_master_format(wbx_ctx* ctx, int out_format);
 wbx_status wbx_sync(wbx_ctx* ctx);
+/* Waits like wbx_sync and reports what no other call may have had the chance to: a render of >= 1024 blocks that adds in
+ * the reference's order as chained 128-track pieces checks every hand-over between its workgroups, and a failed one makes
+ * that render's master INVALID (WBX_ERR_DEVICE; later renders walk whole member lists instead).  wbx_fetch,
+ * wbx_fetch_interleaved, wbx_engine_process, wbx_engine_fetch_plan and wbx_dist_sync return that status themselves; a
+ * host that reads a caller-owned master target (wbx_set_master_target) directly — it never fetches — must call this
+ * (or one of those) before it trusts the buffer.  The failure is latched: every render since the last report counts.
+ * Replaces nothing in the reference (engine.cpp:1600-1617 is one thread, one order). */
+wbx_status wbx_render_status(wbx_ctx* ctx);
 /* Order `stream` (a hipStream_t; NULL = the ctx stream) after every kernel that writes the results of the last
  * submit / render (master, bus sums, peaks).  The sum of a render runs on a stream of its own beside the next mix:
  * work the CALLER enqueues that reads a caller-owned master target (wbx_set_master_target) — a collective, a copy,

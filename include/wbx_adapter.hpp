@@ -142,10 +142,11 @@ struct Error : std::runtime_error {
 struct Engine;
 
 // The audio-side half of engine/vu_meter.h (push_samples, :20-30) runs on the GPU as running per-track maxima;
-// Engine::fetch_levels() moves them in here with the reference's CAS-max.  The UI-rate decay (VUMeter::update /
-// get_value) is not part of this path: the host keeps its own meter for that and feeds it take_level().
+// Engine::fetch_levels() moves them in here with the reference's CAS-max.  update() / get_value() keep the UI code that
+// is written against Track::level_meter compiling unchanged (ui/controls.cpp: level_meter[c].update(...), .get_value()).
 struct VUMeter {
   std::atomic<float> level{0.0f};
+  float current_level = 0.0f;   // vu_meter.h:18
   void push_level(float peak) {   // the CAS-max tail of VUMeter::push_samples, vu_meter.h:26-29
     float seen = level.load(std::memory_order_relaxed);
     while (seen < peak && !level.compare_exchange_weak(seen, peak, std::memory_order_release, std::memory_order_relaxed)) {
@@ -153,6 +154,18 @@ struct VUMeter {
   }
   // the maximum since the last call; resets it (what the host's own VUMeter::update starts from)
   float take_level() { return level.exchange(0.0f, std::memory_order_acq_rel); }
+  // UI rate, vu_meter.h:32-44: the meter jumps up to a new maximum at once and falls back towards the newest one through a
+  // one-pole release whose time constant is 1 / (frame_rate * speed) frames
+  void update(float frame_rate, float speed) {
+    const float peak = take_level();
+    if (peak > current_level) {
+      current_level = peak;
+      return;
+    }
+    const float release = 1.0f - std::exp(-1.0f / (frame_rate * speed));
+    current_level += (peak - current_level) * release;
+  }
+  float get_value() const { return current_level; }
 };
 
 struct Track {   // track.h:110-139

@@ -260,8 +260,10 @@ void wbo_sampler_stream(wbo_sampler* s, const wbo_sample* smp, uint32_t num_chan
 }
 
 /* dst_frames: size of the destination buffers.  When Track::process hands Sampler::stream an event_length that
- * wrapped around (uint32 arithmetic at track.cpp:669 with events out of buffer order — possible after edits
- * while playing), the reference writes past the end of the block buffer: undefined behaviour.  Oracle and
+ * wrapped around (uint32 arithmetic at track.cpp:669 with events out of buffer order — after edits while playing,
+ * and WITHOUT any edit when a clip edge falls exactly on a block edge: `% buffer_size` at track.cpp:359-361,423-425
+ * then yields buffer_offset 0 for an event that belongs to the END of the block, behind events with larger
+ * offsets), the reference writes past the end of the block buffer: undefined behaviour.  Oracle and
  * product both DEFINE that case: the write is clipped to the block, the sampler offset still advances by
  * the full (wrapped) length exactly as sampler.cpp:103,209 compute it. */
 static void sampler_stream_impl(wbo_sampler* s, const wbo_sample* smp, uint32_t num_channels, uint32_t num_samples,
@@ -364,7 +366,10 @@ wbo_engine* wbo_engine_create(uint32_t out_channels, uint32_t buffer_size, uint3
 
 void wbo_engine_destroy(wbo_engine* e) {
   if (!e) return;
-  for (uint32_t i = 0; i < e->n_tracks; i++) free(e->tracks[i].clips);
+  for (uint32_t i = 0; i < e->n_tracks; i++) {
+    free(e->tracks[i].clips);
+    free(e->tracks[i].free_uids);
+  }
   free(e->tracks);
   free(e->samples);
   for (int c = 0; c < 16; c++) free(e->mixbuf[c]);
@@ -444,6 +449,7 @@ int wbo_engine_add_track(wbo_engine* e) {
 /* engine.cpp:210-218 (the track object goes away with everything it owns) */
 void wbo_engine_delete_track(wbo_engine* e, uint32_t slot) {
   free(e->tracks[slot].clips);
+  free(e->tracks[slot].free_uids);
   memmove(&e->tracks[slot], &e->tracks[slot + 1], (e->n_tracks - slot - 1) * sizeof(wbo_track));
   e->n_tracks--;
 }
@@ -641,25 +647,49 @@ static int cmp_clip(const void* a, const void* b) {
   return (x > y) - (x < y);
 }
 
-/* Track::update_clip_ordering, track.cpp:159-180: drop deleted clips, sort by min_time */
+/* Pool<Clip>::free (core/memory.h:80-86) as Track::destroy_clip calls it (track.h:165-168): the chunk is zeroed and pushed
+ * on the head of the pool's free list */
+static void free_clip_uid(wbo_track* t, uint32_t uid) {
+  if (t->n_free_uids == t->cap_free_uids) {
+    t->cap_free_uids = t->cap_free_uids ? t->cap_free_uids * 2 : 8;
+    t->free_uids = (uint32_t*)realloc(t->free_uids, t->cap_free_uids * sizeof(uint32_t));
+  }
+  t->free_uids[t->n_free_uids++] = uid;
+}
+
+/* Pool<Clip>::allocate (core/memory.h:65-78) as Track::allocate_clip calls it (track.h:156-158): the head of the free
+ * list — the chunk freed LAST — else a chunk that has never been used */
+static uint32_t alloc_clip_uid(wbo_engine* e, wbo_track* t) {
+  if (t->n_free_uids) return t->free_uids[--t->n_free_uids];
+  return ++e->next_clip_uid;
+}
+
+/* Track::update_clip_ordering, track.cpp:159-180: drop deleted clips (destroyed at once, in list order: :170-172), sort
+ * by min_time */
 static void update_clip_ordering(wbo_track* t) {
   uint32_t n = 0;
-  for (uint32_t i = 0; i < t->n_clips; i++)
-    if (!t->clips[i].deleted) t->clips[n++] = t->clips[i];
+  for (uint32_t i = 0; i < t->n_clips; i++) {
+    if (t->clips[i].deleted)
+      free_clip_uid(t, t->clips[i].uid);
+    else
+      t->clips[n++] = t->clips[i];
+  }
   t->n_clips = n;
   qsort(t->clips, t->n_clips, sizeof(wbo_clip), cmp_clip);
 }
 
-static wbo_clip* push_clip(wbo_engine* e, wbo_track* t) {
+static wbo_clip* push_clip_uid(wbo_track* t, uint32_t uid) {
   if (t->n_clips == t->cap_clips) {
     t->cap_clips = t->cap_clips ? t->cap_clips * 2 : 4;
     t->clips = (wbo_clip*)realloc(t->clips, t->cap_clips * sizeof(wbo_clip));
   }
   wbo_clip* c = &t->clips[t->n_clips++];
   memset(c, 0, sizeof(*c));
-  c->uid = ++e->next_clip_uid;
+  c->uid = uid;
   return c;
 }
+
+static wbo_clip* push_clip(wbo_engine* e, wbo_track* t) { return push_clip_uid(t, alloc_clip_uid(e, t)); }
 
 static double clip_shift(const wbo_engine* e, const wbo_clip* c, double relative_pos) {
   return wbo_shift_clip_content(c->start_offset, c->speed, (double)e->samples[c->sample].sample_rate, relative_pos,
@@ -678,7 +708,9 @@ static void reserve_track_region(wbo_engine* e, wbo_track* t, uint32_t first_cli
       wbo_clip* nc = push_clip(e, t);                              /* may move t->clips */
       clip = &t->clips[first_clip];
       uint32_t uid = nc->uid;
-      *nc = copy;
+      *nc = copy;                                                  /* Clip(const Clip&), clip.h:91-111: `deleted` and */
+      nc->internal_state_changed = 0;                              /* `internal_state_changed` keep their defaults   */
+      nc->deleted = 0;
       nc->uid = uid;
       nc->min_time = max;
       nc->start_offset = clip_shift(e, nc, clip->min_time - max);
@@ -718,8 +750,9 @@ int wbo_engine_add_audio_clip(wbo_engine* e, int track, double min_time, double 
   const int front = !empty && !back && t->clips[0].min_time > max_time;
   uint32_t qf = 0, ql = 0;
   const int hit = (!empty && !back && !front) ? query_clip_by_range(t, min_time, max_time, &qf, &ql) : 0;
+  const uint32_t uid = alloc_clip_uid(e, t);                       /* :302 the Clip object exists before the list is touched */
   if (hit) reserve_track_region(e, t, qf, ql, min_time, max_time, 0);
-  wbo_clip* c = push_clip(e, t);
+  wbo_clip* c = push_clip_uid(t, uid);
   c->min_time = min_time;
   c->max_time = max_time;
   c->start_offset = start_offset;
@@ -957,7 +990,15 @@ static void log_stream(wbo_engine* e, const wbo_track* t, uint32_t dst_start, ui
 }
 
 /* current_audio_event.clip->audio.gain is read at every stream call (track.cpp:676,716): follow the clip by
- * identity so that set_clip_gain takes effect on the clip that is already playing */
+ * identity so that set_clip_gain takes effect on the clip that is already playing.
+ *
+ * Quirk Q10 — the clip that is sounding was destroyed by an edit (delete_clip, delete_region, or an add / move / resize
+ * whose reserve_track_region covered it): Track::update_clip_ordering destroys it at once (track.cpp:159-175),
+ * Pool::free zeroes its chunk (core/memory.h:80-86), no event follows for the track, and Track::process keeps streaming
+ * current_audio_event through the dangling pointer: `gain` reads 0.0f — the sampler keeps advancing, the track is
+ * silent until its next event.  (Use after free in the reference, deterministic in the compiled engine: the chunk stays
+ * mapped.)  When a later add / split on the same track takes the chunk over, the read returns the NEW clip's gain: the
+ * uid stands for the chunk (alloc_clip_uid / free_clip_uid), so the search below finds exactly that clip. */
 static void refresh_current_gain(wbo_track* t) {
   if (t->current_event.type != WBO_EV_PLAY) return;
   for (uint32_t i = 0; i < t->n_clips; i++)
@@ -965,6 +1006,7 @@ static void refresh_current_gain(wbo_track* t) {
       t->cur_gain = t->clips[i].gain;
       return;
     }
+  t->cur_gain = 0.0f;
 }
 
 /* track.cpp:587-736 (no plugin: write_buffer == output_buffer; Q6 fenced off) */

@@ -89,7 +89,8 @@ typedef struct wbo_clip {     /* src/engine/clip.h:39-45,55-75 (audio fields onl
   int sample;                 /* index into engine sample table */
   int internal_state_changed;
   int deleted;                /* Clip::deleted (clip.h:63), swept by update_clip_ordering */
-  uint32_t uid;               /* stable identity: the reference holds Clip* pointers across re-sorts */
+  uint32_t uid;               /* identity = the pool chunk of the Clip object (the reference holds Clip* pointers across
+                               * re-sorts); unique among live clips, re-used LIFO per track like Pool<Clip>'s chunks */
 } wbo_clip;
 
 typedef struct wbo_event {    /* src/engine/event.h:66-74 */
@@ -121,6 +122,10 @@ typedef struct wbo_track {
   float block_peak[2];                                /* max|m| of the last processed block */
   int bus;                                            /* extension A13: sub-bus id, -1 = none */
   int ui_solo;                                        /* ui_parameter_state.solo, track.h:52 (UI flag read by solo_track) */
+  /* Track::clip_allocator (track.h:105, core/memory.h:40-86): a clip's uid stands for the pool chunk its Clip object lives
+   * in.  Pool::free pushes the chunk on a LIFO free list and Pool::allocate pops it, so a clip created after another one
+   * was destroyed takes over that one's chunk — and its identity for anything still pointing at the chunk. */
+  uint32_t* free_uids; uint32_t n_free_uids, cap_free_uids;
 } wbo_track;
 
 typedef struct wbo_seglog {  /* one Sampler::stream call issued by Track::process (track.cpp:678,718) */

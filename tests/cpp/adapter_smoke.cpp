@@ -72,6 +72,15 @@ int main() {
   g_engine.fetch_levels();
   if (!(g_engine.tracks[0]->level_meter[0].take_level() > 0.0f) || !(g_engine.tracks[1]->level_meter[1].take_level() > 0.0f)) return 4;
   if (g_engine.tracks[0]->level_meter[0].take_level() != 0.0f) return 4;   // (read and reset)
+  {   // the UI-rate half the reference's controls call on Track::level_meter (vu_meter.h:32-44): attack at once, release by a one-pole
+    wbx::VUMeter& vm = g_engine.tracks[1]->level_meter[0];
+    vm.push_level(0.5f);
+    vm.update(60.0f, 0.25f);
+    if (vm.get_value() != 0.5f) return 4;
+    vm.update(60.0f, 0.25f);            // nothing new: falls by (1 - exp(-1/15)) of the way to 0
+    const float expect = 0.5f + (0.0f - 0.5f) * (1.0f - std::exp(-1.0f / (60.0f * 0.25f)));
+    if (vm.get_value() != expect || !(vm.get_value() < 0.5f)) return 4;
+  }
   // the effect slot exists and stays empty
   wbx_plugin fx{nullptr, nullptr};
   if (g_engine.add_plugin_to_track(t0, &fx) != nullptr || t0->plugin_instance != nullptr) return 5;

@@ -121,11 +121,13 @@ def edit_session_spec(seed):
     return spec
 
 
-def run_edit_script(seed, spec, e, eng, on_block, steps=24):
+def run_edit_script(seed, spec, e, eng, on_block, steps=24, sounding_bias=True):
     """The same random edits through the oracle `e` and an engine `eng` with the reference-shaped method names
     (whitebox_amd.engine.Engine or tests/host_sim.HostSimEngine); after every edit the sorted clip lists must agree
-    bit for bit, then on_block(step, op) renders one block on both and compares what it can."""
+    bit for bit, then on_block(step, op) renders one block on both and compares what it can.  Returns the number of
+    (block, track) pairs that streamed through a destroyed clip (quirk Q10)."""
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed ^ 0xD46)
     n_tracks, beat = spec.n_tracks, 24000.0
 
     def both(fn_o, fn_p):
@@ -147,12 +149,52 @@ def run_edit_script(seed, spec, e, eng, on_block, steps=24):
         assert clip_rows(eng.clips(eng.tracks[t])) == clip_rows(e.clips(t)), t
     e.play()
     eng.play()
+    hits = 0
     for step in range(steps):
         # one edit per step on a random track, then one block
         t = int(rng.integers(0, n_tracks))
         n = len(e.clips(t))
         op = int(rng.integers(0, 6))
-        if n and op == 0:
+        # A third of the steps aim at the clip that is SOUNDING (quirk Q10: an edit destroys it, no event follows, the
+        # reference streams on through the freed Clip whose gain now reads 0.0f — or the gain of a newer clip that took
+        # the pool chunk over).  Ops 6-8 are drawn from a generator of their own so that the scripts of earlier rounds
+        # keep their op sequence where no such op is drawn.
+        ph = e.playhead
+        if sounding_bias and rng2.random() < 0.34:
+            playing = [tt for tt in range(n_tracks) if e.sounding(tt)]
+            if playing:
+                t = int(rng2.choice(playing))
+                n = len(e.clips(t))
+                op = int(rng2.integers(6, 10))
+        if op == 6:      # a new clip over the playhead: reserve_track_region trims / deletes what is playing
+            mn = max(0.0, ph - float(rng2.uniform(0, 3000)) / beat)
+            mx = ph + float(rng2.uniform(600, 4000)) / beat
+            g = float(np.float32(rng2.choice([1.0, 0.5, 0.25])))
+            both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, g),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, g))
+        elif op == 7:    # the next clip's left edge dragged back across the playhead (no shift / stretch: no state change)
+            cl = e.clips(t)
+            nxt = [i for i, c in enumerate(cl) if c[0] > ph]
+            if nxt:
+                i = nxt[0]
+                rel = -(cl[i][0] - ph) - float(rng2.uniform(100, 3000)) / beat
+                both(lambda: e.resize_clip(t, i, rel, 0.0, 1.0 / 96.0, True, False, False),
+                     lambda: eng.resize_clip(eng.tracks[t], i, rel, 0.0, 1.0 / 96.0, True, False, False))
+            else:
+                mn, mx = max(0.0, ph - 2000.0 / beat), ph + 2500.0 / beat
+                both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, 1.0),
+                     lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, 1.0))
+        elif op == 8:    # a region delete around the playhead
+            mn = max(0.0, ph - float(rng2.uniform(0, 6000)) / beat)
+            mx = ph + float(rng2.uniform(100, 6000)) / beat
+            both(lambda: e.delete_region(t, mn, mx), lambda: eng.delete_region(eng.tracks[t], mn, mx))
+        elif op == 9:    # a clip far ahead: it takes over the pool chunk of whatever the track destroyed last
+            mn = ph + float(rng2.uniform(6000, 9000)) / beat
+            mx = mn + float(rng2.uniform(300, 2000)) / beat
+            g = float(np.float32(rng2.choice([0.75, 0.5, 1.25])))
+            both(lambda: e.add_audio_clip(t, mn, mx, 0.0, t, 1.0, g),
+                 lambda: eng.add_audio_clip(eng.tracks[t], "c", mn, mx, 0.0, t, 1.0, g))
+        elif n and op == 0:
             i, rel = int(rng.integers(0, n)), float(rng.normal(0, 1500)) / beat
             both(lambda: e.move_clip(t, i, rel), lambda: eng.move_clip(eng.tracks[t], i, rel))
         elif n and op == 1:
@@ -178,3 +220,5 @@ def run_edit_script(seed, spec, e, eng, on_block, steps=24):
         for tt in range(n_tracks):
             assert clip_rows(eng.clips(eng.tracks[tt])) == clip_rows(e.clips(tt)), (step, op, tt)
         on_block(step, op)
+        hits += sum(1 for tt in range(n_tracks) if e.dangling(tt))
+    return hits

@@ -59,7 +59,8 @@ class _Track(C.Structure):
                 ("sampler", _Sampler),
                 ("volume", C.c_float), ("pan", C.c_float), ("pan_coeffs", C.c_float * 2), ("mute", C.c_int),
                 ("msgs", _Msg * 64), ("n_msgs", C.c_uint32),
-                ("level", C.c_float * 2), ("block_peak", C.c_float * 2), ("bus", C.c_int), ("ui_solo", C.c_int)]
+                ("level", C.c_float * 2), ("block_peak", C.c_float * 2), ("bus", C.c_int), ("ui_solo", C.c_int),
+                ("free_uids", C.c_void_p), ("n_free_uids", C.c_uint32), ("cap_free_uids", C.c_uint32)]
 
 
 class Clip(C.Structure):
@@ -350,6 +351,19 @@ class OracleEngine:
 
     def track(self, t) -> _Track:
         return self.e.contents.tracks[t]
+
+    def sounding(self, t) -> bool:
+        """current_audio_event of the track is a PlaySample (a Sampler::stream call follows in the next block)"""
+        return self.track(t).current_event.type == 2
+
+    def dangling(self, t) -> bool:
+        """the track streams through a clip an edit has destroyed (quirk Q10): current_audio_event.clip names a pool
+        chunk no live clip of the track occupies"""
+        tr = self.track(t)
+        if tr.current_event.type != 2:
+            return False
+        n = self.L.wbo_track_clip_count(self.e, t)
+        return all(self.L.wbo_track_clip(self.e, t, i).contents.uid != tr.cur_clip_uid for i in range(n))
 
     def events(self, t):
         tr = self.track(t)

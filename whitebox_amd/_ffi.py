@@ -83,6 +83,7 @@ SYMBOLS = {
     "wbx_fetch_interleaved": (C.c_int, [_vp, C.c_int, _vp]),
     "wbx_set_master_format": (C.c_int, [_vp, C.c_int]),
     "wbx_sync": (C.c_int, [_vp]),
+    "wbx_render_status": (C.c_int, [_vp]),
     "wbx_master_ready": (C.c_int, [_vp, _vp]),
     "wbx_partial_master": (C.c_int, [_vp, _pp, C.POINTER(_sz)]),
     "wbx_finalize_master": (C.c_int, [_vp, _vp, _u32, C.c_int, _vp]),

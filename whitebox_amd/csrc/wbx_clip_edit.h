@@ -151,8 +151,27 @@ inline bool query_clip_by_range(const std::vector<HostClip>& c, double min, doub
   return true;
 }
 
-// Track::update_clip_ordering, track.cpp:159-180
-inline void update_clip_ordering(std::vector<HostClip>& c) {
+// A clip's uid stands for the pool chunk its Clip object occupies in the reference (Track::clip_allocator, track.h:105):
+// Pool::free pushes a destroyed clip's chunk on a LIFO free list, Pool::allocate pops it (core/memory.h:65-86), so the
+// next clip created on the track takes over the chunk — and with it the identity of whatever still points there
+// (current_audio_event.clip of a clip that was sounding when an edit destroyed it, track.cpp:676,716).
+struct ClipIds {
+  std::vector<uint32_t> free_list;   // chunks of destroyed clips, most recently freed last
+  uint32_t* fresh;                   // the session's counter of never-used ids
+  uint32_t take() {
+    if (!free_list.empty()) {
+      const uint32_t id = free_list.back();
+      free_list.pop_back();
+      return id;
+    }
+    return ++*fresh;
+  }
+};
+
+// Track::update_clip_ordering, track.cpp:159-180: deleted clips are destroyed at once, in list order (:170-172)
+inline void update_clip_ordering(std::vector<HostClip>& c, ClipIds& ids) {
+  for (const HostClip& x : c)
+    if (x.deleted) ids.free_list.push_back(x.d.uid);
   c.erase(std::remove_if(c.begin(), c.end(), [](const HostClip& x) { return x.deleted; }), c.end());
   const auto by_start = [](const HostClip& a, const HostClip& b) { return a.d.min_time < b.d.min_time; };
   // appending in timeline order is the common edit: a linear check instead of a sort of thousands of clips
@@ -160,10 +179,10 @@ inline void update_clip_ordering(std::vector<HostClip>& c) {
 }
 
 // Engine::reserve_track_region, engine.cpp:478-569.  `rate_of(sample)` gives the asset's sample rate;
-// ignore_uid = 0 ignores nothing; `next_uid` numbers a clip created by a split.
+// ignore_uid = 0 ignores nothing; `ids` names a clip created by a split (track->clip_allocator.allocate(), :503).
 template <class RateOf>
 inline void reserve_track_region(std::vector<HostClip>& c, uint32_t first_clip, uint32_t last_clip, double min, double max,
-                                 uint32_t ignore_uid, double beat_duration, RateOf rate_of, uint32_t* next_uid) {
+                                 uint32_t ignore_uid, double beat_duration, RateOf rate_of, ClipIds& ids) {
   if (c.empty()) return;
   auto shifted = [&](const HostClip& k, double rel) {
     return shift_clip_content(k.d.start_offset, k.d.speed, rate_of(k.d.sample), rel, beat_duration);
@@ -171,8 +190,10 @@ inline void reserve_track_region(std::vector<HostClip>& c, uint32_t first_clip, 
   if (first_clip == last_clip) {   // :493-533
     if (c[first_clip].d.uid == ignore_uid) return;
     if (min > c[first_clip].d.min_time && max < c[first_clip].d.max_time) {   // the region splits the clip in two
-      HostClip right = c[first_clip];
-      right.d.uid = ++*next_uid;
+      HostClip right = c[first_clip];   // Clip(const Clip&), clip.h:91-111: internal_state_changed keeps its default
+      right.d.uid = ids.take();
+      right.d.internal_state_changed = 0;
+      right.flag_dirty = true;          // (a new object: no live device flag belongs to it, whatever its id named before)
       right.d.min_time = max;
       right.d.start_offset = shifted(right, c[first_clip].d.min_time - max);
       c[first_clip].d.max_time = min;

@@ -127,6 +127,7 @@ struct wbx_ctx {
   bool chain_now = false;             // ... as chained workgroup-sized pieces (render_chains_groups)
   uint32_t chain_epoch = 0;
   DevBuf<uint32_t> d_chain;           // chained renders: the "running sum is out" words
+  uint32_t* d_sticky_status = nullptr;   // failure bits (32 | 64) of every chained render since the last report (render_status)
   uint32_t exact_min_blocks = 1024;   // renders of at least this many blocks do, when the library picks the grouping
                                       // (WBX_EXACT_MIN_BLOCKS; 0 = never)
   DevBuf<uint32_t> d_order;
@@ -295,6 +296,7 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows);
 wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);
+wbx_status render_status(wbx_ctx* c);      // the latched hand-over failures of chained renders (the streams must be idle)
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err);
 bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K);
 bool render_chains_groups(const wbx_ctx* c, uint32_t K);
@@ -305,6 +307,7 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
 // wbx_dist.hip
 float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);
 const float* dist_mix_init(wbx_ctx* c, uint32_t K, hipStream_t mix_stream, wbx_status* st);
+bool dist_receives_running_sum(const wbx_ctx* c);   // chain mode, rank > 0: every render continues the previous rank's sum
 hipError_t dist_mix_issued(wbx_ctx* c, hipStream_t mix_stream);
 void dist_destroy(wbx_ctx* c);
 

@@ -223,6 +223,7 @@ struct MixArgs {
   uint32_t chain_epoch;         // this render's tag, 1 .. 2^28-1 (words are zeroed on allocation and when the tag wraps)
   uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
                                 // device's in-order workgroup dispatch is not what it is documented to be)
+  uint32_t* chain_sticky;       // ... and of this one, which belongs to the context and is cleared only when a host call reports it
   unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][4] start / end wall-clock ticks, HW_ID, XCC_ID, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise

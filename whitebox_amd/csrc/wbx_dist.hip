@@ -143,6 +143,10 @@ float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err) {
   return d->master[d->slot];
 }
 
+bool dist_receives_running_sum(const wbx_ctx* c) {
+  return c->dist && c->dist->mode == WBX_DIST_CHAIN && c->dist->rank > 0;
+}
+
 // called by launch_mix_sum after dist_begin_render and before the mix launch: what this render's sum starts from.  Chain
 // mode, rank > 0: the receive of rank - 1's running master for this render is enqueued on the exchange stream and the mix
 // stream is made to wait for it.
@@ -408,7 +412,7 @@ extern "C" wbx_status wbx_dist_sync(wbx_ctx* c) {
   WBX_HIP(c, hipStreamSynchronize(c->dist->comm_stream));
   drain_events(c);
   drain_exchange_timers(c->dist);
-  return WBX_OK;
+  return render_status(c);   // (a chained render whose hand-over failed has handed an invalid partial on: say so)
 }
 
 extern "C" wbx_status wbx_dist_result_rank(wbx_ctx* c, uint32_t* rank) {

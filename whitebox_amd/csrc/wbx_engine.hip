@@ -181,6 +181,7 @@ extern "C" wbx_status wbx_engine_set_audio_channel_config(wbx_engine* e, uint32_
   WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, hipStreamSynchronize(c->sum_stream));
   WBX_EHIP(e, sync_main(c));
+  WBX_EHIP(e, hipStreamSynchronize(e->levels_stream));   // (a meter read in flight: d_levels is cleared below)
   drain_events(c);
   c->cfg.channels = output_channels;
   c->cfg.block_frames = buffer_size;
@@ -285,6 +286,9 @@ wbx_status permute_tracks_locked(wbx_engine* e, const std::vector<uint32_t>& ord
   WBX_EHIP(e, hipStreamSynchronize(c->plan_stream));
   WBX_EHIP(e, join_sum(c));
   WBX_EHIP(e, sync_main(c));
+  // (a meter read of the UI thread may still be in flight on its own stream — wbx_engine_levels drops the editor lock
+  //  before it waits: its exchange-with-zero must not land in the slots rewritten below)
+  WBX_EHIP(e, hipStreamSynchronize(e->levels_stream));
   const uint32_t new_n = (uint32_t)order.size();
   if (e->state_tracks) {
     const uint32_t C = c->cfg.channels;
@@ -656,12 +660,25 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   if (N == 0) {
     // Engine::process with an empty track list: output_buffer.clear() and the transport advance (engine.cpp:1598,
     // :1619-1623) — silence
+    // — or, with a running master to continue (wbx_set_master_init; WBX_DIST_CHAIN on a rank whose shard is empty: more ranks
+    // than tracks, or all of its tracks deleted), that sum handed on unchanged: the receive must be posted like any other
+    // render's, or the previous rank's send is never matched and the sum of all earlier ranks is lost
     WBX_EHIP(e, join_sum(c));
     WBX_EHIP(e, c->d_master.ensure((size_t)K * C * F));
+    const bool continues = c->master_init || dist_receives_running_sum(c);
+    if (c->master_format && (c->dist || continues))
+      return efail(e, WBX_ERR_UNSUPPORTED, "an empty session continues a running master / feeds a multi-GPU exchange in planar fp32 only");
     hipError_t me = hipSuccess;
     float* master = begin_master(c, s, &me);
     WBX_EHIP(e, me);
-    {   // (all-zero bytes are silence in every output format; packed 24-bit counts its 3 bytes per sample)
+    if (continues) {
+      wbx_status ist = WBX_OK;
+      const float* init = c->dist ? dist_mix_init(c, K, s, &ist) : c->master_init;
+      if (ist != WBX_OK) return cfail(e, ist);
+      launch_clamp_into(init, master, (size_t)K * C * F, c->clamp ? 1 : 0, s);   // (the clamp follows the last addition: none here)
+      if (c->dist) WBX_EHIP(e, dist_mix_issued(c, s));
+      WBX_EHIP(e, hipGetLastError());
+    } else {   // (all-zero bytes are silence in every output format; packed 24-bit counts its 3 bytes per sample)
       const size_t eb = c->master_format == WBX_OUT_I16 ? 2 : c->master_format == WBX_OUT_I24 ? 3 : 4;
       WBX_EHIP(e, hipMemsetAsync(master, 0, (size_t)K * C * F * eb, s));
     }

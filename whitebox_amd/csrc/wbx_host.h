@@ -28,17 +28,17 @@
 
 namespace wbx {
 
-// core/thread.h:11-35
+// The editor lock: what the reference's Spinlock (core/thread.h:11-35) is to Engine::process and the edit calls — a
+// test-and-test-and-set flag; a waiter watches the flag with plain loads and gives its time slice away between looks.
 struct SpinLock {
-  std::atomic<bool> lock_{false};
-  bool try_lock() noexcept { return !lock_.load(std::memory_order_relaxed) && !lock_.exchange(true, std::memory_order_acquire); }
+  std::atomic_flag held = ATOMIC_FLAG_INIT;
+  bool try_lock() noexcept { return !held.test(std::memory_order_relaxed) && !held.test_and_set(std::memory_order_acquire); }
   void lock() noexcept {
-    for (;;) {
-      if (!lock_.exchange(true, std::memory_order_acquire)) return;
-      while (lock_.load(std::memory_order_relaxed)) std::this_thread::yield();
-    }
+    while (held.test_and_set(std::memory_order_acquire))
+      do std::this_thread::yield();
+      while (held.test(std::memory_order_relaxed));
   }
-  void unlock() noexcept { lock_.store(false, std::memory_order_release); }
+  void unlock() noexcept { held.clear(std::memory_order_release); }
 };
 
 struct LockGuard {
@@ -56,33 +56,41 @@ struct ParamMsg {       // TrackMessage::ParamChange (track.h:75-90): parameter 
   double value;
 };
 
-// ConcurrentRingBuffer<TrackMessage>, core/queue.h:142-196: one producer (UI thread), one consumer (audio thread),
-// one slot kept free, the producer yields while the ring is full.
+// The track's parameter-message queue — the contract of the reference's ConcurrentRingBuffer<TrackMessage> (core/queue.h:
+// 142-196) as Track uses it (track.cpp:22-27 set_capacity(64)): one producer (UI thread), one consumer (audio thread), 63
+// messages in flight at most, the producer yields while it is full.  Two free-running message counts over a 64-slot array;
+// each side keeps its last view of the other's count and looks again only when that view says "full" / "empty", so an
+// uncontended push or pop touches one shared cache line, not two.
 struct ParamRing {
-  static constexpr uint32_t kCapacity = 64;   // Track::Track: track_msg_queue.set_capacity(64), track.cpp:22-27
-  alignas(64) std::atomic<uint32_t> write_pos{0};
-  alignas(64) std::atomic<uint32_t> read_pos{0};
-  ParamMsg data[kCapacity];
+  static constexpr uint32_t kSlots = 64, kInFlight = kSlots - 1;
+  struct alignas(64) Side {
+    std::atomic<uint32_t> count{0};   // messages pushed (producer side) / popped (consumer side) so far
+    uint32_t other_seen = 0;          // the opposite count as last read by this side's thread
+  };
+  Side pushed, popped;
+  ParamMsg slot[kSlots];
 
   bool try_push(const ParamMsg& m) {
-    const uint32_t w = write_pos.load(std::memory_order_relaxed);
-    const uint32_t r = read_pos.load(std::memory_order_acquire);
-    const uint32_t next = (w + 1) % kCapacity;
-    if (next == r) return false;
-    data[w] = m;
-    write_pos.store(next, std::memory_order_release);
+    const uint32_t n = pushed.count.load(std::memory_order_relaxed);
+    if (n - pushed.other_seen >= kInFlight) {
+      pushed.other_seen = popped.count.load(std::memory_order_acquire);
+      if (n - pushed.other_seen >= kInFlight) return false;
+    }
+    slot[n & (kSlots - 1)] = m;
+    pushed.count.store(n + 1, std::memory_order_release);
     return true;
   }
   void push(const ParamMsg& m) {
     while (!try_push(m)) std::this_thread::yield();
   }
   bool pop(ParamMsg& m) {
-    const uint32_t w = write_pos.load(std::memory_order_acquire);
-    uint32_t r = read_pos.load(std::memory_order_relaxed);
-    if (w == r) return false;
-    m = data[r];
-    r = (r + 1) % kCapacity;
-    read_pos.store(r, std::memory_order_release);
+    const uint32_t n = popped.count.load(std::memory_order_relaxed);
+    if (popped.other_seen == n) {
+      popped.other_seen = pushed.count.load(std::memory_order_acquire);
+      if (popped.other_seen == n) return false;
+    }
+    m = slot[n & (kSlots - 1)];
+    popped.count.store(n + 1, std::memory_order_release);
     return true;
   }
 };
@@ -111,6 +119,7 @@ struct SampleMeta {        // what the clip edits and the kernel-instance choice
 
 struct HostTrack {
   std::vector<HostClip> clips;          // sorted by min_time (Track::update_clip_ordering, track.cpp:159-180)
+  edit::ClipIds clip_ids;                   // Track::clip_allocator (track.h:105): which identity a new clip takes over
   // audio-side parameter_state (track.h:129), touched by the audio thread only
   float volume = 0.0f, pan = 0.0f, pan_coeffs[2] = {0.0f, 0.0f};
   bool mute = false;
@@ -175,6 +184,7 @@ struct HostSession {
   // message ring like any later change: the audio-side parameter_state stays zero until the first block drains them
   uint32_t add_track_locked() {
     tracks.emplace_back(new HostTrack());
+    tracks.back()->clip_ids.fresh = &next_clip_uid;
     const uint32_t t = (uint32_t)tracks.size() - 1;
     set_volume(t, 0.0f);
     set_pan(t, 0.0f);
@@ -299,7 +309,7 @@ struct HostSession {
   // after a clip-list edit: Track::update_clip_ordering + reset_playback_state(playhead, true)
   // (engine.cpp:360,395,405,416,426,437,449,459,473)
   void finish_edit(HostTrack& t) {
-    edit::update_clip_ordering(t.clips);
+    edit::update_clip_ordering(t.clips, t.clip_ids);
     reset_playback_state(t, playhead, true);
     clips_dirty = true;
     clips_edited = true;
@@ -316,9 +326,10 @@ struct HostSession {
     const bool back = !empty && t.clips.back().d.max_time < min_time;
     const bool front = !empty && !back && t.clips.front().d.min_time > max_time;
     ClipQuery q{};
+    const uint32_t uid = t.clip_ids.take();   // engine.cpp:302: the Clip object exists before the list is touched
     if (!empty && !back && !front && edit::query_clip_by_range(t.clips, min_time, max_time, &q))
       edit::reserve_track_region(t.clips, q.first, q.last, min_time, max_time, 0u, bd,
-                                 [&](uint32_t smp) { return rate_of_sample(smp); }, &next_clip_uid);
+                                 [&](uint32_t smp) { return rate_of_sample(smp); }, t.clip_ids);
     HostClip c{};
     c.d.min_time = min_time;
     c.d.max_time = max_time;
@@ -327,7 +338,8 @@ struct HostSession {
     c.d.gain = gain;
     c.d.sample = sample;
     c.d.internal_state_changed = 0;
-    c.d.uid = ++next_clip_uid;
+    c.d.uid = uid;
+    c.flag_dirty = true;   // (a new object: no live device flag belongs to it, whatever its id named before)
     t.clips.push_back(c);
     note_clip(c.d);
     finish_edit(t);
@@ -344,7 +356,7 @@ struct HostSession {
     ClipQuery q{};
     if (edit::query_clip_by_range(t.clips, mn, mx, &q))
       edit::reserve_track_region(t.clips, q.first, q.last, mn, mx, uid, bd, [&](uint32_t smp) { return rate_of_sample(smp); },
-                                 &next_clip_uid);
+                                 t.clip_ids);
     for (auto& c : t.clips)
       if (c.d.uid == uid) {
         c.d.min_time = mn;
@@ -369,7 +381,7 @@ struct HostSession {
     ClipQuery q{};
     if (edit::query_clip_by_range(t.clips, r.min, r.max, &q))
       edit::reserve_track_region(t.clips, q.first, q.last, r.min, r.max, c0.uid, bd,
-                                 [&](uint32_t s2) { return rate_of_sample(s2); }, &next_clip_uid);
+                                 [&](uint32_t s2) { return rate_of_sample(s2); }, t.clip_ids);
     for (auto& c : t.clips)
       if (c.d.uid == c0.uid) {
         if (left_side)
@@ -398,7 +410,7 @@ struct HostSession {
     ClipQuery q{};
     if (!edit::query_clip_by_range(t.clips, min, max, &q)) return;
     edit::reserve_track_region(t.clips, q.first, q.last, min, max, 0u, beat_duration.load(std::memory_order_relaxed),
-                               [&](uint32_t smp) { return rate_of_sample(smp); }, &next_clip_uid);
+                               [&](uint32_t smp) { return rate_of_sample(smp); }, t.clip_ids);
     finish_edit(t);
   }
 

@@ -1389,8 +1389,16 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
           spins++;
         }
         const bool chain_ok = (chain_seen & ~0xFu) == chain_tag;
-        if (!chain_ok && a.chain_status) atomicOr(a.chain_status, 32u);
-        if (chain_ok && (chain_seen & 0xFu) != my_xcc && a.chain_status) atomicOr(a.chain_status, 64u);
+        // (the per-plan word goes with its plan buffer three renders later; the context's own word keeps the failure until a
+        //  host call has reported it: wbx_render_status and every fetch / sync that returns a status)
+        if (!chain_ok && a.chain_status) {
+          atomicOr(a.chain_status, 32u);
+          atomicOr(a.chain_sticky, 32u);
+        }
+        if (chain_ok && (chain_seen & 0xFu) != my_xcc && a.chain_status) {
+          atomicOr(a.chain_status, 64u);
+          atomicOr(a.chain_sticky, 64u);
+        }
       }
       __syncthreads();
       if (active && bvalid) {

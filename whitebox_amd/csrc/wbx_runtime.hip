@@ -142,7 +142,10 @@ bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
 // WBX_CHAIN=0: walk the lists whole.
 bool render_chains_groups(const wbx_ctx* c, uint32_t K) {
   const char* e = std::getenv("WBX_CHAIN");
-  const bool off = (e && e[0] == '0') || c->chain_broken;   // (a reported hand-over failure: whole-list walks from then on)
+  // (a reported hand-over failure: whole-list walks from then on.  WBX_MIX_ALT=1 runs two renders' mixes side by side, and
+  //  the words of both would share d_chain with only the epoch to tell them apart: render i+1's pieces overwrite words
+  //  render i's successors still poll — no chaining there)
+  const bool off = (e && e[0] == '0') || c->chain_broken || c->mix_alternate;
   // (K a multiple of 32: every instance's grid then has an x extent that is a multiple of 8, which keeps the pieces of a
   //  block on one XCD — what the chain's L2-level hand-over rests on; other lengths walk the lists whole)
   return render_walks_whole_lists(c, K) && !off && c->longest_list > c->cfg.group_size && (K % 32u) == 0u;
@@ -360,6 +363,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // hand-overs cost more than the few microseconds of overlap they could buy
   const bool sum_beside = c->sum_overlap && K >= kOverlapMinBlocks;
   hipStream_t ss = sum_beside ? c->sum_stream : c->stream;
+  // (argument checks first: once dist_mix_init has posted this render's receive, a failure would leave it unmatched)
+  if (c->master_format && c->dist) return fail(c, WBX_ERR_UNSUPPORTED, "wbx_set_master_format: a multi-GPU partial master stays planar fp32");
+  if (c->n_buses && (c->master_init || dist_receives_running_sum(c)))
+    return fail(c, WBX_ERR_UNSUPPORTED, "a running master (wbx_set_master_init / WBX_DIST_CHAIN) cannot be continued through sub-buses");
   // where this render's master goes (the ctx's own buffer, the caller's target, or the multi-GPU ring slot) and what its
   // sum starts from (zero; wbx_set_master_init's running sum; chain mode: the previous rank's, received for this render)
   float* master_dst = nullptr;
@@ -370,7 +377,6 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     wbx_status ist = WBX_OK;
     m.init = c->dist ? dist_mix_init(c, K, ms, &ist) : c->master_init;
     if (ist != WBX_OK) return ist;
-    if (m.init && c->n_buses) return fail(c, WBX_ERR_UNSUPPORTED, "a running master (wbx_set_master_init) cannot be continued through sub-buses");
   }
   m.n_tracks = N;
   m.n_groups = n_groups;
@@ -402,6 +408,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   }
   m.chain = nullptr;
   m.chain_status = nullptr;
+  m.chain_sticky = nullptr;
   if (chained) {   // one "sum is out" word per (workgroup column, group), tagged with this render's epoch: no clearing
     const size_t words = (size_t)K * m.tiles * n_groups;   // between renders (a memset here waits out the previous sum)
     const size_t had = c->d_chain.cap;
@@ -414,6 +421,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     m.chain_epoch = c->chain_epoch;
     m.chain = c->d_chain.p;
     m.chain_status = PB(c).counters + 1;
+    m.chain_sticky = c->d_sticky_status;
   }
   {
     static const bool dbg = std::getenv("WBX_DBG_CLOCK") != nullptr;   // diagnostic: per-workgroup start / end times of the mix
@@ -474,7 +482,6 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.groups = d_groups;
   s.master = master_dst;
   if (c->master_format) {   // the device format is the sum's epilogue: interleaved samples instead of planar fp32
-    if (c->dist) return fail(c, WBX_ERR_UNSUPPORTED, "wbx_set_master_format: a multi-GPU partial master stays planar fp32");
     s.out_il = master_dst;
     s.out_format = (uint32_t)c->master_format;
   }
@@ -648,10 +655,11 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     }
     (void)hipMemset(B.counters, 0, 4 * sizeof(uint32_t));
   }
-  if (c->d_zero.ensure(cfg->block_frames + 8) != hipSuccess) {
+  if (c->d_zero.ensure(cfg->block_frames + 8) != hipSuccess || hipMalloc((void**)&c->d_sticky_status, sizeof(uint32_t)) != hipSuccess) {
     wbx_destroy(c);
     return WBX_ERR_OOM;
   }
+  (void)hipMemset(c->d_sticky_status, 0, sizeof(uint32_t));
   (void)hipMemset(c->d_zero.p, 0, (cfg->block_frames + 8) * sizeof(float));
   *out = c;
   return WBX_OK;
@@ -704,6 +712,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   c->d_gains.release();
   c->d_conv.release();
   c->d_chain.release();
+  if (c->d_sticky_status) (void)hipFree(c->d_sticky_status);
   c->d_dbg.release();
   c->d_zero.release();
   for (int i = 0; i < kEventRing; i++) {
@@ -1353,6 +1362,25 @@ wbx_status wbx::plan_status_to_error(wbx_ctx* c, uint32_t bits) {
   return WBX_OK;
 }
 
+// Chained renders report a failed hand-over through a word of the context that outlives their plan buffers: read it (the
+// streams are idle), clear it, turn it into the error — and into whole-list walks from then on.
+wbx_status wbx::render_status(wbx_ctx* c) {
+  if (!c->d_sticky_status || c->chain_epoch == 0u) return WBX_OK;   // (no chained render so far)
+  uint32_t bits = 0;
+  WBX_HIP(c, hipMemcpy(&bits, c->d_sticky_status, sizeof(bits), hipMemcpyDeviceToHost));
+  if (!bits) return WBX_OK;
+  WBX_HIP(c, hipMemset(c->d_sticky_status, 0, sizeof(uint32_t)));
+  return plan_status_to_error(c, bits & 96u);
+}
+
+extern "C" wbx_status wbx_render_status(wbx_ctx* c) {
+  if (!c) return WBX_ERR_INVALID;
+  (void)hipSetDevice(c->cfg.device);
+  WBX_HIP(c, sync_main(c));
+  drain_events(c);
+  return render_status(c);
+}
+
 extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* peaks, float* buses) {
   if (!c) return WBX_ERR_INVALID;
   if (c->last_K == 0) return fail(c, WBX_ERR_FAILED, "nothing submitted");
@@ -1381,7 +1409,9 @@ extern "C" wbx_status wbx_fetch(wbx_ctx* c, float* const* master_planar, float* 
   drain_events(c);
   uint32_t pc[4] = {0, 0, 0, 0};
   WBX_HIP(c, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
-  return plan_status_to_error(c, pc[1]);
+  const wbx_status rs = render_status(c);   // (an earlier, unfetched render's failure counts too)
+  const wbx_status ps = plan_status_to_error(c, pc[1]);
+  return ps != WBX_OK ? ps : rs;
 }
 
 extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* dst) {
@@ -1406,14 +1436,14 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
         for (uint32_t b = 0; b < K; b++) std::memcpy((char*)dst + (size_t)b * F * C * 3, (const char*)c->last_master + (size_t)b * F * C * 3, (size_t)F * 3);
       else
         std::memcpy(dst, c->last_master, (size_t)K * F * C * eb);
-      return WBX_OK;
+      return render_status(c);
     }
     if (out_format == WBX_OUT_I24)
       WBX_HIP(c, hipMemcpy2DAsync(dst, (size_t)F * C * 3, c->last_master, (size_t)F * C * 3, (size_t)F * 3, K, hipMemcpyDeviceToHost, c->stream));
     else
       WBX_HIP(c, hipMemcpyAsync(dst, c->last_master, (size_t)K * F * C * eb, hipMemcpyDeviceToHost, c->stream));
     WBX_HIP(c, sync_main(c));
-    return WBX_OK;
+    return render_status(c);
   }
   if (out_format == WBX_OUT_I24) {
     // convert_f32_to_interleaved_i24 (audio_format_conv.cpp:22-43) writes byte 3*i.. of EVERY channel's sample i — the
@@ -1423,14 +1453,14 @@ extern "C" wbx_status wbx_fetch_interleaved(wbx_ctx* c, int out_format, void* ds
     launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);
     WBX_HIP(c, hipMemcpy2DAsync(dst, (size_t)F * C * 3, c->d_conv.p, (size_t)F * 3, (size_t)F * 3, K, hipMemcpyDeviceToHost, c->stream));
     WBX_HIP(c, sync_main(c));
-    return WBX_OK;
+    return render_status(c);
   }
   const size_t bytes = (size_t)K * F * C * eb;
   WBX_HIP(c, c->d_conv.ensure(bytes));
   launch_convert(c->last_master, c->d_conv.p, K, F, C, out_format, c->stream);   // pinned staging is device-readable too
   WBX_HIP(c, hipMemcpyAsync(dst, c->d_conv.p, bytes, hipMemcpyDeviceToHost, c->stream));
   WBX_HIP(c, sync_main(c));
-  return WBX_OK;
+  return render_status(c);
 }
 
 extern "C" wbx_status wbx_partial_master(wbx_ctx* c, void** device_ptr, size_t* n_floats) {

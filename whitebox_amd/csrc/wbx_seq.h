@@ -739,9 +739,14 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
   DClip* clips = const_cast<DClip*>(a.clips) + c0;
   if (a.clips_changed && st.cur_type == EV_PLAY) {
     // the reference reads current_audio_event.clip->audio.gain at every stream call (track.cpp:676,716):
-    // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity
+    // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity.  A clip an edit DESTROYED
+    // while it was sounding (Track::update_clip_ordering, track.cpp:159-175) reads 0.0f from then on — Pool::free has
+    // zeroed its chunk (core/memory.h:80-86): the sampler keeps advancing, the track is silent until its next event —
+    // unless a newer clip of the track has taken the chunk over (the uid stands for the chunk: wbx_clip_edit.h ClipIds).
+    float gain = 0.0f;
     for (uint32_t i = 0; i < nc; i++)
-      if (clips[i].uid == st.cur_clip_uid) st.cur_gain = clips[i].gain;
+      if (clips[i].uid == st.cur_clip_uid) gain = clips[i].gain;
+    st.cur_gain = gain;
   }
   TrackCache cache;
   cache.clip_idx = 0xFFFFFFFFu;

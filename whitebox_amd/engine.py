@@ -195,6 +195,11 @@ class MixContext:
     def sync(self):
         _check(self.L.wbx_sync(self.h), "wbx_sync", self.h)
 
+    def render_status(self):
+        """wait, then raise if a chained render since the last report lost a hand-over (its master is invalid): what a host
+        that reads its own master target instead of fetching must call before it trusts the buffer"""
+        _check(self.L.wbx_render_status(self.h), "wbx_render_status", self.h)
+
     def master_ready(self, stream: Optional[int] = None):
         """Order `stream` (None: the ctx stream) after the kernels that write the last render's results."""
         _check(self.L.wbx_master_ready(self.h, stream), "wbx_master_ready", self.h)
