@@ -270,33 +270,44 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
-def verify_head(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks, chain=False, n_check=8):
+def verify_blocks_of(K, tail):
+    """which blocks of a K-block step are compared with the oracle: the first 8; with `tail` also one per 256 and the last 8"""
+    head = list(range(min(8, K)))
+    if not tail or K <= 16:
+        return head
+    return sorted(set(head + list(range(255, K, 256)) + list(range(K - 8, K))))
+
+
+def verify_render(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks, chain=False, tail=True):
     """What did the timed loop compute?  After it, the transport is rewound (Engine::stop + play), one more step of K
-    blocks is rendered exactly like the timed ones, and its first `n_check` blocks are compared with the CPU oracle
-    built from the same seeds: the device sequencer's stream-call log and the per-track peaks bit for bit, the master
-    bit for bit when the render adds in the reference's order, within 1e-6 RMS otherwise.  Outside the timed region;
-    the oracle only checks (bench.py's timed path never touches it)."""
-    import oracle_ffi as O
-    n_check = min(n_check, K)
-    got = host_master.array[:n_check * 2 * F].reshape(n_check, 2, F).copy()
-    res = {"blocks": n_check, "tracks": n_tracks * world}
+    blocks is rendered exactly like the timed ones, and blocks of it — the first 8 and, `tail`, one per 256 and the LAST 8
+    (chain words, epoch tags and the XCD hand-over of a chained render all act far behind its head) — are compared with the
+    CPU oracle built from the same seeds: the device sequencer's stream-call log and the per-track peaks bit for bit, the
+    master bit for bit when the render adds in the reference's order, within 1e-6 RMS otherwise.  Outside the timed
+    region; the oracle only checks (bench.py's timed path never touches it).  tests/oracle_tail.py: the oracle's tracks
+    sharded over the host's cores between compared blocks, one sequential Engine::process on them."""
+    import oracle_tail as OT
+    from whitebox_amd.engine import plan_rows_of_blocks
+    t_start = time.perf_counter()
+    check = verify_blocks_of(K, tail)
+    res = {"blocks": len(check), "tracks": n_tracks * world, "head_blocks": min(8, K),
+           "tail_blocks": [b for b in check if b >= 8], "last_block_checked": check[-1]}
     L = eng.L
     ng, longest, ref = C.c_uint32(), C.c_uint32(), C.c_int()
     L.wbx_render_order(eng.ctx.h, K, C.byref(ng), C.byref(longest), C.byref(ref))
     res["summation"] = (f"{ng.value} workgroup-level group(s) per block, longest {longest.value} tracks: "
                         + ("the reference's order" if ref.value else "grouped order"))
-    e = build_oracle_session(workload, n_tracks, world, n_check, clip_blocks, session_blocks)
-    e.enable_seglog()
-    e.play()
-    om, opk, orows = [], [], []
-    for b in range(n_check):
-        m, _ = e.process()
-        om.append(m)
-        opk.append(e.peaks())
-        orows += [(b, t, ds, min(ln, 0xFFFF), O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g))
-                  for (t, ds, ln, off, spd, g, smp) in e.seglog()]
-    e.close()
-    om, opk = np.stack(om), np.stack(opk)
+    _, _, n_buses, _ = WORKLOADS[workload]
+    descs = []
+    for r in range(world):
+        seed, amp, tracks = track_layout(workload, n_tracks, r, world, session_blocks, clip_blocks)
+        for (gt, tfmt, trate, v, p, bus, clips) in tracks:
+            frames = int(math.ceil((session_blocks + 2) * F * (WORKLOADS[workload][1] / SR))) + 64   # build_device_session's
+            descs.append(OT.TrackDesc(seed, gt, tfmt, 2, trate, frames, amp, v, p, False, (r * n_buses + bus) if n_buses else -1,
+                                      [(a, b, off, 1.0, 1.0) for (a, b, off) in clips]))
+    want = OT.oracle_at_blocks(descs, check, block=F, channels=2, sample_rate=SR, bpm=120.0, n_buses=n_buses * world)
+    got = host_master.array[:K * 2 * F].reshape(K, 2, F)[check].copy()
+    om = np.stack([want[b][0] for b in check])
     d = got.astype(np.float64) - om.astype(np.float64)
     res["rms"] = float(np.sqrt(np.mean(d * d)))
     res["max_abs"] = float(np.abs(d).max())
@@ -304,16 +315,49 @@ def verify_head(eng, host_master, workload, n_tracks, rank, world, K, clip_block
     # peaks and plan rows: this rank's tracks (the other ranks' never leave their GPU)
     first = rank * n_tracks
     _, pk, _ = eng.ctx.fetch(peaks=True)
-    res["peaks_equal"] = bool(np.array_equal(pk[:n_check], opk[:, first:first + n_tracks, :2]))
-    plan = eng.fetch_plan(max_records=n_check * n_tracks * 4)
-    rows = [(b, t + first, bo, ns, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g))
-            for (b, t, bo, ns, na, smp, off, spd, g, fl) in plan if b < n_check]
-    want = [r for r in orows if first <= r[1] < first + n_tracks]
-    res["plan_rows_equal"] = rows == want
-    res["plan_rows"] = len(want)
+    res["peaks_equal"] = all(bool(np.array_equal(pk[b], want[b][1][first:first + n_tracks])) for b in check)
+    rows = plan_rows_of_blocks(eng.fetch_plan_array(), check)
+    n_rows, rows_ok = 0, True
+    for b in check:
+        mine = [(t - first, *rest) for (t, *rest) in want[b][2] if first <= t < first + n_tracks]
+        n_rows += len(mine)
+        rows_ok = rows_ok and [tuple(x) for x in rows[b]] == [tuple(x) for x in mine]
+    res["plan_rows_equal"] = bool(rows_ok)
+    res["plan_rows"] = n_rows
     res["ok"] = bool(res["peaks_equal"] and res["plan_rows_equal"]
                      and (res["master_bit_exact"] if (ref.value and (world == 1 or chain)) else res["rms"] <= 1e-6))
+    res["seconds"] = time.perf_counter() - t_start
     return res
+
+
+def rccl_log_path(rank):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wbx_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_r{rank}.log")
+
+
+def parse_rccl_transports(path, rank):
+    """What carried this rank's exchange, from RCCL's own log (NCCL_DEBUG=INFO): every connection it sets up is announced as
+    `<a>[dev] -> <b>[dev] ... via P2P/IPC` (peer-to-peer: xGMI / PCIe between two devices), `via SHM/...` (host shared memory)
+    or `via NET/Socket/n` / `via NET/IB/n` (a network transport: what ranks that share one device fall back to).
+    -> {"kinds": ["p2p" | "shm" | "socket" | "net:<name>", ...], "peers": {peer: [kind, ...]}, "lines": n}"""
+    import re
+    kinds, peers, n = set(), {}, 0
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return {"kinds": [], "peers": {}, "lines": 0, "note": "no RCCL log"}
+    for ln in text.splitlines():
+        m = re.search(r"(\d+)\[[^\]]*\] -> (\d+)\[[^\]]*\].*? via (\S+)", ln)
+        if not m:
+            continue
+        n += 1
+        a, b, via = int(m.group(1)), int(m.group(2)), m.group(3)
+        v = via.upper()
+        kind = ("p2p" if v.startswith("P2P") else "shm" if v.startswith("SHM") else "socket" if v.startswith("NET/SOCKET")
+                else "net:" + via.split("/")[1] if v.startswith("NET/") and "/" in via else via.lower())
+        kinds.add(kind)
+        peer = b if a == rank else a
+        peers.setdefault(str(peer), set()).add(kind)
+    return {"kinds": sorted(kinds), "peers": {k: sorted(v) for k, v in sorted(peers.items())}, "lines": n}
 
 
 def free_port():
@@ -382,7 +426,7 @@ def self_launch(n, rank_cmd=None, poll_s=0.05, grace_s=5.0):
 
 
 def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, warmup, ramp, clip_blocks=0.0,
-                 use_dist=False, dist_mode=0, mem_budget=96e9, latency_blocks=0, verify=True):
+                 use_dist=False, dist_mode=0, mem_budget=96e9, latency_blocks=0, verify=True, verify_tail=True):
     """Build the session in HBM, run warmup + ramp untimed steps straight into `steps` timed ones, return the measurements."""
     from whitebox_amd.dist import Dist, PinnedBuffer
     desc, src_rate, n_buses, fmt = WORKLOADS[workload]
@@ -482,17 +526,28 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
         step()
         drain()
         if rank == result_rank:
-            ver = verify_head(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks,
-                              chain=dist is not None and dist_mode == 2)
+            ver = verify_render(eng, host_master, workload, n_tracks, rank, world, K, clip_blocks, session_blocks,
+                                chain=dist is not None and dist_mode == 2, tail=verify_tail)
     exch = None
     if dist is not None:
         exch = dist.info()
+        # every rank's own facts, in rank order on every rank: its device, its mix kernel and exchange times, and what RCCL says
+        # carried its connections — a record of the run alone then shows N devices and their transport
+        mine = {"rank": rank, "pci": eng.ctx.device_info()["pci"], "mix_ms_avg": round(mix_ms, 4), "mix_launches": int(mix_n),
+                "exchange_ms_avg": round(exch["exchange_ms_avg"], 4), "transport": parse_rccl_transports(rccl_log_path(rank), rank)}
+        exch["ranks"] = [json.loads(x.decode()) for x in dist.allgather(json.dumps(mine).encode(), 1024)]
         if world > 1:   # what the result rank found travels to rank 0, which prints the line
-            got = dist.allgather(json.dumps({"verify": ver, "master_peak": master_peak}).encode(), 2048)
+            if ver is not None:
+                ver = dict(ver, tail_blocks=ver["tail_blocks"][-12:])
+            got = dist.allgather(json.dumps({"verify": ver, "master_peak": master_peak}).encode(), 3072)
             if rank == 0:
                 back = json.loads(got[result_rank].decode())
                 ver, master_peak = back["verify"], back["master_peak"]
         dist.shutdown()
+        try:
+            os.remove(rccl_log_path(rank))
+        except OSError:
+            pass
     dev = eng.ctx.device_info()
     ng, longest, ref_order = eng.ctx.render_order(K)
     summation = (f"{ng} workgroup-level group(s) per block, longest {longest} tracks: "
@@ -562,7 +617,7 @@ def roofline_of(r, traffic_table):
 
 def config_entry(name, wl, sr, K, traffic_table, extra=""):
     d2 = WORKLOADS[wl]
-    ent = {"workload": f"{wl} — {d2[0]}" + extra,
+    ent = {"name": name, "workload": f"{wl} — {d2[0]}" + extra,
            # like the headline's `value`: master frames/s scaled to the metric's 4096 tracks (c2 has 256)
            "value": (sr["n_tracks"] / 4096.0) * sr["steps"] * K * F / sr["dt"], "unit": "frames/s",
            "master_frames_per_s": sr["steps"] * K * F / sr["dt"], "steps": sr["steps"], "blocks_per_step": K,
@@ -571,6 +626,21 @@ def config_entry(name, wl, sr, K, traffic_table, extra=""):
     if sr.get("verify"):
         ent["verify"] = sr["verify"]
     return ent
+
+
+def compact_entry(ent):
+    """what the one stdout line keeps of a `configs` entry (the full entry goes to stderr as its own JSON line): the line is
+    read by tools that keep only its tail"""
+    rf, v = ent["roofline"], ent.get("verify")
+    out = {"workload": ent["name"],
+           "value": ent["value"], "ms_per_step": ent["ms_per_step"], "blocks_per_step": ent["blocks_per_step"], "tracks": ent["tracks"],
+           "roofline": {"frac": rf["frac"], "frac_step": rf["frac_step"], "achieved": rf["achieved"], "traffic": rf["traffic"],
+                        "kernel": rf["kernel"], "kernel_ms_avg": rf["kernel_ms_avg"]}}
+    if v:
+        out["verify"] = {"ok": v["ok"], "master_bit_exact": v["master_bit_exact"], "rms": v["rms"], "blocks": v["blocks"],
+                         "last_block_checked": v["last_block_checked"], "peaks_equal": v["peaks_equal"],
+                         "plan_rows_equal": v["plan_rows_equal"]}
+    return out
 
 
 def main():
@@ -599,15 +669,20 @@ def main():
     ap.add_argument("--latency-blocks", type=int, default=50, help="K=1 Engine::process calls timed after the run")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="run the multi-GPU code path (RCCL exchange + clamp on root) even with one rank")
-    ap.add_argument("--dist-mode", default="reduce", choices=["reduce", "ordered", "chain"],
-                    help="exchange: one ncclReduce; gather + fixed-order add on the root (bit-reproducible); or a chain — "
-                    "rank g continues rank g-1's running master (the reference's sequential order across GPUs: bit-exact)")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "reduce", "ordered", "chain"],
+                    help="exchange: a chain — rank g continues rank g-1's running master (the reference's sequential order "
+                    "across GPUs: bit-exact; `auto` takes it for renders of >= 1024 blocks, whose shards add in that order too); "
+                    "one ncclReduce (`auto` for shorter renders); or gather + fixed-order add on the root (bit-reproducible).  "
+                    "reduce / ordered add SHARD sums: within 1e-6 RMS up to about half of full scale (profiles/r03_level_probe.txt)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: BASELINE configs[4]'s 32768 tracks split over "
                     "the N ranks (default: weak scaling, 4096 tracks per GPU)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other single-GPU configurations "
                     "(c2, c4, c3 cut into clips, i16r, the sustained run) that fill the line's `configs` object")
-    ap.add_argument("--no-verify", action="store_true", help="skip the check of the rendered head against the CPU oracle "
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the rendered step against the CPU oracle "
                     "(after the timed loop, outside the timed region)")
+    ap.add_argument("--no-verify-tail", action="store_true", help="compare only the first 8 blocks of the verified step with the "
+                    "oracle (default: also one block per 256 and the last 8 — the oracle's tracks run sharded over the host's "
+                    "cores between compared blocks, a few seconds per configuration)")
     ap.add_argument("--sustain-blocks", type=int, default=655360, help="blocks of the sustained-clock run in `configs` "
                     "(2 000 steps of 256 blocks' worth: >= 1.5 s of uninterrupted load)")
     args = ap.parse_args()
@@ -639,10 +714,16 @@ def main():
     K = args.blocks
     ramp = args.ramp_steps if args.ramp_steps is not None else max(6, 10240 // K)
     use_dist = world > 1 or args.force_dist_path
+    if args.dist_mode == "auto":
+        args.dist_mode = "chain" if K >= 1024 else "reduce"
     dist_mode = {"reduce": 0, "ordered": 1, "chain": 2}[args.dist_mode]
+    if use_dist:   # RCCL's own account of its connections (parse_rccl_transports), one file per rank
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,SHM,NET")
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log_path(rank)
     r = run_workload(W, synth, args, args.workload, rank, world, n_tracks=n_tracks, K=K, steps=args.steps,
                      warmup=args.warmup, ramp=ramp, clip_blocks=args.clip_blocks, use_dist=use_dist,
-                     dist_mode=dist_mode, latency_blocks=args.latency_blocks, verify=not args.no_verify)
+                     dist_mode=dist_mode, latency_blocks=args.latency_blocks, verify=not args.no_verify, verify_tail=not args.no_verify_tail)
     # every rank says what it ran on (stderr: stdout carries rank 0's one JSON line)
     print(json.dumps({"rank": rank, "world": world, "device": r["device"], "tracks": n_tracks, "exchange": r["exchange"],
                       "mix_ms_avg": r["mix_ms"], "seconds": r["dt"]}), file=sys.stderr, flush=True)
@@ -675,7 +756,12 @@ def main():
                    "summation": r["summation"],
                    "clip_blocks": args.clip_blocks or None,
                    "session_level": f"amp=0.25/sqrt({total_tracks})", "parallelism": f"tracks sharded x{world}",
-                   "exchange": (f"libwbx wbx_dist_exchange over RCCL, mode {args.dist_mode}" if use_dist else None)},
+                   "exchange": ((f"libwbx wbx_dist_exchange over RCCL, mode {args.dist_mode}: "
+                                 + ("rank g continues rank g-1's running master (ncclSend / ncclRecv), the last rank clamps — the "
+                                    "reference's order across GPUs, bit-exact at any level" if args.dist_mode == "chain" else
+                                    "SHARD sums are added (not the reference's association): within 1e-6 RMS up to about half of "
+                                    "full scale, 1.5e-6 at amp = 1/sqrt(N) over 32768 tracks (profiles/r03_level_probe.txt); "
+                                    "--dist-mode chain is bit-exact")) if use_dist else None)},
         "master_frames_per_s": master_frames / dt,
         "track_frames_per_s": total_tracks * master_frames / dt,
         "realtime_factor": master_frames / dt / SR,
@@ -687,8 +773,16 @@ def main():
         line["verify"] = ver
     if use_dist and r["exchange"]:
         # what the exchange saw: RCCL's world size, which device every rank ran on, the exchange's own time
+        ranks = r["exchange"].get("ranks", [])
+        kinds = sorted({k for x in ranks for k in x["transport"]["kinds"]})
         line.update({"rccl_world": r["exchange"]["world"], "devices": r["exchange"]["devices"], "tracks_per_gpu": n_tracks,
-                     "exchange_ms_avg": r["exchange"]["exchange_ms_avg"]})
+                     "exchange_ms_avg": r["exchange"]["exchange_ms_avg"],
+                     # N ranks on N devices?  and what carried the exchange, per RCCL's own log ("p2p" = device to device: xGMI /
+                     # PCIe peer access; "socket" = the loopback network transport ranks that SHARE a device fall back to)
+                     "distinct_devices": len(set(r["exchange"]["devices"])) == r["exchange"]["world"],
+                     "transport": (kinds[0] if len(kinds) == 1 else "none (one rank)" if world == 1 and not kinds
+                                   else "+".join(kinds) if kinds else "unknown"),
+                     "ranks": ranks})
     if r["lat"] is not None:
         line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"],
                                 # the same call for sessions of 8 / 64 tracks (one group: the mix workgroup stores the master itself)
@@ -704,12 +798,12 @@ def main():
                              ("c3_clips5.3", "c3", dict(n_tracks=4096, clip_blocks=5.3)),
                              ("i16r", "i16r", dict(n_tracks=4096))):
             sr = run_workload(W, synth, args, wl, 0, 1, K=K, steps=20, warmup=3, ramp=ramp * (3 if wl == "c2" else 1),
-                              mem_budget=40e9, verify=not args.no_verify, **kw)
+                              mem_budget=40e9, verify=not args.no_verify, verify_tail=not args.no_verify_tail, **kw)
             subs[name] = config_entry(name, wl, sr, K, traffic_table,
                                       f", every track cut into clips of {kw['clip_blocks']} blocks" if kw.get("clip_blocks") else "")
         # renders of 256 blocks: the grouped summation order (within 1e-6 RMS), the operating point of rounds 1-2
         sr = run_workload(W, synth, args, "c3", 0, 1, n_tracks=4096, K=256, steps=20, warmup=3, ramp=40, mem_budget=40e9,
-                          verify=not args.no_verify)
+                          verify=not args.no_verify, verify_tail=not args.no_verify_tail)
         subs["c3_K256_grouped"] = config_entry("c3_K256_grouped", "c3", sr, 256, traffic_table, ", 256-block renders (128-track groups)")
         # sustained clocks: the headline configuration for >= 1.5 s of consecutive steps
         s_steps = max(20, -(-args.sustain_blocks // K))
@@ -719,9 +813,22 @@ def main():
         for name, ent in subs.items():
             if ent.get("verify") and not ent["verify"]["ok"]:
                 failed.append(name)
-        line["configs"] = subs
+        # the full entries: their own JSON line on stderr (tools/profile_round.sh keeps it); the stdout line carries the compact form
+        print(json.dumps({"configs_full": subs}), file=sys.stderr, flush=True)
+        line["configs"] = {k: compact_entry(v) for k, v in subs.items()}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n_tracks, args.cpu_seconds)
+    # the headline once more at the very END of the line: a reader that keeps only the tail of a long line still sees it
+    rf = line["roofline"]
+    line["headline"] = {"value": value, "unit": "frames/s", "n_gpus": world, "ms_per_step": line["ms_per_step"],
+                        "roofline_frac": rf["frac"], "roofline_frac_step": rf["frac_step"], "kernel_ms_avg": rf["kernel_ms_avg"],
+                        "verify_ok": None if ver is None else ver["ok"],
+                        "master_bit_exact": None if ver is None else ver["master_bit_exact"],
+                        "last_block_checked": None if ver is None else ver["last_block_checked"],
+                        "latency_ms_per_block": line.get("latency_mode", {}).get("ms_per_block"),
+                        "cpu_baseline_frames_per_s": line.get("cpu_baseline", {}).get("value"),
+                        "configs_ok": [k for k in line.get("configs", {}) if line["configs"][k].get("verify", {}).get("ok")],
+                        "configs_failed": failed}
     print(json.dumps(line), flush=True)
     if failed:
         print(f"bench.py: the rendered head differs from the CPU oracle in: {', '.join(failed)}", file=sys.stderr, flush=True)

@@ -79,7 +79,8 @@ int main() {
     if (vm.get_value() != 0.5f) return 4;
     vm.update(60.0f, 0.25f);            // nothing new: falls by (1 - exp(-1/15)) of the way to 0
     const float expect = 0.5f + (0.0f - 0.5f) * (1.0f - std::exp(-1.0f / (60.0f * 0.25f)));
-    if (vm.get_value() != expect || !(vm.get_value() < 0.5f)) return 4;
+    // (within an ulp or two: the compiler folds this expression, the meter calls expf at run time)
+    if (std::fabs(vm.get_value() - expect) > 1e-6f || !(vm.get_value() < 0.5f)) return 4;
   }
   // the effect slot exists and stays empty
   wbx_plugin fx{nullptr, nullptr};

@@ -98,3 +98,21 @@ def test_a_stale_rendezvous_file_is_not_taken_for_this_launch(tmp_path, monkeypa
     os.replace(tmp, path)
     th.join(timeout=30)
     assert got["id"] == bytes([2]) * 128
+
+
+def test_rccl_transport_lines_are_recognised(tmp_path):
+    """bench.py reads what carried a rank's exchange from RCCL's own log: peer-to-peer between devices (xGMI / PCIe), host
+    shared memory, or a network transport (what ranks that share one device fall back to)"""
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "runc:71:102 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC",
+        "runc:71:102 [0] NCCL INFO Channel 01/0 : 0[1c000] -> 2[1d000] via SHM/direct/direct",
+        "runc:71:102 [0] NCCL INFO Channel 00/0 : 0[0] -> 3[0] [send] via NET/Socket/0",
+        "runc:71:102 [0] NCCL INFO Channel 00/0 : 3[0] -> 0[0] [receive] via NET/Socket/0",
+        "runc:71:102 [0] NCCL INFO Channel 00/0 : 0[0] -> 4[0] [send] via NET/IB/1/GDRDMA",
+        "runc:71:102 [0] NCCL INFO Connected all rings", ""]))
+    got = bench.parse_rccl_transports(str(log), 0)
+    assert got["kinds"] == ["net:IB", "p2p", "shm", "socket"] and got["lines"] == 5
+    assert got["peers"] == {"1": ["p2p"], "2": ["shm"], "3": ["socket"], "4": ["net:IB"]}
+    assert bench.parse_rccl_transports(str(tmp_path / "absent.log"), 0)["kinds"] == []

@@ -112,6 +112,7 @@ def test_bench_multi_gpu_launch_paths():
         # what the exchange saw, and the head of the run against the oracle
         assert line["rccl_world"] == 1 and len(line["devices"]) == 1 and line["devices"][0].count(":") == 2
         assert line["exchange_ms_avg"] > 0.0 and line["tracks_per_gpu"] == 256
+        assert line["distinct_devices"] is True and len(line["ranks"]) == 1 and line["ranks"][0]["mix_ms_avg"] > 0
         assert line["verify"]["ok"] and line["verify"]["peaks_equal"] and line["verify"]["plan_rows_equal"]
 
 
@@ -145,6 +146,11 @@ def test_ranks_that_share_the_device_exchange_over_rccl(world):
             assert v["master_bit_exact"], v
         ranks = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"rank"')]
         assert sorted(x["rank"] for x in ranks) == list(range(world))       # every rank said what it ran on
+        # the record alone says what this run was: world processes on ONE device, the exchange over RCCL's socket transport
+        # (N ranks on N devices would read distinct_devices true and transport "p2p")
+        assert line["distinct_devices"] is False and line["transport"] == "socket", (line["transport"], line["ranks"])
+        assert [x["rank"] for x in line["ranks"]] == list(range(world))
+        assert all(x["mix_ms_avg"] > 0 and x["exchange_ms_avg"] > 0 and x["transport"]["kinds"] == ["socket"] for x in line["ranks"])
         assert all(x["exchange"]["world"] == world and x["exchange"]["mode"] == mode for x in ranks)
 
 

@@ -472,6 +472,16 @@ class Engine:
         _check(self.L.wbx_engine_levels(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), n), "wbx_engine_levels", self.h, True)
         return out
 
+    def fetch_plan_array(self) -> np.ndarray:
+        """the whole plan of the last render as a structured array (PLAN_DTYPE), ordered by (block, track, call): what a
+        check of blocks deep inside a long render slices (millions of records: no Python list)"""
+        n = C.c_size_t()
+        self.L.wbx_engine_fetch_plan(self.h, None, 0, C.byref(n))
+        buf = np.zeros(max(1, n.value), dtype=PLAN_DTYPE)
+        _check(self.L.wbx_engine_fetch_plan(self.h, buf.ctypes.data_as(C.POINTER(_ffi.PlanRecord)), n.value, C.byref(n)),
+               "wbx_engine_fetch_plan", self.h, True)
+        return buf[:n.value]
+
     def fetch_plan(self, max_records: Optional[int] = None):
         """The Sampler::stream calls of the last render, ordered by (block, track, call); `max_records` keeps the first
         ones only (the head of a long render)."""
@@ -485,6 +495,22 @@ class Engine:
         got = n.value if max_records is None else min(n.value, max_records)
         return [(r.block, r.track, r.buffer_offset, r.num_samples, r.num_actual, r.sample, r.sample_offset,
                  r.playback_speed, r.gain, r.flags) for r in arr[:got]]
+
+
+PLAN_DTYPE = np.dtype([("block", "<u4"), ("track", "<u4"), ("buffer_offset", "<u4"), ("num_samples", "<u4"), ("num_actual", "<u4"),
+                       ("sample", "<u4"), ("sample_offset", "<f8"), ("playback_speed", "<f8"), ("gain", "<f4"), ("flags", "<u4")])
+
+
+def plan_rows_of_blocks(plan: np.ndarray, blocks) -> dict:
+    """{block: [(track, buffer_offset, num_samples, offset bits, speed bits, gain bits), ...]} of a fetch_plan_array result"""
+    out = {}
+    for b in blocks:
+        lo, hi = np.searchsorted(plan["block"], [b, b + 1])
+        p = plan[lo:hi]
+        out[int(b)] = list(zip(p["track"].tolist(), p["buffer_offset"].tolist(), p["num_samples"].tolist(),
+                               p["sample_offset"].view(np.uint64).tolist(), p["playback_speed"].view(np.uint64).tolist(),
+                               p["gain"].view(np.uint32).tolist()))
+    return out
 
 
 def build_engine(spec, max_blocks: int = 8, group_size: int = 0, device: int = 0, device_synth: bool = False,

@@ -38,14 +38,14 @@ def clip_channel(seed: int, track: int, chan: int, frames: int, amp: float, firs
     return (v * np.float32(amp)).astype(np.float32)
 
 
-def clip_channel_i16(seed: int, track: int, chan: int, frames: int) -> np.ndarray:
-    idx = np.arange(frames, dtype=np.uint64)
+def clip_channel_i16(seed: int, track: int, chan: int, frames: int, first: int = 0) -> np.ndarray:
+    idx = np.arange(first, first + frames, dtype=np.uint64)
     u = splitmix64(clip_key(seed, track, chan) ^ idx)
     return ((u >> np.uint64(48)).astype(np.int64) - 32768).astype(np.int16)
 
 
-def clip_channel_i32(seed: int, track: int, chan: int, frames: int, bits: int = 32) -> np.ndarray:
-    idx = np.arange(frames, dtype=np.uint64)
+def clip_channel_i32(seed: int, track: int, chan: int, frames: int, bits: int = 32, first: int = 0) -> np.ndarray:
+    idx = np.arange(first, first + frames, dtype=np.uint64)
     u = splitmix64(clip_key(seed, track, chan) ^ idx)
     q = (u >> np.uint64(64 - bits)).astype(np.int64) - (1 << (bits - 1))
     return q.astype(np.int32)
@@ -175,3 +175,19 @@ def make_session(name: str, n_tracks: int, *, clip_channels: int = 2, src_rate: 
     return SessionSpec(name=name, n_tracks=n_tracks, seed=seed, samples=samples, clips=clips, volumes_db=vols,
                        pans=pans, mutes=mutes, n_buses=n_buses, track_bus=track_bus, bpm=bpm,
                        sample_rate=sample_rate, block=block)
+
+
+def cut_into_clips(spec: SessionSpec, clip_blocks: float, session_blocks: int) -> SessionSpec:
+    """Every track of a one-clip-per-track session cut into back-to-back clips of `clip_blocks` blocks, each reading on
+    from where the previous one stopped, staggered per track (bench.py --clip-blocks builds the same layout)."""
+    beat_frames = spec.sample_rate * 60.0 / spec.bpm
+    L = clip_blocks * spec.block
+    clips = []
+    for t in range(spec.n_tracks):
+        rate = spec.samples[t].rate
+        pos = -((t * 37) % 512) / 512.0 * L
+        while pos < (session_blocks + 1) * spec.block:
+            a, b = max(pos, 0.0), pos + L
+            clips.append(ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * (rate / spec.sample_rate)))
+            pos = b
+    return dataclasses.replace(spec, clips=clips)
