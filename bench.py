@@ -544,10 +544,11 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
                 back = json.loads(got[result_rank].decode())
                 ver, master_peak = back["verify"], back["master_peak"]
         dist.shutdown()
-        try:
-            os.remove(rccl_log_path(rank))
-        except OSError:
-            pass
+        if not os.environ.get("WBX_KEEP_RCCL_LOG"):
+            try:
+                os.remove(rccl_log_path(rank))
+            except OSError:
+                pass
     dev = eng.ctx.device_info()
     ng, longest, ref_order = eng.ctx.render_order(K)
     summation = (f"{ng} workgroup-level group(s) per block, longest {longest} tracks: "
@@ -718,8 +719,8 @@ def main():
         args.dist_mode = "chain" if K >= 1024 else "reduce"
     dist_mode = {"reduce": 0, "ordered": 1, "chain": 2}[args.dist_mode]
     if use_dist:   # RCCL's own account of its connections (parse_rccl_transports), one file per rank
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,SHM,NET")
+        os.environ["NCCL_DEBUG"] = "INFO"          # (whatever level the environment asked for: the connection lines are INFO)
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,P2P,SHM,NET"
         os.environ["NCCL_DEBUG_FILE"] = rccl_log_path(rank)
     r = run_workload(W, synth, args, args.workload, rank, world, n_tracks=n_tracks, K=K, steps=args.steps,
                      warmup=args.warmup, ramp=ramp, clip_blocks=args.clip_blocks, use_dist=use_dist,

@@ -74,6 +74,7 @@ int main() {
   if (g_engine.tracks[0]->level_meter[0].take_level() != 0.0f) return 4;   // (read and reset)
   {   // the UI-rate half the reference's controls call on Track::level_meter (vu_meter.h:32-44): attack at once, release by a one-pole
     wbx::VUMeter& vm = g_engine.tracks[1]->level_meter[0];
+    (void)vm.take_level();              // (what fetch_levels left there)
     vm.push_level(0.5f);
     vm.update(60.0f, 0.25f);
     if (vm.get_value() != 0.5f) return 4;

@@ -1,0 +1,193 @@
+// wbx_callback.h — the real-time callback as ONE launch.
+//
+// The reference's only caller is the audio thread: one Engine::process per device period (audio_io_pulseaudio.cpp:396-466,
+// audio_io_wasapi.cpp:708).  As three dependent launches — sequencer, mix, sum — a block cost ~35 us of launch-to-launch
+// latency whatever it computed.  callback_kernel is those three in one dispatch, without a device-wide barrier:
+//
+//   1. prologue  every workgroup is a track group of the block (the grid of mix_kernel for K = 1); its first lanes run the
+//                sequencer (wbx_seq.h plan_track: Track::process_event + the segment loop, one lane per track) for the
+//                group's OWN tracks — every track belongs to exactly one group — and write rows and templates where the
+//                mix expects them;
+//   2. mix       mix_body (wbx_mix.h), unchanged: the group's sum goes to `partial` (a one-group session: straight to the
+//                master);
+//   3. epilogue  the group sums become the master without a fourth party.  ONE workgroup adding the 256 group sums of a
+//                4096-track block moves 1 MiB through one CU's L1 (64 B per clock: 8 us before any latency — measured 15-19);
+//                so when the grid fits the device at once (at most one workgroup per CU: they are all resident), the
+//                workgroups meet at a ticket counter and EACH adds a share of the block's frames (sum_block, wbx_sum.h — the
+//                same code and the same order of additions as sum_kernel: a lane owns 4 frames and walks the groups in
+//                order), clamps, converts and stores them into pinned host memory; the one that finishes last copies the
+//                plan status and then writes the launch's sequence number, which the audio thread polls: no completion
+//                signal, no interrupt between the device and the callback's return.  A grid larger than the device keeps
+//                "the last workgroup adds everything" (a spin barrier would wait for workgroups that cannot start).
+//
+// Results are those of the three-launch path bit for bit (same functions, same order).  Occupancy does not matter here, so
+// the instances are built for two waves per SIMD (256 registers): the sequencer's locals stay in registers.
+#pragma once
+#include "wbx_mix.h"
+#include "wbx_seq.h"
+#include "wbx_sum.h"
+
+namespace wbx {
+
+struct CallbackArgs {
+  uint32_t* done;      // device, two words: workgroups that have stored their group sum / their share of the master — counted
+                       // from `base`, never reset (nobody knows when the last poller has left)
+  uint32_t spread;     // every workgroup adds a share of the master (the grid is resident at once); 0: the last one adds it all
+  uint32_t base;       // what `done[0]` reads when this launch starts
+  uint32_t* flag;      // pinned host: `seq` once master and status are out.  (One word per workgroup, the host waiting for all of
+                       // them, was tried instead of the second ticket: 3 us less on the device, 6 us more until the audio thread
+                       // had seen all 256 — the words share cache lines the polling core keeps losing to the next write.)
+  uint32_t seq;
+  uint32_t n_wgs;
+  uint32_t fenced;     // A/B aid (WBX_CB_FENCED=1): release / acquire fences instead of write-through stores + s_waitcnt
+  unsigned long long* dbg;   // diagnostic (WBX_CB_DBG=1): [n_wgs][6] wall-clock ticks at start / plan done / mix done / ticket / end, XCC id
+};
+
+template <int U, int FAM>
+__global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p, SumArgs s, CallbackArgs cb) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wg = blockIdx.y;
+  if (cb.dbg && tid == 0u) {
+    cb.dbg[6u * wg] = wall_clock64();
+    cb.dbg[6u * wg + 5u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+  }
+  {
+    // -- 1. the sequencer of this group's tracks, for the one block (Engine::process's transport: engine.cpp:1578-1585)
+    __shared__ DBlockTime s_time;
+    if (tid == 0u) block_times(p, &s_time);
+    __syncthreads();
+    const DGroup grp = a.groups[blockIdx.y];
+    for (uint32_t i = tid; i < grp.count; i += 256u) plan_track(p, a.order[grp.first + i], &s_time);
+    // rows, templates and per-track state are out (acknowledged by the L2 this CU sits behind: the vector L1 writes through)
+    // before any lane of the workgroup stages them.  No cache maintenance: nothing of this was in this CU's L1 before.
+    if (cb.fenced) __threadfence();
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 1u] = wall_clock64();
+  // -- 2. the mix of this group (512-frame stereo / 1024-frame mono: one workgroup per block and group)
+  mix_body<U, true, FAM, 1, 1, 1, 256>(a);
+  if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 2u] = wall_clock64();
+
+  // -- 3. the block's sum.  The group sums cross XCDs (each has its own L2): mix_body stored this group's with agent-scope
+  // stores (MixArgs::partial_through: written through to memory, acknowledged before the ticket is taken).  They are read
+  // with ordinary 16-B loads: an XCD's L2 cannot hold an older copy of another group's row — the launch began with clean
+  // caches and nothing on that XCD has touched those lines since — so every one of them misses and is answered by memory.
+  // No L2 write-back / invalidate anywhere: a release / acquire fence pair cost every one of the 256 workgroups of a
+  // 4096-track block its share of an L2 flush (measured: 77 -> 120 us per block), and reading the sums past the L2 dword by
+  // dword (agent-scope loads) cost 56 us.
+  __shared__ uint32_t s_ticket;
+  bool report = true;   // this workgroup writes the flag
+  if (!a.fused_master) {
+    if (cb.fenced) __threadfence();
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged ...
+    __syncthreads();                 // ... every wave's
+    if (tid == 0u) {
+      // (spread: the counter is never reset — nobody knows when the last poller has left; the host hands every launch the
+      //  count all earlier launches have left behind, cb.base)
+      uint32_t n = __hip_atomic_fetch_add(cb.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u - cb.base;
+      if (cb.spread) {   // wait for the others (all resident: the host spreads only grids of at most one workgroup per CU)
+        uint32_t spins = 0u;
+        while (n < cb.n_wgs && spins < 2000000u) {   // (bounded: ~1 s; a give-up is reported — status bit 5 — never a hang)
+          __builtin_amdgcn_s_sleep(1);
+          n = __hip_atomic_load(cb.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cb.base;
+          spins++;
+        }
+        if (n < cb.n_wgs && s.status_src) atomicOr(s.status_src + 1, 32u);
+      }
+      s_ticket = n;
+    }
+    __syncthreads();
+    if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 3u] = wall_clock64();
+    if (!cb.spread && s_ticket != cb.n_wgs) return;
+    if (cb.fenced) __threadfence();
+    const uint32_t F = s.block_frames, C = s.channels;
+    // a lane owns a slot (4 frames of one channel; interleaved output: of every channel) and walks the groups in order
+    const uint32_t n_slots = (s.out_il ? F : C * F) >> 2;
+    auto add_slot = [&](uint32_t slot, const PartialFromLds* lds) {
+      if (lds) {
+        if (s.out_il) {
+          if (s.n_buses) sum_block<16, true, true, true, PartialFromLds>(s, 0u, slot, lds);
+          else sum_block<16, false, true, true, PartialFromLds>(s, 0u, slot, lds);
+        } else {
+          if (s.n_buses) sum_block<16, true, false, true, PartialFromLds>(s, 0u, slot, lds);
+          else sum_block<16, false, false, true, PartialFromLds>(s, 0u, slot, lds);
+        }
+      } else if (s.out_il) {
+        if (s.n_buses) sum_block<16, true, true, true>(s, 0u, slot);
+        else sum_block<16, false, true, true>(s, 0u, slot);
+      } else {
+        if (s.n_buses) sum_block<16, true, false, true>(s, 0u, slot);
+        else sum_block<32, false, false, true>(s, 0u, slot);
+      }
+    };
+    if (cb.spread && cb.n_wgs <= 256u) {
+      // Spread: workgroup w owns slots w, w + n_wgs, ...  A lane walking the 256 groups of a 4096-track block by itself is
+      // eight dependent memory round trips (32 loads in flight); instead the workgroup's 256 lanes fetch (slot, group) pairs —
+      // one 16-B load each, ONE round trip — into LDS, and one lane per slot adds them from there in group order.
+      __shared__ f4 s_part[2][256];
+      const uint32_t ng = s.n_groups;
+      const uint32_t spr = 256u / ng;                 // slots a round covers (n_wgs == n_groups <= 256: at least one)
+      const size_t stride = (size_t)C * F;
+      const uint32_t ls = tid / ng, g = tid - ls * ng;
+      for (uint32_t k0 = 0u; wg + k0 * cb.n_wgs < n_slots; k0 += spr) {
+        const uint32_t slot = wg + (k0 + ls) * cb.n_wgs;
+        if (ls < spr && slot < n_slots) {
+          const float* src = s.partial + (size_t)g * stride + (size_t)slot * 4u;
+          s_part[0][ls * ng + g] = *reinterpret_cast<const f4*>(src);
+          if (s.out_il && C > 1u) s_part[1][ls * ng + g] = *reinterpret_cast<const f4*>(src + F);
+        }
+        __syncthreads();
+        const uint32_t my = wg + (k0 + tid) * cb.n_wgs;
+        if (tid < spr && my < n_slots) {
+          const PartialFromLds lds{{&s_part[0][tid * ng], &s_part[(s.out_il && C > 1u) ? 1 : 0][tid * ng]}, s.out_il ? F : 0xFFFFFFFFu};
+          add_slot(my, &lds);
+        }
+        __syncthreads();
+      }
+    } else {
+      const uint32_t first = cb.spread ? wg + cb.n_wgs * tid : tid, step = cb.spread ? cb.n_wgs * 256u : 256u;
+      for (uint32_t slot = first; slot < n_slots; slot += step) add_slot(slot, nullptr);
+    }
+    // the plan's counters go to the host with workgroup 0's share (spread: beside the others' sums, not behind the second
+    // ticket) / with the last workgroup's master
+    if (!cb.spread || wg == 0u) {
+      if (s.status_dst && tid < 4u) {   // (as sum_kernel does: the plan's counters for the host, cleared for the buffer's next plan)
+        const uint32_t queued = __hip_atomic_load(s.status_src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(s.status_dst + tid, __hip_atomic_load(s.status_src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s.zero_status && queued == 0u) __hip_atomic_store(s.status_src + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (cb.spread) {   // whoever stores its share last reports (its own stores and, through the ticket, everybody's are acknowledged)
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0u) s_ticket = __hip_atomic_fetch_add(cb.done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u - cb.base;
+      __syncthreads();
+      report = s_ticket == cb.n_wgs;
+    }
+  }
+  if (!report) return;
+  // master and status (pinned host memory) went out as system-scope stores: once this workgroup's are acknowledged — every
+  // wave's — they are on their way to the host in front of its flag
+  if (cb.fenced) __threadfence_system();
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0u) {
+    __hip_atomic_store(cb.flag, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (cb.dbg) cb.dbg[6u * wg + 4u] = wall_clock64();
+  }
+}
+
+#define WBX_CALLBACK(U, FAM)                                                                             \
+  {                                                                                                      \
+    name = "wbx::callback_kernel<" #U ", " #FAM ">";                                                     \
+    hipLaunchKernelGGL((callback_kernel<U, FAM>), dim3(1, a.n_groups, 1), dim3(256), 0, st, a, p, s, cb); \
+  }
+
+// one per family (wbx_mix_fam<N>.hip); -> the instance's name
+const char* launch_callback_fam0(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, bool window, hipStream_t st);
+const char* launch_callback_fam1(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, hipStream_t st);
+const char* launch_callback_fam2(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, hipStream_t st);
+
+}  // namespace wbx

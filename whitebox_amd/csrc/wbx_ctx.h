@@ -25,6 +25,10 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
 const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s, hipEvent_t t0 = nullptr,
                        hipEvent_t t1 = nullptr);   // -> the instance's name
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
+// the one-block callback as one launch (wbx_callback.h): sequencer + mix + sum + completion flag -> the instance's name
+const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s, uint32_t* done, uint32_t done_base, bool spread,
+                            uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st);
+uint32_t callback_spread_limit();      // grids of at most this many workgroups are resident at once (the device's CU count)
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
@@ -140,6 +144,7 @@ struct wbx_ctx {
     DevBuf<DRow> prows;               // [K][N] 16-B plan rows
     DevBuf<DTrackBlock> tmpl;         // templates the rows point at (one per steady run / per block with events)
     uint32_t tmpl_cap = 0;
+    bool static_tmpl = false;         // the last plan into this buffer gave track t the templates 2t, 2t + 1 (no allocation count)
     DevBuf<DSeg> pool;
     uint32_t pool_chunks = 0;
     DevBuf<DBlockTime> times;         // [K] per-block transport records of a batch render (PlanArgs::times)
@@ -189,6 +194,17 @@ struct wbx_ctx {
 
   uint32_t last_K = 0, last_N = 0;
   uint32_t* status_dst = nullptr;     // set by wbx_engine_process around its render: where sum_kernel drops the plan status
+  // the one-launch callback (wbx_callback.h): set by wbx_engine_process around its render — the sequencer's arguments (the
+  // launch then runs plan + mix + sum as one kernel), the pinned word the kernel writes `cb_seq` into when master and status
+  // are out, and whether launch_mix_sum took that path
+  const PlanArgs* cb_plan = nullptr;
+  uint32_t* cb_flag = nullptr;
+  uint32_t cb_seq = 0;
+  bool cb_launched = false;
+  uint32_t* d_cb_done = nullptr;      // device: "workgroups done" ticket counter, never reset: launches count from cb_base
+  uint32_t cb_base = 0;
+  uint32_t cb_flags = 1;              // completion words the launch writes (one, or one per workgroup: cb_flag[0 .. cb_flags))
+  uint32_t cb_flag_cap = 1;           // ... and how many the engine's pinned block holds
   bool zero_status = false;           // ... and whether it clears the counters for the buffer's next plan
   bool buses_alias_partials = false;  // see build_routing
   const float* last_buses = nullptr;  // where the last render's bus sums are: d_buses or the partial buffer
@@ -303,6 +319,7 @@ bool render_chains_groups(const wbx_ctx* c, uint32_t K);
 int mix_family(const wbx_ctx* c);
 bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
+bool callback_is_one_launch(const wbx_ctx* c);
 
 // wbx_dist.hip
 float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);

@@ -178,7 +178,8 @@ struct PlanArgs {
   uint32_t masked_rows;         // the mix instance of this render takes partial-coverage rows (one segment, or a
                                 // ROW_PAIR) in its hot loop: do not queue them for the pre-render pass.  1: fp32 rows
                                 // (unity / window); 2: also integer PCM at unity speed (masked_kind, wbx_seq.h)
-  uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders)
+  uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders); 0: none —
+                                // track t owns templates 2t, 2t + 1 (the one-launch callback; tmpl_cap >= 2 * n_tracks)
   uint32_t lanes;               // tracks per wave of plan_kernel (64, or fewer for sessions cut into many clips: a wave
                                 // executes every branch any of its tracks takes, so its time is set by the number of
                                 // clip boundaries in the wave — fewer tracks per wave, more waves side by side)
@@ -223,6 +224,8 @@ struct MixArgs {
   uint32_t chain_epoch;         // this render's tag, 1 .. 2^28-1 (words are zeroed on allocation and when the tag wraps)
   uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
                                 // device's in-order workgroup dispatch is not what it is documented to be)
+  uint32_t partial_through;     // the one-launch callback: the group sum is written THROUGH to memory (agent-scope stores) — a
+                                // workgroup behind another XCD's L2 adds the group sums in this same launch
   uint32_t* chain_sticky;       // ... and of this one, which belongs to the context and is cleared only when a host call reports it
   unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][4] start / end wall-clock ticks, HW_ID, XCC_ID, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies

@@ -5,6 +5,8 @@
 // all per-block work.  Threading is the reference's (wbx_host.h): one audio thread in wbx_engine_process / _render
 // holding the editor lock for its host side, one UI thread whose edits take the same lock and whose
 // wbx_track_set_volume / _pan / _mute go through the per-track SPSC ring without it.
+#include <chrono>
+
 #include "wbx_ctx.h"
 #include "wbx_host.h"
 #include "wbx_seq.h"
@@ -29,6 +31,10 @@ struct wbx_engine {
   bool gains_valid[kRing] = {};
   int gains_slot = -1;                  // the buffer plans currently read
   std::vector<float> gains_tmp;
+  // the one-block callback reads the gains from a device copy (refreshed, in stream order, only when a parameter changed):
+  // a read of pinned host memory is the longest round trip in its sequencer's latency chain
+  DevBuf<float> d_gains_cb;
+  uint64_t gains_gen = 0, d_gains_cb_gen = ~0ull;   // how often the pinned gains were rebuilt / which build the copy mirrors
   // the per-block transport records of a batch render (PlanArgs::times): K dependent additions, done here on the host — it
   // repeats that arithmetic anyway to keep its own transport — and moved in front of the plan by a kernel that reads this
   // pinned table (one lane of the GPU beside a running mix took 0.15-0.2 ms for 2048 blocks).  A ring of eight: the host
@@ -42,7 +48,10 @@ struct wbx_engine {
   // Engine::process (one block per call): pinned, device-mapped host staging the sum kernel writes the block into
   // and the plan status lands in — the callback path then needs no copy-engine transfer at all
   float* h_block = nullptr;             // [C][F]
-  uint32_t* h_status = nullptr;         // plan counters [4]
+  uint32_t* h_status = nullptr;         // plan counters [4]; from [8]: the one-launch callback's completion words (its sequence
+                                        // number, one word or one per workgroup), kCbFlags of them
+  static constexpr uint32_t kCbFlags = 256;
+  uint32_t cb_seq = 0;                  // ... of the last launch
   bool in_process = false;              // render_locked runs inside wbx_engine_process, which waits for the block: the
                                         // pinned tables need no completion events
   bool gen_skipped = false;             // ... and left the pre-render launch out (expecting an empty queue)
@@ -146,6 +155,7 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
   e->d_clip_first.release();
   e->d_state.release();
   e->d_levels.release();
+  e->d_gains_cb.release();
   for (int i = 0; i < kRing; i++) {
     if (e->h_patch[i]) (void)hipHostFree(e->h_patch[i]);
     if (e->patch_done[i]) (void)hipEventDestroy(e->patch_done[i]);
@@ -702,6 +712,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     hs.build_gains_locked(e->gains_tmp);
     std::memcpy(e->h_gains[slot], e->gains_tmp.data(), e->gains_tmp.size() * sizeof(float));
     e->gains_slot = slot;
+    e->gains_gen++;
   }
 
   // -- clip lists
@@ -773,7 +784,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration));
   if (st != WBX_OK) return cfail(e, st);
-  st = ensure_template_capacity(c, hs.template_hint(K));
+  st = ensure_template_capacity(c, std::max(hs.template_hint(K), (size_t)2 * N));   // (2 N: the one-launch callback's static pairs)
   if (st != WBX_OK) return cfail(e, st);
 
   // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
@@ -870,7 +881,26 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, hipStreamWaitEvent(ps, e->plan_handover, 0));
   }
   e->last_plan_stream = ps;
-  launch_plan(a, ps);
+  // The one-block callback of a session whose clip boundaries stay in the hot loop: the pre-render queue is empty
+  // unless a block holds three or more stream calls or overlapping ones.  Leave the launch out; wbx_engine_process
+  // looks at the queue counter afterwards and repeats pre-render + mix for the (rare) block that needed it.
+  // (sessions whose boundary blocks do go through the pre-render pass take the same bet when the block can be one launch:
+  //  a steady block — nearly all — wins two launches, a boundary block pays the repeat)
+  e->gen_skipped = e->in_process && !hs.any_slow_clip && (c->masked_rows || (K == 1u && callback_is_one_launch(c)));
+  // ... and then sequencer, mix and sum are ONE launch (wbx_callback.h): every mix workgroup plans its own tracks first, the
+  // last one to finish sums the block and tells the host
+  const bool one_launch = e->gen_skipped && K == 1u && callback_is_one_launch(c);
+  B.static_tmpl = one_launch;
+  if (one_launch) a.tmpl_reserve = 0u;   // track t owns templates 2t, 2t + 1: no allocation round trip in the latency chain
+  if (one_launch) {
+    if (e->d_gains_cb_gen != e->gains_gen || e->d_gains_cb.cap < (size_t)N * 2) {
+      WBX_EHIP(e, e->d_gains_cb.ensure(std::max<size_t>((size_t)c->cfg.max_tracks, N) * 2));
+      WBX_EHIP(e, hipMemcpyAsync(e->d_gains_cb.p, e->h_gains[e->gains_slot], (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, ps));
+      e->d_gains_cb_gen = e->gains_gen;
+    }
+    a.gains = e->d_gains_cb.p;
+  }
+  if (!one_launch) launch_plan(a, ps);
   if (!e->in_process) {
     if (patch_slot >= 0) {
       WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
@@ -879,10 +909,6 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, hipEventRecord(e->gains_done[e->gains_slot], ps));   // (re-recorded by every plan that reads the buffer)
     e->gains_valid[e->gains_slot] = true;
   }
-  // The one-block callback of a session whose clip boundaries stay in the hot loop: the pre-render queue is empty
-  // unless a block holds three or more stream calls or overlapping ones.  Leave the launch out; wbx_engine_process
-  // looks at the queue counter afterwards and repeats pre-render + mix for the (rare) block that needed it.
-  e->gen_skipped = e->in_process && c->masked_rows && !hs.any_slow_clip;
   if (!e->gen_skipped) {
     st = launch_pre_render(c, K, ps);
     if (st != WBX_OK) return cfail(e, st);
@@ -898,10 +924,17 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->uniform_speed = hs.uniform_window_speed();
   const int mix_parity = (int)(c->render_seq % kRing);
+  c->cb_plan = one_launch ? &a : nullptr;
+  if (one_launch) {
+    c->cb_flag = e->h_status + 8;
+    c->cb_flag_cap = wbx_engine::kCbFlags;
+    c->cb_seq = ++e->cb_seq;
+  }
   st = launch_mix_sum(c, K, N);
+  c->cb_plan = nullptr;
   if (st != WBX_OK) return cfail(e, st);
   B.consumed = c->mix_done[mix_parity];   // recorded right after the mix: the plan buffer is free before the sum runs
-  B.consumed_valid = true;
+  B.consumed_valid = !c->cb_launched;   // (the one-launch callback records no event: wbx_engine_process waits for the launch itself)
 
   // -- transport: the host repeats the arithmetic of Engine::process (engine.cpp:1578-1585, :1619-1623) that
   //    the plan kernel performs for its K blocks, so both sides hold the same playhead / sample_position bits
@@ -958,15 +991,50 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
   } restore{c, saved_format};
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
   if (!e->h_block) WBX_EHIP(e, hipHostMalloc((void**)&e->h_block, (size_t)C * F * sizeof(float), hipHostMallocDefault));
-  if (!e->h_status) WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  if (!e->h_status) {
+    WBX_EHIP(e, hipHostMalloc((void**)&e->h_status, (8 + wbx_engine::kCbFlags) * sizeof(uint32_t), hipHostMallocDefault));
+    std::memset(e->h_status, 0, (8 + wbx_engine::kCbFlags) * sizeof(uint32_t));
+  }
   c->master_target = e->h_block;          // sum_kernel's stores go over PCIe into the staging block,
   c->status_dst = e->h_status;            // and it drops the plan status next to it
   e->in_process = true;
   c->zero_status = true;
+  c->cb_launched = false;
   wbx_status st = render_locked(e, 1);
   e->in_process = false;
+  const bool one_launch = st == WBX_OK && c->cb_launched;
   if (st == WBX_OK && e->hs.n_tracks() != 0) {
-    if (hipError_t he = sync_main(c); he != hipSuccess) st = WBX_ERR_DEVICE;
+    if (one_launch) {
+      // the kernel's own word: master and status are in host memory when it reads this launch's number.  Polled — no
+      // completion signal between the device and the return of the callback; a launch that never reports (a device fault)
+      // falls through to the stream's own error after two seconds
+      // (one word, or one per workgroup when every workgroup stores a share of the master: all of them)
+      volatile uint32_t* flag = e->h_status + 8;
+      const uint32_t n_flags = c->cb_flags, seq = e->cb_seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      uint32_t spins = 0, have = 0;
+      while (have < n_flags) {
+        if (flag[have] == seq) {
+          have++;
+          continue;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+          (void)sync_main(c);
+          for (have = 0; have < n_flags && flag[have] == seq; have++) {
+          }
+          if (have < n_flags) {   // the launch never reported: start the ticket count afresh
+            st = efail(e, WBX_ERR_DEVICE, "the one-launch callback did not report its block");
+            if (c->d_cb_done) (void)hipMemset(c->d_cb_done, 0, 2 * sizeof(uint32_t));
+            c->cb_base = 0;
+          }
+          break;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (hipError_t he = sync_main(c); he != hipSuccess) {
+      st = WBX_ERR_DEVICE;
+    }
     if (st == WBX_OK) {
       PB(c).counters_zero = e->h_status[2] == 0u;   // (sum_kernel cleared them unless something was queued)
       e->plan_status_on_host = true;
@@ -986,7 +1054,7 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
   c->master_target = nullptr;
   c->status_dst = nullptr;
   if (st != WBX_OK) return st;
-  WBX_EHIP(e, sync_main(c));
+  if (!one_launch) WBX_EHIP(e, sync_main(c));
   for (int i = 0; i < kRing; i++) e->patch_valid[i] = e->gains_valid[i] = false;   // every plan that read them is over
   drain_events(c);
   if (out_format == 0) {
@@ -1070,7 +1138,7 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   else
     WBX_EHIP(e, hipMemcpy(pc, PB(c).counters, sizeof(pc), hipMemcpyDeviceToHost));
   std::vector<DRow> rows((size_t)K * N);
-  const uint32_t nt = std::min(pc[3], PB(c).tmpl_cap);
+  const uint32_t nt = std::min(PB(c).static_tmpl ? 2u * N : pc[3], PB(c).tmpl_cap);
   std::vector<DTrackBlock> tmpl(nt);
   if (!rows.empty()) WBX_EHIP(e, hipMemcpy(rows.data(), PB(c).prows.p, rows.size() * sizeof(DRow), hipMemcpyDeviceToHost));
   if (nt) WBX_EHIP(e, hipMemcpy(tmpl.data(), PB(c).tmpl.p, nt * sizeof(DTrackBlock), hipMemcpyDeviceToHost));

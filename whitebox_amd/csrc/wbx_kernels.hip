@@ -21,6 +21,8 @@
 
 #include "wbx_mix.h"
 #include "wbx_seq.h"
+#include "wbx_sum.h"
+#include "wbx_callback.h"
 
 namespace wbx {
 
@@ -335,24 +337,6 @@ __global__ __launch_bounds__(256, 6) void gen_kernel(GenArgs a) {
 // with bus u = in-order sum of its groups (AudioBuffer::mix order, audio_buffer.h:73-82), then the
 // clamp of engine.cpp:1627-1636.  Groups arrive sorted: direct ones first, then by bus.
 // ------------------------------------------------------------------------------------------------
-// float -> int32 as the reference's x86 build converts (cvttss2si / cvttsd2si): truncation toward zero, and the
-// "integer indefinite" 0x80000000 for NaN and for anything outside [-2^31, 2^31) — the GPU's own conversion saturates
-// and maps NaN to 0, which differs whenever the master is left un-clamped or holds NaN.
-__device__ __forceinline__ int x86_cvtt_f32(float t) { return (t >= -2147483648.0f && t < 2147483648.0f) ? (int)t : (int)0x80000000; }
-__device__ __forceinline__ int x86_cvtt_f64(double t) { return (t >= -2147483648.0 && t < 2147483648.0) ? (int)t : (int)0x80000000; }
-
-// One sample of the master in an interleaved device format (core/audio_format_conv.cpp:5-20 i16, :45-60 i24 in 32-bit
-// containers, :62-77 i32): asymmetric scales, truncation toward zero, the x86 conversion results.
-__device__ __forceinline__ int to_i16(float v) { return x86_cvtt_f32(v > 0.0f ? __fmul_rn(v, 32767.0f) : __fmul_rn(v, 32768.0f)); }
-__device__ __forceinline__ int to_i24(float v) { return v > 0.0f ? x86_cvtt_f32(__fmul_rn(v, 8388607.0f)) : x86_cvtt_f32(__fmul_rn(v, 8388608.0f)); }
-__device__ __forceinline__ int to_i32(float v) { return x86_cvtt_f64(v > 0.0f ? __dmul_rn((double)v, 2147483647.0) : __dmul_rn((double)v, 2147483648.0)); }
-
-// PF = group partials in flight per lane: 16 for batch renders (the kernel runs beside the next mix and must stay small),
-// 32 for the one-block callback, whose sum is a chain of dependent HBM round trips — 128 groups are four of them, not eight
-// IL: the master leaves as INTERLEAVED device-format samples (SumArgs::out_format: what the audio back end hands the
-// device, audio_io_pulseaudio.cpp:419-461 -> AudioBuffer::interleave_samples_to -> core/audio_format_conv.cpp) instead
-// of planar fp32 — the conversion is the epilogue of the sum, no separate launch and no planar round trip.  A lane then
-// owns 4 frames of EVERY channel (grid.y covers F/4 slots).
 template <int PF, bool BUSES, bool IL = false>
 __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   if (a.status_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {
@@ -363,144 +347,10 @@ __global__ __launch_bounds__(64) void sum_kernel(SumArgs a) {
   const uint32_t F = a.block_frames, C = a.channels;
   const uint32_t slot = blockIdx.y * 64u + threadIdx.x;
   if (slot >= ((IL ? F : C * F) >> 2)) return;
-  const size_t stride = (size_t)C * F;
   // a wave walks blocks blockIdx.x, + gridDim.x, ...: the launch stays a few waves per CU however long the render is, so the
   // NEXT render's mix (other stream) finds free wave slots at once — a sum that fills every slot of the chip with waves
   // waiting on their PCIe stores holds that mix back for its whole duration
-  for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
-
-  // the master of elements e0 .. e0+3 of the block ([C][F] order): groups in order, buses in order, clamp
-  auto sum_at = [&](size_t e0) {
-  const float* p = a.partial + (size_t)b * a.n_groups * stride + e0;
-  f4 master = {0.0f, 0.0f, 0.0f, 0.0f};
-  f4 busacc = {0.0f, 0.0f, 0.0f, 0.0f};
-  int cur = -1;
-  if constexpr (!BUSES) {
-    // no sub-buses (the reference's own topology): every group goes straight into the master, in order — nothing but
-    // the loads, PF of them in flight, and the adds.  (Chained render: the pieces before the last hold intermediate
-    // running sums; the last one holds THE sum.)
-    for (uint32_t g0 = a.chain ? a.n_groups - 1u : 0u; g0 < a.n_groups; g0 += PF) {
-      f4 v[PF];
-#pragma unroll
-      for (int i = 0; i < PF; i++) {
-        const uint32_t g = g0 + i < a.n_groups ? g0 + i : a.n_groups - 1u;   // (clamped: straight-line loads)
-        v[i] = *reinterpret_cast<const f4*>(p + (size_t)g * stride);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // all PF loads are issued before the first add waits for one
-#pragma unroll
-      for (int i = 0; i < PF; i++) {
-        if (g0 + i < a.n_groups) {   // (a predicate, not a break: the unrolled array must stay in registers)
-          master.x = __fadd_rn(master.x, v[i].x);
-          master.y = __fadd_rn(master.y, v[i].y);
-          master.z = __fadd_rn(master.z, v[i].z);
-          master.w = __fadd_rn(master.w, v[i].w);
-        }
-      }
-    }
-  } else
-  for (uint32_t g0 = 0; g0 < a.n_groups; g0 += PF) {
-    f4 v[PF];
-#pragma unroll
-    for (int i = 0; i < PF; i++)
-      if (g0 + i < a.n_groups) v[i] = *reinterpret_cast<const f4*>(p + (size_t)(g0 + i) * stride);
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-      if (g0 + i >= a.n_groups) break;
-      if (a.chain && (a.groups[g0 + i].flags & GROUP_CHAIN_OUT)) continue;   // an intermediate running sum of a chained list
-      const int bus = a.groups[g0 + i].bus;
-      if (bus != cur) {
-        if (cur >= 0) {
-          if (a.buses) *reinterpret_cast<f4*>(a.buses + ((size_t)b * a.n_buses + cur) * stride + e0) = busacc;
-          master.x = __fadd_rn(master.x, busacc.x);
-          master.y = __fadd_rn(master.y, busacc.y);
-          master.z = __fadd_rn(master.z, busacc.z);
-          master.w = __fadd_rn(master.w, busacc.w);
-        }
-        busacc = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        cur = bus;
-      }
-      if (bus < 0) {
-        master.x = __fadd_rn(master.x, v[i].x);
-        master.y = __fadd_rn(master.y, v[i].y);
-        master.z = __fadd_rn(master.z, v[i].z);
-        master.w = __fadd_rn(master.w, v[i].w);
-      } else {
-        busacc.x = __fadd_rn(busacc.x, v[i].x);
-        busacc.y = __fadd_rn(busacc.y, v[i].y);
-        busacc.z = __fadd_rn(busacc.z, v[i].z);
-        busacc.w = __fadd_rn(busacc.w, v[i].w);
-      }
-    }
-  }
-  if (cur >= 0) {
-    if (a.buses) *reinterpret_cast<f4*>(a.buses + ((size_t)b * a.n_buses + cur) * stride + e0) = busacc;
-    master.x = __fadd_rn(master.x, busacc.x);
-    master.y = __fadd_rn(master.y, busacc.y);
-    master.z = __fadd_rn(master.z, busacc.z);
-    master.w = __fadd_rn(master.w, busacc.w);
-  }
-  if (a.clamp) {   // engine.cpp:1627-1636: compare, don't min/max (NaN passes through unchanged)
-    master.x = master.x > 1.0f ? 1.0f : (master.x < -1.0f ? -1.0f : master.x);
-    master.y = master.y > 1.0f ? 1.0f : (master.y < -1.0f ? -1.0f : master.y);
-    master.z = master.z > 1.0f ? 1.0f : (master.z < -1.0f ? -1.0f : master.z);
-    master.w = master.w > 1.0f ? 1.0f : (master.w < -1.0f ? -1.0f : master.w);
-  }
-  return master;
-  };
-
-  if constexpr (!IL) {
-    const size_t e0 = (size_t)slot * 4u;
-    *reinterpret_cast<f4*>(a.master + (size_t)b * stride + e0) = sum_at(e0);
-  } else {
-    const uint32_t j0 = slot * 4u;
-    f4 m[2];
-    m[0] = sum_at(j0);
-    m[1] = C > 1u ? sum_at((size_t)F + j0) : m[0];
-    const float s[2][4] = {{m[0].x, m[0].y, m[0].z, m[0].w}, {m[1].x, m[1].y, m[1].z, m[1].w}};
-    const size_t f0 = (size_t)b * F + j0;   // first frame of the lane in the whole render
-    // (stereo: the lane's 4 frames x 2 channels leave as one or two 16-byte stores — the destination is usually pinned host
-    //  memory, where narrow stores waste the PCIe write path)
-    uint32_t w[8];   // the 8 interleaved samples of a stereo lane as 32-bit words (i16: packed in pairs into w[0..3])
-    const uint32_t fmt = a.out_format;
-    if (fmt == 5u) {   // packed 24-bit: the reference's writer has no channel term in its destination index (audio_format_conv.cpp:
-      // 22-43), so a block's region of F*C*3 bytes holds the LAST channel's samples in its first 3*F bytes; the rest is
-      // never written.  12 bytes per lane: three dword stores.
-      const int q0 = to_i24(s[1][0]), q1 = to_i24(s[1][1]), q2 = to_i24(s[1][2]), q3 = to_i24(s[1][3]);   // (s[1] = the last channel, also for mono)
-      uint32_t* o = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.out_il) + (size_t)b * F * C * 3u + (size_t)j0 * 3u);
-      o[0] = ((uint32_t)q0 & 0xFFFFFFu) | ((uint32_t)q1 << 24);
-      o[1] = (((uint32_t)q1 >> 8) & 0xFFFFu) | ((uint32_t)q2 << 16);
-      o[2] = (((uint32_t)q2 >> 16) & 0xFFu) | ((uint32_t)q3 << 8);
-      continue;
-    }
-    auto conv = [&](float v) -> uint32_t {
-      return fmt == 3u ? (uint32_t)(uint16_t)(int16_t)to_i16(v) : fmt == 6u ? (uint32_t)(to_i24(v) & 0xFFFFFF)
-             : fmt == 7u ? (uint32_t)to_i32(v) : __float_as_uint(v);
-    };
-    if (C == 2u) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        w[2 * k] = conv(s[0][k]);
-        w[2 * k + 1] = conv(s[1][k]);
-      }
-      if (fmt == 3u) {
-        uint4 o = {w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
-        *reinterpret_cast<uint4*>(reinterpret_cast<int16_t*>(a.out_il) + f0 * 2u) = o;
-      } else {
-        uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.out_il) + f0 * 2u);
-        o[0] = uint4{w[0], w[1], w[2], w[3]};
-        o[1] = uint4{w[4], w[5], w[6], w[7]};
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) w[k] = conv(s[0][k]);
-      if (fmt == 3u) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<int16_t*>(a.out_il) + f0) = uint2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
-      } else {
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.out_il) + f0) = uint4{w[0], w[1], w[2], w[3]};
-      }
-    }
-  }
-  }   // blocks of this wave
+  for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) sum_block<PF, BUSES, IL>(a, b, slot);   // wbx_sum.h
 }
 
 // buses with no member groups stay zero: cleared before the launch by the runtime.
@@ -670,6 +520,27 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   if (family == 1) return launch_mix_fam1(a, n_blocks, s, t0, t1);
   if (family == 2) return launch_mix_fam2(a, n_blocks, variant, s, t0, t1);
   return launch_mix_fam0(a, n_blocks, variant, s, t0, t1);
+}
+
+uint32_t callback_spread_limit() {
+  static const uint32_t n_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return (uint32_t)(n > 0 ? n : 0);
+  }();
+  static const bool no_spread = [] { const char* v = std::getenv("WBX_CB_SPREAD"); return v && v[0] == '0'; }();   // A/B aid
+  return no_spread ? 0u : (n_cus < 256u ? n_cus : 256u);
+}
+
+const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s0, uint32_t* done, uint32_t done_base, bool spread,
+                            uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st) {
+  SumArgs s = s0;
+  s.n_blocks = 1u;
+  static const bool fenced = [] { const char* v = std::getenv("WBX_CB_FENCED"); return v && v[0] == '1'; }();   // A/B aid
+  CallbackArgs cb{done, spread ? 1u : 0u, done_base, flag, seq, m.n_groups, fenced ? 1u : 0u, dbg};
+  if (family == 1 || family == 3) return launch_callback_fam1(m, p, s, cb, st);   // (3 = 1 without the per-frame taps: one instance serves both)
+  if (family == 2) return launch_callback_fam2(m, p, s, cb, st);
+  return launch_callback_fam0(m, p, s, cb, window_rows, st);
 }
 
 void launch_sum(const SumArgs& a0, uint32_t n_blocks, hipStream_t s) {

@@ -26,6 +26,19 @@ __device__ __forceinline__ const T WBX_GLOBAL* as_global(const void* p) {
 }
 
 // reference math::clamp (core_math.h:33-37)
+// 16 bytes to (pinned) HOST memory, acknowledged only when the write is on its way to the host: a system-scope store.  The
+// one-launch callback (wbx_callback.h) tells the audio thread "master and status are there" with a flag it writes from inside
+// the kernel; an ordinary store is acknowledged by the L2 at once, and the flag — another wave's store, another L2 channel —
+// overtook the data (measured: the left channel of the first block read as zeros).  s_waitcnt vmcnt(0) behind THIS store
+// waits for the real acknowledgement.
+__device__ __forceinline__ void store_f4_system(float* p, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_u4_system(void* p, uint4 u) {
+  const f4 v = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
   float m = x < hi ? x : hi;
   return m > lo ? m : lo;
@@ -210,8 +223,10 @@ struct RowT {
 //         row costs it once instead of once per channel, and one set of record scalars serves both.  Workgroups of
 //         128 lanes = one 512-frame block)
 // ------------------------------------------------------------------------------------------------
-template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1, int T = 256 / CL>
-__global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
+// (the kernel's body as a function: mix_kernel below is nothing else; the one-launch callback — wbx_callback.h — runs the
+//  sequencer of the workgroup's tracks in front of it and the block's sum behind it)
+template <int U, bool FULL, int FAM, int SB, int CW, int CL, int T>
+__device__ __forceinline__ void mix_body(const MixArgs& a) {
   // FAM: which chunk modes the instance carries — every mode it carries costs registers in all the others.
   //   0  fp32 (unity / window) and integer PCM at unity speed: U, W, WN, WNU, I16, I32, MU, MIXED
   //   1  everything: also per-frame taps, 16-bit / 24-bit / 32-bit window rows, windows of several formats in one chunk
@@ -1501,7 +1516,10 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   if (a.fused_master) {   // (wave-uniform) this workgroup's sum IS the block's: what sum_kernel would do with one group
     if (a.fused_status_dst && blockIdx.x == 0u && tid < 4u) {
       const uint32_t queued = a.fused_status_src[2];
-      a.fused_status_dst[tid] = a.fused_status_src[tid];
+      if (a.partial_through)
+        __hip_atomic_store(a.fused_status_dst + tid, a.fused_status_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else
+        a.fused_status_dst[tid] = a.fused_status_src[tid];
       if (a.fused_zero_status && queued == 0u) a.fused_status_src[tid] = 0u;
     }
     if (active && bvalid) {
@@ -1518,14 +1536,26 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
           m.z = m.z > 1.0f ? 1.0f : (m.z < -1.0f ? -1.0f : m.z);
           m.w = m.w > 1.0f ? 1.0f : (m.w < -1.0f ? -1.0f : m.w);
         }
-        *reinterpret_cast<f4*>(a.fused_master + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0) = m;
+        float* mo = a.fused_master + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;
+        if (a.partial_through)   // (wave-uniform) the one-launch callback: the host is told by a flag from inside this launch
+          store_f4_system(mo, m);
+        else
+          *reinterpret_cast<f4*>(mo) = m;
       }
     }
   } else if (active && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
       float* out = a.partial + (((size_t)b * a.n_groups + g) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;
-      *reinterpret_cast<f4*>(out) = acc.c[ch];   // (chained: the running sum for the next piece — the L1 writes through to the XCD's L2)
+      if (a.partial_through) {   // (wave-uniform) the one-launch callback: read by a workgroup behind another L2 in this same launch
+        uint32_t* o = reinterpret_cast<uint32_t*>(out);
+        __hip_atomic_store(o + 0, __float_as_uint(acc.c[ch].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, __float_as_uint(acc.c[ch].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, __float_as_uint(acc.c[ch].z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 3, __float_as_uint(acc.c[ch].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<f4*>(out) = acc.c[ch];   // (chained: the running sum for the next piece — the L1 writes through to the XCD's L2)
+      }
     }
   }
   if (chain_out) {
@@ -1533,6 +1563,11 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
     __syncthreads();                 // ... of every wave of the workgroup
     if (tid == 0u) __hip_atomic_store(chain_word, chain_tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1, int T = 256 / CL>
+__global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
+  mix_body<U, FULL, FAM, SB, CW, CL, T>(a);
 }
 
 // one instance, launched; t0 / t1 (optional): events that take the kernel's own start and end times (hipExtLaunchKernelGGL:

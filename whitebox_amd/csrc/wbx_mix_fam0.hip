@@ -1,6 +1,9 @@
 // wbx_mix_fam0.hip — mix_kernel instances of family 0: fp32 rows (unity / 5-sample window) and integer PCM at unity speed
 // (chunk modes U, W, WN, WNU, I16, I32, MU, MIXED).  What the BASELINE configurations 2-5 take.
+#include <cstdlib>
+
 #include "wbx_mix.h"
+#include "wbx_callback.h"
 
 namespace wbx {
 
@@ -75,6 +78,25 @@ const char* launch_mix_fam0(const MixArgs& a, uint32_t n_blocks, int variant, hi
 #undef WBX_V
     default: WBX_MIX(2, true, 4, 0, 1, 1, 1, 256, grid, block) break;
   }
+  return name;
+}
+
+// the one-launch callback (wbx_callback.h), 512-frame stereo / 1024-frame mono blocks: sessions with resampled or integer-PCM
+// clips stage two rows per pipeline batch, fp32 sessions at the session rate four
+const char* launch_callback_fam0(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, bool window, hipStream_t st) {
+  const char* name = "";
+  // (a callback workgroup is a latency chain — one pipeline batch per memory round trip — and has a CU to itself: many rows
+  //  per batch.  WBX_CB_U=2|4|8: A/B aid)
+  static const int u = [] { const char* v = std::getenv("WBX_CB_U"); return v ? std::atoi(v) : 0; }();
+  (void)window;
+  // (measured, 16 tracks per workgroup: the rows that pad the last pipeline batch are rendered like real ones, and a
+  //  callback workgroup is bound by instruction issue — U = 2: 11.3 us, 4: 11.6, 8: 13.4)
+  if (u == 8)
+    WBX_CALLBACK(8, 0)
+  else if (u == 4)
+    WBX_CALLBACK(4, 0)
+  else
+    WBX_CALLBACK(2, 0)
   return name;
 }
 

@@ -2,6 +2,7 @@
 // recorded, resampled integer PCM above 0.999), 16 / 24 / 32-bit window rows, windows of several storage formats in one
 // chunk (MW, MWN).  Sessions with such clips take it; so does every block shape the lean families have no instance for.
 #include "wbx_mix.h"
+#include "wbx_callback.h"
 
 namespace wbx {
 
@@ -47,6 +48,12 @@ const char* launch_mix_fam1(const MixArgs& a, uint32_t n_blocks, hipStream_t s, 
   }
   // (W = 4 although this instance spills a few registers there: at W = 3 it is 5-10 % slower)
   WBX_MIX(2, true, 4, 1, 1, 1, 1, 256, grid, block)
+  return name;
+}
+
+const char* launch_callback_fam1(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, hipStream_t st) {
+  const char* name = "";
+  WBX_CALLBACK(2, 1)
   return name;
 }
 

@@ -2,6 +2,7 @@
 // exactly 1 (CD-rate files in a 48 kHz project): chunk modes U, I16, MU, WI, WIN, WINU; a chunk that holds a pre-rendered
 // fp32 row next to 16-bit window rows goes one row at a time.
 #include "wbx_mix.h"
+#include "wbx_callback.h"
 
 namespace wbx {
 
@@ -21,6 +22,12 @@ const char* launch_mix_fam2(const MixArgs& a, uint32_t n_blocks, int variant, hi
     WBX_MIX(2, true, 3, 2, 1, 1, 2, 256, dim3(n_blocks, a.n_groups, 1), dim3(256))
   else
     WBX_MIX(2, true, 4, 2, 1, 1, 1, 256, grid, block)
+  return name;
+}
+
+const char* launch_callback_fam2(const MixArgs& a, const PlanArgs& p, const SumArgs& s, const CallbackArgs& cb, hipStream_t st) {
+  const char* name = "";
+  WBX_CALLBACK(2, 2)
   return name;
 }
 

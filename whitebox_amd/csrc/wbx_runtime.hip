@@ -324,6 +324,15 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   return window_clips ? 0u : 2u;
 }
 
+// Does a one-block render of wbx_engine_process run as ONE launch (wbx_callback.h)?  Blocks that are exactly one 256-lane
+// workgroup (512-frame stereo, 1024-frame mono: the instances that exist), no multi-GPU exchange.  WBX_CALLBACK_FUSED=0: the
+// three launches of earlier rounds (A/B aid; results are identical).
+bool callback_is_one_launch(const wbx_ctx* c) {
+  static const bool off = [] { const char* v = std::getenv("WBX_CALLBACK_FUSED"); return v && v[0] == '0'; }();
+  const uint32_t S4 = c->cfg.block_frames >> 2;
+  return !off && !c->dist && c->cfg.channels * S4 == 256u && (S4 % 64u) == 0u && !c->mix_unroll;
+}
+
 // where the master of the render about to be issued goes; `writer` is the stream its last writer runs on
 float* begin_master(wbx_ctx* c, hipStream_t writer, hipError_t* err) {
   *err = hipSuccess;
@@ -435,7 +444,9 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   if (m.tiles > 1) WBX_HIP(c, hipMemsetAsync(m.peaks, 0, (size_t)K * N * C * sizeof(float), ms));
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
-  if (m.n_groups) {
+  const bool one_launch = c->cb_plan != nullptr && K == 1u && m.n_groups != 0u && callback_is_one_launch(c);
+  c->cb_launched = false;
+  if (m.n_groups && !one_launch) {
     if (timed) {
       if (c->ev_pending == kEventRing) {
         WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
@@ -456,7 +467,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
-  WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));
+  if (!one_launch) WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));   // (one launch: recorded behind it, below)
   if (ms != c->stream) c->alt_pending = pp;
   // A master bound for pinned host memory leaves a batch render through a device staging buffer and the copy engine.  Stored
   // by the sum kernel itself, its megabytes of posted writes fill the GPU's upstream queue in a few microseconds and drain at
@@ -511,7 +522,35 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     c->buses_clean = true;
   }
   if (ss == c->stream && ms != c->stream) c->alt_pending = -1;            // (the main stream has just joined that mix)
-  if (!fused) launch_sum(s, K, ss);
+  if (one_launch) {
+    // sequencer + mix + sum in one dispatch; the kernel itself tells the host when master and status are out (cb_flag)
+    if (!c->d_cb_done) {
+      WBX_HIP(c, hipMalloc((void**)&c->d_cb_done, 2 * sizeof(uint32_t)));
+      WBX_HIP(c, hipMemsetAsync(c->d_cb_done, 0, 2 * sizeof(uint32_t), ms));
+      c->cb_base = 0;
+    }
+    unsigned long long* cb_dbg = nullptr;
+    {
+      static const bool dbg = std::getenv("WBX_CB_DBG") != nullptr;   // diagnostic: the phases of every workgroup (tools/cb_clocks.py)
+      if (dbg) {
+        c->dbg_wgs = ((size_t)6 * m.n_groups + 3) / 4;
+        WBX_HIP(c, c->d_dbg.ensure(4 * c->dbg_wgs));
+        cb_dbg = c->d_dbg.p;
+      }
+    }
+    m.partial_through = (std::getenv("WBX_CB_FENCED") && std::getenv("WBX_CB_FENCED")[0] == '1') ? 0u : 1u;
+    // every workgroup adds a share of the master when the whole grid is resident at once (at most one workgroup per CU: two
+    // fit) and the engine's pinned block has a completion word for each of them
+    const bool spread = !fused && m.n_groups <= callback_spread_limit();
+    c->cb_flags = 1u;
+    c->mix_kernel_name = launch_callback(m, *c->cb_plan, s, c->d_cb_done, c->cb_base, spread, c->cb_flag, c->cb_seq, mix_family(c),
+                                         c->has_window_clips || c->has_integer_clips, cb_dbg, ms);
+    if (!fused) c->cb_base += m.n_groups;   // (a one-group block takes no ticket)
+    c->cb_launched = true;
+    // (no event behind it: wbx_engine_process waits for the launch's own word before it returns, nothing can overlap it)
+  } else if (!fused) {
+    launch_sum(s, K, ss);
+  }
   if (stage_bytes) WBX_HIP(c, hipMemcpyAsync(master_home, master_dst, stage_bytes, hipMemcpyDeviceToHost, ss));
   if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
@@ -713,6 +752,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   c->d_conv.release();
   c->d_chain.release();
   if (c->d_sticky_status) (void)hipFree(c->d_sticky_status);
+  if (c->d_cb_done) (void)hipFree(c->d_cb_done);
   c->d_dbg.release();
   c->d_zero.release();
   for (int i = 0; i < kEventRing; i++) {

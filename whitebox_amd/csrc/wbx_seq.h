@@ -40,6 +40,17 @@ __host__ __device__ inline uint32_t u32_of_ceil(double x) {
   return (uint32_t)(uint64_t)(long long)c;
 }
 
+// the plan's status word (PlanArgs::status): tracks raise their bits side by side — on the device an atomic OR (the one-launch
+// callback reads the word in the same launch, from behind another L2: a plain read-modify-write could stay in a cache)
+__host__ __device__ inline void raise_status(uint32_t* status, uint32_t bits) {
+  if (!status) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicOr(status, bits);
+#else
+  status[0] |= bits;
+#endif
+}
+
 // segment 0 of a track-block lives inline in the record
 __host__ __device__ inline void set_seg0(DTrackBlock* tb, const DSeg& s) {
   tb->src[0] = s.src[0];
@@ -151,7 +162,7 @@ struct BlockWalker {
     c = (*pool_count)++;
 #endif
     if (c >= pool_chunks) {
-      if (status) status[0] |= 1u;
+      raise_status(status, 1u);
       return false;
     }
     chunk = c;
@@ -162,7 +173,7 @@ struct BlockWalker {
   // where call number `nseg` (>= 2) of this block goes in the overflow pool
   __host__ __device__ DSeg* slot() {
     if (nseg >= kMaxSegs) {
-      if (status) status[0] |= 2u;
+      raise_status(status, 2u);
       return nullptr;
     }
     if (nseg == 2 && !alloc_chunk()) return nullptr;
@@ -214,7 +225,7 @@ struct BlockWalker {
       if (buffer_offset + (uint64_t)n > n_samples) {       // the reference would write out of bounds here
         n = buffer_offset < n_samples ? n_samples - buffer_offset : 0;
         seg.flags |= SEG_CLIPPED;
-        if (status) status[0] |= 4u;
+        raise_status(status, 4u);
       }
       seg.len = (uint16_t)n;
       st->sample_offset = next_sample_offset;                                                    // :209
@@ -402,6 +413,10 @@ __host__ __device__ inline uint8_t classify(const DTrackBlock& tb, uint32_t bloc
 __host__ __device__ inline uint32_t alloc_template(const PlanArgs& a, TrackCache* cache, uint32_t n = 1u) {
   if (cache->tmpl_next + n > cache->tmpl_end) {
     uint32_t base;
+    if (a.tmpl_reserve == 0u) {   // (a track's static pair is used up: cannot happen in a one-block render)
+      raise_status(a.status, 16u);
+      return 0xFFFFFFFFu;
+    }
     const uint32_t take = a.tmpl_reserve > n ? a.tmpl_reserve : n;
 #if defined(__HIP_DEVICE_COMPILE__)
     base = atomicAdd(a.tmpl_count, take);
@@ -410,7 +425,7 @@ __host__ __device__ inline uint32_t alloc_template(const PlanArgs& a, TrackCache
     *a.tmpl_count += take;
 #endif
     if (base + take > a.tmpl_cap) {
-      if (a.status) a.status[0] |= 16u;
+      raise_status(a.status, 16u);
       return 0xFFFFFFFFu;
     }
     cache->tmpl_next = base;
@@ -589,8 +604,8 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
 #endif
     if (row < a.gen_cap)
       a.gen_list[row] = tmpl_index;
-    else if (a.status)
-      a.status[0] |= 8u;
+    else
+      raise_status(a.status, 8u);
   }
 }
 
@@ -754,6 +769,26 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
   cache.smp_idx = 0xFFFFFFFFu;
   cache.fin_tmpl = 0xFFFFFFFFu;
   cache.tmpl_next = cache.tmpl_end = 0u;
+  if (a.tmpl_reserve == 0u) {   // one-block renders: the track owns templates 2t and 2t + 1 (a block takes one, or a ROW_PAIR's two)
+    cache.tmpl_next = 2u * t;   // — no atomic round trip in the callback's latency chain
+    cache.tmpl_end = 2u * t + 2u;
+  }
+  // The records the track is about to use — the clip it stands on, the clip behind it, the sample that is playing — are
+  // fetched TOGETHER, as soon as the state names them: the sequencer is one lane per track, and finding them one after the
+  // other (state -> clip -> sample) is three dependent memory round trips in front of a one-block render.  (Filling the
+  // cache changes no result: every use of a cached record compares its index first.)
+  if (st.has_clip_idx && st.clip_idx < nc) {
+    cache.clip = clips[st.clip_idx];
+    cache.clip_idx = st.clip_idx;
+    if (st.clip_idx + 1u < nc) {
+      cache.next = clips[st.clip_idx + 1u];
+      cache.next_idx = st.clip_idx + 1u;
+    }
+  }
+  if (st.cur_type == EV_PLAY) {
+    cache.smp = a.samples[st.cur_sample];
+    cache.smp_idx = st.cur_sample;
+  }
   const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
   uint32_t b = 0;
   while (b < a.n_blocks) {
