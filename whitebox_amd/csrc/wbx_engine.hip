@@ -850,7 +850,11 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.sample_position = hs.sample_position;
   a.beat_duration = beat_duration;
   a.times = nullptr;
-  if (plan_beside && !c->has_cut_tracks) {
+  // (WBX_PLAN_LDS_TABLE=0: A/B aid — the device-memory table for cut sessions too.  Measured again in round 4, with the run
+  //  end estimated instead of searched: plan of c3 cut into 5.3-block clips 5.4 ms from LDS, 10.9 ms from device memory, 4 /
+  //  2 / 1 tracks per wave 12-25 ms: every record look-up at a clip boundary is a memory round trip for its lane)
+  static const bool lds_table_for_cut = [] { const char* v = std::getenv("WBX_PLAN_LDS_TABLE"); return !(v && v[0] == '0'); }();
+  if (plan_beside && (!c->has_cut_tracks || !lds_table_for_cut)) {
     // Batch render of a session whose tracks are single clips (a steady run per track, a handful of look-ups): the transport
     // records live in device memory and the sequencer takes the register-capped instance — nothing in LDS, a wave no larger
     // than a mix wave, so it runs BESIDE the previous mix instead of in the drain at its end.  Sessions cut into clips

@@ -556,7 +556,7 @@ struct HostSession {
     (void)K;
     if (const char* e = std::getenv("WBX_PLAN_LANES")) {   // tuning knob; measured on c3 cut into clips of 5.3 / 20 blocks:
       const int v = std::atoi(e);                          // 64, 32, 16 and 8 tracks per wave within 2 % of each other
-      if (v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
+      if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
     }
     return 64u;
   }

@@ -653,8 +653,36 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   // fp64 addition of a positive step (engine.cpp:1582,1621), so start_time and end_time are non-decreasing
   // in the block index: min_time < start_time only needs checking at the first block, and the last block
   // with max_time > end_time is found by bisection — no per-block LDS read on the critical path below.
-  if (!(min_time < times[b].start_time)) return 0;
+  const DBlockTime t_b = times[b];
+  if (!(min_time < t_b.start_time)) return 0;
+  // n_time = the first i with !(max_time > times[b + i].end_time).  The windows advance by one (rounded) block length per
+  // block, so the answer is known to within a block or two from ONE record: estimate, then let the table itself decide —
+  // the same predicate on the same records as a bisection, a couple of look-ups instead of eleven (a session cut into
+  // clips searches once per clip, and each look-up is a memory round trip for the lane).
   uint32_t lo = 0, hi = a.n_blocks - b;
+  {
+    const double dt = t_b.end_time - t_b.start_time;
+    const double est = (max_time - t_b.end_time) / dt;
+    if (dt > 0.0 && est >= 0.0 && est < (double)hi) {
+      uint32_t i = (uint32_t)est;
+      uint32_t steps = 0;
+      while (i < hi && max_time > times[b + i].end_time && steps < 8u) {
+        i++;
+        steps++;
+      }
+      while (i > 0u && !(max_time > times[b + i - 1u].end_time) && steps < 8u) {
+        i--;
+        steps++;
+      }
+      if (steps < 8u) {   // (i is the answer: every block below it passes, block i does not — or i == hi)
+        lo = hi = i;
+      }
+    } else if (dt > 0.0 && est >= (double)hi && max_time > times[b + hi - 1u].end_time) {
+      lo = hi;            // the clip outlasts the render
+    } else if (dt > 0.0 && est < 0.0 && !(max_time > t_b.end_time)) {
+      hi = 0u;            // it ends inside this very block
+    }
+  }
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
     if (max_time > times[b + mid].end_time)
