@@ -107,6 +107,12 @@ wbx_status cfail(wbx_engine* e, wbx_status s) {
     }                                                               \
   } while (0)
 
+// A/B aid (WBX_FORCE_CUT=1): an uncut session through the instances a session cut into clips takes
+bool force_cut_instances() {
+  static const bool on = [] { const char* v = std::getenv("WBX_FORCE_CUT"); return v && v[0] == '1'; }();
+  return on;
+}
+
 bool sample_in_use_cb(void* owner, uint32_t sample) { return static_cast<wbx_engine*>(owner)->hs.sample_referenced(sample); }
 
 }  // namespace
@@ -777,7 +783,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_stride_clips = hs.any_stride_clip;
   c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
-  c->has_cut_tracks = hs.cut_tracks != 0;
+  c->has_cut_tracks = hs.cut_tracks != 0 || force_cut_instances();
   c->short_render_now = K < kOverlapMinBlocks;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance; reads the flags above)
   c->chain_now = render_chains_groups(c, K);
@@ -841,7 +847,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_stride_clips = hs.any_stride_clip;
   c->has_taps_clips = hs.any_taps_clip;
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
-  c->has_cut_tracks = hs.cut_tracks != 0;
+  c->has_cut_tracks = hs.cut_tracks != 0 || force_cut_instances();
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   a.masked_rows = c->masked_rows;
   a.tmpl_reserve = HostSession::template_reserve(K);
