@@ -5,7 +5,7 @@
 # 256-block renders.  Counters are never combined with trace domains other than --kernel-trace.
 # usage (on the GPU box): tools/profile_round.sh [tag]      -> gpurun_out/<tag>/ ; then tools/refresh_profiles.sh <tag> <round>
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -66,6 +66,21 @@ pmc c3_L5.3 --clip-blocks 5.3
 pmc i16r --workload i16r
 pmc c3_K256 --blocks 256
 cd $R
+# round 4: the one-block callback as one launch — kernel trace of 400 wbx_engine_process calls per session size (one dispatch
+# each), the phases of the launch (tools/cb_clocks.py), and the same with the three launches of earlier rounds
+cd /tmp
+for N in 4096 64 8; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_callback_N$N -o cb -- python $R/tools/callback_calls.py $N 400 > $O/kt_callback_N$N.log 2>&1
+done
+cd $R
+( for N in 4096 1024 256 64 8; do timeout 120 python tools/cb_clocks.py c3 $N; done ) > $O/callback_clocks.txt 2>&1
+( echo "== one launch (default)"; timeout 300 python bench.py $B --no-verify --steps 3 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['latency_mode'])";
+  echo "== three launches (WBX_CALLBACK_FUSED=0)"; WBX_CALLBACK_FUSED=0 timeout 300 python bench.py $B --no-verify --steps 3 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['latency_mode'])" ) > $O/callback_latency_ab.txt 2>&1
+# rank processes that share the one GPU (RCCL's socket transport): world 2 and 8, chain mode (the default for >= 1024-block renders)
+for Wd in 2 8; do
+  WBX_SHARE_DEVICE=1 timeout 900 python bench.py --gpus $Wd --blocks 1024 --steps 4 --warmup 1 --ramp-steps 2 --session-blocks 2048 $B --latency-blocks 0 \
+    > $O/bench_world${Wd}_shared_chain.json 2> $O/bench_world${Wd}_shared_chain.err
+done
 find $O -name "*.csv" -size +8M -delete
 find $O -name "*.db" -delete
 ls -R $O | head -60

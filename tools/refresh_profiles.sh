@@ -3,7 +3,7 @@
 # usage (in the repo root): tools/refresh_profiles.sh <tag> [round prefix, default r03]
 set -e
 TAG=${1:?tag}
-RN=${2:-r03}
+RN=${2:-r04}
 O=gpurun_out/$TAG
 for f in $O/bench_*.json; do W=$(basename $f .json); W=${W#bench_}; grep "^{" $f | tail -1 > profiles/${RN}_bench_$W.json; done
 cp $O/pytest_gpu.log profiles/${RN}_pytest_gpu.log

@@ -30,8 +30,8 @@
 namespace wbx {
 
 struct CallbackArgs {
-  uint32_t* done;      // device, two words: workgroups that have stored their group sum / their share of the master — counted
-                       // from `base`, never reset (nobody knows when the last poller has left)
+  uint32_t* done;      // device, two counters of kCbLanes words kCbStride apart each: workgroups that have stored their group
+                       // sum / their share of the master — counted from `base`, never reset
   uint32_t spread;     // every workgroup adds a share of the master (the grid is resident at once); 0: the last one adds it all
   uint32_t base;       // what `done[0]` reads when this launch starts
   uint32_t* flag;      // pinned host: `seq` once master and status are out.  (One word per workgroup, the host waiting for all of
@@ -43,6 +43,29 @@ struct CallbackArgs {
   unsigned long long* dbg;   // diagnostic (WBX_CB_DBG=1): [n_wgs][6] wall-clock ticks at start / plan done / mix done / ticket / end, XCC id
 };
 
+// A ticket counter 256 workgroups arrive at within a microsecond is ONE address at the memory-side atomic unit: the arrivals
+// serialise (≈20 ns each: 5-6 us before the last one is through).  The counter is therefore kCbLanes words, kCbStride words
+// apart (different memory channels): workgroup w adds to word w % kCbLanes, and whoever needs the total reads all of them —
+// lanes 0..15 of a wave, one load each, one round trip — and adds them up.  tid < 64 must call these together.
+constexpr uint32_t kCbLanes = 16, kCbStride = 64;
+__device__ __forceinline__ uint32_t cb_total(const uint32_t* cnt, uint32_t lane) {
+  uint32_t v = lane < kCbLanes ? __hip_atomic_load(cnt + lane * kCbStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  v += (uint32_t)__shfl_xor((int)v, 8, 64);
+  v += (uint32_t)__shfl_xor((int)v, 4, 64);
+  v += (uint32_t)__shfl_xor((int)v, 2, 64);
+  v += (uint32_t)__shfl_xor((int)v, 1, 64);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// arrive, then the total as it stands once this workgroup's own arrival is through (the workgroup whose arrival is the
+// last one to complete sees them all)
+__device__ __forceinline__ uint32_t cb_arrive(uint32_t* cnt, uint32_t wg, uint32_t lane) {
+  uint32_t old = 0u;
+  if (lane == 0u) old = __hip_atomic_fetch_add(cnt + (wg % kCbLanes) * kCbStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);   // (the returned value orders the reads below behind the arrival)
+  asm volatile("" ::"s"(old) : "memory");
+  return cb_total(cnt, lane);
+}
+
 template <int U, int FAM>
 __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p, SumArgs s, CallbackArgs cb) {
   const uint32_t tid = threadIdx.x;
@@ -51,18 +74,33 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     cb.dbg[6u * wg] = wall_clock64();
     cb.dbg[6u * wg + 5u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
   }
+  constexpr uint32_t kCbMail = kStage;   // tracks whose plan goes through LDS: one staged chunk
+  __shared__ __attribute__((aligned(16))) DRow s_mail_rows[kCbMail];
+  __shared__ __attribute__((aligned(16))) DTrackBlock s_mail_tmpl[2 * kCbMail];
   {
     // -- 1. the sequencer of this group's tracks, for the one block (Engine::process's transport: engine.cpp:1578-1585)
     __shared__ DBlockTime s_time;
     if (tid == 0u) block_times(p, &s_time);
     __syncthreads();
     const DGroup grp = a.groups[blockIdx.y];
-    for (uint32_t i = tid; i < grp.count; i += 256u) plan_track(p, a.order[grp.first + i], &s_time);
+    // The rows and templates also go into LDS (the first kCbMail tracks of the group: all of them in the callback
+    // configuration): the mix stages its first chunk from there — order -> rows -> templates were three dependent memory round
+    // trips in front of the first clip load.  The copies in memory (wbx_engine_fetch_plan, the pre-render repeat) are written
+    // as before; nobody waits for them unless the group is longer than one chunk.
+    for (uint32_t i = tid; i < grp.count; i += 256u)
+      plan_track(p, a.order[grp.first + i], &s_time, i < kCbMail ? &s_mail_rows[i] : nullptr, i < kCbMail ? &s_mail_tmpl[2u * i] : nullptr);
     // rows, templates and per-track state are out (acknowledged by the L2 this CU sits behind: the vector L1 writes through)
     // before any lane of the workgroup stages them.  No cache maintenance: nothing of this was in this CU's L1 before.
     if (cb.fenced) __threadfence();
-    __builtin_amdgcn_s_waitcnt(0);
+    if (grp.count > kCbMail)
+      __builtin_amdgcn_s_waitcnt(0);
+    else
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS copies; the memory copies complete behind the mix's back
     __syncthreads();
+    if (grp.count <= kStage && !cb.fenced) {
+      a.cb_rows = s_mail_rows;
+      a.cb_tmpl = s_mail_tmpl;
+    }
   }
   if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 1u] = wall_clock64();
   // -- 2. the mix of this group (512-frame stereo / 1024-frame mono: one workgroup per block and group)
@@ -82,23 +120,25 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     if (cb.fenced) __threadfence();
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged ...
     __syncthreads();                 // ... every wave's
-    if (tid == 0u) {
-      // (spread: the counter is never reset — nobody knows when the last poller has left; the host hands every launch the
-      //  count all earlier launches have left behind, cb.base)
-      uint32_t n = __hip_atomic_fetch_add(cb.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u - cb.base;
+    if (tid < 64u) {
+      // (the counters are never reset — nobody knows when the last poller has left; the host hands every launch the count
+      //  all earlier launches have left behind, cb.base)
+      uint32_t n = cb_arrive(cb.done, wg, tid) - cb.base;
       if (cb.spread) {   // wait for the others (all resident: the host spreads only grids of at most one workgroup per CU)
         uint32_t spins = 0u;
         while (n < cb.n_wgs && spins < 2000000u) {   // (bounded: ~1 s; a give-up is reported — status bit 5 — never a hang)
           __builtin_amdgcn_s_sleep(1);
-          n = __hip_atomic_load(cb.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cb.base;
+          n = cb_total(cb.done, tid) - cb.base;
           spins++;
         }
-        if (n < cb.n_wgs && s.status_src) atomicOr(s.status_src + 1, 32u);
+        if (tid == 0u && n < cb.n_wgs && s.status_src) atomicOr(s.status_src + 1, 32u);
       }
-      s_ticket = n;
+      if (tid == 0u) s_ticket = n;
     }
     __syncthreads();
     if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 3u] = wall_clock64();
+    // (not spread: whoever sees the full count adds everything — two workgroups whose arrivals complete together may both
+    //  see it and both store the same master: harmless)
     if (!cb.spread && s_ticket != cb.n_wgs) return;
     if (cb.fenced) __threadfence();
     const uint32_t F = s.block_frames, C = s.channels;
@@ -162,9 +202,12 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     if (cb.spread) {   // whoever stores its share last reports (its own stores and, through the ticket, everybody's are acknowledged)
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
-      if (tid == 0u) s_ticket = __hip_atomic_fetch_add(cb.done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u - cb.base;
+      if (tid < 64u) {
+        const uint32_t n = cb_arrive(cb.done + kCbLanes * kCbStride, wg, tid) - cb.base;
+        if (tid == 0u) s_ticket = n;
+      }
       __syncthreads();
-      report = s_ticket == cb.n_wgs;
+      report = s_ticket == cb.n_wgs;   // (as above: two may see it, both write the same word)
     }
   }
   if (!report) return;

@@ -47,6 +47,7 @@ constexpr int kEventRing = 64;
 // track plan kernel is starved for CU slots while a mix runs, so it needs that much slack to stay off the critical path.
 constexpr int kRing = 3;
 constexpr uint32_t kPaceRing = 64;
+constexpr uint32_t kCbDoneWords = 2 * 16 * 64;   // wbx_ctx::d_cb_done: two counters of kCbLanes words, kCbStride apart (wbx_callback.h)
 constexpr uint32_t kOverlapMinBlocks = 8;   // renders shorter than this run plan, mix and sum on the main stream
 
 // Clip audio lives in slabs of 1 GiB carved up in order (64-KiB granules): a session of thousands of clips is a few

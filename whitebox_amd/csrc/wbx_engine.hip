@@ -1035,7 +1035,7 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
           }
           if (have < n_flags) {   // the launch never reported: start the ticket count afresh
             st = efail(e, WBX_ERR_DEVICE, "the one-launch callback did not report its block");
-            if (c->d_cb_done) (void)hipMemset(c->d_cb_done, 0, 2 * sizeof(uint32_t));
+            if (c->d_cb_done) (void)hipMemset(c->d_cb_done, 0, kCbDoneWords * sizeof(uint32_t));
             c->cb_base = 0;
           }
           break;

@@ -525,8 +525,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   if (one_launch) {
     // sequencer + mix + sum in one dispatch; the kernel itself tells the host when master and status are out (cb_flag)
     if (!c->d_cb_done) {
-      WBX_HIP(c, hipMalloc((void**)&c->d_cb_done, 2 * sizeof(uint32_t)));
-      WBX_HIP(c, hipMemsetAsync(c->d_cb_done, 0, 2 * sizeof(uint32_t), ms));
+      WBX_HIP(c, hipMalloc((void**)&c->d_cb_done, kCbDoneWords * sizeof(uint32_t)));   // (two spread counters: wbx_callback.h)
+      WBX_HIP(c, hipMemsetAsync(c->d_cb_done, 0, kCbDoneWords * sizeof(uint32_t), ms));
       c->cb_base = 0;
     }
     unsigned long long* cb_dbg = nullptr;
