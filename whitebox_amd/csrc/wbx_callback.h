@@ -74,33 +74,20 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     cb.dbg[6u * wg] = wall_clock64();
     cb.dbg[6u * wg + 5u] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
   }
-  constexpr uint32_t kCbMail = kStage;   // tracks whose plan goes through LDS: one staged chunk
-  __shared__ __attribute__((aligned(16))) DRow s_mail_rows[kCbMail];
-  __shared__ __attribute__((aligned(16))) DTrackBlock s_mail_tmpl[2 * kCbMail];
   {
     // -- 1. the sequencer of this group's tracks, for the one block (Engine::process's transport: engine.cpp:1578-1585)
     __shared__ DBlockTime s_time;
     if (tid == 0u) block_times(p, &s_time);
     __syncthreads();
     const DGroup grp = a.groups[blockIdx.y];
-    // The rows and templates also go into LDS (the first kCbMail tracks of the group: all of them in the callback
-    // configuration): the mix stages its first chunk from there — order -> rows -> templates were three dependent memory round
-    // trips in front of the first clip load.  The copies in memory (wbx_engine_fetch_plan, the pre-render repeat) are written
-    // as before; nobody waits for them unless the group is longer than one chunk.
-    for (uint32_t i = tid; i < grp.count; i += 256u)
-      plan_track(p, a.order[grp.first + i], &s_time, i < kCbMail ? &s_mail_rows[i] : nullptr, i < kCbMail ? &s_mail_tmpl[2u * i] : nullptr);
+    for (uint32_t i = tid; i < grp.count; i += 256u) plan_track(p, a.order[grp.first + i], &s_time);
     // rows, templates and per-track state are out (acknowledged by the L2 this CU sits behind: the vector L1 writes through)
     // before any lane of the workgroup stages them.  No cache maintenance: nothing of this was in this CU's L1 before.
+    // (Handing rows and templates to the mix through LDS as well — its staging then reads no memory — was measured: the mix
+    //  phase stayed at 11.5 us, the sequencer phase grew by 0.5 us, an 8-track block by 2 us.  Not kept.)
     if (cb.fenced) __threadfence();
-    if (grp.count > kCbMail)
-      __builtin_amdgcn_s_waitcnt(0);
-    else
-      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS copies; the memory copies complete behind the mix's back
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (grp.count <= kStage && !cb.fenced) {
-      a.cb_rows = s_mail_rows;
-      a.cb_tmpl = s_mail_tmpl;
-    }
   }
   if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 1u] = wall_clock64();
   // -- 2. the mix of this group (512-frame stereo / 1024-frame mono: one workgroup per block and group)

@@ -224,10 +224,6 @@ struct MixArgs {
   uint32_t chain_epoch;         // this render's tag, 1 .. 2^28-1 (words are zeroed on allocation and when the tag wraps)
   uint32_t* chain_status;       // ... bit 5 of this word is set when a wait for a predecessor gave up (never, unless the
                                 // device's in-order workgroup dispatch is not what it is documented to be)
-  // the one-launch callback: the rows ([tracks of the group]) and templates ([2 per track]) of the workgroup's own tracks as the
-  // sequencer prologue left them in LDS — the first chunk is staged from there instead of from memory.  Null otherwise.
-  const DRow* cb_rows;
-  const DTrackBlock* cb_tmpl;
   uint32_t partial_through;     // the one-launch callback: the group sum is written THROUGH to memory (agent-scope stores) — a
                                 // workgroup behind another XCD's L2 adds the group sums in this same launch
   uint32_t* chain_sticky;       // ... and of this one, which belongs to the context and is cleared only when a host call reports it

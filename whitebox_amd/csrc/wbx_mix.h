@@ -1226,9 +1226,9 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         uint32_t o1 = 0u;
         if (chunk_i == 0u) {
           uint32_t o0 = 0u;
-          if (tid < cn && !a.cb_rows) o0 = a.order[grp.first + tid];
+          if (tid < cn) o0 = a.order[grp.first + tid];
           if (tid < ncn) o1 = a.order[grp.first + n0 + tid];
-          if (tid < cn) row = a.cb_rows ? a.cb_rows[tid] : a.rows[(size_t)bx * N + o0];   // (cb_rows: wave-uniform, wbx_callback.h)
+          if (tid < cn) row = a.rows[(size_t)bx * N + o0];
         } else {
           row = rows_cur[tid];
           o1 = s_ord[tid];
@@ -1273,10 +1273,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           const DRow row = rows_cur[mp & 0x7FFFu];
           const bool live = in && !(row.flags & ROW_SILENT);
           // (a lane without a live record reads template 0: the load stays unconditional, its result is dropped)
-          // (the one-launch callback, first chunk: the templates lie in LDS, two per local track)
-          const DTrackBlock* tsrc = (a.cb_tmpl && chunk_i == 0u) ? a.cb_tmpl + (live ? 2u * (mp & 0x7FFFu) + (mp >> 15) : 0u)
-                                                                  : a.tmpl + (live ? row.tmpl + (mp >> 15) : 0u);
-          wq[it] = reinterpret_cast<const uint4*>(tsrc)[q];
+          wq[it] = reinterpret_cast<const uint4*>(a.tmpl + (live ? row.tmpl + (mp >> 15) : 0u))[q];
         }
       }
 #pragma unroll

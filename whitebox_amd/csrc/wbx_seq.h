@@ -131,11 +131,6 @@ struct TrackCache {
   // templates are reserved kTmplReserve at a time: one atomic round trip per reservation instead of one per block
   // with events (a session cut into short clips has an event in every few blocks of every track)
   uint32_t tmpl_next, tmpl_end;
-  // The one-launch callback (wbx_callback.h): the lane's row and its template(s) of the ONE block also go into the mix
-  // workgroup's LDS (the workgroup that plans the track is the one that mixes it) — the mix then stages them without three
-  // dependent memory round trips.  mail_tmpl[0], [1]: the block's template, and the second one of a ROW_PAIR.  Null elsewhere.
-  DRow* mail_row;
-  DTrackBlock* mail_tmpl;
 };
 constexpr uint32_t kTmplReserve = 8;   // PlanArgs::tmpl_reserve of batch renders (1 for the one-block callback)
 
@@ -565,17 +560,6 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
         dstq[5] = srcq1[1];
         dstq[6] = srcq1[2];
         dstq[7] = srcq1[3];
-        if (cache->mail_tmpl) {
-          uint4* mq = reinterpret_cast<uint4*>(cache->mail_tmpl);
-          mq[0] = srcq[0];
-          mq[1] = srcq[1];
-          mq[2] = srcq[2];
-          mq[3] = srcq[3];
-          mq[4] = srcq1[0];
-          mq[5] = srcq1[1];
-          mq[6] = srcq1[2];
-          mq[7] = srcq1[3];
-        }
         row.tmpl = ti;
         row.flags = ROW_PAIR | ((rec.kind == KIND_SILENT && kind1 == KIND_SILENT) ? ROW_SILENT : 0u);
       }
@@ -595,13 +579,6 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
           dstq[1] = srcq[1];
           dstq[2] = srcq[2];
           dstq[3] = srcq[3];
-          if (cache->mail_tmpl) {
-            uint4* mq = reinterpret_cast<uint4*>(cache->mail_tmpl);
-            mq[0] = srcq[0];
-            mq[1] = srcq[1];
-            mq[2] = srcq[2];
-            mq[3] = srcq[3];
-          }
           row.tmpl = ti;
           row.flags = rec.kind == KIND_SILENT ? ROW_SILENT : 0u;
           if (finished) {
@@ -616,7 +593,6 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
       }
     }
     *reinterpret_cast<uint4*>(&a.rows[(size_t)b * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
-    if (cache->mail_row) *reinterpret_cast<uint4*>(cache->mail_row) = *reinterpret_cast<const uint4*>(&row);
     tmpl_index = row.tmpl;
   }
   if (tb->kind == KIND_GENERIC && tmpl_index != 0xFFFFFFFFu) {   // queue it for the pre-render pass
@@ -730,13 +706,6 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     dstq[1] = srcq[1];
     dstq[2] = srcq[2];
     dstq[3] = srcq[3];
-    if (cache->mail_tmpl) {
-      uint4* mq = reinterpret_cast<uint4*>(cache->mail_tmpl);
-      mq[0] = srcq[0];
-      mq[1] = srcq[1];
-      mq[2] = srcq[2];
-      mq[3] = srcq[3];
-    }
   }
   DRow row;
   row.tmpl = ti;
@@ -758,7 +727,6 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     for (; n < n_safe; n++) {
       row.pos = off;
       *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&row);
-      if (cache->mail_row) *reinterpret_cast<uint4*>(cache->mail_row) = *reinterpret_cast<const uint4*>(&row);
       dst += a.n_tracks;
       off = off + step;                                    // sampler.cpp:209
     }
@@ -768,7 +736,6 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     if (!(off + guard <= cnt && (cnt - off) < qmax && off < 2147483000.0)) break;
     row.pos = off;
     *reinterpret_cast<uint4*>(&a.rows[(size_t)(b + n) * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
-    if (cache->mail_row) *reinterpret_cast<uint4*>(cache->mail_row) = *reinterpret_cast<const uint4*>(&row);
     off = off + step;                                      // sampler.cpp:209
     n++;
   }
@@ -798,8 +765,7 @@ __host__ __device__ inline void block_times(const PlanArgs& a, DBlockTime* times
 
 // One track through the K blocks of a render: what a lane of plan_kernel does (and the host harness of the tests,
 // track by track).  Applies the pending state patch, then alternates steady runs and general blocks.
-__host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const DBlockTime* times, DRow* mail_row = nullptr,
-                                           DTrackBlock* mail_tmpl = nullptr) {
+__host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const DBlockTime* times) {
   DTrackState st = a.state[t];
   if (a.patch) {
     const DPatch p = a.patch[t];
@@ -831,8 +797,6 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
   cache.smp_idx = 0xFFFFFFFFu;
   cache.fin_tmpl = 0xFFFFFFFFu;
   cache.tmpl_next = cache.tmpl_end = 0u;
-  cache.mail_row = mail_row;     // (one-block renders only: the row written last is the block's)
-  cache.mail_tmpl = mail_tmpl;
   if (a.tmpl_reserve == 0u) {   // one-block renders: the track owns templates 2t and 2t + 1 (a block takes one, or a ROW_PAIR's two)
     cache.tmpl_next = 2u * t;   // — no atomic round trip in the callback's latency chain
     cache.tmpl_end = 2u * t + 2u;
