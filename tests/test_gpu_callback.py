@@ -1,0 +1,194 @@
+"""The audio callback as ONE launch (wbx_callback.h: sequencer prologue + mix + spread sum + completion word), the path
+wbx_engine_process takes for 512-frame stereo and 1024-frame mono blocks.  Reference call site: one Engine::process per device
+period (audio_io_pulseaudio.cpp:396-466).  Against the oracle — per-track peaks and stream calls bit for bit, the master bit for
+bit when one group holds a whole member list (the reference's order), within 1e-6 RMS otherwise — and against the batch render
+of the same engine configuration (bit-identical: same functions, same order of additions)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import whitebox_amd as W
+from whitebox_amd import synth
+from whitebox_amd.engine import build_engine
+
+pytestmark = pytest.mark.gpu
+RMS_TOL = 1e-6
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def plan_rows(plan):
+    return [(b, t, bo, ns, O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (b, t, bo, ns, na, smp, off, spd, g, fl) in plan]
+
+
+def oracle_rows(e, block):
+    return [(block, t, ds, min(ln, 0xFFFF), O.f64_bits(off), O.f64_bits(spd), O.f32_bits(g), smp)
+            for (t, ds, ln, off, spd, g, smp) in e.seglog()]
+
+
+def callback_group(n):       # what a max_blocks = 1 engine picks (wbx_runtime.hip build_routing)
+    return 16 if n > 1024 else 32 if n > 64 else 64
+
+
+return_names = []      # the kernel names of the last run_callback call
+
+
+def run_callback(spec, K, edits=None, check_plan=True, every_block_one_launch=True):
+    """K blocks through Engine::process against the oracle block by block; `edits`: {block: fn(oracle, engine)} applied before it"""
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+    del return_names[:]
+    masters, names = [], []
+    one_group = spec.n_tracks <= 64 and not spec.n_buses
+    for b in range(K):
+        if edits and b in edits:
+            edits[b](e, eng)
+        om, _ = e.process()
+        eng.process(None, out, float(spec.sample_rate))
+        m = np.stack(out.channel_buffers)
+        names.append(eng.ctx.kernel_name())
+        if one_group:
+            assert np.array_equal(bits(m), bits(om)), b
+        else:
+            d = m.astype(np.float64) - om.astype(np.float64)
+            assert float(np.sqrt(np.mean(d * d))) <= RMS_TOL, b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        # (by value: a muted track's peak is -0.0 in the reference — math::abs(-0.0f) is -0.0f and math::max keeps it — and +0.0
+        #  here, where magnitudes are compared as unsigned integers)
+        assert np.array_equal(pk[0], e.peaks()[:, :spec.channels]), b
+        if check_plan:
+            assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), b
+        masters.append(m.copy())
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
+    e.close()
+    eng.close()
+    # (a block that queued records for the pre-render pass was repeated through the three kernels: its name is a mix_kernel's)
+    one = [n.startswith("wbx::callback_kernel<") for n in names]
+    assert all(one) or not every_block_one_launch, names
+    return_names.extend(names)
+    return np.stack(masters)
+
+
+@pytest.mark.parametrize("n_tracks", [1, 8, 64, 65, 200, 1025, 4096])
+@pytest.mark.parametrize("kw", [dict(src_rate=44100), dict(src_rate=44100, fmt="i16"), dict(src_rate=44100, fmt="i24"), dict()],
+                         ids=["f32_441", "i16_441", "i24_441", "f32_unity"])
+def test_one_launch_callback_equals_the_oracle_and_the_batch_render(n_tracks, kw):
+    """every family's callback instance (0: fp32, 2: 16-bit resampled, 1 / 3: 24-bit resampled), one group / a few groups / one
+    workgroup per CU; then the same blocks as ONE batch render with the callback's track groups: bit-identical"""
+    K = 5
+    spec = synth.make_session("cb", n_tracks, n_blocks=K, seed=0xCB00 + n_tracks, seek=n_tracks <= 200, **kw)
+    if kw.get("fmt"):      # integer clips are full scale: the session level (master peak ~0.4) goes into the faders, as in bench.py
+        spec.volumes_db = [v + 20.0 * float(np.log10(0.25 / np.sqrt(n_tracks))) for v in spec.volumes_db]
+    got = run_callback(spec, K, check_plan=n_tracks <= 1025, every_block_one_launch=n_tracks > 200)
+    eng = build_engine(spec, max_blocks=K, group_size=callback_group(n_tracks))
+    eng.play()
+    eng.render(K)
+    batch, _, _ = eng.ctx.fetch()
+    eng.close()
+    assert np.array_equal(bits(got), bits(batch))
+
+
+def test_one_launch_callback_more_groups_than_the_device_has_cus():
+    """8192 tracks = 512 workgroups: more than one per CU, so no ticket barrier — the workgroup that sees the full count adds
+    all group sums"""
+    spec = synth.make_session("cb8k", 8192, src_rate=44100, n_blocks=3, seed=0xCB8)
+    run_callback(spec, 3, check_plan=False)
+
+
+@pytest.mark.parametrize("n_tracks,n_buses", [(48, 3), (256, 8), (4096, 64)])
+def test_one_launch_callback_with_sub_buses(n_tracks, n_buses):
+    """bus sums (bit-exact when a bus is one group) and master through the spread sum's sub-bus branch"""
+    K = 4
+    spec = synth.make_session("cbbus", n_tracks, n_blocks=K, seed=0xCBB, n_buses=n_buses)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+    per_bus = n_tracks // n_buses
+    for b in range(K):
+        om, obus = e.process(want_buses=True)
+        eng.process(None, out, 48000.0)
+        assert eng.ctx.kernel_name().startswith("wbx::callback_kernel<")
+        m = np.stack(out.channel_buffers)
+        _, pk, bus = eng.ctx.fetch(peaks=True, buses=True)
+        assert np.array_equal(pk[0], e.peaks())
+        if per_bus <= callback_group(n_tracks):      # every bus is one group: the reference's order
+            assert np.array_equal(bits(bus[0]), bits(obus)) and np.array_equal(bits(m), bits(om)), b
+        else:
+            d = m.astype(np.float64) - om.astype(np.float64)
+            assert float(np.sqrt(np.mean(d * d))) <= RMS_TOL
+    e.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("n_tracks", [24, 300])
+@pytest.mark.parametrize("channels", [2, 1])
+def test_one_launch_callback_device_formats(n_tracks, channels):
+    """wbx_engine_process_interleaved: the conversion as the epilogue of the spread sum (one group: of the mix workgroup's
+    sum kernel stand-in) — bytes equal to the batch render's sum-kernel epilogue, every format; 1024-frame blocks for mono"""
+    K = 3
+    block = 512 if channels == 2 else 1024
+    spec = synth.make_session("cbfmt", n_tracks, n_blocks=K, amp=0.3 / np.sqrt(n_tracks / 24), seed=0xCBF, src_rate=44100, block=block)
+    spec.channels = channels
+    eng = build_engine(spec, max_blocks=1)
+    ref = build_engine(spec, max_blocks=K, group_size=callback_group(n_tracks))
+    for fmt in ("i16", "i24", "i24_x8", "i32", "f32"):
+        ref.ctx.set_master_format(fmt)
+        ref.play()
+        ref.render(K)
+        want = ref.ctx.fetch_interleaved(fmt).view(np.uint8).reshape(K, -1)
+        ref.stop()
+        eng.play()
+        for b in range(K):
+            got = eng.process_interleaved(fmt)
+            if fmt == "i24":      # (the reference's packed writer leaves all but the first 3*F bytes of a block untouched)
+                assert np.array_equal(got.view(np.uint8)[:3 * block], want[b][:3 * block]), (fmt, b)
+            else:
+                assert np.array_equal(got.view(np.uint8), want[b]), (fmt, b)
+        eng.stop()
+    eng.close()
+    ref.close()
+
+
+def test_one_launch_callback_parameter_and_clip_edits_between_blocks():
+    """the device copy of the gains follows every parameter change; clip edits re-upload the lists; stop / play / tempo /
+    playhead jumps go through the pinned patches — all between one-launch blocks"""
+    spec = synth.make_session("cbedit", 130, src_rate=44100, n_blocks=40, seed=0xCBE)
+
+    def vol(t, db):
+        return lambda e, eng: (e.set_volume(t, db), eng.tracks[t].set_volume(db))
+
+    def pan_mute(e, eng):
+        e.set_pan(7, -0.4); eng.tracks[7].set_pan(-0.4)
+        e.set_mute(100, True); eng.tracks[100].set_mute(True)
+
+    def gain_and_clip(e, eng):
+        e.set_clip_gain(3, 0, 0.5); eng.set_clip_gain(eng.tracks[3], 0, 0.5)
+        e.add_audio_clip(5, 0.1, 0.3, 17.0, 9, 0.8, 0.7); eng.add_audio_clip(eng.tracks[5], "x", 0.1, 0.3, 17.0, 9, 0.8, 0.7)
+
+    def stop_play(e, eng):
+        e.stop(); eng.stop(); e.set_bpm(97.0); eng.set_bpm(97.0); e.set_playhead(0.05); eng.set_playhead_position(0.05); e.play(); eng.play()
+
+    run_callback(spec, 14, edits={2: vol(0, -9.0), 3: vol(129, 2.0), 5: pan_mute, 7: gain_and_clip, 10: stop_play, 12: vol(64, -40.0)},
+                 every_block_one_launch=False)
+    assert sum(n.startswith("wbx::callback_kernel<") for n in return_names) >= 10, return_names
+
+
+def test_one_launch_callback_repeats_blocks_that_queue_pre_render_rows():
+    """clips shorter than a block put three stream calls into many blocks: the one-launch block reports a non-empty queue and
+    the block is pre-rendered and mixed again through the three kernels (clips of 0.7 blocks: nearly every block; of 2.6
+    blocks: some) — and a block without such a track-block is one launch again"""
+    from test_gpu_parity import _boundary_session
+    run_callback(_boundary_session(90, 8, 512, 0.7), 8, every_block_one_launch=False)
+    assert any(n.startswith("wbx::mix_kernel<") for n in return_names), return_names
+    run_callback(_boundary_session(90, 8, 512, 2.6), 8, every_block_one_launch=False)
+    assert any(n.startswith("wbx::callback_kernel<") for n in return_names), return_names
