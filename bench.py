@@ -557,7 +557,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     host_master.close()
 
     # K = 1 latency mode, the drop-in's real operating point: the audio callback, Engine::process one block at a time,
-    # on an engine configured the way a callback host configures it (max_blocks = 1: 64-track groups)
+    # on an engine configured the way a callback host configures it (max_blocks = 1: many small track groups, wbx_runtime.hip build_routing)
     lat = None
     lat_small = {}
     lat_median = {}
@@ -590,8 +590,8 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
 
     if rank == 0 and latency_blocks > 0 and dist is None:
         lat = callback_latency(n_tracks)
-        # ... and for sessions of the size a DAW project usually has (up to 64 tracks: ONE group — the reference's order
-        # bit for bit, and the mix workgroup stores the master itself: two launches instead of three)
+        # ... and for sessions of the size a DAW project usually has (up to 64 tracks: one group, or one track per group — the
+        # reference's order bit for bit either way)
         for small in (8, 64):
             if small < n_tracks:
                 lat_small[str(small)] = 1e3 * callback_latency(small)
@@ -797,7 +797,7 @@ def main():
         line["latency_mode"] = {"blocks_per_call": 1, "ms_per_block": 1e3 * r["lat"], "frames_per_s": F / r["lat"],
                                 "calls": args.latency_blocks, "launches_per_call": 1 if "callback_kernel" in (r.get("lat_kernel") or "") else 3,
                                 "ms_per_block_median_of_8_runs": {str(k): 1e3 * v for k, v in r["lat_median"].items()},
-                                # the same call for sessions of 8 / 64 tracks (one group: the mix workgroup stores the master itself)
+                                # the same call for sessions of 8 / 64 tracks (8: one group, the mix workgroup stores the master itself; 64: one track per group)
                                 "ms_per_block_small_sessions": r.get("lat_small") or None}
 
     # the other single-GPU configurations of BASELINE.json (configs[1], configs[3]), the headline session cut into

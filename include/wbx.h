@@ -80,7 +80,8 @@ typedef struct wbx_config {
                               128-track workgroups that continue each other's running sum, the blocks of the render supply
                               the parallelism (blocks shorter than 256 lanes count by the workgroup: 2048 blocks of 256
                               frames, 4096 of 128 — wbx_render_order tells); shorter renders take groups of 128 (when
-                              max_blocks == 1, the audio-callback configuration: 64; 32 for sessions of more than 64 and 16 for more than 1024
+                              max_blocks == 1, the audio-callback configuration: one group up to 16 tracks and one TRACK per group up to
+                              64 — both the reference's order bit for bit — then 4 / 8 / 16 tracks above 64 / 256 / 512
                               tracks), within 1e-6 RMS of the reference's order at mix-bus levels (DESIGN.md "Summation
                               order" states the levels). */
   uint32_t max_segments;   /* extra (beyond one per track-block) segment slots per launch; 0 = default */

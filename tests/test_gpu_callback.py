@@ -30,7 +30,7 @@ def oracle_rows(e, block):
 
 
 def callback_group(n):       # what a max_blocks = 1 engine picks (wbx_runtime.hip build_routing)
-    return 16 if n > 1024 else 32 if n > 64 else 64
+    return 64 if n <= 16 else 1 if n <= 64 else 4 if n <= 256 else 8 if n <= 512 else 16
 
 
 return_names = []      # the kernel names of the last run_callback call
@@ -46,7 +46,7 @@ def run_callback(spec, K, edits=None, check_plan=True, every_block_one_launch=Tr
     eng.play()
     del return_names[:]
     masters, names = [], []
-    one_group = spec.n_tracks <= 64 and not spec.n_buses
+    one_group = spec.n_tracks <= 64 and not spec.n_buses      # one group, or one track per group: the reference's order
     for b in range(K):
         if edits and b in edits:
             edits[b](e, eng)
@@ -77,7 +77,7 @@ def run_callback(spec, K, edits=None, check_plan=True, every_block_one_launch=Tr
     return np.stack(masters)
 
 
-@pytest.mark.parametrize("n_tracks", [1, 8, 64, 65, 200, 1025, 4096])
+@pytest.mark.parametrize("n_tracks", [1, 8, 16, 17, 64, 65, 200, 300, 600, 1025, 4096])
 @pytest.mark.parametrize("kw", [dict(src_rate=44100), dict(src_rate=44100, fmt="i16"), dict(src_rate=44100, fmt="i24"), dict()],
                          ids=["f32_441", "i16_441", "i24_441", "f32_unity"])
 def test_one_launch_callback_equals_the_oracle_and_the_batch_render(n_tracks, kw):
@@ -121,7 +121,7 @@ def test_one_launch_callback_with_sub_buses(n_tracks, n_buses):
         m = np.stack(out.channel_buffers)
         _, pk, bus = eng.ctx.fetch(peaks=True, buses=True)
         assert np.array_equal(pk[0], e.peaks())
-        if per_bus <= callback_group(n_tracks):      # every bus is one group: the reference's order
+        if per_bus <= callback_group(n_tracks) or callback_group(n_tracks) == 1:      # every bus is one group, or every track: the reference's order
             assert np.array_equal(bits(bus[0]), bits(obus)) and np.array_equal(bits(m), bits(om)), b
         else:
             d = m.astype(np.float64) - om.astype(np.float64)

@@ -60,9 +60,16 @@ void drain_events(wbx_ctx* c) {
 // audio_buffer.h:73-82: bit-exact master).  Which set a render takes: render_walks_whole_lists().
 void build_routing(wbx_ctx* c, uint32_t n_tracks) {
   uint32_t G = c->cfg.group_size;
-  // the callback configuration, large session: more workgroups for the one block — 32-track groups, 16 from 1024 tracks on
-  // (4096 tracks: 256 workgroups, one per CU; 49.5 -> 47.0 us per block, tools/ab.py latency_groups)
-  if (c->auto_group && c->cfg.max_blocks == 1 && n_tracks > 64u) G = n_tracks > 1024u ? kStage / 8 : kStage / 4;
+  // the callback configuration: the one block's latency is a chain of dependent work per workgroup (≈0.4 us a track row), so
+  // the library cuts a session into MANY small groups and lets the spread sum of callback_kernel add them (tools/cb_groups.py,
+  // profiles/r04_callback_groups.txt — us per 512-frame block, one group / the choice below: 24 tracks 27.6 / 25.9, 64 tracks
+  // 42.9 / 25.6, 256 tracks 48.2 (64-track groups) / 26.1, 1024 tracks 47.0 / 30.5).  Up to 16 tracks: one group, whose
+  // workgroup stores the master itself.  Up to 64 tracks: one track per group — the master is then the in-order sum of the
+  // track buffers, which IS the reference's summation (engine.cpp:1600-1617), bit for bit as with one group.  Above that
+  // groups of 4 / 8 / 16 (at most ≈64 workgroups below 1024 tracks: past that the ticket barrier's cost grows faster than
+  // the rows per workgroup shrink; 4096 tracks: 256 workgroups, one per CU).
+  if (c->auto_group && c->cfg.max_blocks == 1)
+    G = n_tracks <= 16u ? kStage / 2 : n_tracks <= 64u ? 1u : n_tracks <= 256u ? 4u : n_tracks <= 512u ? 8u : kStage / 8;
   c->order.clear();
   c->groups.clear();
   c->groups_exact.clear();
@@ -622,9 +629,10 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (!c) return WBX_ERR_OOM;
   c->cfg = *cfg;
   // default 128: one staging round per workgroup; a context that can only render one block per call (the audio
-  // callback) takes 64, 32 for sessions of more than 64 tracks and 16 above 1024 (build_routing) — more workgroups for the one block,
-  // whose mix is a latency chain per workgroup; the block's group sums are then added by sum_kernel<32> in four rounds
-  // of loads.  Sessions of up to 64 tracks stay one group: the reference's summation order, bit for bit.
+  // callback) takes many small groups instead — one group up to 16 tracks, ONE TRACK per group up to 64 (both: the
+  // reference's summation order, bit for bit), 4 / 8 / 16 tracks above 64 / 256 / 512 (build_routing) — more workgroups
+  // for the one block, whose mix is a latency chain per workgroup; the block's group sums are added by the callback
+  // kernel's spread sum (by sum_kernel when the block shape takes the three-launch path).
   c->auto_group = c->cfg.group_size == 0;
   if (c->cfg.group_size == 0) c->cfg.group_size = c->cfg.max_blocks == 1 ? kStage / 2 : kStage;
   if (const char* u = std::getenv("WBX_MIX_VARIANT")) c->mix_unroll = std::atoi(u);
