@@ -412,6 +412,15 @@ wbx_status wbx_engine_levels(wbx_engine* e, float* levels, uint32_t n_tracks);
  * Together with the UI thread's own log this reconstructs the exact state every block was rendered from. */
 wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_seen, uint64_t* drained, uint32_t n_tracks);
 
+/* How the device sequencer planned the renders so far (diagnostic; no reference counterpart — Track::process_event,
+ * track.cpp:258-451, is one thread).  Long renders of sessions cut into clips are planned by one lane per (track, SEGMENT of
+ * the render) instead of one lane per track: a segment's lane works out the state its first block starts from by itself and a
+ * second pass checks every seam against the state the segment before really ended with, planning again — in one walk, from the
+ * true state — whatever follows a seam that did not hold (results are the one-walk plan's either way).
+ *   out[0]  renders planned by segments     out[1]  tracks that had a seam that did not hold
+ *   out[2]  segments planned again          out[3]  segments per track of the last such render */
+wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4]);
+
 /* The plan the device sequencer produced for the last process/render: one record per Sampler::stream
  * call, ordered by (block, track, call).  For seek-math parity checks (bit patterns, not tolerances). */
 typedef struct wbx_plan_record {

@@ -38,6 +38,12 @@ struct HostSim {
   uint32_t last_K = 0, last_N = 0;
   bool clips_uploaded = false;
   uint32_t masked_rows = 0;   // plan as for a mix instance that takes partial rows / ROW_PAIRs in its hot loop
+  // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track): blocks per segment (0: one walk per
+  // track), and what the seam check found — renders planned that way, tracks with a seam that did not hold, segments redone
+  uint32_t seg_len = 0;
+  bool table_flags = false;
+  uint32_t flags_left = 0;    // set internal_state_changed flags of the table (the sequencer counts down as it clears them)
+  uint64_t seg_renders = 0, seg_tracks_redone = 0, seg_segments_redone = 0, seg_lanes = 0;
 };
 
 extern "C" {
@@ -53,6 +59,13 @@ HostSim* hsim_create(uint32_t max_tracks, uint32_t max_blocks, uint32_t block_fr
 }
 void hsim_destroy(HostSim* s) { delete s; }
 void hsim_set_masked_rows(HostSim* s, uint32_t on) { s->masked_rows = on; }
+void hsim_set_segments(HostSim* s, uint32_t seg_len) { s->seg_len = seg_len; }
+void hsim_segment_stats(HostSim* s, uint64_t* out4) {
+  out4[0] = s->seg_renders;
+  out4[1] = s->seg_tracks_redone;
+  out4[2] = s->seg_segments_redone;
+  out4[3] = s->seg_lanes;
+}
 
 // (row flags, template kind) of every (block, track) of the last render — how the sequencer classified each track-block
 int hsim_row_kinds(HostSim* s, uint32_t* flags, uint32_t* kinds, size_t cap) {
@@ -241,6 +254,9 @@ int hsim_render(HostSim* s, uint32_t K) {
     if (s->clips_uploaded && !s->clips.empty()) hs.merge_live_flags_locked(s->clips.data(), s->clips.size());
     hs.flatten_clips_locked(s->clips, s->clip_first);
     s->clips_uploaded = true;
+    s->flags_left = 0;
+    for (const DClip& dc : s->clips) s->flags_left += dc.internal_state_changed != 0 ? 1u : 0u;
+    s->table_flags = s->flags_left != 0u;
   }
   if (s->state.size() < N) s->state.resize(N, DTrackState{});
   const DPatch* patch = nullptr;
@@ -251,7 +267,11 @@ int hsim_render(HostSim* s, uint32_t K) {
   }
   hs.routing_dirty = false;
   s->rows.assign((size_t)K * N, DRow{});
-  s->tmpl.assign(hs.template_hint(K) + 64, DTrackBlock{});
+  // (the conditions of wbx_engine.hip plan_segment_length with a forced segment length)
+  if (s->table_flags && s->flags_left == 0u) s->table_flags = false;
+  const uint32_t L = (s->seg_len && s->seg_len < K && playing && !s->table_flags) ? s->seg_len : 0u;
+  const uint32_t S = L ? (K + L - 1u) / L : 1u;
+  s->tmpl.assign(hs.template_hint(K, S) + 64, DTrackBlock{});
   s->gen_list.assign(hs.gen_rows_hint(K) + 64, 0u);
   const uint32_t pool_chunks = (uint32_t)std::max<size_t>(1024, (size_t)s->max_blocks * hs.max_tracks / 8);
   s->pool.assign((size_t)pool_chunks * kChunk, DSeg{});
@@ -281,6 +301,7 @@ int hsim_render(HostSim* s, uint32_t K) {
   a.sample_rate = (double)hs.dst_rate;
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
+  a.flags_left = &s->flags_left;
   hs.clips_edited = false;
   a.masked_rows = s->masked_rows;
   a.tmpl_reserve = HostSession::template_reserve(K);
@@ -289,7 +310,23 @@ int hsim_render(HostSim* s, uint32_t K) {
   a.beat_duration = beat_duration;
   std::vector<DBlockTime> times(K);
   block_times(a, times.data());
-  for (uint32_t t = 0; t < N; t++) plan_track(a, t, times.data());
+  if (L) {
+    // every lane of plan_seg_kernel, in an order no lane may rely on (segments backwards, tracks forwards), then the seam pass
+    a.tmpl_reserve = 8u;
+    std::vector<DTrackState> guess((size_t)N * S), ends((size_t)N * S);
+    const DBlockTime* tv = times.data();
+    for (uint32_t sg = S; sg-- > 0u;)
+      for (uint32_t t = 0; t < N; t++) plan_segment(a, t, sg, L, S, tv, guess.data(), ends.data());
+    for (uint32_t t = 0; t < N; t++) {
+      const uint32_t redone = plan_fix_track(a, t, L, S, tv, guess.data(), ends.data());
+      s->seg_tracks_redone += redone ? 1u : 0u;
+      s->seg_segments_redone += redone;
+    }
+    s->seg_renders++;
+    s->seg_lanes += (uint64_t)N * (S - 1u);
+  } else {
+    for (uint32_t t = 0; t < N; t++) plan_track(a, t, times.data());
+  }
   hs.advance_transport_locked(K, F, beat_duration);
   return WBX_OK;
 }

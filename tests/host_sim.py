@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         L.hsim_template_capacity.argtypes = [C.c_void_p]
         L.hsim_set_masked_rows.restype = None
         L.hsim_set_masked_rows.argtypes = [C.c_void_p, C.c_uint32]
+        L.hsim_set_segments.restype = None
+        L.hsim_set_segments.argtypes = [C.c_void_p, C.c_uint32]
+        L.hsim_segment_stats.restype = None
+        L.hsim_segment_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         sig = {
             "hsim_set_bpm": [C.c_double], "hsim_set_playhead_position": [C.c_double],
             "hsim_add_track": [C.POINTER(C.c_uint32)],
@@ -176,6 +180,16 @@ class HostSimEngine:
 
     def template_capacity(self): return self.L.hsim_template_capacity(self.h)
 
+    def set_segments(self, seg_len):
+        """plan batch renders by segments of seg_len blocks (wbx_seq.h plan_segment), 0 = one walk per track"""
+        self.L.hsim_set_segments(self.h, int(seg_len))
+
+    def segment_stats(self):
+        """(renders planned by segments, tracks with a seam that did not hold, segments planned again, speculative lanes)"""
+        out = (C.c_uint64 * 4)()
+        self.L.hsim_segment_stats(self.h, out)
+        return tuple(int(x) for x in out)
+
     def set_masked_rows(self, level):
         """plan as for a mix instance that renders partial-coverage rows / ROW_PAIRs in its hot loop (PlanArgs::masked_rows:
         1 / True fp32 rows, 2 also integer PCM at unity speed)"""
@@ -214,10 +228,11 @@ class HostSimEngine:
         return seen.value, list(dr[:n])
 
 
-def build_sim_engine(spec, max_blocks=8, masked_rows=False) -> HostSimEngine:
+def build_sim_engine(spec, max_blocks=8, masked_rows=False, segments=0) -> HostSimEngine:
     """The same construction sequence as whitebox_amd.engine.build_engine, without audio."""
     eng = HostSimEngine(max(spec.n_tracks, 1), spec.block, spec.sample_rate, spec.channels, max_blocks=max_blocks)
     eng.set_masked_rows(masked_rows)
+    eng.set_segments(segments)
     eng.set_bpm(spec.bpm)
     if spec.playhead_start:
         eng.set_playhead_position(spec.playhead_start)

@@ -663,11 +663,18 @@ def test_clip_boundaries_in_the_hot_loop(monkeypatch, masked, clip_blocks, block
 @pytest.mark.parametrize("fmts,rates,family", [(("f32",), (44100, 48000), 0), (("i24", "i16"), (44100, 48000), 1), (("i16",), (44100,), 1)])
 @pytest.mark.parametrize("clip_blocks,block,channels,instance", [(1.3, 128, 2, "1, 2, 1, 64>"), (2.2, 256, 2, "1, 1, 1, 128>"),
                                                                  (0.7, 512, 1, "1, 1, 1, 128>"), (1.7, 256, 1, "1, 1, 1, 64>")])
-def test_clip_boundaries_in_the_hot_loop_short_blocks(clip_blocks, block, channels, instance, fmts, rates, family):
+@pytest.mark.parametrize("packed", ["1", "0", "default"])
+def test_clip_boundaries_in_the_hot_loop_short_blocks(monkeypatch, packed, clip_blocks, block, channels, instance, fmts, rates, family):
     """... and for blocks shorter than a 256-lane workgroup — 128-frame stereo, 256-frame stereo, 256 / 512-frame mono, the
-    buffer sizes of a low-latency device: a session cut into clips takes the one-block-per-workgroup instances (a wave, or
-    two), which stage the sequencer's masked rows like the full-size ones.  Families 0 and 1 hold them; the 16-bit-only
+    buffer sizes of a low-latency device: a session cut into clips takes instances that stage the sequencer's masked rows
+    like the full-size ones: one block per workgroup (a wave, or two), or the PACKED instances (mix_kernel_x: 2 or 4 blocks
+    per workgroup, the two-pass staging per sub-block) — the library's choice for 128-frame stereo blocks in renders of 8
+    blocks and more, WBX_PACKED_X=1 / 0 forces them on every shape / off.  Families 0 and 1 hold both sets; the 16-bit-only
     and the no-per-frame-taps families borrow family 1's."""
+    if packed != "default":
+        monkeypatch.setenv("WBX_PACKED_X", packed)
+    else:
+        packed = "1" if (block, channels) == (128, 2) else "0"
     n_blocks = 9
     spec = _boundary_session(40, n_blocks, block, clip_blocks, channels)
     for i, smp in enumerate(spec.samples):
@@ -682,10 +689,35 @@ def test_clip_boundaries_in_the_hot_loop_short_blocks(clip_blocks, block, channe
     eng.render(n_blocks)
     eng.ctx.fetch()
     name = eng.ctx.kernel_name()
-    if block == 256 and channels == 2 and fmts in (("f32",), ("i16",)):   # (the lean families have their own one-wave instance for this shape)
-        assert name == f"wbx::mix_kernel<2, true, 3, {0 if fmts == ('f32',) else 2}, 1, 1, 2, 64>"
+    sb, cw = {(128, 2): (4, 2), (256, 2): (2, 1), (512, 1): (2, 1), (256, 1): (4, 1)}[(block, channels)]
+    if block == 256 and channels == 2 and fmts == ("i16",):   # (the 16-bit family has its own one-wave instance for this shape)
+        assert name == "wbx::mix_kernel<2, true, 3, 2, 1, 1, 2, 64>"
+    elif packed != "0":
+        assert name == f"wbx::mix_kernel_x<2, 4, {family}, {sb}, {cw}, 1>", name
+    elif block == 256 and channels == 2 and fmts == ("f32",):   # (... and so has the lean fp32 one)
+        assert name == "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>"
     else:
         assert name == f"wbx::mix_kernel<2, true, 3, {family}, 1, " + instance[3:], name
+    eng.close()
+
+
+@pytest.mark.parametrize("packed", ["1"])
+@pytest.mark.parametrize("block,channels,n_tracks,group,n_blocks", [(128, 2, 300, 0, 18), (256, 2, 200, 128, 11), (512, 1, 150, 70, 9),
+                                                                      (256, 1, 130, 0, 14), (128, 2, 70, 33, 35)])
+def test_packed_masked_rows_many_chunks(monkeypatch, packed, block, channels, n_tracks, group, n_blocks):
+    """The packed masked-row instances over groups longer than one staged chunk (32 / 64 / 128 tracks per sub-block), render
+    lengths that leave the last workgroup with empty sub-blocks, clips shorter than a block (pairs in most track-blocks) and
+    longer ones: stream-call log, peaks and master against the oracle."""
+    monkeypatch.setenv("WBX_PACKED_X", packed)
+    for clip_blocks in (1.1, 2.3):
+        spec = _boundary_session(n_tracks, n_blocks, block, clip_blocks, channels)
+        check_against_oracle(spec, n_blocks, group_size=group if group else (n_tracks if n_tracks <= 128 else 0),
+                             expect_exact=(group == 0 and n_tracks <= 128))
+    eng = build_engine(spec, max_blocks=n_blocks, group_size=group)
+    eng.play()
+    eng.render(n_blocks)
+    eng.ctx.fetch()
+    assert eng.ctx.kernel_name().startswith("wbx::mix_kernel_x<2, "), eng.ctx.kernel_name()
     eng.close()
 
 
@@ -1967,7 +1999,7 @@ def test_clip_storage_slabs_grow_and_are_reused():
     (dict(fmt="i24", src_rate=44100), 512, "wbx::mix_kernel<1, true, 3, 3, 1, 1, 2, 128>"),     # resampled 24-bit: everything but per-frame taps
     (dict(fmt="i24", src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 1, 1, 1, 1, 128>"),   # ... cut, 256 frames: a wave per channel
     (dict(fmt="i24", src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 1, 2, 1, 1, 256>"),     # ... one clip per track: two blocks per workgroup
-    (dict(src_rate=44100, seek=True), 128, "wbx::mix_kernel<2, true, 3, 0, 1, 2, 1, 64>"),      # 128-frame blocks, cut: one wave = one block, a channel per half
+    (dict(src_rate=44100, seek=True), 128, "wbx::mix_kernel_x<2, 4, 0, 4, 2, 1>"),             # 128-frame blocks, cut: four blocks per workgroup, masked rows
     (dict(src_rate=96000), 512, "wbx::mix_kernel<2, true, 4, 1, 1, 1, 1, 256>"),                # per-frame taps: everything
     (dict(src_rate=44100), 256, "wbx::mix_kernel<2, true, 4, 0, 2, 1, 1, 256>"),                # 256-frame blocks, one clip per track
     (dict(src_rate=44100, seek=True), 256, "wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 64>"),      # ... cut: one wave = one block

@@ -25,7 +25,7 @@ def oracle_rows(e, block):
             for (t, ds, ln, off, spd, g, smp) in e.seglog()]
 
 
-def check_session(spec, n_blocks, batch, masked=False):
+def check_session(spec, n_blocks, batch, masked=False, segments=0):
     e = O.build_oracle_engine(spec)
     e.enable_seglog()
     e.play()
@@ -33,11 +33,13 @@ def check_session(spec, n_blocks, batch, masked=False):
     for b in range(n_blocks):
         e.process()
         rows += oracle_rows(e, b)
-    sim = HS.build_sim_engine(spec, max_blocks=n_blocks, masked_rows=masked)
+    sim = HS.build_sim_engine(spec, max_blocks=n_blocks, masked_rows=masked, segments=segments)
     sim.play()
     if batch:
         sim.render(n_blocks)
         got = plan_rows(sim.fetch_plan())
+        if segments:
+            SEG_STATS.append(sim.segment_stats())
     else:
         got = []
         for b in range(n_blocks):
@@ -59,6 +61,73 @@ def test_host_sequencer_random_sessions_batched(seed, masked):
     planned for a mix instance that renders clip boundaries in its hot loop (masked rows, ROW_PAIRs)"""
     spec, n_blocks = FZ.random_session(seed)
     check_session(spec, n_blocks, batch=True, masked=masked)
+
+
+SEG_STATS = []   # segment_stats() of every session planned by segments in this process
+
+
+@pytest.mark.parametrize("masked,segments", [(0, 2), (1, 3), (4, 5), (1, 1)])
+@pytest.mark.parametrize("seed", range(0, 160))
+def test_host_sequencer_random_sessions_by_segments(seed, masked, segments):
+    """... the same sessions with the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track: what
+    plan_seg_kernel + plan_fix_kernel run on the device), segments of 1 / 2 / 3 / 5 blocks, the lanes in an order nothing may
+    rely on: the stream-call log, the transport and the state the next render starts from are the one-walk plan's — whether a
+    seam's guess held or the rest of the track was planned again."""
+    spec, n_blocks = FZ.random_session(seed)
+    check_session(spec, n_blocks, batch=True, masked=masked, segments=segments)
+
+
+@pytest.mark.parametrize("seed", range(0, 40))
+def test_host_sequencer_segments_then_more_renders(seed):
+    """a segmented render hands the NEXT render the right state: the session in three batches (segmented, block by block,
+    segmented again) against the oracle's block-by-block log"""
+    spec, n_blocks = FZ.random_session(seed + 100000)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    e.play()
+    rows = []
+    for b in range(n_blocks):
+        e.process()
+        rows += oracle_rows(e, b)
+    sim = HS.build_sim_engine(spec, max_blocks=n_blocks, masked_rows=1, segments=2)
+    sim.play()
+    cuts = [0, n_blocks // 3, n_blocks // 3 + 1, n_blocks]
+    got = []
+    for lo, hi in zip(cuts, cuts[1:]):
+        if hi > lo:
+            sim.render(hi - lo)
+            got += [(lo + r[0],) + r[1:] for r in plan_rows(sim.fetch_plan())]
+    assert got == rows
+    e.close()
+    sim.close()
+
+
+def test_segment_guesses_mostly_hold():
+    """The point of the segmented plan is that a seam's guess nearly always holds (a miss is planned again in one walk: right,
+    but slow).  Over sessions of back-to-back clips — what the plan is for — no seam may miss; over the fuzz sessions above
+    (overlapping clips, edits, sub-block clips) most hold."""
+    beat_frames = 48000 * 60.0 / 120.0
+    for clip_blocks, n_blocks, seg in ((5.3, 96, 8), (1.3, 64, 4), (0.8, 48, 6), (20.0, 128, 16)):
+        samples, clips = [], []
+        n_tracks = 24
+        for t in range(n_tracks):
+            samples.append(synth.SampleSpec(seed_track=t, channels=2, rate=[48000, 44100][t % 2], frames=int((n_blocks + 2) * 512 * 1.2), fmt="f32", amp=0.02))
+            L = clip_blocks * 512
+            pos = -((t * 37) % 101) / 101.0 * L
+            k = 0
+            while pos < (n_blocks + 1) * 512:
+                a, b = max(pos, 0.0), pos + L * (0.7 if (t + k) % 4 == 0 else 1.0)   # some gaps, mostly back to back
+                if b > a:
+                    clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.9, speed=1.0, gain=1.0, sample=t))
+                pos += L
+                k += 1
+        spec = synth.SessionSpec(name="segs", n_tracks=n_tracks, seed=1, samples=samples, clips=clips, volumes_db=[0.0] * n_tracks,
+                                 pans=[0.0] * n_tracks, mutes=[False] * n_tracks, block=512, channels=2)
+        del SEG_STATS[:]
+        check_session(spec, n_blocks, batch=True, masked=1, segments=seg)
+        renders, tracks_redone, segs_redone, lanes = SEG_STATS[-1]
+        assert renders == 1 and lanes == n_tracks * ((n_blocks + seg - 1) // seg - 1)
+        assert tracks_redone == 0 and segs_redone == 0, (clip_blocks, SEG_STATS[-1])
 
 
 @pytest.mark.parametrize("masked", [0, 1, 4])

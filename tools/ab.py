@@ -90,6 +90,23 @@ def presets(other_lib=None):
     P["formats"] = [case(w, "", f"--workload {w} {STD}") for w in ("i16r", "i24r", "mixr", "mixfmt", "i16", "d96")]
     P["cuts"] = [case(f"{w} L={l}", "", f"--workload {w} {'--clip-blocks %s' % l if l else ''} {STD}")
                  for w in ("c3", "i16", "i16r", "i24r", "mixr") for l in (0, 5.3, 20)]
+    # round 4: short blocks of sessions cut into clips — the packed masked-row instances (WBX_PACKED_X=1: on every shape,
+    # measured with a full-length-chunk variant "2" as well, since removed) against the one-block-per-workgroup ones (0); "uncut*" = the uncut session forced
+    # through the same instances (WBX_FORCE_CUT=1), "uncut" alone = the plain packed instance it normally takes
+    P["packed"] = [case(f"F={f} uncut plain-packed", "", f"--block-frames {f} {STD}") for f in (128, 256)] + \
+                  [case(f"F={f} {('L=%s' % l) if l else 'uncut*'} X={x}", f"WBX_PACKED_X={x}" + ("" if l else " WBX_FORCE_CUT=1"),
+                        f"--block-frames {f} {'--clip-blocks %s' % l if l else ''} {STD}")
+                   for f in (128, 256) for l in (0, 5.3, 40) for x in (0, 1)]
+    P["packed1024"] = [case(f"F={f} L=5.3 K=1024 X={x}", f"WBX_PACKED_X={x}", f"--block-frames {f} --clip-blocks 5.3 --blocks 1024 {STD}")
+                       for f in (128, 256) for x in (0, 1)]
+    # round 4: the sequencer cut along the time axis (WBX_PLAN_SEG=0: one lane per track) on sessions cut into clips
+    P["planseg"] = [case(f"{lab} seg={'on' if sg else 'off'}", "" if sg else "WBX_PLAN_SEG=0", args)
+                    for (lab, args) in (("c3 L=5.3", f"--clip-blocks 5.3 {STD}"), ("c3 L=5.3 F=128", f"--block-frames 128 --clip-blocks 5.3 {STD}"),
+                                        ("c3 L=5.3 F=256", f"--block-frames 256 --clip-blocks 5.3 {STD}"),
+                                        ("c2 L=5.3", "--workload c2 --clip-blocks 5.3 --steps 20 --warmup 3 --ramp-steps 60"),
+                                        ("c2 uncut", "--workload c2 --steps 20 --warmup 3 --ramp-steps 60"),
+                                        ("i16r L=5.3", f"--workload i16r --clip-blocks 5.3 {STD}"), ("c3 L=20", f"--clip-blocks 20 {STD}"))
+                    for sg in (1, 0)]
     if other_lib:   # head-to-head of two builds of libwbx.so
         P["lib"] = [case(f"{w} {'other' if o else 'this'}", f"WBX_LIB={other_lib}" if o else "", f"--workload {w} {STD}")
                     for w in ("c3", "c4", "i16r", "c2") for o in (0, 1)]

@@ -9,6 +9,7 @@
 //   DTrackBlock[]  [K][N] one 64-B record per (block, track): what to render — the "plan"
 //   partial        [K][NG][C][F] fp32 group sums,  master [K][C][F],  bus [K][NB][C][F],  peaks [K][N][C]
 #pragma once
+#include <cstdlib>
 #include <stdint.h>
 
 namespace wbx {
@@ -180,9 +181,18 @@ struct PlanArgs {
                                 // (unity / window); 2: also integer PCM at unity speed (masked_kind, wbx_seq.h)
   uint32_t tmpl_reserve;        // templates a track reserves per atomic (8 for batch renders, 1 for one-block renders); 0: none —
                                 // track t owns templates 2t, 2t + 1 (the one-launch callback; tmpl_cap >= 2 * n_tracks)
+  uint32_t* flags_left;         // (optional, host memory) how many clips of the table still carry internal_state_changed: the
+                                // sequencer counts down as it clears them (track.cpp:373,392,418)
   uint32_t lanes;               // tracks per wave of plan_kernel (64, or fewer for sessions cut into many clips: a wave
                                 // executes every branch any of its tracks takes, so its time is set by the number of
                                 // clip boundaries in the wave — fewer tracks per wave, more waves side by side)
+};
+
+struct SegArgs {                // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track)
+  DTrackState* guess;           // [N][n_segs] the state a segment's lane arrived at its first block with
+  DTrackState* ends;            // [N][n_segs] ... and left its last block with
+  uint32_t* stats;              // [2] tracks with a seam that did not hold, segments planned again (running totals; may be null)
+  uint32_t seg_len, n_segs;     // blocks per segment, segments per render (n_segs * seg_len >= n_blocks)
 };
 
 struct GenArgs {                // pre-render of KIND_GENERIC track-blocks into scratch rows
@@ -270,5 +280,15 @@ struct MipArgs {
   MipNode* tile_nodes;        // [tiles + tiles/4 + 1] the level-5 node of every tile, then scratch of the upper levels
   uint32_t n_tiles;
 };
+
+// Does a render of n_blocks short blocks (shorter than a 256-lane workgroup) of a session cut into clips take the PACKED
+// masked-row instance (mix_kernel_x) instead of one block per workgroup?  Measured (tools/ab.py packed, profiles/r04_ab_packed.txt):
+// 128-frame stereo (four blocks per workgroup) +5-9 % over the one-wave instance; 256-frame stereo / 512-frame mono (two blocks)
+// 6-13 % BEHIND theirs — those keep one block per workgroup.  Renders of a few blocks: one workgroup per block is the shorter
+// chain.  WBX_PACKED_X=0|1: A/B aid, tests (1 = every shape that has a packed instance).
+inline int packed_masked_variant(uint32_t n_blocks, bool stereo128) {
+  if (const char* v = std::getenv("WBX_PACKED_X")) return std::atoi(v) != 0 ? 1 : 0;   // (per launch of a batch render: tests flip it)
+  return (stereo128 && n_blocks >= 8u) ? 1 : 0;
+}
 
 }  // namespace wbx

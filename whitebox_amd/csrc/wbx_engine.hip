@@ -58,6 +58,16 @@ struct wbx_engine {
   bool plan_status_on_host = false;     // the counters of the last plan are in h_status (the device copy was cleared)
   size_t d_clips_count = 0;
   bool clips_uploaded = false;          // the device holds a clip table (its internal_state_changed flags are live)
+  // the sequencer cut along the time axis (wbx_seq.h plan_segment): seam states of the render being planned — one buffer, the
+  // two plan kernels that use it run back to back on one stream — and its running statistics
+  DevBuf<DTrackState> d_seam;           // [2][N][segments]: guesses, end states
+  DevBuf<uint32_t> d_seg_stats;         // [2] tracks with a seam that did not hold, segments planned again
+  hipStream_t seam_stream = nullptr;    // the stream that used d_seam last
+  hipEvent_t seam_done = nullptr;
+  bool table_flags = false;             // the uploaded clip table holds a set internal_state_changed flag (segmented plans off)
+  uint32_t* h_flags_left = nullptr;     // pinned: how many of them are left — the sequencer counts down as it clears them
+  uint64_t seg_renders = 0;             // renders planned by segments so far
+  uint32_t seg_last_segs = 0;           // ... segments per track of the last one
   uint32_t state_tracks = 0;            // tracks that have device state
   std::vector<DClip> flat;              // staging of the clip table upload
   std::vector<uint32_t> first;
@@ -106,6 +116,41 @@ wbx_status cfail(wbx_engine* e, wbx_status s) {
       return WBX_ERR_DEVICE;                                        \
     }                                                               \
   } while (0)
+
+// Blocks per segment when the sequencer of this render is cut along the time axis (wbx_seq.h: plan_segment), 0 = one lane
+// per track walks all K blocks.  Taken by batch renders of sessions with tracks cut into clips — a chain of dependent look-ups
+// per clip boundary and lane: c3 cut into 5.3-block clips planned 2048 blocks in 5.4 ms (4.4 ms for 128-frame blocks, in front
+// of a 2.6 ms mix) — while the transport runs and no clip carries a set internal_state_changed flag (the sequencer clears
+// those in passing, track.cpp:373,392,418: the run-up of one lane and the real walk of another would race for them).
+// About 32 k lanes: segments of K * N / 32768 blocks, at least 32 (a run-up is a handful of look-ups and a few blocks long).
+// WBX_PLAN_SEG=0: off; =<n>: segments of n blocks (A/B aid, tests).
+uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing) {
+  uint32_t forced = 0u;
+  if (const char* v = std::getenv("WBX_PLAN_SEG")) {
+    if (v[0] == '0' && v[1] == 0) return 0u;
+    forced = (uint32_t)std::atoi(v);
+  }
+  if (e->table_flags && e->h_flags_left && *reinterpret_cast<volatile uint32_t*>(e->h_flags_left) == 0u)
+    e->table_flags = false;   // every flag of the table has been cleared by a plan that is over
+  if (!playing || e->table_flags || e->in_process || N == 0u) return 0u;
+  if (forced) return forced < K ? forced : 0u;
+  if (!e->hs.cut_tracks || K < 128u) return 0u;
+  {
+    // Worth it only when the one-lane walk would NOT hide behind the previous render's mix: the segment lanes are many more
+    // waves beside that mix and cost it 1-4 % (measured: c3 / i16r cut into 5.3-block clips at 512 frames, where the 5.4 ms
+    // walk hides behind a 6-6.5 ms mix).  The walk is a latency chain, ~14 us per clip start whatever the track count; the mix
+    // moves N * K * F * C * 4 bytes at ~5 TB/s.
+    const uint32_t F = e->ctx->cfg.block_frames, C = e->ctx->cfg.channels;
+    const double bd = e->hs.beat_duration.load(std::memory_order_relaxed);
+    const double beats = (double)K * ((double)F / (double)e->ctx->cfg.sample_rate) / bd;
+    const double walk_us = 14.0 * (double)e->hs.clip_starts_between(e->hs.playhead, e->hs.playhead + beats);
+    const double mix_us = (double)N * (double)K * (double)F * (double)C * 4.0 / 5.0e6;
+    if (walk_us < 0.9 * mix_us) return 0u;
+  }
+  uint32_t len = 32u;
+  while ((uint64_t)(K / len) * N > 49152u && len < K) len *= 2u;
+  return len < K ? len : 0u;
+}
 
 // A/B aid (WBX_FORCE_CUT=1): an uncut session through the instances a session cut into clips takes
 bool force_cut_instances() {
@@ -168,6 +213,8 @@ extern "C" void wbx_engine_destroy(wbx_engine* e) {
     if (e->h_gains[i]) (void)hipHostFree(e->h_gains[i]);
     if (e->gains_done[i]) (void)hipEventDestroy(e->gains_done[i]);
   }
+  if (e->seam_done) (void)hipEventDestroy(e->seam_done);
+  if (e->h_flags_left) (void)hipHostFree(e->h_flags_left);
   for (int i = 0; i < wbx_engine::kTimesRing; i++) {
     if (e->h_times[i]) (void)hipHostFree(e->h_times[i]);
     if (e->times_done[i]) (void)hipEventDestroy(e->times_done[i]);
@@ -737,6 +784,11 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     WBX_EHIP(e, e->d_clip_first.ensure(N + 1));
     e->d_clips_count = e->flat.size();
     e->clips_uploaded = true;
+    if (!e->h_flags_left) WBX_EHIP(e, hipHostMalloc((void**)&e->h_flags_left, 64, hipHostMallocDefault));
+    uint32_t set_flags = 0;   // (both streams were drained above: nothing counts down right now)
+    for (const DClip& dc : e->flat) set_flags += dc.internal_state_changed != 0 ? 1u : 0u;
+    *e->h_flags_left = set_flags;
+    e->table_flags = set_flags != 0u;
     if (!e->flat.empty()) WBX_EHIP(e, hipMemcpy(e->d_clips.p, e->flat.data(), e->flat.size() * sizeof(DClip), hipMemcpyHostToDevice));
     WBX_EHIP(e, hipMemcpy(e->d_clip_first.p, e->first.data(), e->first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
@@ -790,7 +842,10 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
   st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration));
   if (st != WBX_OK) return cfail(e, st);
-  st = ensure_template_capacity(c, std::max(hs.template_hint(K), (size_t)2 * N));   // (2 N: the one-launch callback's static pairs)
+  // the sequencer of this render: one lane per track, or — long renders of sessions cut into clips — per (track, segment)
+  const uint32_t seg_len = plan_segment_length(e, K, N, playing);
+  const uint32_t n_segs = seg_len ? (K + seg_len - 1u) / seg_len : 1u;
+  st = ensure_template_capacity(c, std::max(hs.template_hint(K, n_segs), (size_t)2 * N));   // (2 N: the one-launch callback's static pairs)
   if (st != WBX_OK) return cfail(e, st);
 
   // -- plan (sequencer on the device) + pre-render on the plan stream, into the other plan buffer; it may run
@@ -838,6 +893,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.sample_rate = sample_rate;
   a.playing = playing ? 1u : 0u;
   a.clips_changed = hs.clips_edited ? 1u : 0u;
+  a.flags_left = e->h_flags_left;
   hs.clips_edited = false;
   c->short_render_now = K < kOverlapMinBlocks;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance below)
@@ -860,7 +916,8 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   //  end estimated instead of searched: plan of c3 cut into 5.3-block clips 5.4 ms from LDS, 10.9 ms from device memory, 4 /
   //  2 / 1 tracks per wave 12-25 ms: every record look-up at a clip boundary is a memory round trip for its lane)
   static const bool lds_table_for_cut = [] { const char* v = std::getenv("WBX_PLAN_LDS_TABLE"); return !(v && v[0] == '0'); }();
-  if (plan_beside && (!c->has_cut_tracks || !lds_table_for_cut)) {
+  if (seg_len) a.tmpl_reserve = 8u;   // (a lane plans seg_len blocks, not K: a smaller reservation strands less)
+  if (seg_len || (plan_beside && (!c->has_cut_tracks || !lds_table_for_cut))) {
     // Batch render of a session whose tracks are single clips (a steady run per track, a handful of look-ups): the transport
     // records live in device memory and the sequencer takes the register-capped instance — nothing in LDS, a wave no larger
     // than a mix wave, so it runs BESIDE the previous mix instead of in the drain at its end.  Sessions cut into clips
@@ -910,7 +967,30 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     }
     a.gains = e->d_gains_cb.p;
   }
-  if (!one_launch) launch_plan(a, ps);
+  if (seg_len) {
+    // one lane per (track, segment) + the pass that checks the seams (plan_fix_kernel); the seam states live in one buffer
+    const size_t per = (size_t)N * n_segs;
+    if (e->seam_stream && e->seam_stream != ps) {   // (its last user ran on the other stream)
+      if (!e->seam_done) WBX_EHIP(e, hipEventCreateWithFlags(&e->seam_done, hipEventDisableTiming));
+      WBX_EHIP(e, hipEventRecord(e->seam_done, e->seam_stream));
+      WBX_EHIP(e, hipStreamWaitEvent(ps, e->seam_done, 0));
+    }
+    if (e->d_seam.cap < 2 * per) {
+      if (e->seam_stream) WBX_EHIP(e, hipStreamSynchronize(e->seam_stream));
+      WBX_EHIP(e, e->d_seam.ensure(2 * per));
+    }
+    if (!e->d_seg_stats.p) {
+      WBX_EHIP(e, e->d_seg_stats.ensure(2));
+      WBX_EHIP(e, hipMemsetAsync(e->d_seg_stats.p, 0, 2 * sizeof(uint32_t), ps));
+    }
+    e->seam_stream = ps;
+    SegArgs g{e->d_seam.p, e->d_seam.p + per, e->d_seg_stats.p, seg_len, n_segs};
+    launch_plan_segments(a, g, plan_beside, ps);
+    e->seg_renders++;
+    e->seg_last_segs = n_segs;
+  } else if (!one_launch) {
+    launch_plan(a, ps);
+  }
   if (!e->in_process) {
     if (patch_slot >= 0) {
       WBX_EHIP(e, hipEventRecord(e->patch_done[patch_slot], ps));
@@ -1132,6 +1212,21 @@ extern "C" wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_see
     if (n_tracks > e->hs.n_tracks()) return WBX_ERR_INVALID;
     for (uint32_t t = 0; t < n_tracks; t++) drained[t] = e->hs.tracks[t]->drained;
   }
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4]) {
+  if (!e || !out) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  uint32_t st[2] = {0u, 0u};
+  if (e->d_seg_stats.p && e->seam_stream) {
+    WBX_EHIP(e, hipStreamSynchronize(e->seam_stream));
+    WBX_EHIP(e, hipMemcpy(st, e->d_seg_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+  }
+  out[0] = e->seg_renders;
+  out[1] = st[0];
+  out[2] = st[1];
+  out[3] = e->seg_last_segs;
   return WBX_OK;
 }
 

@@ -571,8 +571,24 @@ struct HostSession {
     return 64u;
   }
   static uint32_t template_reserve(uint32_t K) { return K >= 64u ? 32u : K >= 8u ? 8u : 1u; }
-  size_t template_hint(uint32_t K) const {
-    const size_t all = (size_t)K * n_tracks(), stranded = (size_t)(template_reserve(K) + 1u) * n_tracks();
+  // clip starts a track meets between two playhead positions — the most over a sample of up to 16 tracks (two binary searches
+  // each): what the one-lane-per-track sequencer's time is made of
+  size_t clip_starts_between(double from_beat, double to_beat) const {
+    const size_t N = tracks.size();
+    size_t most = 0;
+    for (size_t k = 0; k < 16 && k < N; k++) {
+      const auto& cl = tracks[N <= 16 ? k : k * (N - 1) / 15]->clips;
+      auto lo = std::lower_bound(cl.begin(), cl.end(), from_beat, [](const HostClip& c, double v) { return c.d.min_time < v; });
+      auto hi = std::lower_bound(cl.begin(), cl.end(), to_beat, [](const HostClip& c, double v) { return c.d.min_time < v; });
+      if (hi > lo) most = std::max(most, (size_t)(hi - lo));
+    }
+    return most;
+  }
+  // (lanes: lanes per track of the sequencer — more than one when it is cut along the time axis; every lane may strand a
+  //  reservation and splits a steady run at its seam)
+  size_t template_hint(uint32_t K, uint32_t lanes = 1u) const {
+    const size_t all = (size_t)K * n_tracks();
+    const size_t stranded = (size_t)((lanes > 1u ? 8u : template_reserve(K)) + (lanes > 1u ? 3u : 1u)) * n_tracks() * lanes;
     if (any_crawl_clip) return 2 * all + stranded;
     return std::min(2 * all, 2 * boundary_blocks_hint(K) + 3 * (size_t)n_tracks() + 64) + stranded;
   }

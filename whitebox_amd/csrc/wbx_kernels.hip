@@ -55,6 +55,45 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanArgs a) { plan_body(a); }
 // end, and the next mix waited for it.  The spills (scratch) make it slower alone; beside a mix it is hidden.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void plan_kernel_beside(PlanArgs a) { plan_body(a); }
 
+// The sequencer cut along the time axis (wbx_seq.h, plan_segment): workgroup = 64 tracks x ONE segment of seg_len blocks, so
+// that the transport records its lanes look at all the time — the segment's own and a margin either side — are one window in
+// LDS (a few KiB instead of the 64 KiB of all K records: the workgroups fit beside a running mix); the occasional look further
+// back (the run-up of a long clip) goes to the device table.
+constexpr uint32_t kSegMargin = 48;   // records in front of the segment (the run-up of a clip of a session cut into clips) and behind it
+__device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  DBlockTime* win = reinterpret_cast<DBlockTime*>(s_raw);
+  const uint32_t s = blockIdx.y, b0 = s * g.seg_len;
+  const uint32_t w0 = b0 > kSegMargin ? b0 - kSegMargin : 0u;
+  const uint32_t w1 = b0 + g.seg_len + kSegMargin < a.n_blocks ? b0 + g.seg_len + kSegMargin : a.n_blocks;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.times + w0);
+    uint4* dst = reinterpret_cast<uint4*>(win);
+    const uint32_t n16 = (w1 - w0) * (uint32_t)(sizeof(DBlockTime) / 16u);
+    for (uint32_t i = threadIdx.x; i < n16; i += 64u) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= a.n_tracks) return;
+  const TimesWindow tv{a.times, win, w0, w1};
+  plan_segment(a, t, s, g.seg_len, g.n_segs, tv, g.guess, g.ends);
+}
+__global__ __launch_bounds__(64) void plan_seg_kernel(PlanArgs a, SegArgs g) { plan_seg_body(a, g); }
+// (the register-capped form, as plan_kernel_beside: a wave that fits the hole one retiring mix wave leaves)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void plan_seg_kernel_beside(PlanArgs a, SegArgs g) { plan_seg_body(a, g); }
+
+// ... and its second pass: one lane per track checks the seams in order and plans again, in one walk, whatever follows the
+// first guess that did not hold (rare: g.stats counts the lanes and the segments replaced)
+__global__ __launch_bounds__(64) void plan_fix_kernel(PlanArgs a, SegArgs g) {
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= a.n_tracks) return;
+  const uint32_t redone = plan_fix_track(a, t, g.seg_len, g.n_segs, a.times, g.guess, g.ends);
+  if (redone && g.stats) {
+    atomicAdd(g.stats + 0, 1u);
+    atomicAdd(g.stats + 1, redone);
+  }
+}
+
 // the host's table of per-block transport records (pinned memory) -> device memory, in front of a batch render's plan.  A
 // kernel of our own, not hipMemcpyAsync: the runtime's host-to-device path made the submitting thread wait for the stream
 // (measured: the renders of a 256-track session then ran one after the other instead of overlapped)
@@ -496,6 +535,17 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(plan_kernel_beside, dim3(nb), dim3(64), 0, s, a);
   else
     hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(64), a.times ? 0 : a.n_blocks * sizeof(DBlockTime), s, a);
+}
+
+void launch_plan_segments(const PlanArgs& a, const SegArgs& g, bool beside, hipStream_t s) {
+  const dim3 grid((a.n_tracks + 63u) / 64u, g.n_segs);
+  const size_t lds = (size_t)(g.seg_len + 2u * kSegMargin) * sizeof(DBlockTime);
+  static const bool roomy = [] { const char* v = std::getenv("WBX_PLAN_BESIDE"); return v && v[0] == '0'; }();   // A/B aid
+  if (beside && !roomy)
+    hipLaunchKernelGGL(plan_seg_kernel_beside, grid, dim3(64), lds, s, a, g);
+  else
+    hipLaunchKernelGGL(plan_seg_kernel, grid, dim3(64), lds, s, a, g);
+  hipLaunchKernelGGL(plan_fix_kernel, dim3((a.n_tracks + 63u) / 64u), dim3(64), 0, s, a, g);
 }
 
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {

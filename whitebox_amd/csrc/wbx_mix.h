@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "wbx_dev.h"
@@ -225,7 +226,7 @@ struct RowT {
 // ------------------------------------------------------------------------------------------------
 // (the kernel's body as a function: mix_kernel below is nothing else; the one-launch callback — wbx_callback.h — runs the
 //  sequencer of the workgroup's tracks in front of it and the block's sum behind it)
-template <int U, bool FULL, int FAM, int SB, int CW, int CL, int T>
+template <int U, bool FULL, int FAM, int SB, int CW, int CL, int T, int X = 0>
 __device__ __forceinline__ void mix_body(const MixArgs& a) {
   // FAM: which chunk modes the instance carries — every mode it carries costs registers in all the others.
   //   0  fp32 (unity / window) and integer PCM at unity speed: U, W, WN, WNU, I16, I32, MU, MIXED
@@ -245,10 +246,16 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   constexpr uint32_t kT = (uint32_t)T;   // lanes per workgroup (CL = 2: one block of 4 * T frames — 256, 512 or 1024)
   // tracks staged at a time (four sub-blocks: half, to keep 4 workgroups per CU in LDS; one-wave workgroups: half, so
   // that twelve of them fit — 12.6 KiB each)
-  constexpr uint32_t kSt = SB == 4 ? kStage / 2 : kT == 64u ? kStage / 2 : kStage;
+  // X (round 4): a PACKED instance (SB = 2 / 4 blocks per workgroup) that takes masked rows too — short blocks of a session cut
+  // into clips used to leave the packed instances for one-wave workgroups.  1: half the tracks per chunk, so that the doubled
+  // row space costs no LDS (occupancy as before); [2: the packed instances' own chunk length at twice the LDS — three
+  // workgroups per CU; measured 3-10 % behind 1 and not instantiated]
+  constexpr bool XP = X != 0;
+  static_assert(!XP || (SB > 1 && FULL), "masked rows in a packed instance");
+  constexpr uint32_t kSt = XP ? (kStage >> (X == 1 ? 1 : 0)) / (SB == 4 ? 2u : 1u) : SB == 4 ? kStage / 2 : kT == 64u ? kStage / 2 : kStage;
   // EXP: the instance takes the sequencer's masked rows (MixArgs::masked_rows): a track-block with a clip boundary in
   // it is a ROW_PAIR of two single-segment records, so a chunk of kSt tracks stages up to 2 * kSt rows
-  constexpr bool EXP = SB == 1 && FULL && (kSt == 128 || kT == 64u);
+  constexpr bool EXP = XP || (SB == 1 && FULL && (kSt == 128 || kT == 64u));
   constexpr uint32_t kMaxRows = EXP ? 2 * kSt : kSt;
   constexpr uint32_t kRecs = kMaxRows + 2 * U + 4;      // staged records + null padding for the last batches
   __shared__ __attribute__((aligned(16))) DTrackBlock s_tb[SB * kRecs];   // [sub-block][record]
@@ -256,11 +263,14 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   constexpr uint32_t kPS = (CL == 2 && kWaves == 4u) ? 8u : 4u;   // peak slots per record: one per (wave, channel of the wave)
   __shared__ uint32_t s_pk[SB * kRecs * kPS];   // FULL: one slot per (record, wave[, channel]), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[kPS];         // FULL: sub-block * C + channel a slot holds (unused slots: none)
-  __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? 2 * kSt : 1];   // EXP: the plan rows of this chunk and (prefetched) of the next
-  __shared__ uint32_t s_ord[EXP ? kSt : 1];       // EXP: the routing-order entries of the next chunk (prefetched)
-  __shared__ uint16_t s_map[EXP ? 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
-  __shared__ uint16_t s_off[EXP ? kSt + 1 : 1];   // EXP: local track -> its first staged row
+  // (XP: everything per sub-block; the rows of the chunk only — a packed instance walks two to four chunks, no prefetch)
+  __shared__ __attribute__((aligned(16))) DRow s_rows[XP ? SB * kSt : EXP ? 2 * kSt : 1];   // EXP: the plan rows of this chunk and (prefetched) of the next
+  __shared__ uint32_t s_ord[(EXP && !XP) ? kSt : 1];       // EXP: the routing-order entries of the next chunk (prefetched)
+  __shared__ uint16_t s_map[EXP ? SB * 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
+  __shared__ uint16_t s_off[EXP ? SB * (kSt + 1) : 1];   // EXP: local track -> its first staged row
   __shared__ uint32_t s_wpairs[3];                // EXP: pairs in waves 0 and 1, staged rows of the chunk
+  __shared__ uint32_t s_hp[XP ? 8 : 1];           // XP: pairs per 32-lane half of the row-fetching lanes
+  __shared__ uint32_t s_tot[XP ? SB : 1];         // XP: staged rows of each sub-block
   __shared__ int s_shape;                         // the row shapes the chunk holds (OR over its records)
 
   // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Consecutive blocks
@@ -1204,7 +1214,85 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
     // stage the group's records (per-track gain / pan / resample parameters) in LDS: 4 x 16 B per record.
     // A record = the template its 16-B plan row points at, with the row's position patched in when the template
     // is shared by a run of blocks; silent rows become all-zero records (kind 0).
-    if constexpr (EXP) {
+    if constexpr (XP) {
+      // The same two passes per SUB-BLOCK (every sub-block is a block of its own: other plan rows, other pairs, another
+      // number of staged rows).  Pass 1, one lane per (sub-block, track): routing entry -> plan row (kept in LDS for pass 2),
+      // a pair counts twice; the prefix sum runs over the 32-lane halves of the fetching waves (a sub-block's tracks are one,
+      // two or four halves).  Pass 2 copies the template quads of all sub-blocks through the maps, all loads in flight at once.
+      constexpr uint32_t kHalves = kSt / 32u;   // 32-lane halves per sub-block
+      uint32_t before = 0u;
+      bool is_pair = false;
+      const uint32_t psb = tid / kSt, pt = tid - psb * kSt;   // (lanes below SB * kSt)
+      if (tid < SB * kSt) {
+        DRow row;
+        row.pos = 0.0;
+        row.tmpl = 0xFFFFFFFFu;
+        row.flags = ROW_SILENT;
+        const uint32_t bb = bx * SB + psb;
+        if (pt < cn && bb < a.n_blocks) row = a.rows[(size_t)bb * N + a.order[grp.first + chunk0 + pt]];
+        *reinterpret_cast<uint4*>(&s_rows[tid]) = *reinterpret_cast<const uint4*>(&row);
+        is_pair = (row.flags & (ROW_PAIR | ROW_SILENT)) == ROW_PAIR;
+        const unsigned long long half = (lane & 32u) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+        const unsigned long long bal = __ballot(is_pair) & half;
+        before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if ((lane & 31u) == 0u) s_hp[tid >> 5] = (uint32_t)__popcll(bal);
+      }
+      __syncthreads();
+      if (tid < SB * kSt) {
+        uint32_t off = pt + before, total = cn;
+#pragma unroll
+        for (uint32_t h = 0; h < kHalves; h++) {
+          const uint32_t n = s_hp[psb * kHalves + h];
+          if (psb * kHalves + h < (tid >> 5)) off += n;
+          total += n;
+        }
+        if (pt < cn) {
+          s_off[psb * (kSt + 1u) + pt] = (uint16_t)off;
+          s_map[psb * 2u * kSt + off] = (uint16_t)pt;
+          if (is_pair) s_map[psb * 2u * kSt + off + 1u] = (uint16_t)(pt | 0x8000u);
+        }
+        if (pt == 0u) {
+          s_off[psb * (kSt + 1u) + cn] = (uint16_t)total;
+          s_tot[psb] = total;
+        }
+      }
+      __syncthreads();
+      cn2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tot[sub]);   // this wave's sub-block
+      constexpr uint32_t kQ = (SB * kRecs * 4u + kT - 1u) / kT;
+      uint4 wq[kQ];
+      uint32_t tq = tid;
+      asm volatile("" : "+v"(tq));
+#pragma unroll
+      for (uint32_t it = 0; it < kQ; it++) {
+        const uint32_t i = tq + it * kT, sbq = i / (kRecs * 4u), r4 = i - sbq * (kRecs * 4u), rec = r4 >> 2, q = r4 & 3u;
+        const bool in = sbq < (uint32_t)SB && rec < s_tot[sbq < (uint32_t)SB ? sbq : 0u];
+        const uint32_t mp = s_map[in ? sbq * 2u * kSt + rec : 0u];
+        const DRow row = s_rows[(in ? sbq * kSt : 0u) + (mp & 0x7FFFu)];
+        const bool live = in && !(row.flags & ROW_SILENT);
+        // (a lane without a live record reads template 0: the load stays unconditional, its result is dropped)
+        wq[it] = reinterpret_cast<const uint4*>(a.tmpl + (live ? row.tmpl + (mp >> 15) : 0u))[q];
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < kQ; it++) {
+        const uint32_t i = tq + it * kT, sbq = i / (kRecs * 4u), r4 = i - sbq * (kRecs * 4u), rec = r4 >> 2, q = r4 & 3u;
+        if (i < SB * kRecs * 4u) {
+          uint4 w = {0u, 0u, 0u, 0u};
+          if (rec < s_tot[sbq]) {
+            const uint32_t mp = s_map[sbq * 2u * kSt + rec];
+            const DRow row = s_rows[sbq * kSt + (mp & 0x7FFFu)];
+            if (!(row.flags & ROW_SILENT)) {
+              w = wq[it];
+              if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
+                const uint2 pb = *reinterpret_cast<const uint2*>(&row.pos);
+                w.x = pb.x;
+                w.y = pb.y;
+              }
+            }
+          }
+          reinterpret_cast<uint4*>(s_tb)[i] = w;
+        }
+      }
+    } else if constexpr (EXP) {
       // Rows may be ROW_PAIRs (a clip boundary inside the block: two single-segment templates; only with
       // MixArgs::masked_rows).  Pass 1, one lane per track: the 16-B plan row (fetched by the previous chunk's staging,
       // except for the first chunk), a pair counts as two staged rows, wave-ballot prefix sum -> the track's first
@@ -1337,8 +1425,9 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
     __syncthreads();
     // which row shapes does this chunk hold?  (bit 0 fp32 unity, 1 fp32 window, 2 16-bit, 3 24/32-bit)
     int shape = 0;
-    for (uint32_t i0 = tid; i0 < SB * cn2; i0 += kT) {
-      const uint32_t i = SB > 1 ? (i0 / cn2) * kRecs + i0 % cn2 : i0;
+    for (uint32_t i0 = tid; i0 < SB * (XP ? kMaxRows : cn2); i0 += kT) {
+      if (XP && i0 % kMaxRows >= s_tot[XP ? i0 / kMaxRows : 0u]) continue;   // (XP: every sub-block has its own number of staged rows)
+      const uint32_t i = XP ? (i0 / kMaxRows) * kRecs + i0 % kMaxRows : SB > 1 ? (i0 / cn2) * kRecs + i0 % cn2 : i0;
       const int k = s_tb[i].kind & KIND_MASK;
       shape |= k == KIND_UNITY ? 1 : k == KIND_WINDOW ? (s_tb[i].format == FMT_F32 ? 2 : 128) : k == KIND_UNITY_I16 ? 4 : k == KIND_UNITY_I32 ? 8
                : k == KIND_STRIDE ? 64 : k == KIND_WINDOW_I16 ? 32 : 0;
@@ -1378,7 +1467,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
       DTrackBlock& r = s_tb[i];
       // (KIND_GENERIC: only when the one-block callback skipped the pre-render pass on the expectation of an empty queue;
       //  the host then repeats pre-render + mix for that block — here the record counts as silence)
-      if ((SB > 1 ? i % kRecs : i) >= cn2 || (r.kind & KIND_MASK) == KIND_SILENT || (r.kind & KIND_MASK) == KIND_GENERIC) {
+      if ((SB > 1 ? i % kRecs : i) >= (XP ? s_tot[XP ? i / kRecs : 0u] : cn2) || (r.kind & KIND_MASK) == KIND_SILENT || (r.kind & KIND_MASK) == KIND_GENERIC) {
         r.src[0] = a.zero_page;
         r.src[1] = a.zero_page;
         r.pos = 0.0;
@@ -1477,16 +1566,16 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(a.peaks) + ((size_t)bb * N + track) * C + ch;
       uint32_t pk = 0u;   // peaks are non-negative floats: uint order == float order
       if (FULL && CW == 2) {
-        const uint32_t r0 = EXP ? s_off[rec] : rec;   // (EXP: the track's staged row, or the two of its pair)
-        const uint32_t r1 = EXP ? s_off[rec + 1u] : rec + 1u;
+        const uint32_t r0 = EXP ? s_off[sb * (kSt + 1u) + rec] : rec;   // (EXP: the track's staged row, or the two of its pair)
+        const uint32_t r1 = EXP ? s_off[sb * (kSt + 1u) + rec + 1u] : rec + 1u;
         for (uint32_t rr = r0; rr < r1; rr++) {
           const uint32_t v = s_pk[(sb * kRecs + rr) * kPS + ch];
           pk = pk > v ? pk : v;
         }
       } else if (FULL) {
         // (EXP: the track's staged row, or the two of its pair — one peak over both stream calls)
-        const uint32_t r0 = EXP ? s_off[rec] : rec;
-        const uint32_t r1 = EXP ? s_off[rec + 1u] : rec + 1u;
+        const uint32_t r0 = EXP ? s_off[sb * (kSt + 1u) + rec] : rec;
+        const uint32_t r1 = EXP ? s_off[sb * (kSt + 1u) + rec + 1u] : rec + 1u;
         for (uint32_t rr = r0; rr < r1; rr++) {
           const uint32_t* slots = &s_pk[(sb * kRecs + rr) * kPS];
 #pragma unroll
@@ -1569,6 +1658,12 @@ template <int U, bool FULL, int W, int FAM, int SB, int CW = 1, int CL = 1, int 
 __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   mix_body<U, FULL, FAM, SB, CW, CL, T>(a);
 }
+// the packed instances (SB blocks per 256-lane workgroup) that take masked rows: a kernel of its own, so that the names of
+// the others stay what every profile of earlier rounds calls them
+template <int U, int W, int FAM, int SB, int CW, int X>
+__global__ __launch_bounds__(256, W) void mix_kernel_x(MixArgs a) {
+  mix_body<U, true, FAM, SB, CW, 1, 256, X>(a);
+}
 
 // one instance, launched; t0 / t1 (optional): events that take the kernel's own start and end times (hipExtLaunchKernelGGL:
 // the time stamps of its dispatch packet — no event packets of their own in the stream).  -> the instance's name as
@@ -1577,6 +1672,13 @@ __global__ __launch_bounds__(T, W) void mix_kernel(MixArgs a) {
   {                                                                                                            \
     name = "wbx::mix_kernel<" #U ", " #FULL ", " #W ", " #FAM ", " #SB ", " #CW ", " #CL ", " #T ">";          \
     hipExtLaunchKernelGGL((mix_kernel<U, FULL, W, FAM, SB, CW, CL, T>), GRID, BLOCK, 0, s, t0, t1, 0, a);      \
+  }
+
+// a packed instance that takes masked rows (X = 1: half-length chunks)
+#define WBX_MIX_X(U, W, FAM, SB, CW, X, GRID)                                                                  \
+  {                                                                                                            \
+    name = "wbx::mix_kernel_x<" #U ", " #W ", " #FAM ", " #SB ", " #CW ", " #X ">";                            \
+    hipExtLaunchKernelGGL((mix_kernel_x<U, W, FAM, SB, CW, X>), GRID, dim3(256), 0, s, t0, t1, 0, a);          \
   }
 
 // the instances of one family (wbx_mix_fam<N>.hip); `variant`: 10 * U + W, or >= 1000 for both channels of a frame per lane

@@ -13,6 +13,23 @@ const char* launch_mix_fam0(const MixArgs& a, uint32_t n_blocks, int variant, hi
   const uint32_t S4 = a.block_frames >> 2;
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
+  if (!full && a.masked_rows) {
+    // short blocks of a session cut into clips, renders of 8 blocks and more: the packed instances that take masked rows
+    // (2 or 4 blocks per workgroup like the ones below, the staging of the one-block instances per sub-block)
+    const bool st128 = S4 == 32u && a.channels == 2u, two = S4 % 64u == 0u && lanes == 128u, four = S4 == 64u && lanes == 64u;
+    const int x = packed_masked_variant(n_blocks, st128);
+    if (x && (st128 || two || four)) {
+      const uint32_t sb = st128 ? 4u : 256u / lanes;
+      const dim3 gx((n_blocks + sb - 1u) / sb, a.n_groups, 1);
+      if (st128)
+        WBX_MIX_X(2, 4, 0, 4, 2, 1, gx)
+      else if (two)
+        WBX_MIX_X(2, 4, 0, 2, 1, 1, gx)
+      else
+        WBX_MIX_X(2, 4, 0, 4, 1, 1, gx)
+      return name;
+    }
+  }
   // variant >= 1000, stereo 256-frame blocks: one wave = one block with both channels of a frame in a lane
   if (variant >= 1000 && a.channels == 2u && S4 == 64u) {
     WBX_MIX(2, true, 3, 0, 1, 1, 2, 64, grid, dim3(64))

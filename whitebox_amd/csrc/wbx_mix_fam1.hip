@@ -13,6 +13,22 @@ const char* launch_mix_fam1(const MixArgs& a, uint32_t n_blocks, hipStream_t s, 
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (!full && a.masked_rows) {
+    // short blocks of a session cut into clips, renders of 8 blocks and more: the packed instances that take masked rows
+    const bool st128 = S4 == 32u && a.channels == 2u, two = S4 % 64u == 0u && lanes == 128u, four = S4 == 64u && lanes == 64u;
+    const int x = packed_masked_variant(n_blocks, st128);
+    if (x && (st128 || two || four)) {
+      const uint32_t sb = st128 ? 4u : 256u / lanes;
+      const dim3 gx((n_blocks + sb - 1u) / sb, a.n_groups, 1);
+      if (st128)
+        WBX_MIX_X(2, 4, 1, 4, 2, 1, gx)
+      else if (two)
+        WBX_MIX_X(2, 4, 1, 2, 1, 1, gx)
+      else
+        WBX_MIX_X(2, 4, 1, 4, 1, 1, gx)
+      return name;
+    }
+  }
+  if (!full && a.masked_rows) {
     // short blocks of a session cut into clips: one block per workgroup (a wave, or two), the instances that take the
     // sequencer's masked rows — clip boundaries stay in the hot loop instead of going through the pre-render pass
     if (S4 == 32u && a.channels == 2u) {          // 128-frame stereo: one wave, a channel per half-wave

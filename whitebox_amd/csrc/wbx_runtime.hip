@@ -126,21 +126,34 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 // What counts is the number of workgroup COLUMNS, not of blocks: the instances for blocks shorter than a workgroup put 2 or 4
 // consecutive blocks into one, and a 1024-block render of 128-frame blocks through them is 256 columns — 256 chains, or 256
 // walks, on a device that holds a thousand workgroups (measured: 0.30 of the roofline instead of 0.60).
-static uint32_t blocks_per_workgroup(const wbx_ctx* c) {
+// (-> blocks per workgroup; *resident: how many workgroups of that instance the device holds at once, in units of the 1024
+//  that the four-wave instances come to.  A chained piece waits for its predecessor while it occupies a slot: with fewer
+//  columns than resident workgroups several pieces of a block are resident TOGETHER and all but one of them wait — measured
+//  on the one-wave instances, 3072 resident: 0.25 of the roofline at 1024 columns, 0.45 at 2048, against 0.6 unchained)
+static uint32_t blocks_per_workgroup(const wbx_ctx* c, uint32_t K, uint32_t* resident) {
   const uint32_t C = c->cfg.channels, S4 = c->cfg.block_frames >> 2, lanes = C * S4;
+  *resident = 1u;
   if ((lanes % 256u == 0u) && (S4 % 64u == 0u)) return 1u;
   const char* e = std::getenv("WBX_MASKED_ROWS");
   const bool short_ok = (C == 2u && S4 == 32u) || (S4 % 64u == 0u && lanes == 128u) || (S4 == 64u && lanes == 64u);
-  if (short_ok && c->has_cut_tracks && !(e && e[0] == '0')) return 1u;   // the one-block-per-workgroup instances (masked rows)
+  const uint32_t packed = (C == 2u && S4 == 32u) ? 4u : (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) ? 256u / lanes : 1u;
   const int fam = mix_family(c);
-  if (C == 2u && S4 == 64u && (fam == 0 || fam == 2) && (c->has_integer_clips || c->has_cut_tracks)) return 1u;   // one wave = one block
-  if (C == 2u && S4 == 32u) return 4u;
-  if (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) return 256u / lanes;
-  return 1u;
+  if (short_ok && c->has_cut_tracks && !(e && e[0] == '0')) {   // masked rows ...
+    if (!(fam == 2 && C == 2u && S4 == 64u) && packed_masked_variant(K, C == 2u && S4 == 32u)) return packed;   // ... in the packed instances
+    *resident = lanes <= 64u ? 3u : 2u;
+    return 1u;                                                   // ... in the one-block-per-workgroup instances
+  }
+  if (C == 2u && S4 == 64u && (fam == 0 || fam == 2) && (c->has_integer_clips || c->has_cut_tracks)) {   // one wave = one block
+    *resident = 3u;
+    return 1u;
+  }
+  return packed;
 }
 
 bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
-  return c->auto_group && c->exact_min_blocks != 0u && K / blocks_per_workgroup(c) >= c->exact_min_blocks;
+  uint32_t resident = 1u;
+  const uint32_t bpw = blocks_per_workgroup(c, K, &resident);
+  return c->auto_group && c->exact_min_blocks != 0u && K / bpw >= c->exact_min_blocks * resident;
 }
 
 // ... and of those, which chain the workgroup-sized pieces instead of walking a list in one workgroup: the same order of

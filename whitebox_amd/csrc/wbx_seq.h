@@ -149,12 +149,14 @@ struct BlockWalker {
   uint32_t start_sample;
   uint32_t nseg;
   uint32_t chunk;
+  bool dry;                 // advance the state only: no record, no pool chunk, no status bit (plan_segment's run-up)
 
   // The second stream call of a block is kept in `seg1` (the usual clip boundary: one clip ends, the next starts —
   // it becomes template tmpl + 1 of a ROW_PAIR and never touches the pool); the overflow pool is only allocated
   // when a third call arrives (or, for a pair the hot loop cannot take, when the block is finished).
   DSeg seg1;
   __host__ __device__ bool alloc_chunk() {
+    if (dry) return false;
     uint32_t c;
 #if defined(__HIP_DEVICE_COMPILE__)
     c = atomicAdd(pool_count, 1u);
@@ -172,6 +174,7 @@ struct BlockWalker {
   }
   // where call number `nseg` (>= 2) of this block goes in the overflow pool
   __host__ __device__ DSeg* slot() {
+    if (dry) return nullptr;
     if (nseg >= kMaxSegs) {
       raise_status(status, 2u);
       return nullptr;
@@ -269,10 +272,19 @@ struct BlockWalker {
 
 // clip->internal_state_changed = false (track.cpp:373,392,418): the cached copy always, the clip list in
 // HBM only when the flag was actually set.
-__host__ __device__ inline void clear_state_changed(DClip* cached, DClip* global) {
+// (flags_left, optional: a count of the set flags in the table, in host memory — the host plans by segments only while it
+//  reads zero there, plan_segment below)
+__host__ __device__ inline void clear_state_changed(DClip* cached, DClip* global, uint32_t* flags_left) {
   if (cached->internal_state_changed) {
     cached->internal_state_changed = 0;
     global->internal_state_changed = 0;
+    if (flags_left) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __hip_atomic_fetch_sub(flags_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+      flags_left[0] -= 1u;
+#endif
+    }
   }
 }
 
@@ -286,7 +298,7 @@ __host__ __device__ inline uint32_t mod_buffer(uint64_t x, uint32_t buffer_size)
 // Track::process_event, audio branch — track.cpp:258-451.  MIDI clips and recording are out of scope.
 __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint32_t num_clips, double start_time,
                                               double end_time, double sample_position, double beat_duration,
-                                              double sample_rate, uint32_t buffer_size) {
+                                              double sample_rate, uint32_t buffer_size, uint32_t* flags_left = nullptr) {
   DTrackState* st = w.st;
   if (num_clips == 0) {                                          // :268-284
     if (st->refresh_voice) {
@@ -353,20 +365,20 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
       double sample_offset = sample_position + offset_from_start;
       uint32_t buffer_offset = mod_buffer((uint64_t)sample_offset, buffer_size);
       w.on_event(EV_PLAY, buffer_offset, clip->speed, (uint64_t)clip->start_offset, clip);
-      clear_state_changed(clip, &clips[next_clip]);
+      clear_state_changed(clip, &clips[next_clip], flags_left);
     } else if (start_time > min_time && !st->partially_ended) {  // :375-393 started in the middle
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
       uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
-      clear_state_changed(clip, &clips[next_clip]);
+      clear_state_changed(clip, &clips[next_clip], flags_left);
     } else if (clip->internal_state_changed && st->partially_ended) {  // :394-419
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
       uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
-      clear_state_changed(clip, &clips[next_clip]);
+      clear_state_changed(clip, &clips[next_clip], flags_left);
     }
 
     if (max_time <= end_time) {                                  // :421-434 reaching the end of the clip
@@ -462,9 +474,10 @@ __host__ __device__ inline uint8_t masked_kind(const DSeg& s, uint32_t block_fra
 }
 
 // One track, one block: Track::process minus the per-sample work (track.cpp:587-736).
+// `dry`: only the track's state moves on — nothing is allocated or stored (plan_segment's run-up to its first block)
 __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
                                                  DClip* clips, uint32_t num_clips, TrackCache* cache,
-                                                 const DBlockTime& bt, float gl, float gr) {
+                                                 const DBlockTime& bt, float gl, float gr, bool dry = false) {
   // the record is assembled in registers and written to HBM once, as four 16-B stores: building it in place
   // would turn every field update into a global store followed (in classify) by a dependent global load
   DTrackBlock rec;
@@ -487,7 +500,8 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
   w.pool = a.pool;
   w.pool_count = a.pool_count;
   w.pool_chunks = a.pool_chunks;
-  w.status = a.status;
+  w.status = dry ? nullptr : a.status;
+  w.dry = dry;
   w.n_samples = a.block_frames;
   w.n_channels = a.channels;
   w.dst_rate = a.sample_rate;
@@ -506,9 +520,10 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
                         cache->clip.max_time > bt.end_time;
     if (!steady)
       process_event(w, clips, num_clips, bt.start_time, bt.end_time, bt.sample_position, bt.beat_duration,
-                    a.sample_rate, a.block_frames);
+                    a.sample_rate, a.block_frames, a.flags_left);
     w.finish();
   }
+  if (dry) return;
   tb->g[0] = gl;
   tb->g[1] = gr;
   tb->nseg = (uint8_t)w.nseg;
@@ -616,9 +631,12 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
 // comparisons, the tail guard, one fp64 add and the 64-B store per block.  The records are field-for-field
 // what plan_track_block produces (the parity tests compare them with the oracle's call log).  Returns the
 // number of blocks planned (0: the general path must handle block b).
+// `end`: plan no further than block end - 1 (the render's length, or a segment's seam); `dry`: as in plan_track_block.
+// TV: the per-block transport records — a plain array, or TimesWindow (a window of them in LDS, the rest in device memory).
+template <class TV>
 __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t t, uint32_t b, DTrackState* st,
                                                     uint32_t num_clips, TrackCache* cache,
-                                                    const DBlockTime* times, float gl, float gr) {
+                                                    const TV& times, float gl, float gr, uint32_t end, bool dry = false) {
   if (!(a.playing && st->cur_type == EV_PLAY && st->has_clip_idx && !st->refresh_voice && st->partially_ended &&
         st->clip_idx < num_clips && cache->clip_idx == st->clip_idx && !cache->clip.internal_state_changed &&
         cache->smp_idx == st->cur_sample))
@@ -659,7 +677,7 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   // block, so the answer is known to within a block or two from ONE record: estimate, then let the table itself decide —
   // the same predicate on the same records as a bisection, a couple of look-ups instead of eleven (a session cut into
   // clips searches once per clip, and each look-up is a memory round trip for the lane).
-  uint32_t lo = 0, hi = a.n_blocks - b;
+  uint32_t lo = 0, hi = end - b;
   {
     const double dt = t_b.end_time - t_b.start_time;
     const double est = (max_time - t_b.end_time) / dt;
@@ -697,6 +715,16 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
   rec.pos = off;
   rec.kind = classify(rec, F);
   if (rec.kind == KIND_GENERIC || rec.kind == KIND_SILENT) return 0;   // general path (pre-render queue)
+  if (dry) {   // the positions of the run, nothing else: the same additions in the same order
+    uint32_t n = 0;
+    while (n < n_time) {
+      if (!(off + guard <= cnt && (cnt - off) < qmax && off < 2147483000.0)) break;
+      off = off + step;                                    // sampler.cpp:209
+      n++;
+    }
+    st->sample_offset = off;
+    return n;
+  }
   const uint32_t ti = alloc_template(a, cache);
   if (ti == 0xFFFFFFFFu) return 0;
   {
@@ -763,9 +791,9 @@ __host__ __device__ inline void block_times(const PlanArgs& a, DBlockTime* times
   }
 }
 
-// One track through the K blocks of a render: what a lane of plan_kernel does (and the host harness of the tests,
-// track by track).  Applies the pending state patch, then alternates steady runs and general blocks.
-__host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const DBlockTime* times) {
+// The state a track enters a render with: what the previous render left, the pending patch applied, the playing clip's gain
+// re-read after an edit.
+__host__ __device__ inline DTrackState plan_initial_state(const PlanArgs& a, uint32_t t, const DClip* clips, uint32_t nc) {
   DTrackState st = a.state[t];
   if (a.patch) {
     const DPatch p = a.patch[t];
@@ -777,9 +805,6 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
     if (p.flags & PATCH_REFRESH) st.refresh_voice = p.refresh_voice;
     if (p.flags & PATCH_STOP) st.cur_type = EV_NONE;   // Track::stop, track.cpp:249-256
   }
-  const uint32_t c0 = a.clip_first[t];
-  const uint32_t nc = a.clip_first[t + 1] - c0;
-  DClip* clips = const_cast<DClip*>(a.clips) + c0;
   if (a.clips_changed && st.cur_type == EV_PLAY) {
     // the reference reads current_audio_event.clip->audio.gain at every stream call (track.cpp:676,716):
     // after an edit (set_clip_gain, re-sorted list) find the playing clip again by identity.  A clip an edit DESTROYED
@@ -791,42 +816,201 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
       if (clips[i].uid == st.cur_clip_uid) gain = clips[i].gain;
     st.cur_gain = gain;
   }
-  TrackCache cache;
-  cache.clip_idx = 0xFFFFFFFFu;
-  cache.next_idx = 0xFFFFFFFFu;
-  cache.smp_idx = 0xFFFFFFFFu;
-  cache.fin_tmpl = 0xFFFFFFFFu;
-  cache.tmpl_next = cache.tmpl_end = 0u;
-  if (a.tmpl_reserve == 0u) {   // one-block renders: the track owns templates 2t and 2t + 1 (a block takes one, or a ROW_PAIR's two)
-    cache.tmpl_next = 2u * t;   // — no atomic round trip in the callback's latency chain
-    cache.tmpl_end = 2u * t + 2u;
+  return st;
+}
+
+// The records the track is about to use — the clip it stands on, the clip behind it, the sample that is playing — are
+// fetched TOGETHER, as soon as the state names them: the sequencer is one lane per track, and finding them one after the
+// other (state -> clip -> sample) is three dependent memory round trips in front of a one-block render.  (Filling the
+// cache changes no result: every use of a cached record compares its index first.)
+__host__ __device__ inline void plan_cache_init(const PlanArgs& a, uint32_t t, const DTrackState& st, const DClip* clips, uint32_t nc,
+                                                TrackCache* cache) {
+  cache->clip_idx = 0xFFFFFFFFu;
+  cache->next_idx = 0xFFFFFFFFu;
+  cache->smp_idx = 0xFFFFFFFFu;
+  cache->fin_tmpl = 0xFFFFFFFFu;
+  cache->tmpl_next = cache->tmpl_end = 0u;
+  if (a.tmpl_reserve == 0u) {    // one-block renders: the track owns templates 2t and 2t + 1 (a block takes one, or a ROW_PAIR's two)
+    cache->tmpl_next = 2u * t;   // — no atomic round trip in the callback's latency chain
+    cache->tmpl_end = 2u * t + 2u;
   }
-  // The records the track is about to use — the clip it stands on, the clip behind it, the sample that is playing — are
-  // fetched TOGETHER, as soon as the state names them: the sequencer is one lane per track, and finding them one after the
-  // other (state -> clip -> sample) is three dependent memory round trips in front of a one-block render.  (Filling the
-  // cache changes no result: every use of a cached record compares its index first.)
   if (st.has_clip_idx && st.clip_idx < nc) {
-    cache.clip = clips[st.clip_idx];
-    cache.clip_idx = st.clip_idx;
+    cache->clip = clips[st.clip_idx];
+    cache->clip_idx = st.clip_idx;
     if (st.clip_idx + 1u < nc) {
-      cache.next = clips[st.clip_idx + 1u];
-      cache.next_idx = st.clip_idx + 1u;
+      cache->next = clips[st.clip_idx + 1u];
+      cache->next_idx = st.clip_idx + 1u;
     }
   }
   if (st.cur_type == EV_PLAY) {
-    cache.smp = a.samples[st.cur_sample];
-    cache.smp_idx = st.cur_sample;
+    cache->smp = a.samples[st.cur_sample];
+    cache->smp_idx = st.cur_sample;
   }
-  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
-  uint32_t b = 0;
-  while (b < a.n_blocks) {
-    b += plan_steady_run(a, t, b, &st, nc, &cache, times, gl, gr);   // tight loop over the common case
-    if (b < a.n_blocks) {
-      plan_track_block(a, t, b, &st, clips, nc, &cache, times[b], gl, gr);
+}
+
+// blocks [b, end) of one track: steady runs and general blocks in turn
+template <class TV>
+__host__ __device__ inline void plan_blocks(const PlanArgs& a, uint32_t t, DTrackState* st, DClip* clips, uint32_t nc, TrackCache* cache,
+                                            const TV& times, float gl, float gr, uint32_t b, uint32_t end, bool dry) {
+  while (b < end) {
+    b += plan_steady_run(a, t, b, st, nc, cache, times, gl, gr, end, dry);   // tight loop over the common case
+    if (b < end) {
+      plan_track_block(a, t, b, st, clips, nc, cache, times[b], gl, gr, dry);
       b++;
     }
   }
+}
+
+// One track through the K blocks of a render: what a lane of plan_kernel does (and the host harness of the tests,
+// track by track).  Applies the pending state patch, then alternates steady runs and general blocks.
+template <class TV>
+__host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const TV& times) {
+  const uint32_t c0 = a.clip_first[t];
+  const uint32_t nc = a.clip_first[t + 1] - c0;
+  DClip* clips = const_cast<DClip*>(a.clips) + c0;
+  DTrackState st = plan_initial_state(a, t, clips, nc);
+  TrackCache cache;
+  plan_cache_init(a, t, st, clips, nc, &cache);
+  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
+  plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, 0u, a.n_blocks, false);
   a.state[t] = st;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The sequencer of a long render, cut ALONG THE TIME AXIS (round 4).  One lane per track walks the K blocks of a render one
+// after the other; a session cut into clips is a chain of dependent record look-ups per clip boundary, 4096 tracks are 64
+// waves, and the plan of a 2048-block render of such a session took 5.4 ms beside a 6.5 ms mix (and 4.4 ms in front of a
+// 2.6 ms mix of 128-frame blocks).  The state a track has at block b is a function of what happened before b — but nearly
+// always of very little of it: a clip that STARTS FROM ITS BEGINNING (track.cpp:357-374) resets the sampler and every field
+// of the event state that a later block reads.  So the render is cut into segments of L blocks, one lane per (track,
+// segment); the lane of segment s > 0
+//   1. finds the last clip start in front of its first block b0 (binary search over the track's clips, one look at the
+//      transport records) — or, when no clip of the track started inside this render before b0, takes the track's real
+//      entry state and block 0,
+//   2. runs the very same sequencer code DRY from there to b0 (state only: no template, no row, no queue entry) — a few blocks
+//      for a session cut into clips, a loop of fp64 additions for one long clip,
+//   3. notes the state it arrived with (its GUESS for block b0), plans its own blocks for real, notes the state it ends with.
+// plan_fix_track then walks the seams of a track in order: segment s stands if its guess equals, bit for bit, the state
+// segment s - 1 ended with (segment 0 starts from the truth, so by induction every standing segment was planned from the
+// state the one-lane walk would have had); at the first seam that differs — a clip the sequencer skipped, overlapping or
+// out-of-order events, anything the shortcut does not foresee — the rest of the track is planned again in one walk from
+// the true state, over the speculative rows.  Results are therefore the serial walk's whatever the guess was; only the time
+// depends on it.  (The templates, pool chunks and queue entries of a replaced segment stay allocated and unused.)
+// Not taken — the host decides, wbx_engine.hip — when a clip flag (internal_state_changed, cleared by the sequencer as it
+// passes: track.cpp:373,392,418) may be set: a dry lane and a real one would race for it.
+// ------------------------------------------------------------------------------------------------------------------------
+
+// the transport records of a segment's neighbourhood in LDS (host: a plain array), all others in device memory
+struct TimesWindow {
+  const DBlockTime* all;   // [K]
+  const DBlockTime* win;   // records w0 .. w1 - 1
+  uint32_t w0, w1;
+  __host__ __device__ DBlockTime operator[](uint32_t i) const {
+    const DBlockTime* p = (i >= w0 && i < w1) ? win + (i - w0) : all + i;
+    return *p;
+  }
+};
+
+// the clip start the lane of a segment that begins at block b0 (> 0) runs up from: -> the block to start at; *st = the state
+// to start with (the guess: "stopped in front of clip j", or the track's entry state at block 0)
+template <class TV>
+__host__ __device__ inline uint32_t plan_anchor(const PlanArgs& a, const DClip* clips, uint32_t nc, const TV& times, uint32_t b0,
+                                                const DTrackState& entry, DTrackState* st) {
+  *st = entry;
+  if (nc == 0u || !a.playing) return 0u;
+  const double T = times[b0].start_time;   // == end_time of block b0 - 1: a clip with min_time <= T has been started by then
+  // j = the last clip with min_time <= T (the list is sorted by min_time; any list gives SOME j, and a wrong one is caught at the seam)
+  uint32_t lo = 0u, hi = nc;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (clips[mid].min_time <= T)
+      lo = mid + 1u;
+    else
+      hi = mid;
+  }
+  if (lo == 0u) return 0u;
+  const uint32_t j = lo - 1u;
+  const double mt = clips[j].min_time;
+  const DBlockTime t0 = times[0];
+  if (!(mt >= t0.start_time)) return 0u;   // it started before this render (or in the middle): the entry state decides
+  // the first block whose window reaches min_time (min_time <= end_time): estimate from the first record, settle on the table
+  const double dt = t0.end_time - t0.start_time;
+  uint32_t i = 0u;
+  if (dt > 0.0) {
+    const double est = (mt - t0.start_time) / dt;
+    i = est >= (double)b0 ? b0 - 1u : (uint32_t)est;
+  }
+  if (i >= b0) i = b0 - 1u;
+  uint32_t steps = 0u;
+  while (i + 1u < b0 && !(mt <= times[i].end_time) && steps < 64u) {
+    i++;
+    steps++;
+  }
+  while (i > 0u && mt <= times[i - 1u].end_time && steps < 64u) {
+    i--;
+    steps++;
+  }
+  if (steps >= 64u) return 0u;             // (a transport the estimate does not fit: walk from the entry state)
+  DTrackState g{};
+  g.has_clip_idx = 1u;
+  g.clip_idx = j;
+  g.cur_type = EV_STOP;
+  *st = g;
+  return i;
+}
+
+// lane (t, s) of the segmented plan; L = blocks per segment.  guess / ends: [N][S]
+template <class TV>
+__host__ __device__ inline void plan_segment(const PlanArgs& a, uint32_t t, uint32_t s, uint32_t L, uint32_t S, const TV& times,
+                                             DTrackState* guess, DTrackState* ends) {
+  const uint32_t c0 = a.clip_first[t];
+  const uint32_t nc = a.clip_first[t + 1] - c0;
+  DClip* clips = const_cast<DClip*>(a.clips) + c0;
+  const DTrackState entry = plan_initial_state(a, t, clips, nc);
+  const uint32_t b0 = s * L, b1 = (b0 + L < a.n_blocks) ? b0 + L : a.n_blocks;
+  DTrackState st = entry;
+  uint32_t from = 0u;
+  if (s > 0u) from = plan_anchor(a, clips, nc, times, b0, entry, &st);
+  TrackCache cache;
+  plan_cache_init(a, t, st, clips, nc, &cache);
+  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
+  if (s > 0u) {
+    plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, from, b0, true);
+    guess[(size_t)t * S + s] = st;
+  }
+  plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, b0, b1, false);
+  ends[(size_t)t * S + s] = st;
+}
+
+__host__ __device__ inline bool same_state(const DTrackState& x, const DTrackState& y) {
+  // (bit patterns: a NaN position must compare equal to itself, -0.0 differs from +0.0)
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(&x);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(&y);
+  bool same = true;
+  for (uint32_t i = 0; i < sizeof(DTrackState) / 4u; i++) same = same && p[i] == q[i];
+  return same;
+}
+
+// the seams of track t in order; -> the number of segments that had to be planned again (0: every guess stood)
+template <class TV>
+__host__ __device__ inline uint32_t plan_fix_track(const PlanArgs& a, uint32_t t, uint32_t L, uint32_t S, const TV& times,
+                                                   const DTrackState* guess, const DTrackState* ends) {
+  uint32_t s = 1u;
+  while (s < S && same_state(guess[(size_t)t * S + s], ends[(size_t)t * S + s - 1u])) s++;
+  if (s == S) {
+    a.state[t] = ends[(size_t)t * S + S - 1u];
+    return 0u;
+  }
+  const uint32_t c0 = a.clip_first[t];
+  const uint32_t nc = a.clip_first[t + 1] - c0;
+  DClip* clips = const_cast<DClip*>(a.clips) + c0;
+  DTrackState st = ends[(size_t)t * S + s - 1u];
+  TrackCache cache;
+  plan_cache_init(a, t, st, clips, nc, &cache);
+  const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
+  plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, s * L, a.n_blocks, false);
+  a.state[t] = st;
+  return S - s;
 }
 
 // Host side: the per-(block, track) stream-call records of a finished plan, rebuilt from the 16-B rows, the templates

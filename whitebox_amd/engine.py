@@ -364,6 +364,12 @@ class Engine:
     def delete_plugin_from_track(self, track: Track):
         _check(self.L.wbx_engine_delete_plugin_from_track(self.h, track.index), "Engine::delete_plugin_from_track", self.h, True)
 
+    def sequencer_stats(self):
+        """(renders planned by segments, tracks with a seam that did not hold, segments planned again, segments per track)"""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.wbx_engine_sequencer_stats(self.h, out), "wbx_engine_sequencer_stats", self.h, True)
+        return tuple(int(x) for x in out)
+
     def thread_stats(self):
         """(locked edits the last process / render had seen, per-track cumulative drained parameter messages)"""
         n = len(self.tracks)
