@@ -513,6 +513,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     tail_ms = eng.ctx.tail_time()
     mix_ms, mix_n = eng.ctx.kernel_time()
     kernel_name = eng.ctx.kernel_name()                 # the instance the library launched (as rocprofv3 names it)
+    seq = eng.sequencer_stats()                        # how the sequencer planned: by (track, segment) lanes? seams that missed?
     if dist is not None:
         dt = dist.max(dt)                              # MAX over ranks
 
@@ -602,7 +603,9 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
             "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "lat_small": lat_small, "lat_median": lat_median, "lat_kernel": lat_kernel[0], "alg": alg, "achieved": achieved,
             "desc": desc, "kernel_name": kernel_name, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
             "clip_blocks": clip_blocks, "workload": workload, "verify": ver, "device": dev, "exchange": exch, "summation": summation,
-            "session_blocks": session_blocks}
+            "session_blocks": session_blocks,
+            "sequencer": {"renders_by_segments": seq[0], "tracks_with_a_missed_seam": seq[1], "segments_replanned": seq[2],
+                          "segments_per_track": seq[3]}}
 
 
 def roofline_of(r, traffic_table):
@@ -777,6 +780,7 @@ def main():
         "realtime_factor": master_frames / dt / SR,
         "host_enqueue_ms_max": 1e3 * r["enq_max"],
         "master_peak": r["master_peak"],
+        "sequencer": r["sequencer"],
         "roofline": roofline_of(r, traffic_table),
     }
     if ver is not None:

@@ -38,7 +38,7 @@ struct HostSim {
   uint32_t last_K = 0, last_N = 0;
   bool clips_uploaded = false;
   uint32_t masked_rows = 0;   // plan as for a mix instance that takes partial rows / ROW_PAIRs in its hot loop
-  // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track): blocks per segment (0: one walk per
+  // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_check_seams): blocks per segment (0: one walk per
   // track), and what the seam check found — renders planned that way, tracks with a seam that did not hold, segments redone
   uint32_t seg_len = 0;
   bool table_flags = false;
@@ -316,11 +316,14 @@ int hsim_render(HostSim* s, uint32_t K) {
     std::vector<DTrackState> guess((size_t)N * S), ends((size_t)N * S);
     const DBlockTime* tv = times.data();
     for (uint32_t sg = S; sg-- > 0u;)
-      for (uint32_t t = 0; t < N; t++) plan_segment(a, t, sg, L, S, tv, guess.data(), ends.data());
+      for (uint32_t t = 0; t < N; t++) plan_segment(a, t, sg, L, S, tv, &guess[(size_t)t * S + sg], &ends[(size_t)t * S + sg]);
     for (uint32_t t = 0; t < N; t++) {
-      const uint32_t redone = plan_fix_track(a, t, L, S, tv, guess.data(), ends.data());
-      s->seg_tracks_redone += redone ? 1u : 0u;
-      s->seg_segments_redone += redone;
+      const uint32_t bad = plan_check_seams(a, t, S, guess.data(), ends.data(), [](const DTrackState* p) { return *p; });
+      if (bad < S) {
+        plan_redo_track(a, t, bad, L, tv, ends[(size_t)t * S + bad - 1u]);
+        s->seg_tracks_redone += 1u;
+        s->seg_segments_redone += S - bad;
+      }
     }
     s->seg_renders++;
     s->seg_lanes += (uint64_t)N * (S - 1u);

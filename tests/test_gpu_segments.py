@@ -1,5 +1,5 @@
-"""The sequencer cut along the time axis on the device (plan_seg_kernel + plan_fix_kernel: wbx_seq.h plan_segment /
-plan_fix_track; tests/test_host_sim.py runs the same source on the CPU): long renders of sessions cut into clips are planned
+"""The sequencer cut along the time axis on the device (plan_seg_kernel: wbx_seq.h plan_segment /
+plan_check_seams / plan_redo_track; tests/test_host_sim.py runs the same source on the CPU): long renders of sessions cut into clips are planned
 by one lane per (track, segment) — results must be the one-walk plan's, i.e. the oracle's, bit for bit: stream-call log,
 transport, peaks, master, and the state the NEXT render starts from."""
 import os

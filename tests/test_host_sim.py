@@ -69,8 +69,8 @@ SEG_STATS = []   # segment_stats() of every session planned by segments in this 
 @pytest.mark.parametrize("masked,segments", [(0, 2), (1, 3), (4, 5), (1, 1)])
 @pytest.mark.parametrize("seed", range(0, 160))
 def test_host_sequencer_random_sessions_by_segments(seed, masked, segments):
-    """... the same sessions with the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track: what
-    plan_seg_kernel + plan_fix_kernel run on the device), segments of 1 / 2 / 3 / 5 blocks, the lanes in an order nothing may
+    """... the same sessions with the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_check_seams /
+    plan_redo_track: what plan_seg_kernel runs on the device), segments of 1 / 2 / 3 / 5 blocks, the lanes in an order nothing may
     rely on: the stream-call log, the transport and the state the next render starts from are the one-walk plan's — whether a
     seam's guess held or the rest of the track was planned again."""
     spec, n_blocks = FZ.random_session(seed)

@@ -188,10 +188,12 @@ struct PlanArgs {
                                 // clip boundaries in the wave — fewer tracks per wave, more waves side by side)
 };
 
-struct SegArgs {                // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_fix_track)
+struct SegArgs {                // the sequencer cut along the time axis (wbx_seq.h plan_segment / plan_check_seams)
   DTrackState* guess;           // [N][n_segs] the state a segment's lane arrived at its first block with
   DTrackState* ends;            // [N][n_segs] ... and left its last block with
   uint32_t* stats;              // [2] tracks with a seam that did not hold, segments planned again (running totals; may be null)
+  uint32_t* ticket;             // [N] segments of the track that are planned (the lane that completes it checks the seams and
+                                //     resets it)
   uint32_t seg_len, n_segs;     // blocks per segment, segments per render (n_segs * seg_len >= n_blocks)
 };
 

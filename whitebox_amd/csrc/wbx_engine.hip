@@ -62,6 +62,7 @@ struct wbx_engine {
   // two plan kernels that use it run back to back on one stream — and its running statistics
   DevBuf<DTrackState> d_seam;           // [2][N][segments]: guesses, end states
   DevBuf<uint32_t> d_seg_stats;         // [2] tracks with a seam that did not hold, segments planned again
+  DevBuf<uint32_t> d_seg_ticket;        // [max_tracks] SegArgs::ticket (all zero between launches)
   hipStream_t seam_stream = nullptr;    // the stream that used d_seam last
   hipEvent_t seam_done = nullptr;
   bool table_flags = false;             // the uploaded clip table holds a set internal_state_changed flag (segmented plans off)
@@ -968,7 +969,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     a.gains = e->d_gains_cb.p;
   }
   if (seg_len) {
-    // one lane per (track, segment) + the pass that checks the seams (plan_fix_kernel); the seam states live in one buffer
+    // one lane per (track, segment); the lane that completes a track checks its seams; the seam states live in one buffer
     const size_t per = (size_t)N * n_segs;
     if (e->seam_stream && e->seam_stream != ps) {   // (its last user ran on the other stream)
       if (!e->seam_done) WBX_EHIP(e, hipEventCreateWithFlags(&e->seam_done, hipEventDisableTiming));
@@ -983,8 +984,14 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
       WBX_EHIP(e, e->d_seg_stats.ensure(2));
       WBX_EHIP(e, hipMemsetAsync(e->d_seg_stats.p, 0, 2 * sizeof(uint32_t), ps));
     }
+    if (e->d_seg_ticket.cap < N) {
+      if (e->seam_stream) WBX_EHIP(e, hipStreamSynchronize(e->seam_stream));
+      const size_t cap = std::max<size_t>(N, c->cfg.max_tracks);
+      WBX_EHIP(e, e->d_seg_ticket.ensure(cap));
+      WBX_EHIP(e, hipMemsetAsync(e->d_seg_ticket.p, 0, e->d_seg_ticket.cap * sizeof(uint32_t), ps));
+    }
     e->seam_stream = ps;
-    SegArgs g{e->d_seam.p, e->d_seam.p + per, e->d_seg_stats.p, seg_len, n_segs};
+    SegArgs g{e->d_seam.p, e->d_seam.p + per, e->d_seg_stats.p, e->d_seg_ticket.p, seg_len, n_segs};
     launch_plan_segments(a, g, plan_beside, ps);
     e->seg_renders++;
     e->seg_last_segs = n_segs;

@@ -76,23 +76,47 @@ __device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& 
   const uint32_t t = blockIdx.x * 64u + threadIdx.x;
   if (t >= a.n_tracks) return;
   const TimesWindow tv{a.times, win, w0, w1};
-  plan_segment(a, t, s, g.seg_len, g.n_segs, tv, g.guess, g.ends);
+  DTrackState gs{}, en{};
+  plan_segment(a, t, s, g.seg_len, g.n_segs, tv, &gs, &en);
+  // The seam states go where the lane that completes the track finds them — a lane of another workgroup, maybe behind another
+  // L2: write-through stores, acknowledged before the ticket is taken, read back past the caches (the pattern of the
+  // one-launch callback, wbx_callback.h: no fence — a fence is an L2 write-back for everybody).
+  const size_t at = (size_t)t * g.n_segs + s;
+  auto put = [](DTrackState* dst, const DTrackState& v) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(DTrackState) / 4u; i++) __hip_atomic_store(d + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (s > 0u) put(&g.guess[at], gs);
+  put(&g.ends[at], en);
+  __builtin_amdgcn_s_waitcnt(0);
+  const uint32_t had = __hip_atomic_fetch_add(g.ticket + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (had + 1u != g.n_segs) return;
+  // this lane completed the track: the seams in order.  All stood (nearly always): the track's state for the next render is the
+  // last segment's.  One did not: this lane plans the rest of the track again, from the state the segment before really ended
+  // with (every other lane of the track is done: nobody writes those rows any more).
+  __hip_atomic_store(g.ticket + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto get = [](const DTrackState* src) {
+    DTrackState v;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(DTrackState) / 4u; i++) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  const uint32_t bad = plan_check_seams(a, t, g.n_segs, g.guess, g.ends, get);
+  if (bad < g.n_segs) {   // (rare: the lanes of this wave that are done wait for it)
+    plan_redo_track(a, t, bad, g.seg_len, tv, get(&g.ends[(size_t)t * g.n_segs + bad - 1u]));
+    if (g.stats) {
+      atomicAdd(g.stats + 0, 1u);
+      atomicAdd(g.stats + 1, g.n_segs - bad);
+    }
+  }
 }
 __global__ __launch_bounds__(64) void plan_seg_kernel(PlanArgs a, SegArgs g) { plan_seg_body(a, g); }
 // (the register-capped form, as plan_kernel_beside: a wave that fits the hole one retiring mix wave leaves)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void plan_seg_kernel_beside(PlanArgs a, SegArgs g) { plan_seg_body(a, g); }
-
-// ... and its second pass: one lane per track checks the seams in order and plans again, in one walk, whatever follows the
-// first guess that did not hold (rare: g.stats counts the lanes and the segments replaced)
-__global__ __launch_bounds__(64) void plan_fix_kernel(PlanArgs a, SegArgs g) {
-  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-  if (t >= a.n_tracks) return;
-  const uint32_t redone = plan_fix_track(a, t, g.seg_len, g.n_segs, a.times, g.guess, g.ends);
-  if (redone && g.stats) {
-    atomicAdd(g.stats + 0, 1u);
-    atomicAdd(g.stats + 1, redone);
-  }
-}
 
 // the host's table of per-block transport records (pinned memory) -> device memory, in front of a batch render's plan.  A
 // kernel of our own, not hipMemcpyAsync: the runtime's host-to-device path made the submitting thread wait for the stream
@@ -545,7 +569,6 @@ void launch_plan_segments(const PlanArgs& a, const SegArgs& g, bool beside, hipS
     hipLaunchKernelGGL(plan_seg_kernel_beside, grid, dim3(64), lds, s, a, g);
   else
     hipLaunchKernelGGL(plan_seg_kernel, grid, dim3(64), lds, s, a, g);
-  hipLaunchKernelGGL(plan_fix_kernel, dim3((a.n_tracks + 63u) / 64u), dim3(64), 0, s, a, g);
 }
 
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {

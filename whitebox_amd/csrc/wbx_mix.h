@@ -263,9 +263,9 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   constexpr uint32_t kPS = (CL == 2 && kWaves == 4u) ? 8u : 4u;   // peak slots per record: one per (wave, channel of the wave)
   __shared__ uint32_t s_pk[SB * kRecs * kPS];   // FULL: one slot per (record, wave[, channel]), plain stores; else (record, channel), atomics
   __shared__ uint32_t s_wc[kPS];         // FULL: sub-block * C + channel a slot holds (unused slots: none)
-  // (XP: everything per sub-block; the rows of the chunk only — a packed instance walks two to four chunks, no prefetch)
-  __shared__ __attribute__((aligned(16))) DRow s_rows[XP ? SB * kSt : EXP ? 2 * kSt : 1];   // EXP: the plan rows of this chunk and (prefetched) of the next
-  __shared__ uint32_t s_ord[(EXP && !XP) ? kSt : 1];       // EXP: the routing-order entries of the next chunk (prefetched)
+  // (XP: everything but the routing entries per sub-block)
+  __shared__ __attribute__((aligned(16))) DRow s_rows[EXP ? 2 * SB * kSt : 1];   // EXP: the plan rows of this chunk and (prefetched) of the next
+  __shared__ uint32_t s_ord[EXP ? kSt : 1];       // EXP: the routing-order entries of the next chunk (prefetched)
   __shared__ uint16_t s_map[EXP ? SB * 2 * kSt : 1];   // EXP: staged row -> local track (bit 15: the second record of its pair)
   __shared__ uint16_t s_off[EXP ? SB * (kSt + 1) : 1];   // EXP: local track -> its first staged row
   __shared__ uint32_t s_wpairs[3];                // EXP: pairs in waves 0 and 1, staged rows of the chunk
@@ -1220,17 +1220,37 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
       // a pair counts twice; the prefix sum runs over the 32-lane halves of the fetching waves (a sub-block's tracks are one,
       // two or four halves).  Pass 2 copies the template quads of all sub-blocks through the maps, all loads in flight at once.
       constexpr uint32_t kHalves = kSt / 32u;   // 32-lane halves per sub-block
+      // (as below: the rows of the NEXT chunk and the routing entries of the one after it are fetched while this chunk is
+      //  staged — a packed workgroup walks four chunks of 32 tracks, each seam three dependent round trips otherwise)
+      DRow* rows_cur = s_rows + (chunk_i & 1u) * (SB * kSt);
+      DRow* rows_nxt = s_rows + ((chunk_i & 1u) ^ 1u) * (SB * kSt);
+      const uint32_t n0 = chunk0 + cn, nleft = grp.count - n0, ncn = nleft < kSt ? nleft : kSt;       // the next chunk
+      const uint32_t m0 = n0 + ncn, mleft = grp.count - m0, mcn = mleft < kSt ? mleft : kSt;         // the one after it
       uint32_t before = 0u;
       bool is_pair = false;
       const uint32_t psb = tid / kSt, pt = tid - psb * kSt;   // (lanes below SB * kSt)
+      DRow nrow;
+      nrow.pos = 0.0;
+      nrow.tmpl = 0xFFFFFFFFu;
+      nrow.flags = ROW_SILENT;
+      uint32_t nord = 0u;
       if (tid < SB * kSt) {
-        DRow row;
-        row.pos = 0.0;
-        row.tmpl = 0xFFFFFFFFu;
-        row.flags = ROW_SILENT;
+        DRow row = nrow;
         const uint32_t bb = bx * SB + psb;
-        if (pt < cn && bb < a.n_blocks) row = a.rows[(size_t)bb * N + a.order[grp.first + chunk0 + pt]];
-        *reinterpret_cast<uint4*>(&s_rows[tid]) = *reinterpret_cast<const uint4*>(&row);
+        const bool bval = bb < a.n_blocks;
+        uint32_t o1 = 0u;
+        if (chunk_i == 0u) {
+          uint32_t o0 = 0u;
+          if (pt < cn) o0 = a.order[grp.first + pt];
+          if (pt < ncn) o1 = a.order[grp.first + n0 + pt];
+          if (pt < cn && bval) row = a.rows[(size_t)bb * N + o0];
+          *reinterpret_cast<uint4*>(&rows_cur[tid]) = *reinterpret_cast<const uint4*>(&row);
+        } else {
+          row = rows_cur[tid];
+          o1 = s_ord[pt];
+        }
+        if (pt < ncn && bval) nrow = a.rows[(size_t)bb * N + o1];
+        if (psb == 0u && pt < mcn) nord = a.order[grp.first + m0 + pt];
         is_pair = (row.flags & (ROW_PAIR | ROW_SILENT)) == ROW_PAIR;
         const unsigned long long half = (lane & 32u) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
         const unsigned long long bal = __ballot(is_pair) & half;
@@ -1267,7 +1287,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         const uint32_t i = tq + it * kT, sbq = i / (kRecs * 4u), r4 = i - sbq * (kRecs * 4u), rec = r4 >> 2, q = r4 & 3u;
         const bool in = sbq < (uint32_t)SB && rec < s_tot[sbq < (uint32_t)SB ? sbq : 0u];
         const uint32_t mp = s_map[in ? sbq * 2u * kSt + rec : 0u];
-        const DRow row = s_rows[(in ? sbq * kSt : 0u) + (mp & 0x7FFFu)];
+        const DRow row = rows_cur[(in ? sbq * kSt : 0u) + (mp & 0x7FFFu)];
         const bool live = in && !(row.flags & ROW_SILENT);
         // (a lane without a live record reads template 0: the load stays unconditional, its result is dropped)
         wq[it] = reinterpret_cast<const uint4*>(a.tmpl + (live ? row.tmpl + (mp >> 15) : 0u))[q];
@@ -1279,7 +1299,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           uint4 w = {0u, 0u, 0u, 0u};
           if (rec < s_tot[sbq]) {
             const uint32_t mp = s_map[sbq * 2u * kSt + rec];
-            const DRow row = s_rows[sbq * kSt + (mp & 0x7FFFu)];
+            const DRow row = rows_cur[sbq * kSt + (mp & 0x7FFFu)];
             if (!(row.flags & ROW_SILENT)) {
               w = wq[it];
               if (q == 1u && (row.flags & ROW_POS)) {          // quad 1 = {pos, speed}
@@ -1291,6 +1311,10 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           }
           reinterpret_cast<uint4*>(s_tb)[i] = w;
         }
+      }
+      if (tid < SB * kSt) {   // (arrived with the templates: loads return in order)
+        *reinterpret_cast<uint4*>(&rows_nxt[tid]) = *reinterpret_cast<const uint4*>(&nrow);
+        if (psb == 0u) s_ord[pt] = nord;
       }
     } else if constexpr (EXP) {
       // Rows may be ROW_PAIRs (a clip boundary inside the block: two single-segment templates; only with

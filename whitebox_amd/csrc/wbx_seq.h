@@ -890,11 +890,11 @@ __host__ __device__ inline void plan_track(const PlanArgs& a, uint32_t t, const 
 //   2. runs the very same sequencer code DRY from there to b0 (state only: no template, no row, no queue entry) — a few blocks
 //      for a session cut into clips, a loop of fp64 additions for one long clip,
 //   3. notes the state it arrived with (its GUESS for block b0), plans its own blocks for real, notes the state it ends with.
-// plan_fix_track then walks the seams of a track in order: segment s stands if its guess equals, bit for bit, the state
+// plan_check_seams then walks the seams of a track in order: segment s stands if its guess equals, bit for bit, the state
 // segment s - 1 ended with (segment 0 starts from the truth, so by induction every standing segment was planned from the
 // state the one-lane walk would have had); at the first seam that differs — a clip the sequencer skipped, overlapping or
 // out-of-order events, anything the shortcut does not foresee — the rest of the track is planned again in one walk from
-// the true state, over the speculative rows.  Results are therefore the serial walk's whatever the guess was; only the time
+// the true state (plan_redo_track), over the speculative rows.  Results are therefore the serial walk's whatever the guess was; only the time
 // depends on it.  (The templates, pool chunks and queue entries of a replaced segment stay allocated and unused.)
 // Not taken — the host decides, wbx_engine.hip — when a clip flag (internal_state_changed, cleared by the sequencer as it
 // passes: track.cpp:373,392,418) may be set: a dry lane and a real one would race for it.
@@ -959,10 +959,11 @@ __host__ __device__ inline uint32_t plan_anchor(const PlanArgs& a, const DClip* 
   return i;
 }
 
-// lane (t, s) of the segmented plan; L = blocks per segment.  guess / ends: [N][S]
+// lane (t, s) of the segmented plan; L = blocks per segment.  -> *guess (s > 0): the state it arrived at its first block
+// with, *end: the state it left its last block with (the caller stores them where the seam check finds them: [N][S] each)
 template <class TV>
 __host__ __device__ inline void plan_segment(const PlanArgs& a, uint32_t t, uint32_t s, uint32_t L, uint32_t S, const TV& times,
-                                             DTrackState* guess, DTrackState* ends) {
+                                             DTrackState* guess, DTrackState* end) {
   const uint32_t c0 = a.clip_first[t];
   const uint32_t nc = a.clip_first[t + 1] - c0;
   DClip* clips = const_cast<DClip*>(a.clips) + c0;
@@ -974,12 +975,20 @@ __host__ __device__ inline void plan_segment(const PlanArgs& a, uint32_t t, uint
   TrackCache cache;
   plan_cache_init(a, t, st, clips, nc, &cache);
   const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
-  if (s > 0u) {
-    plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, from, b0, true);
-    guess[(size_t)t * S + s] = st;
+  // (one loop for the run-up and the segment itself — one copy of the sequencer in the kernel — with a stop at the seam)
+  uint32_t b = s > 0u ? from : b0;
+  if (s > 0u && b >= b0) *guess = st;   // (no run-up at all: cannot happen — plan_anchor returns a block in front of b0)
+  while (b < b1) {
+    const bool dry = b < b0;
+    const uint32_t stop = dry ? b0 : b1;
+    b += plan_steady_run(a, t, b, &st, nc, &cache, times, gl, gr, stop, dry);
+    if (b < stop) {
+      plan_track_block(a, t, b, &st, clips, nc, &cache, times[b], gl, gr, dry);
+      b++;
+    }
+    if (dry && b == b0) *guess = st;
   }
-  plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, b0, b1, false);
-  ends[(size_t)t * S + s] = st;
+  *end = st;
 }
 
 __host__ __device__ inline bool same_state(const DTrackState& x, const DTrackState& y) {
@@ -991,26 +1000,36 @@ __host__ __device__ inline bool same_state(const DTrackState& x, const DTrackSta
   return same;
 }
 
-// the seams of track t in order; -> the number of segments that had to be planned again (0: every guess stood)
-template <class TV>
-__host__ __device__ inline uint32_t plan_fix_track(const PlanArgs& a, uint32_t t, uint32_t L, uint32_t S, const TV& times,
-                                                   const DTrackState* guess, const DTrackState* ends) {
+// The seams of track t in order, once all its segments are planned (LD: how a stored state is read — on the device the
+// states were written by other workgroups of the same launch).  -> S when every guess stood (the track's state for the next
+// render is then in place), else the first segment whose guess did not: plan_redo_track plans the track again from there.
+template <class LD>
+__host__ __device__ inline uint32_t plan_check_seams(const PlanArgs& a, uint32_t t, uint32_t S, const DTrackState* guess,
+                                                     const DTrackState* ends, const LD& ld) {
   uint32_t s = 1u;
-  while (s < S && same_state(guess[(size_t)t * S + s], ends[(size_t)t * S + s - 1u])) s++;
-  if (s == S) {
-    a.state[t] = ends[(size_t)t * S + S - 1u];
-    return 0u;
+  DTrackState prev = ld(&ends[(size_t)t * S]);
+  while (s < S) {
+    if (!same_state(ld(&guess[(size_t)t * S + s]), prev)) return s;
+    prev = ld(&ends[(size_t)t * S + s]);
+    s++;
   }
+  a.state[t] = prev;
+  return S;
+}
+
+// segments s .. S - 1 of track t again, in one walk from `from`, the state segment s - 1 really ended with
+template <class TV>
+__host__ __device__ inline void plan_redo_track(const PlanArgs& a, uint32_t t, uint32_t s, uint32_t L, const TV& times,
+                                                const DTrackState& from) {
   const uint32_t c0 = a.clip_first[t];
   const uint32_t nc = a.clip_first[t + 1] - c0;
   DClip* clips = const_cast<DClip*>(a.clips) + c0;
-  DTrackState st = ends[(size_t)t * S + s - 1u];
+  DTrackState st = from;
   TrackCache cache;
   plan_cache_init(a, t, st, clips, nc, &cache);
   const float gl = a.gains[2 * t + 0], gr = a.gains[2 * t + 1];
   plan_blocks(a, t, &st, clips, nc, &cache, times, gl, gr, s * L, a.n_blocks, false);
   a.state[t] = st;
-  return S - s;
 }
 
 // Host side: the per-(block, track) stream-call records of a finished plan, rebuilt from the 16-B rows, the templates
