@@ -31,6 +31,15 @@ for BF in 128 256; do
   WBX_MASKED_ROWS=0 timeout 300 python bench.py --block-frames $BF --blocks 1024 --clip-blocks 5.3 $B > $O/bench_c3_F${BF}_L5.3_prerender.json 2>> $O/bench_default.err
   timeout 300 python bench.py --block-frames $BF --blocks 1024 $B > $O/bench_c3_F${BF}.json 2>> $O/bench_default.err
 done
+# ... at the default render length (2048 blocks), and what the segmented sequencer is worth there (WBX_PLAN_SEG=0: one lane per track)
+for BF in 128 256; do
+  timeout 300 python bench.py --block-frames $BF --clip-blocks 5.3 $B > $O/bench_c3_F${BF}_L5.3_K2048.json 2>> $O/bench_default.err
+  WBX_PLAN_SEG=0 timeout 300 python bench.py --block-frames $BF --clip-blocks 5.3 $B > $O/bench_c3_F${BF}_L5.3_K2048_noseg.json 2>> $O/bench_default.err
+done
+timeout 300 python bench.py --workload c2 --clip-blocks 5.3 $B > $O/bench_c2_L5.3.json 2>> $O/bench_default.err
+WBX_PLAN_SEG=0 timeout 300 python bench.py --workload c2 --clip-blocks 5.3 $B > $O/bench_c2_L5.3_noseg.json 2>> $O/bench_default.err
+WBX_PLAN_SEG=0 timeout 300 python bench.py --clip-blocks 5.3 $B > $O/bench_c3_L5.3_noseg.json 2>> $O/bench_default.err
+( bash tools/seg_prof.sh ) > $O/seg_kernel_stats.txt 2>&1
 for W in i24r mixr; do
   timeout 300 python bench.py --workload $W --clip-blocks 5.3 $B > $O/bench_${W}_L5.3.json 2>> $O/bench_default.err
   WBX_NO_FAM3=1 timeout 300 python bench.py --workload $W $B > $O/bench_${W}_fam1.json 2>> $O/bench_default.err

@@ -8,6 +8,7 @@ O=gpurun_out/$TAG
 for f in $O/bench_*.json; do W=$(basename $f .json); W=${W#bench_}; grep "^{" $f | tail -1 > profiles/${RN}_bench_$W.json; done
 cp $O/pytest_gpu.log profiles/${RN}_pytest_gpu.log
 cp $O/longrun_probe.txt profiles/${RN}_longrun_probe.txt
+[ -f $O/seg_kernel_stats.txt ] && cp $O/seg_kernel_stats.txt profiles/${RN}_seg_kernel_stats.txt
 kof() { python - "$1" <<'PY'
 import json, sys
 print(json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])["config"]["blocks_per_step"])

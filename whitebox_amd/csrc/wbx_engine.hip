@@ -136,18 +136,9 @@ uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing
   if (!playing || e->table_flags || e->in_process || N == 0u) return 0u;
   if (forced) return forced < K ? forced : 0u;
   if (!e->hs.cut_tracks || K < 128u) return 0u;
-  {
-    // Worth it only when the one-lane walk would NOT hide behind the previous render's mix: the segment lanes are many more
-    // waves beside that mix and cost it 1-4 % (measured: c3 / i16r cut into 5.3-block clips at 512 frames, where the 5.4 ms
-    // walk hides behind a 6-6.5 ms mix).  The walk is a latency chain, ~14 us per clip start whatever the track count; the mix
-    // moves N * K * F * C * 4 bytes at ~5 TB/s.
-    const uint32_t F = e->ctx->cfg.block_frames, C = e->ctx->cfg.channels;
-    const double bd = e->hs.beat_duration.load(std::memory_order_relaxed);
-    const double beats = (double)K * ((double)F / (double)e->ctx->cfg.sample_rate) / bd;
-    const double walk_us = 14.0 * (double)e->hs.clip_starts_between(e->hs.playhead, e->hs.playhead + beats);
-    const double mix_us = (double)N * (double)K * (double)F * (double)C * 4.0 / 5.0e6;
-    if (walk_us < 0.9 * mix_us) return 0u;
-  }
+  // (also where the one-lane walk would hide behind the previous mix — c3 / 16-bit sessions cut into 5.3- or 20-block clips at
+  //  512 frames: the segment lanes are done early, the next mix starts 0.06 instead of 0.15 ms behind its predecessor, steps
+  //  0-3 % shorter, never longer: profiles/r04_ab_planseg.txt)
   uint32_t len = 32u;
   while ((uint64_t)(K / len) * N > 49152u && len < K) len *= 2u;
   return len < K ? len : 0u;

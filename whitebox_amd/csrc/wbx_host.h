@@ -571,19 +571,6 @@ struct HostSession {
     return 64u;
   }
   static uint32_t template_reserve(uint32_t K) { return K >= 64u ? 32u : K >= 8u ? 8u : 1u; }
-  // clip starts a track meets between two playhead positions — the most over a sample of up to 16 tracks (two binary searches
-  // each): what the one-lane-per-track sequencer's time is made of
-  size_t clip_starts_between(double from_beat, double to_beat) const {
-    const size_t N = tracks.size();
-    size_t most = 0;
-    for (size_t k = 0; k < 16 && k < N; k++) {
-      const auto& cl = tracks[N <= 16 ? k : k * (N - 1) / 15]->clips;
-      auto lo = std::lower_bound(cl.begin(), cl.end(), from_beat, [](const HostClip& c, double v) { return c.d.min_time < v; });
-      auto hi = std::lower_bound(cl.begin(), cl.end(), to_beat, [](const HostClip& c, double v) { return c.d.min_time < v; });
-      if (hi > lo) most = std::max(most, (size_t)(hi - lo));
-    }
-    return most;
-  }
   // (lanes: lanes per track of the sequencer — more than one when it is cut along the time axis; every lane may strand a
   //  reservation and splits a steady run at its seam)
   size_t template_hint(uint32_t K, uint32_t lanes = 1u) const {
