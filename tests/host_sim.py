@@ -32,8 +32,10 @@ def _stale(out: str) -> bool:
 def build_lib() -> str:
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, "libwbxhostsim.so")
-    if _stale(out):
-        subprocess.check_call(["g++", *FLAGS, "-O2", "-shared", "-fPIC", SRC, "-o", out])
+    if _stale(out):   # (to a name of its own, then renamed: pytest-xdist workers build side by side and must never load half a file)
+        tmp = f"{out}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", *FLAGS, "-O2", "-shared", "-fPIC", SRC, "-o", tmp])
+        os.replace(tmp, out)
     return out
 
 
@@ -41,7 +43,9 @@ def build_tsan() -> str:
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, "host_tsan")
     if _stale(out):
-        subprocess.check_call(["g++", *FLAGS, "-O1", "-g", "-fsanitize=thread", "-DHOST_SIM_MAIN", SRC, "-o", out, "-lpthread"])
+        tmp = f"{out}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", *FLAGS, "-O1", "-g", "-fsanitize=thread", "-DHOST_SIM_MAIN", SRC, "-o", tmp, "-lpthread"])
+        os.replace(tmp, out)
     return out
 
 
