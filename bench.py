@@ -610,7 +610,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
 
 def roofline_of(r, traffic_table):
     key = f"{r['workload']}_K{r['K']}_N{r['n_tracks']}" + (f"_L{r['clip_blocks']}" if r["clip_blocks"] else "")
-    traffic = traffic_table.get(key, {}).get("hbm_bytes_per_launch")
+    traffic = traffic_table.get(key, {}).get("hbm_bytes_per_launch") if F == 512 else None   # (the PMC passes are of 512-frame blocks)
     step_ms = 1e3 * r["dt"] / r["steps"]
     return {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": r["achieved"] / HBM_PEAK_GBS,

@@ -14,7 +14,7 @@ def short(name):
     return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else None
 
 
-ORDER = ["times_copy_kernel", "plan_kernel", "plan_kernel_beside", "gen_kernel", "mix_kernel", "sum_kernel"]
+ORDER = ["times_copy_kernel", "plan_kernel", "plan_kernel_beside", "plan_seg_kernel", "plan_seg_kernel_beside", "gen_kernel", "mix_kernel", "sum_kernel"]
 
 
 def one(trace, bench, title):
