@@ -183,7 +183,6 @@ struct PlanArgs {
                                 // track t owns templates 2t, 2t + 1 (the one-launch callback; tmpl_cap >= 2 * n_tracks)
   uint32_t* flags_left;         // (optional, host memory) how many clips of the table still carry internal_state_changed: the
                                 // sequencer counts down as it clears them (track.cpp:373,392,418)
-  uint32_t rows_through;        // plan rows leave as write-through stores (the segmented plan: store_row, wbx_seq.h)
   uint32_t lanes;               // tracks per wave of plan_kernel (64, or fewer for sessions cut into many clips: a wave
                                 // executes every branch any of its tracks takes, so its time is set by the number of
                                 // clip boundaries in the wave — fewer tracks per wave, more waves side by side)

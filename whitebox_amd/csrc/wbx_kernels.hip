@@ -60,9 +60,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // LDS (a few KiB instead of the 64 KiB of all K records: the workgroups fit beside a running mix); the occasional look further
 // back (the run-up of a long clip) goes to the device table.
 constexpr uint32_t kSegMargin = 48;   // records in front of the segment (the run-up of a clip of a session cut into clips) and behind it
-__device__ __forceinline__ void plan_seg_body(const PlanArgs& a0, const SegArgs& g) {
-  PlanArgs a = a0;
-  a.rows_through = 1u;   // (a missed seam's rows are written a second time, maybe from behind another L2: store_row)
+__device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   DBlockTime* win = reinterpret_cast<DBlockTime*>(s_raw);
   const uint32_t s = blockIdx.y, b0 = s * g.seg_len;

@@ -51,25 +51,6 @@ __host__ __device__ inline void raise_status(uint32_t* status, uint32_t bits) {
 #endif
 }
 
-// A plan row goes to memory.  `through` (PlanArgs::rows_through, the segmented plan): as a write-through store — a segment
-// whose seam guess misses has its rows written AGAIN by the lane that plans the track anew, possibly from behind another
-// XCD's L2; were the first version still a dirty line of this L2, its write-back at the end of the launch could land on top
-// of the second.  Written through (and acknowledged before the lane takes its ticket, plan_seg_kernel), it is in memory
-// before the second version is even computed.
-__host__ __device__ inline void store_row(DRow* dst, const DRow& row, uint32_t through) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (through) {
-    typedef float row_f4 __attribute__((ext_vector_type(4)));
-    const row_f4 v = *reinterpret_cast<const row_f4*>(&row);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-    return;
-  }
-#else
-  (void)through;
-#endif
-  *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&row);
-}
-
 // segment 0 of a track-block lives inline in the record
 __host__ __device__ inline void set_seg0(DTrackBlock* tb, const DSeg& s) {
   tb->src[0] = s.src[0];
@@ -626,7 +607,7 @@ __host__ __device__ inline void plan_track_block(const PlanArgs& a, uint32_t t, 
         }
       }
     }
-    store_row(&a.rows[(size_t)b * a.n_tracks + t], row, a.rows_through);
+    *reinterpret_cast<uint4*>(&a.rows[(size_t)b * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
     tmpl_index = row.tmpl;
   }
   if (tb->kind == KIND_GENERIC && tmpl_index != 0xFFFFFFFFu) {   // queue it for the pre-render pass
@@ -773,7 +754,7 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     DRow* dst = &a.rows[(size_t)b * a.n_tracks + t];
     for (; n < n_safe; n++) {
       row.pos = off;
-      store_row(dst, row, a.rows_through);
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&row);
       dst += a.n_tracks;
       off = off + step;                                    // sampler.cpp:209
     }
@@ -782,7 +763,7 @@ __host__ __device__ inline uint32_t plan_steady_run(const PlanArgs& a, uint32_t 
     // near the clip tail the general path takes over (exact division); 2147483000 is classify's position bound
     if (!(off + guard <= cnt && (cnt - off) < qmax && off < 2147483000.0)) break;
     row.pos = off;
-    store_row(&a.rows[(size_t)(b + n) * a.n_tracks + t], row, a.rows_through);
+    *reinterpret_cast<uint4*>(&a.rows[(size_t)(b + n) * a.n_tracks + t]) = *reinterpret_cast<const uint4*>(&row);
     off = off + step;                                      // sampler.cpp:209
     n++;
   }
