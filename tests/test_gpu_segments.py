@@ -16,8 +16,9 @@ from test_gpu_parity import _boundary_session, bits, check_against_oracle, plan_
 pytestmark = pytest.mark.gpu
 
 
+# WBX_SEGFUZZ_TO widens the seed ranges for a soak run (defaults: seeds 0..39 / 0..11)
 @pytest.mark.parametrize("seg", ["1", "3", "8"])
-@pytest.mark.parametrize("seed", range(0, 40))
+@pytest.mark.parametrize("seed", range(0, int(os.environ.get("WBX_SEGFUZZ_TO", "40"))))
 def test_random_sessions_planned_by_segments(monkeypatch, seed, seg):
     """the first fuzz generator's sessions (overlapping adds, sub-block clips, mid-session playheads, buses) with forced
     segments of 1 / 3 / 8 blocks: whatever the seam guesses do, everything equals the oracle"""
@@ -27,7 +28,7 @@ def test_random_sessions_planned_by_segments(monkeypatch, seed, seg):
 
 
 @pytest.mark.parametrize("kind", ["masked", "integer", "lean16", "everything"])
-@pytest.mark.parametrize("seed", range(0, 12))
+@pytest.mark.parametrize("seed", range(0, max(12, int(os.environ.get("WBX_SEGFUZZ_TO", "40")) // 3)))
 def test_masked_row_sessions_planned_by_segments(monkeypatch, seed, kind):
     monkeypatch.setenv("WBX_PLAN_SEG", "2")
     spec, n_blocks = FZ.random_masked_session(seed, integer_unity=kind == "integer", lean16=kind == "lean16", everything=kind == "everything")
