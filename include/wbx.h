@@ -414,9 +414,9 @@ wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_seen, uint64_t
 
 /* How the device sequencer planned the renders so far (diagnostic; no reference counterpart — Track::process_event,
  * track.cpp:258-451, is one thread).  Long renders of sessions cut into clips are planned by one lane per (track, SEGMENT of
- * the render) instead of one lane per track: a segment's lane works out the state its first block starts from by itself and a
- * second pass checks every seam against the state the segment before really ended with, planning again — in one walk, from the
- * true state — whatever follows a seam that did not hold (results are the one-walk plan's either way).
+ * the render) instead of one lane per track: a segment's lane works out the state its first block starts from by itself, and
+ * the lane that completes a track checks every seam against the state the segment before really ended with, planning again —
+ * in one walk, from the true state — whatever follows a seam that did not hold (results are the one-walk plan's either way).
  *   out[0]  renders planned by segments     out[1]  tracks that had a seam that did not hold
  *   out[2]  segments planned again          out[3]  segments per track of the last such render */
 wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4]);

@@ -63,7 +63,14 @@ constexpr uint32_t kSegMargin = 48;   // records in front of the segment (the ru
 __device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   DBlockTime* win = reinterpret_cast<DBlockTime*>(s_raw);
-  const uint32_t s = blockIdx.y, b0 = s * g.seg_len;
+  // Workgroup -> (64-track group, segment).  Linear workgroup ids are dealt to the 8 XCDs round-robin; the id is laid out so
+  // that id mod 8 = group mod 8: every segment of a track runs on ONE XCD, behind one L2 — the rows of a segment whose seam
+  // guess missed are written a second time by the lane that completes the track, and two versions of a row in two L2s would
+  // reach memory in no defined order.  Segments are dispatched in order (segment 0 of every group first).
+  const uint32_t n_groups = (a.n_tracks + 63u) / 64u, g8 = (n_groups + 7u) / 8u;
+  const uint32_t q = blockIdx.x >> 3, s = q / g8, grp = (q - s * g8) * 8u + (blockIdx.x & 7u);
+  if (grp >= n_groups) return;   // (group counts that are no multiple of 8: the padding of the last octet)
+  const uint32_t b0 = s * g.seg_len;
   const uint32_t w0 = b0 > kSegMargin ? b0 - kSegMargin : 0u;
   const uint32_t w1 = b0 + g.seg_len + kSegMargin < a.n_blocks ? b0 + g.seg_len + kSegMargin : a.n_blocks;
   {
@@ -73,7 +80,7 @@ __device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& 
     for (uint32_t i = threadIdx.x; i < n16; i += 64u) dst[i] = src[i];
   }
   __syncthreads();
-  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t t = grp * 64u + threadIdx.x;
   if (t >= a.n_tracks) return;
   const TimesWindow tv{a.times, win, w0, w1};
   DTrackState gs{}, en{};
@@ -562,7 +569,8 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
 }
 
 void launch_plan_segments(const PlanArgs& a, const SegArgs& g, bool beside, hipStream_t s) {
-  const dim3 grid((a.n_tracks + 63u) / 64u, g.n_segs);
+  const uint32_t n_groups = (a.n_tracks + 63u) / 64u;
+  const dim3 grid(8u * ((n_groups + 7u) / 8u) * g.n_segs);   // (the kernel decodes: id mod 8 = track group mod 8)
   const size_t lds = (size_t)(g.seg_len + 2u * kSegMargin) * sizeof(DBlockTime);
   static const bool roomy = [] { const char* v = std::getenv("WBX_PLAN_BESIDE"); return v && v[0] == '0'; }();   // A/B aid
   if (beside && !roomy)
