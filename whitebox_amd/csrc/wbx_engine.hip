@@ -123,7 +123,8 @@ wbx_status cfail(wbx_engine* e, wbx_status s) {
 // per clip boundary and lane: c3 cut into 5.3-block clips planned 2048 blocks in 5.4 ms (4.4 ms for 128-frame blocks, in front
 // of a 2.6 ms mix) — while the transport runs and no clip carries a set internal_state_changed flag (the sequencer clears
 // those in passing, track.cpp:373,392,418: the run-up of one lane and the real walk of another would race for them).
-// About 32 k lanes: segments of K * N / 32768 blocks, at least 32 (a run-up is a handful of look-ups and a few blocks long).
+// About 16 k lanes: segments of K * N / 24576 blocks rounded up to a power of two, at least 32 (measured, profiles/
+// r04_ab_seglen.txt: 256 tracks best at 32-64 blocks — 16 and 128 are 9-15 % slower —, 4096 tracks x 2048 short blocks at 512).
 // WBX_PLAN_SEG=0: off; =<n>: segments of n blocks (A/B aid, tests).
 uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing) {
   uint32_t forced = 0u;
@@ -140,7 +141,7 @@ uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing
   //  512 frames: the segment lanes are done early, the next mix starts 0.06 instead of 0.15 ms behind its predecessor, steps
   //  0-3 % shorter, never longer: profiles/r04_ab_planseg.txt)
   uint32_t len = 32u;
-  while ((uint64_t)(K / len) * N > 49152u && len < K) len *= 2u;
+  while ((uint64_t)(K / len) * N > 24576u && len < K) len *= 2u;
   return len < K ? len : 0u;
 }
 
