@@ -295,3 +295,41 @@ def test_gpu_destroyed_sounding_clip_in_batch_renders(edit):
     batch(16)
     e.close()
     eng.close()
+
+
+def test_inverted_resize_range_where_the_compiled_reference_dies_is_defined_alike():
+    """Q11: B's RIGHT edge dragged left past B's own start and into A with resize_limit 0 — calc_resize_clip's
+    minimum length is `resize_limit + min_length - min_time` (clip_edit.h:31), negative here, so the new range is inverted
+    (min 24 blocks, max 18); Track::query_clip_by_range (its assert compiled out) answers first_clip 1 > last_clip 0,
+    reserve_track_region trims A's head to `max` (engine.cpp:545-548) and `last_clip--` wraps below zero: the compiled
+    reference asks for 2^32 Clips at :556 and dies.  Oracle and product apply the trims of :541-553 and delete nothing."""
+    spec = session()
+    e = O.build_oracle_engine(spec)
+    sim = HS.build_sim_engine(spec, max_blocks=4, masked_rows=True)
+    e.enable_seglog()
+    e.play()
+    sim.play()
+
+    def blocks(n):
+        for _ in range(n):
+            e.process()
+            sim.render(1)
+            assert plan_rows(sim.fetch_plan()) == oracle_rows(e, 0)
+
+    blocks(6)
+    b = spec.block
+    before = e.clips(0)
+    for x in (_O(e), _P(sim)):
+        x.resize_clip(0, 1, -(12 * b / BEAT), 0.0, 1.0 / 96.0, False, False, False)
+    after = e.clips(0)
+    assert FZ.clip_rows(sim.clips(sim.tracks[0])) == FZ.clip_rows(after)
+    assert len(after) == 2                                            # nothing deleted
+    new_max = before[1][1] - 12 * b / BEAT
+    assert new_max < before[1][0] and new_max < before[0][1]          # inverted, and inside A
+    a, bb = after
+    assert (a[0], a[1]) == (new_max, before[0][1])                    # A's head trimmed to the range's `max` ...
+    assert a[2] > before[0][2]                                        # ... and its content shifted with it (shift_clip_content)
+    assert (bb[0], bb[1]) == (before[1][0], new_max)                  # B keeps its start; its end lies in front of it
+    blocks(30)
+    e.close()
+    sim.close()
