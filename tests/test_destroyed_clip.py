@@ -333,3 +333,43 @@ def test_inverted_resize_range_where_the_compiled_reference_dies_is_defined_alik
     blocks(30)
     e.close()
     sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,rate", [(512, 48000), (128, 44100)])
+def test_gpu_inverted_resize_range_is_defined_like_the_oracle(block, rate):
+    """Q11 on the device (callback path and a batch render behind it): the clip lists, the plan's stream calls, master and
+    per-track peaks stay bit-equal to the oracle after the edit the compiled reference does not survive"""
+    import whitebox_amd as W
+    from whitebox_amd.engine import build_engine
+    spec = session(block=block, rate=rate)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=16)
+    e.enable_seglog()
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+
+    def blocks(n):
+        for _ in range(n):
+            om, _ = e.process()
+            eng.process(None, out, 48000.0)
+            assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0)
+            assert np.array_equal(bits(np.stack(out.channel_buffers)), bits(om))
+            _, pk, _ = eng.ctx.fetch(peaks=True)
+            assert np.array_equal(bits(pk[0]), bits(e.peaks()))
+
+    blocks(6)
+    for x in (_O(e), _P(eng)):
+        x.resize_clip(0, 1, -(12 * spec.block / BEAT), 0.0, 1.0 / 96.0, False, False, False)
+    assert FZ.clip_rows(eng.clips(eng.tracks[0])) == FZ.clip_rows(e.clips(0))
+    assert len(e.clips(0)) == 2
+    blocks(8)
+    eng.render(16)
+    m, pk, _ = eng.ctx.fetch(peaks=True)
+    for b in range(16):
+        om, _ = e.process()
+        assert np.array_equal(bits(m[b]), bits(om)), b
+        assert np.array_equal(bits(pk[b]), bits(e.peaks())), b
+    e.close()
+    eng.close()
