@@ -160,5 +160,47 @@ def main():
     print("golden vectors written to", OUT)
 
 
+
+def mip_inputs():
+    """(name, fmt, data) of the mip-map fixture: every storage format the summariser reads, counts around the level and
+    pair boundaries, plateaus, extremes, float values outside [-1, 1], ±Inf and NaN"""
+    rng = np.random.default_rng(0x3190)
+    out = []
+    for count in (65, 66, 130, 257, 1030, 4099, 9000):
+        f = (rng.standard_normal(count) * 0.4).astype(np.float32)
+        f[rng.integers(0, count, 6)] = [1.0, -1.0, 1.5, -2.25, 0.0, -0.0]
+        out.append((f"f32_{count}", "f32", f))
+        i16 = rng.integers(-32768, 32768, count).astype(np.int16)
+        i16[rng.integers(0, count, 4)] = [32767, -32768, 0, -1]
+        i16[10:40] = 1234                                  # a plateau: min / max order by first occurrence
+        out.append((f"i16_{count}", "i16", i16))
+        i32 = rng.integers(-2**31, 2**31, count).astype(np.int32)
+        i32[rng.integers(0, count, 4)] = [2**31 - 1, -2**31, 0, -1]
+        out.append((f"i32_{count}", "i32", i32))
+    wild = (rng.standard_normal(1030) * 1e6).astype(np.float32)
+    wild[[5, 77, 300]] = [np.inf, -np.inf, np.nan]
+    out.append(("f32_wild_1030", "f32", wild))
+    return out
+
+
+def gen_mip():
+    """tests/golden/mip.npz from the reference's own summarize_for_mipmaps_impl (oracle/_ref/libwbref_mip.so)."""
+    if O.ref_mip() is None:
+        raise SystemExit("oracle/_ref/libwbref_mip.so is not built (needs /root/reference)")
+    arrs = {}
+    for name, fmt, data in mip_inputs():
+        arrs[f"{name}.in"] = data if fmt != "f32" else data.view(np.uint32)      # float inputs as bit patterns (NaN payloads)
+        for q in (0, 1):
+            for level in range(O.oracle_mip_levels(len(data))):
+                arrs[f"{name}.q{q}.l{level}"] = O.ref_mip_level(fmt, data, level, q)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "mip.npz"), **arrs)
+    print("mip.npz:", len(arrs), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mip":     # (the other fixtures are untouched)
+        gen_mip()
+    else:
+        main()
+        gen_mip()

@@ -221,9 +221,12 @@ void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, dou
                                                                    /* track.cpp:258-451 (audio branch) */
 
 /* ---- next rows: clip ingest and waveform mip-maps ---------------------------------
- * PARITY UNPINNED for these two: dsp/sample.cpp needs libsndfile/vorbis/dr_mp3 and gfx/waveform_visual.cpp needs
- * spdlog + the renderer, none of which is in the image, so the reference TUs cannot be compiled here and the
- * reference holds no test or golden vector for them.  The restatements below follow the cited lines. */
+ * Clip ingest: PARITY UNPINNED — dsp/sample.cpp needs libsndfile/vorbis/dr_mp3 (deinterleave_samples is typed on
+ * sf_count_t), absent from the image; the reference holds no test or golden vector for it.
+ * Mip-maps: gfx/waveform_visual.cpp as a whole needs spdlog + the renderer, but its summariser (:9-173) needs only the
+ * reference's core/ headers: oracle/Makefile compiles that function from the file where it lies into
+ * _ref/libwbref_mip.so (ref_mip_driver.cpp), tests/test_oracle_vs_ref.py holds wbo_mip_summarize to it bit for bit and
+ * tests/golden/mip.npz carries its outputs.  The restatements below follow the cited lines. */
 
 /* deinterleave_samples<T>, dsp/sample.cpp:29-43: dst[c][written + j] = src[channels*j + c]; returns written + n.
  * elem = bytes per sample (2: I16, 4: I32/F32). */

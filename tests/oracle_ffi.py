@@ -206,6 +206,31 @@ def ref() -> Optional[C.CDLL]:
     return _ref
 
 
+_ref_mip = None
+REF_MIP_PATH = os.path.join(ORACLE_DIR, "_ref", "libwbref_mip.so")
+
+
+def ref_mip() -> Optional[C.CDLL]:
+    """The reference's own summarize_for_mipmaps_impl (oracle/Makefile: cut out of gfx/waveform_visual.cpp where it lies and
+    compiled unmodified; None where oracle/_ref was never built)."""
+    global _ref_mip
+    if _ref_mip is None:
+        if not build_ref() or not os.path.exists(REF_MIP_PATH):
+            return None
+        R = C.CDLL(REF_MIP_PATH)
+        R.ref_mip_summarize.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        _ref_mip = R
+    return _ref_mip
+
+
+def ref_mip_level(fmt: str, data: np.ndarray, level: int, quality: int) -> np.ndarray:
+    n = lib().wbo_mip_data_count(len(data), level)
+    out = np.zeros(n, dtype=np.int16 if quality else np.int8)
+    d = np.ascontiguousarray(data)
+    ref_mip().ref_mip_summarize(FMT[fmt], len(d), d.ctypes.data, level, 16 if quality else 8, out.ctypes.data)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------

@@ -150,3 +150,21 @@ def test_mipmaps_reject_unsupported():
     with pytest.raises(W.WbxError):
         ctx.fetch_mipmap(0, 0, 1, 100, 0)
     ctx.close()
+
+
+def test_mipmaps_match_the_reference_fixture():
+    """the device's mip levels against tests/golden/mip.npz — outputs of the reference's own summarize_for_mipmaps_impl
+    (oracle/gen_golden.py; every storage format, both qualities, every level, values beyond [-1, 1], ±Inf, NaN)"""
+    from test_oracle_golden import mip_golden_cases
+    n = 0
+    for name, fmt, data, want in mip_golden_cases():
+        ctx = W.MixContext(2)
+        ctx.clip_upload_interleaved(0, fmt, 48000, np.ascontiguousarray(data.reshape(-1, 1)))
+        for q in (0, 1):
+            ctx.build_mipmaps(0, q)
+            for lvl in range(ctx.L.wbx_mip_levels(len(data))):
+                got = ctx.fetch_mipmap(0, lvl, 1, len(data), q)[0]
+                assert np.array_equal(got, want[(q, lvl)]), (name, q, lvl, np.flatnonzero(got != want[(q, lvl)])[:8])
+                n += 1
+        ctx.close()
+    assert n == 82

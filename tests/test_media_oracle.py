@@ -1,7 +1,9 @@
 """CPU tests of the oracle's restatements for the two "next" rows: clip ingest
 (dsp/sample.cpp:29-43) and waveform mip-maps (gfx/waveform_visual.cpp:9-246).  The reference holds no test or
 vector for either and its TUs need libsndfile / the renderer, so these check the restatement against an
-independent numpy formulation of the same published loops (parity with the reference itself: unpinned)."""
+independent numpy formulation of the same published loops (parity with the reference itself: clip ingest unpinned; the
+mip-maps are pinned elsewhere — tests/test_oracle_vs_ref.py::test_mip_summarize_bit_exact against the reference's own summariser,
+tests/test_oracle_golden.py::test_mip_golden against its recorded outputs)."""
 import numpy as np
 import pytest
 

@@ -183,3 +183,32 @@ def test_clip_lower_bound_matches_reference_template(oracle, reflib):
                                                                float(times[n // 2]) + 0.125]:
                 p = times.ctypes.data_as(C.POINTER(C.c_double))
                 assert L.wbo_lower_bound_max_time(p, n, float(v)) == reflib.ref_find_lower_bound_max_time(p, n, float(v)), (n, v)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_mip_summarize_bit_exact(oracle, seed):
+    """wbo_mip_summarize against the reference's own summarize_for_mipmaps_impl (oracle/_ref/libwbref_mip.so: the function's
+    text cut out of gfx/waveform_visual.cpp where it lies and compiled unmodified, oracle/Makefile) — random counts, every
+    storage format, both output widths, every level; float inputs beyond [-1, 1], ±Inf, NaN"""
+    if oracle.ref_mip() is None:
+        pytest.skip("oracle/_ref/libwbref_mip.so not built (no /root/reference here)")
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(25):
+        fmt = str(rng.choice(["f32", "i16", "i32"]))
+        n = int(rng.choice([65, 66, 127, 128, 129, 255, 257, 1000, 4097, 30000, int(rng.integers(65, 120000))]))
+        if fmt == "f32":
+            d = (rng.standard_normal(n) * float(rng.choice([0.2, 0.9, 1.5, 4.0, 1e6]))).astype(np.float32)
+            if rng.random() < 0.3:
+                d[rng.integers(0, n, 3)] = [np.inf, -np.inf, np.nan]
+            if rng.random() < 0.5:
+                d[rng.integers(0, n, 5)] = [1.0, -1.0, 0.999999, -0.0, 0.0]
+        elif fmt == "i16":
+            d = rng.integers(-32768, 32768, n).astype(np.int16)
+            d[rng.integers(0, n, 4)] = [32767, -32768, 0, -1]
+        else:
+            d = rng.integers(-2**31, 2**31, n).astype(np.int32)
+            d[rng.integers(0, n, 4)] = [2**31 - 1, -2**31, 0, -1]
+        for q in (0, 1):
+            for lv in range(oracle.oracle_mip_levels(n)):
+                got, exp = oracle.oracle_mip(fmt, d, lv, q), oracle.ref_mip_level(fmt, d, lv, q)
+                assert np.array_equal(got, exp), (fmt, n, q, lv, np.flatnonzero(got != exp)[:8])
