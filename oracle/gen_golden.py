@@ -198,9 +198,42 @@ def gen_mip():
     print("mip.npz:", len(arrs), "arrays")
 
 
+
+def vu_inputs():
+    """(blocks [n_blocks][n] fp32, reset_every) of the VU fixture: ordinary levels, silence, all -0.0 (a muted track),
+    NaN at the start / middle / end of a block and whole-NaN blocks (the running maximum restarts after a NaN,
+    math::max(a, b) = b < a ? a : b), infinities, resets between blocks"""
+    rng = np.random.default_rng(0x7005)
+    out = []
+    for n in (1, 7, 128, 512):
+        for scale in (0.0, 1e-3, 0.5, 3.0):
+            a = (rng.standard_normal((9, n)) * scale).astype(np.float32)
+            out.append((a, 0))
+        a = (rng.standard_normal((9, n)) * 0.5).astype(np.float32)
+        a[1, 0] = np.nan; a[3, n // 2] = np.nan; a[5, n - 1] = np.nan; a[7, :] = np.nan
+        out.append((a, 0)); out.append((a.copy(), 3))
+        b = (rng.standard_normal((6, n)) * 0.25).astype(np.float32)
+        b[2, :] = -0.0; b[4, n // 3] = np.inf; b[5, 0] = -np.inf
+        out.append((b, 0)); out.append((b.copy(), 2))
+    return out
+
+
+def gen_vu():
+    """tests/golden/vu.npz from the reference's own VUMeter (oracle/_ref/libwbref_vu.so)."""
+    if O.ref_vu() is None:
+        raise SystemExit("oracle/_ref/libwbref_vu.so is not built (needs /root/reference)")
+    arrs = {}
+    for i, (a, reset) in enumerate(vu_inputs()):
+        arrs[f"c{i:02d}.in"] = a.view(np.uint32)
+        arrs[f"c{i:02d}.reset"] = np.array(reset)
+        arrs[f"c{i:02d}.levels"] = O.ref_vu_levels(a, reset).view(np.uint32)
+    np.savez_compressed(os.path.join(OUT, "vu.npz"), **arrs)
+    print("vu.npz:", len(arrs) // 3, "cases")
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "mip":     # (the other fixtures are untouched)
-        gen_mip()
+    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu"):     # (the other fixtures are untouched)
+        {"mip": gen_mip, "vu": gen_vu}[sys.argv[1]]()
     else:
         main()
         gen_mip()
+        gen_vu()

@@ -12,7 +12,9 @@
 //
 // NOT buildable here (and therefore not in this library): engine/engine.cpp, engine/track.cpp,
 // engine/vu_meter.h — they include core/debug.h which needs third-party spdlog (absent from the
-// image; writing a stand-in is not allowed).  dsp/sample.cpp needs libsndfile/dr_mp3/vorbis, so
+// image; writing a stand-in is not allowed).  (Two pieces of such files need nothing of what their file
+// lacks and are compiled on their own, cut out of the file where it lies by oracle/Makefile: struct VUMeter
+// -> ref_vu_driver.cpp, summarize_for_mipmaps_impl of gfx/waveform_visual.cpp -> ref_mip_driver.cpp.)  dsp/sample.cpp needs libsndfile/dr_mp3/vorbis, so
 // wb::Sample's out-of-line constructor/destructor are not linked either: a wb::Sample is
 // materialised below by assigning its public fields inside zeroed storage, and is never destroyed.
 #include <cstdint>

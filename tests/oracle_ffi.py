@@ -231,6 +231,49 @@ def ref_mip_level(fmt: str, data: np.ndarray, level: int, quality: int) -> np.nd
     return out
 
 
+_ref_vu = None
+REF_VU_PATH = os.path.join(ORACLE_DIR, "_ref", "libwbref_vu.so")
+
+
+def ref_vu() -> Optional[C.CDLL]:
+    """The reference's own VUMeter (oracle/Makefile: the struct cut out of engine/vu_meter.h where it lies and compiled
+    unmodified; None where oracle/_ref was never built)."""
+    global _ref_vu
+    if _ref_vu is None:
+        if not build_ref() or not os.path.exists(REF_VU_PATH):
+            return None
+        R = C.CDLL(REF_VU_PATH)
+        R.ref_vu_push_blocks.argtypes = [c_f32p, C.c_uint32, C.c_uint32, C.c_uint32, c_f32p]
+        _ref_vu = R
+    return _ref_vu
+
+
+def oracle_vu_levels(blocks: np.ndarray, reset_every: int = 0) -> np.ndarray:
+    """what wb_oracle.c does per track and channel at the end of Track::process (track.cpp:732 -> vu_meter.h:20-30):
+    p = wbo_abs_max(block); if (level < p) level = p — `blocks` is [n_blocks][n] fp32; the level after every block"""
+    L = lib()
+    L.wbo_abs_max.restype = C.c_float
+    L.wbo_abs_max.argtypes = [c_f32p, C.c_uint32]
+    level = np.float32(0.0)
+    out = np.zeros(len(blocks), np.float32)
+    for b, blk in enumerate(blocks):
+        if reset_every and b and b % reset_every == 0:
+            level = np.float32(0.0)
+        a = np.ascontiguousarray(blk, dtype=np.float32)
+        p = np.float32(L.wbo_abs_max(a.ctypes.data_as(c_f32p), len(a)))
+        if level < p:
+            level = p
+        out[b] = level
+    return out
+
+
+def ref_vu_levels(blocks: np.ndarray, reset_every: int = 0) -> np.ndarray:
+    a = np.ascontiguousarray(blocks, dtype=np.float32)
+    out = np.zeros(len(a), np.float32)
+    ref_vu().ref_vu_push_blocks(a.ctypes.data_as(c_f32p), a.shape[1], a.shape[0], reset_every, out.ctypes.data_as(c_f32p))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------

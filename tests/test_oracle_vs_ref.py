@@ -212,3 +212,29 @@ def test_mip_summarize_bit_exact(oracle, seed):
             for lv in range(oracle.oracle_mip_levels(n)):
                 got, exp = oracle.oracle_mip(fmt, d, lv, q), oracle.ref_mip_level(fmt, d, lv, q)
                 assert np.array_equal(got, exp), (fmt, n, q, lv, np.flatnonzero(got != exp)[:8])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_vu_meter_bit_exact(oracle, seed):
+    """wbo_abs_max + the level update of wb_oracle.c against the reference's own VUMeter::push_samples / level (oracle/_ref/
+    libwbref_vu.so: the struct cut out of engine/vu_meter.h where it lies and compiled unmodified) — NaN, ±Inf, -0.0 blocks,
+    resets"""
+    if oracle.ref_vu() is None:
+        pytest.skip("oracle/_ref/libwbref_vu.so not built (no /root/reference here)")
+    rng = np.random.default_rng(7100 + seed)
+    for _ in range(60):
+        n, nb = int(rng.choice([1, 7, 64, 128, 512])), int(rng.integers(1, 12))
+        a = (rng.standard_normal((nb, n)) * float(rng.choice([0.0, 1e-3, 0.5, 3.0]))).astype(np.float32)
+        k = int(rng.integers(0, 5))
+        if k == 0:
+            a[rng.integers(0, nb), rng.integers(0, n)] = np.nan
+        elif k == 1:
+            a[rng.integers(0, nb), rng.integers(0, n)] = np.inf
+            a[rng.integers(0, nb), rng.integers(0, n)] = -np.inf
+        elif k == 2:
+            a[rng.integers(0, nb)] = -0.0
+        elif k == 3:
+            a[rng.integers(0, nb), :] = np.nan
+        reset = int(rng.choice([0, 0, 2, 3]))
+        got, exp = oracle.oracle_vu_levels(a, reset), oracle.ref_vu_levels(a, reset)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (k, n, reset, got, exp)
