@@ -25,6 +25,7 @@
 #include "core/audio_buffer.h"
 #include "core/audio_format_conv.h"
 #include "core/core_math.h"
+#include "core/memory.h"
 #include "core/panning_law.h"
 #include "dsp/dsp_ops.h"
 #include "dsp/sampler.h"
@@ -274,6 +275,48 @@ void ref_f32_to_i32(int32_t* dst, const float* const* src, size_t off, size_t n,
 }
 void ref_f32_to_f32(float* dst, const float* const* src, size_t off, size_t n, uint32_t nch) {
   wb::convert_to_interleaved_f32(dst, src, off, n, nch);
+}
+
+
+// Pool<Clip> (core/memory.h:41-110), the allocator behind Track::allocate_clip / destroy_clip (track.h:156-168): which chunk
+// an allocation gets (the one freed last, else a fresh one) and what a freed chunk holds.  ops[i] > 0: allocate (the i-th
+// live object gets handle = number of allocations so far, 1-based; the chunk is filled with 0xFF like a live object);
+// ops[i] < 0: free the object with handle -ops[i].  out[i]: for an allocation the chunk's identity (1-based order in which
+// chunks were first handed out); for a free 1 when every byte of the chunk behind the free-list link reads zero afterwards
+// (the `audio.gain` a dangling Clip* then reads), else 0.
+int ref_pool_script(const int* ops, int n, int* out) {
+  wb::Pool<wb::Clip> pool;                   // one per script, like a Track's clip_allocator (track.h:117)
+  void* seen[4096];
+  int n_seen = 0;
+  void* by_handle[4096] = {};
+  int n_alloc = 0;
+  for (int i = 0; i < n; i++) {
+    if (ops[i] > 0) {
+      void* p = pool.allocate();
+      if (!p || n_alloc >= 4095) return -1;
+      std::memset(p, 0xFF, sizeof(wb::Clip));
+      by_handle[++n_alloc] = p;
+      int id = 0;
+      for (int k = 0; k < n_seen; k++)
+        if (seen[k] == p) id = k + 1;
+      if (!id) {
+        if (n_seen >= 4096) return -1;
+        seen[n_seen++] = p;
+        id = n_seen;
+      }
+      out[i] = id;
+    } else {
+      void* p = by_handle[-ops[i]];
+      if (!p) return -2;
+      by_handle[-ops[i]] = nullptr;
+      pool.free(p);
+      const unsigned char* b = (const unsigned char*)p;
+      int zero = 1;
+      for (size_t k = sizeof(wb::PoolChunk); k < sizeof(wb::Clip); k++) zero &= b[k] == 0;
+      out[i] = zero;
+    }
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -238,3 +238,58 @@ def test_vu_meter_bit_exact(oracle, seed):
         reset = int(rng.choice([0, 0, 2, 3]))
         got, exp = oracle.oracle_vu_levels(a, reset), oracle.ref_vu_levels(a, reset)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (k, n, reset, got, exp)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_clip_chunks_follow_the_reference_pool(oracle, reflib, seed):
+    """Q10's allocator statements (wb_oracle.c alloc_clip_uid / free_clip_uid: a clip's uid names its Pool<Clip> chunk) against
+    the reference's own Pool<Clip> (core/memory.h:41-110, compiled into _ref): random adds, single deletes and region deletes
+    that destroy several clips at once (in list order, track.cpp:170-172) on one oracle track, mirrored as allocate / free on the
+    pool — every new clip's uid is the identity of the chunk the pool hands out, and a freed chunk reads zero behind its
+    free-list link (the gain a dangling Clip* reads)"""
+    reflib.ref_pool_script.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(4400 + seed)
+    e = oracle.OracleEngine(2, 64, 48000)
+    e.set_bpm(120.0)
+    sid = e.add_sample("f32", 1, 48000, 64, [np.zeros(80, np.float32)])
+    e.add_track()
+    ops, want = [], []          # the mirrored pool script and, per allocation, the oracle's uid
+    handle_of = {}              # clip slot (its min_time / 10) -> pool handle
+    n_alloc, next_slot = 0, 0
+
+    def uids():
+        n = oracle.lib().wbo_track_clip_count(e.e, 0)
+        cl = [oracle.lib().wbo_track_clip(e.e, 0, i).contents for i in range(n)]
+        return {int(round(c.min_time / 10.0)): c.uid for c in cl}
+
+    for _ in range(400):
+        live = sorted(handle_of)
+        r = rng.random()
+        if r < 0.5 or not live:
+            slot = next_slot
+            next_slot += 1
+            assert e.add_audio_clip(0, 10.0 * slot, 10.0 * slot + 1.0, 0.0, sid, 1.0, 1.0) == 0
+            n_alloc += 1
+            handle_of[slot] = n_alloc
+            ops.append(1)
+            want.append(uids()[slot])
+        elif r < 0.8:
+            slot = int(rng.choice(live))
+            assert e.delete_clip(0, live.index(slot)) == 0
+            ops.append(-handle_of.pop(slot))
+            want.append(1)
+        else:
+            a = int(rng.integers(0, len(live)))
+            b = min(len(live) - 1, a + int(rng.integers(0, 4)))
+            e.delete_region(0, 10.0 * live[a] - 0.5, 10.0 * live[b] + 1.5)
+            for slot in live[a:b + 1]:          # destroyed in list order
+                ops.append(-handle_of.pop(slot))
+                want.append(1)
+        assert sorted(uids()) == sorted(handle_of)
+    out = (C.c_int * len(ops))()
+    assert reflib.ref_pool_script((C.c_int * len(ops))(*ops), len(ops), out) == 0
+    first = min(w for o, w in zip(ops, want) if o > 0)          # the oracle's uids count from the engine's first clip
+    got = [x for x in out]
+    exp = [w - first + 1 if o > 0 else 1 for o, w in zip(ops, want)]
+    assert got == exp
+    e.close()
