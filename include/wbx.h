@@ -421,6 +421,15 @@ wbx_status wbx_engine_thread_stats(wbx_engine* e, uint64_t* edits_seen, uint64_t
  *   out[2]  segments planned again          out[3]  segments per track of the last such render */
 wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4]);
 
+/* How wbx_engine_process — the audio callback, audio_io_pulseaudio.cpp:396-466 calling Engine::process once per device
+ * period — has run so far (diagnostic; no reference counterpart).  A block is ONE launch where an instance exists for the
+ * block shape; its sum is spread over all workgroups behind a barrier that needs the whole grid resident at once.  A workgroup
+ * that waits there too long (a CU mask, a device shared with another process) gives up; the block is then mixed and summed
+ * again through three launches — its result is the same — and the engine stops spreading.
+ *   out[0]  blocks that ran as one launch       out[1]  ... of those, with the sum spread over the workgroups
+ *   out[2]  blocks mixed again after a give-up  out[3]  1 when the engine has stopped spreading */
+wbx_status wbx_engine_callback_stats(wbx_engine* e, uint64_t out[4]);
+
 /* The plan the device sequencer produced for the last process/render: one record per Sampler::stream
  * call, ordered by (block, track, call).  For seek-math parity checks (bit patterns, not tolerances). */
 typedef struct wbx_plan_record {

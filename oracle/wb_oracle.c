@@ -197,7 +197,14 @@ static inline double clampd(double x, double lo, double hi) {
 
 /* dsp/sampler.cpp:34-59 sample_linear<T,Fmt>; normalisers from :7-18.
  * Q1: the reference indexes src_channels[i] with NO "% channels" wrap here (reads out of bounds for
- * a mono clip into a stereo bus); the build DEFINES the wrap (i % channels) for both paths. */
+ * a mono clip into a stereo bus); the build DEFINES the wrap (i % channels) for both paths.
+ * Q12: a NEGATIVE playback speed (calc_resize_clip with stretch, clip_edit.h:59-67,110-118: sample_count /
+ * (old_length + num_samples) goes negative when a clip is shrunk by more than its sample's stretched length) makes the
+ * position run backwards and below zero; `src_sample[ix]` with ix < 0 (sampler.cpp:53-54) then reads the heap in front
+ * of the channel array — undefined behaviour, in the compiled reference whatever the allocator left there (its value
+ * changes from run to run).  The build DEFINES a tap at a negative index as 0 (the mirror image of the 16 zero frames
+ * behind a clip, Q2); positions, ix = trunc(x) and the NEGATIVE fraction fx = x - ix are the reference's arithmetic. */
+#define TAP(src, k) ((k) < 0 ? 0 : (src)[(k)])
 static void linear_f32(const wbo_sample* smp, uint32_t nch, uint32_t n, uint32_t boff, float gain, double speed,
                        double pos, float* const* out) {
   for (int32_t i = 0; i < (int32_t)nch; i++) {
@@ -207,8 +214,8 @@ static void linear_f32(const wbo_sample* smp, uint32_t nch, uint32_t n, uint32_t
       const double x = pos + ((double)j * speed);
       const int64_t ix = (int64_t)x;
       const float fx = (float)(x - (double)ix);
-      const float a = (float)(1.0f * (float)src[ix]);
-      const float b = (float)(1.0f * (float)src[ix + 1]);
+      const float a = (float)(1.0f * (float)TAP(src, ix));
+      const float b = (float)(1.0f * (float)TAP(src, ix + 1));
       const float s = a + fx * (b - a);
       dst[j] += s * gain;
     }
@@ -225,8 +232,8 @@ static void linear_i16(const wbo_sample* smp, uint32_t nch, uint32_t n, uint32_t
       const double x = pos + ((double)j * speed);
       const int64_t ix = (int64_t)x;
       const float fx = (float)(x - (double)ix);
-      const float a = (float)(norm * (float)src[ix]);
-      const float b = (float)(norm * (float)src[ix + 1]);
+      const float a = (float)(norm * (float)TAP(src, ix));
+      const float b = (float)(norm * (float)TAP(src, ix + 1));
       const float s = a + fx * (b - a);
       dst[j] += s * gain;
     }
@@ -242,8 +249,8 @@ static void linear_i32c(const wbo_sample* smp, double norm, uint32_t nch, uint32
       const double x = pos + ((double)j * speed);
       const int64_t ix = (int64_t)x;
       const float fx = (float)(x - (double)ix);
-      const float a = (float)(norm * (double)src[ix]);
-      const float b = (float)(norm * (double)src[ix + 1]);
+      const float a = (float)(norm * (double)TAP(src, ix));
+      const float b = (float)(norm * (double)TAP(src, ix + 1));
       const float s = a + fx * (b - a);
       dst[j] += s * gain;
     }

@@ -222,3 +222,123 @@ def run_edit_script(seed, spec, e, eng, on_block, steps=24, sounding_bias=True):
         on_block(step, op)
         hits += sum(1 for tt in range(n_tracks) if e.dangling(tt))
     return hits
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# "wild" sessions (round 5): the corners of what the reference's API accepts, all at once
+# ----------------------------------------------------------------------------------------------------------------------
+WILD_RATES = [22050, 32000, 44100, 48000, 88200, 96000, 192000]
+WILD_BLOCKS = [32, 64, 100, 128, 440, 512, 1000, 2048]      # (the product takes multiples of 4 frames)
+
+
+def _wild_clip(rng, t, samples, unit, total, around=None):
+    """one clip of track t: sub-frame, sub-block and many-block lengths, edges snapped to block edges now and then, start
+    offsets beyond the sample's end, crawling (0.01) and racing (8) stretch factors, NEGATIVE ones (what a stretch-shrink past
+    the sample's own length leaves behind — quirk Q12), gains of exactly 0"""
+    mn = float(rng.uniform(0, total)) if around is None else max(0.0, around + float(rng.normal(0, 3 * unit)))
+    ln = float(rng.choice([1e-6, 0.01, 0.5, 1.0, 1.0, 3.3, 10.0])) * unit * float(rng.uniform(0.5, 1.5))
+    if rng.random() < 0.25:
+        mn, ln = round(mn / unit) * unit, max(1, round(ln / unit)) * unit
+    s = int(rng.integers(0, len(samples)))
+    so = float(rng.choice([0.0, 0.0, float(rng.integers(0, samples[s].frames + 50)), float(rng.uniform(0, 100))]))
+    sp = float(rng.choice([1.0, 1.0, 0.5, 2.0, 0.01, 8.0, float(rng.uniform(0.2, 3.0)), -float(rng.uniform(0.05, 2.0))]))
+    g = float(np.float32(rng.choice([1.0, 0.0, 0.5, 2.0, float(rng.uniform(0, 2))])))
+    return synth.ClipSpec(track=t, min_beat=mn, max_beat=mn + ln, start_offset=so, speed=sp, gain=g, sample=s)
+
+
+def wild_session(seed):
+    """1-5 tracks over 1-4 shared samples of 5 … 200 000 frames (every storage format, 8 … 192 kHz), session rates 22.05 …
+    192 kHz, blocks of 32 … 2048 frames (100, 440 and 1000 among them), any tempo, up to 13 clips per track laid out at random
+    (overlapping adds trim / split / delete each other), a playhead that may start anywhere.  Returns (spec, n_blocks)."""
+    rng = np.random.default_rng(seed * 7907 + 5)
+    sr = int(rng.choice(WILD_RATES))
+    block = int(rng.choice(WILD_BLOCKS))
+    bpm = float(rng.uniform(30.0, 300.0)) if rng.random() < 0.7 else float(rng.choice([120.0, 60.0, 90.0, 128.0]))
+    nt, ns = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+    samples = []
+    for i in range(ns):
+        fmt = str(rng.choice(["f32", "i16", "i24", "i32"]))
+        rate = int(rng.choice([8000, 11025, 22050, 44100, 48000, 96000, sr, sr]))
+        frames = int(rng.choice([5, 17, 300, 5000, 50000, 200000]))
+        samples.append(synth.SampleSpec(i, int(rng.integers(1, 3)), rate, frames, fmt, 0.2 if fmt == "f32" else 1.0))
+    unit = block / (sr * 60.0 / bpm)            # one block, in beats
+    n_blocks = int(rng.integers(12, 40))
+    total = n_blocks * unit
+    clips = [_wild_clip(rng, t, samples, unit, total) for t in range(nt) for _ in range(int(rng.integers(0, 14)))]
+    spec = synth.SessionSpec(f"wild{seed}", nt, 0xBEEF00 + seed, samples, clips,
+                             [float(np.float32(rng.uniform(-80, 6))) for _ in range(nt)],
+                             [float(np.float32(rng.uniform(-1, 1))) for _ in range(nt)],
+                             [bool(rng.random() < 0.1) for _ in range(nt)], bpm=bpm, sample_rate=sr, block=block, channels=int(rng.choice([2, 2, 1])),
+                             playhead_start=float(rng.choice([0.0, 0.0, float(rng.uniform(0, total))])))
+    return spec, n_blocks
+
+
+def run_wild_script(seed, spec, n_blocks, e, eng, on_block, edits=True):
+    """Plays the session block by block on the oracle `e` and an engine `eng` (whitebox_amd.engine.Engine or
+    tests/host_sim.HostSimEngine); with `edits`, 0-2 operations of everything a host can do go between two blocks: parameter
+    messages, stop / play, seeks, tempo changes, clip gain / delete / move / resize (shift, stretch — shrinks that leave a
+    NEGATIVE speed behind included), adds around the playhead, region deletes, track moves and deletes.  The clip lists must
+    agree bit for bit after every operation; on_block(b, trail) renders and compares one block.  Returns the number of stream
+    calls that ran a tap index below zero (quirk Q12)."""
+    rng = np.random.default_rng(seed * 104729 + 71)
+    unit = spec.block / (spec.sample_rate * 60.0 / spec.bpm)
+    total = n_blocks * unit
+    nt = spec.n_tracks
+    trail, q12 = [], 0
+    for t in range(nt):
+        assert clip_rows(eng.clips(eng.tracks[t])) == clip_rows(e.clips(t)), ("initial clip list", t)
+    e.play()
+    eng.play()
+    for b in range(n_blocks):
+        for _ in range(int(rng.integers(0, 3)) if edits else 0):
+            if nt == 0:
+                break
+            t = int(rng.integers(0, nt))
+            cl = e.clips(t)
+            n, op, ph = len(cl), int(rng.integers(0, 14)), e.playhead
+            T = eng.tracks[t]
+            trail.append((b, op, t))
+            if op == 0:
+                v = float(np.float32(rng.uniform(-80, 6))); e.set_volume(t, v); T.set_volume(v)
+            elif op == 1:
+                v = float(np.float32(rng.uniform(-1, 1))); e.set_pan(t, v); T.set_pan(v)
+            elif op == 2:
+                m = bool(rng.integers(0, 2)); e.set_mute(t, m); T.set_mute(m)
+            elif op == 3:
+                e.stop(); eng.stop()
+                if rng.random() < 0.8:
+                    e.play(); eng.play()
+            elif op == 4:
+                bt = float(rng.uniform(0, total)); e.set_playhead(bt); eng.set_playhead_position(bt)
+            elif op == 5:
+                nb = float(rng.uniform(30, 300)); e.set_bpm(nb); eng.set_bpm(nb)
+            elif op == 6 and n:
+                i, g = int(rng.integers(0, n)), float(np.float32(rng.uniform(0, 2)))
+                e.set_clip_gain(t, i, g); eng.set_clip_gain(T, i, g)
+            elif op == 7 and n:
+                i = int(rng.integers(0, n)); e.delete_clip(t, i); eng.delete_clip(T, i)
+            elif op == 8 and n:
+                i, rel = int(rng.integers(0, n)), float(rng.normal(0, 4 * unit))
+                e.move_clip(t, i, rel); eng.move_clip(T, i, rel)
+            elif op == 9 and n:
+                i, rel = int(rng.integers(0, n)), float(rng.normal(0, 2 * unit))
+                left, shift, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                span = cl[i][1] - cl[i][0]      # the new edge stays on its own side of the other one (the inverted range is Q11)
+                rel = min(rel, span * 0.9) if left else max(rel, -span * 0.9)
+                e.resize_clip(t, i, rel, 0.0, 1.0 / 96.0, left, shift, stretch); eng.resize_clip(T, i, rel, 0.0, 1.0 / 96.0, left, shift, stretch)
+            elif op == 10:
+                c = _wild_clip(rng, t, spec.samples, unit, total, around=ph)
+                e.add_audio_clip(t, c.min_beat, c.max_beat, c.start_offset, c.sample, c.speed, c.gain)
+                eng.add_audio_clip(T, "w", c.min_beat, c.max_beat, c.start_offset, c.sample, c.speed, c.gain)
+            elif op == 11:
+                mn = max(0.0, ph + float(rng.normal(0, 3 * unit))); mx = mn + float(rng.uniform(0.1, 5)) * unit
+                e.delete_region(t, mn, mx); eng.delete_region(T, mn, mx)
+            elif op == 12 and nt > 1 and rng.random() < 0.3:
+                a_, b_ = int(rng.integers(0, nt)), int(rng.integers(0, nt)); e.move_track(a_, b_); eng.move_track(a_, b_)
+            elif op == 13 and nt > 1 and rng.random() < 0.15:
+                sl = int(rng.integers(0, nt)); e.delete_track(sl); eng.delete_track(sl); nt -= 1
+            for tt in range(nt):
+                assert clip_rows(eng.clips(eng.tracks[tt])) == clip_rows(e.clips(tt)), ("clip list", trail[-1], tt)
+        on_block(b, trail)
+        q12 += sum(1 for sg in e.seglog() if sg[4] < 0 and sg[2] > 0 and sg[3] + (sg[2] - 1) * sg[4] <= -1.0)
+    return q12

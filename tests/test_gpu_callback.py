@@ -192,3 +192,67 @@ def test_one_launch_callback_repeats_blocks_that_queue_pre_render_rows():
     assert any(n.startswith("wbx::mix_kernel<") for n in return_names), return_names
     run_callback(_boundary_session(90, 8, 512, 2.6), 8, every_block_one_launch=False)
     assert any(n.startswith("wbx::callback_kernel<") for n in return_names), return_names
+
+
+def test_callback_grid_shrinks_from_more_than_the_device_to_a_spread_grid():
+    """4608 tracks (288 workgroups: "the last one adds everything", only the FIRST ticket counter moves) — then tracks are
+    deleted down to 4096 and 3000 (one workgroup per CU or fewer: the spread sum, whose second counter has a base of its own).
+    With one base for both counters the first spread block after the large ones waited for a count that had wrapped: no
+    report, a two-second time-out, WBX_ERR_DEVICE (round-4 advisor).  Every block against the oracle."""
+    n0 = 4608
+    spec = synth.make_session("cbshrink", n0, src_rate=44100, n_blocks=12, seed=0xC5B1)
+    e = O.build_oracle_engine(spec)
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+    n = n0
+    spread_before = eng.callback_stats()[1]
+    for b in range(10):
+        if b in (3, 6):
+            target = 4096 if b == 3 else 3000
+            while n > target:          # from the back: the remaining tracks keep their slots
+                n -= 1
+                e.delete_track(n)
+                eng.delete_track(n)
+        om, _ = e.process()
+        eng.process(None, out, float(spec.sample_rate))
+        assert eng.ctx.kernel_name().startswith("wbx::callback_kernel<"), b
+        m = np.stack(out.channel_buffers)
+        d = m.astype(np.float64) - om.astype(np.float64)
+        assert float(np.sqrt(np.mean(d * d))) <= RMS_TOL, b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0][:n], e.peaks()[:n, :spec.channels]), b
+    launches, spread, give_ups, off = eng.callback_stats()
+    assert launches == 10 and spread - spread_before == 7 and give_ups == 0 and off == 0
+    e.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("n_tracks", [300, 4096])
+def test_callback_give_up_at_the_spread_barrier_mixes_the_block_again(monkeypatch, n_tracks):
+    """WBX_CB_SPIN_BOUND=0: every workgroup that reaches the spread barrier before the last one gives up at once — what a grid
+    that is not resident at once (a CU mask, a shared device) ends in after 50 ms.  The launch reports it, the block is mixed and
+    summed again through three launches — same plan, same result — and the engine stops spreading."""
+    monkeypatch.setenv("WBX_CB_SPIN_BOUND", "0")
+    spec = synth.make_session("cbgiveup", n_tracks, src_rate=44100, n_blocks=6, seed=0xC5B2)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+    for b in range(5):
+        om, _ = e.process()
+        eng.process(None, out, float(spec.sample_rate))
+        m = np.stack(out.channel_buffers)
+        d = m.astype(np.float64) - om.astype(np.float64)
+        assert float(np.sqrt(np.mean(d * d))) <= RMS_TOL, b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0], e.peaks()[:, :spec.channels]), b
+        if n_tracks <= 1025:
+            assert plan_rows(eng.fetch_plan()) == oracle_rows(e, 0), b
+    launches, spread, give_ups, off = eng.callback_stats()
+    assert launches == 5 and spread == 1 and give_ups == 1 and off == 1     # block 0 gave up; blocks 1-4: the last workgroup adds
+    e.close()
+    eng.close()

@@ -155,6 +155,7 @@ SYMBOLS = {
     "wbx_engine_levels": (C.c_int, [_vp, C.POINTER(_f), _u32]),
     "wbx_engine_thread_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u32]),
     "wbx_engine_sequencer_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "wbx_engine_callback_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "wbx_engine_fetch_plan": (C.c_int, [_vp, C.POINTER(PlanRecord), _sz, C.POINTER(_sz)]),
 }
 

@@ -33,13 +33,19 @@ struct CallbackArgs {
   uint32_t* done;      // device, two counters of kCbLanes words kCbStride apart each: workgroups that have stored their group
                        // sum / their share of the master — counted from `base`, never reset
   uint32_t spread;     // every workgroup adds a share of the master (the grid is resident at once); 0: the last one adds it all
-  uint32_t base;       // what `done[0]` reads when this launch starts
+  uint32_t base;       // what the first counter reads when this launch starts (every multi-group launch arrives there)
+  uint32_t base2;      // ... the second one (only spread launches arrive there: it has a base of its own)
+  uint32_t* elect;     // device word: the launch number of the last launch whose reporter has been chosen (not spread: of the
+                       // workgroups that see the full count, the first to swap its launch's number in adds and reports);
+                       // elect[1]: the number of the last launch in which a workgroup gave up at the spread barrier
+  uint32_t* gave_up;   // pinned host: `seq` — written in front of `flag` — when a workgroup of this launch gave up at the spread barrier
   uint32_t* flag;      // pinned host: `seq` once master and status are out.  (One word per workgroup, the host waiting for all of
                        // them, was tried instead of the second ticket: 3 us less on the device, 6 us more until the audio thread
                        // had seen all 256 — the words share cache lines the polling core keeps losing to the next write.)
   uint32_t seq;
   uint32_t n_wgs;
   uint32_t fenced;     // A/B aid (WBX_CB_FENCED=1): release / acquire fences instead of write-through stores + s_waitcnt
+  uint32_t spin_bound; // polls of the spread barrier before a workgroup gives up (WBX_CB_SPIN_BOUND: tests force the give-up path)
   unsigned long long* dbg;   // diagnostic (WBX_CB_DBG=1): [n_wgs][6] wall-clock ticks at start / plan done / mix done / ticket / end, XCC id
 };
 
@@ -113,20 +119,30 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
       uint32_t n = cb_arrive(cb.done, wg, tid) - cb.base;
       if (cb.spread) {   // wait for the others (all resident: the host spreads only grids of at most one workgroup per CU)
         uint32_t spins = 0u;
-        while (n < cb.n_wgs && spins < 2000000u) {   // (bounded: ~1 s; a give-up is reported — status bit 5 — never a hang)
+        // (bounded: ~50 ms, a thousand times what the slowest workgroup of a block takes; a give-up is reported — status bit 5 —
+        //  never a hang: the host mixes the block again through three launches and the context stops spreading)
+        while (n < cb.n_wgs && spins < cb.spin_bound) {
           __builtin_amdgcn_s_sleep(1);
           n = cb_total(cb.done, tid) - cb.base;
           spins++;
         }
-        if (tid == 0u && n < cb.n_wgs && s.status_src) atomicOr(s.status_src + 1, 32u);
+        // (a give-up: noted in a device word — written through, acknowledged before this workgroup takes its second ticket —
+        //  which the workgroup that reports the launch hands to the host)
+        if (tid == 0u && n < cb.n_wgs) __hip_atomic_store(cb.elect + 1, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (tid == 0u) s_ticket = n;
     }
     __syncthreads();
     if (cb.dbg && tid == 0u) cb.dbg[6u * wg + 3u] = wall_clock64();
     // (not spread: whoever sees the full count adds everything — two workgroups whose arrivals complete together may both
-    //  see it and both store the same master: harmless)
-    if (!cb.spread && s_ticket != cb.n_wgs) return;
+    //  see it; ONE of them is chosen, or the second would copy the plan's counters after the first has cleared them)
+    if (!cb.spread) {
+      if (s_ticket != cb.n_wgs) return;
+      __shared__ uint32_t s_chosen;
+      if (tid == 0u) s_chosen = __hip_atomic_exchange(cb.elect, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cb.seq ? 1u : 0u;
+      __syncthreads();
+      if (!s_chosen) return;
+    }
     if (cb.fenced) __threadfence();
     const uint32_t F = s.block_frames, C = s.channels;
     // a lane owns a slot (4 frames of one channel; interleaved output: of every channel) and walks the groups in order
@@ -190,11 +206,11 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid < 64u) {
-        const uint32_t n = cb_arrive(cb.done + kCbLanes * kCbStride, wg, tid) - cb.base;
+        const uint32_t n = cb_arrive(cb.done + kCbLanes * kCbStride, wg, tid) - cb.base2;
         if (tid == 0u) s_ticket = n;
       }
       __syncthreads();
-      report = s_ticket == cb.n_wgs;   // (as above: two may see it, both write the same word)
+      report = s_ticket == cb.n_wgs;   // (two may see it: both write the same word, the status went out with workgroup 0's share)
     }
   }
   if (!report) return;
@@ -204,6 +220,10 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0u) {
+    if (cb.spread && cb.gave_up && __hip_atomic_load(cb.elect + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cb.seq) {
+      __hip_atomic_store(cb.gave_up, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_s_waitcnt(0);   // (on its way to the host in front of the flag)
+    }
     __hip_atomic_store(cb.flag, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (cb.dbg) cb.dbg[6u * wg + 4u] = wall_clock64();
   }

@@ -27,8 +27,8 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
                        hipEvent_t t1 = nullptr);   // -> the instance's name
 void launch_sum(const SumArgs& a, uint32_t n_blocks, hipStream_t s);
 // the one-block callback as one launch (wbx_callback.h): sequencer + mix + sum + completion flag -> the instance's name
-const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s, uint32_t* done, uint32_t done_base, bool spread,
-                            uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st);
+const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s, uint32_t* done, uint32_t done_base, uint32_t done_base2, bool spread,
+                            uint32_t* gave_up, uint32_t spin_bound, uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st);
 uint32_t callback_spread_limit();      // grids of at most this many workgroups are resident at once (the device's CU count)
 void launch_clamp(float* buf, size_t n, hipStream_t s);
 void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStream_t s);
@@ -201,10 +201,17 @@ struct wbx_ctx {
   // are out, and whether launch_mix_sum took that path
   const PlanArgs* cb_plan = nullptr;
   uint32_t* cb_flag = nullptr;
+  uint32_t* cb_gave_up = nullptr;     // pinned word: the launch's number when one of its workgroups gave up at the spread barrier
   uint32_t cb_seq = 0;
   bool cb_launched = false;
   uint32_t* d_cb_done = nullptr;      // device: "workgroups done" ticket counter, never reset: launches count from cb_base
-  uint32_t cb_base = 0;
+  uint32_t cb_base = 0;               // ... the first counter (every multi-group launch arrives there)
+  uint32_t cb_base2 = 0;              // ... the second one (only launches whose workgroups each add a share of the master)
+  uint64_t cb_launches = 0, cb_spread_launches = 0;   // one-launch callbacks issued / ... with the spread sum
+  bool seg_broken = false;            // plan_seg_kernel found its XCD layout broken (status bit 7): one lane per track from then on
+  uint32_t cb_spin_bound = 40000;     // polls of the spread barrier before a workgroup gives up (~50 ms; WBX_CB_SPIN_BOUND, read at wbx_create)
+  bool cb_no_spread = false;          // a spread launch gave up waiting for the whole grid (not resident at once: a CU mask, a
+                                      // device shared with another process): the context keeps to "the last workgroup adds"
   uint32_t cb_flags = 1;              // completion words the launch writes (one, or one per workgroup: cb_flag[0 .. cb_flags))
   uint32_t cb_flag_cap = 1;           // ... and how many the engine's pinned block holds
   bool zero_status = false;           // ... and whether it clears the counters for the buffer's next plan
@@ -311,6 +318,7 @@ wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks);
 wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status ensure_template_capacity(wbx_ctx* c, size_t n);
 wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows);
+wbx_status ensure_pool_slack(wbx_ctx* c);   // twice the default overflow pool (renders planned by segments; not when the host fixed max_segments)
 wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on);
 wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status plan_status_to_error(wbx_ctx* c, uint32_t bits);

@@ -52,6 +52,7 @@ struct wbx_engine {
                                         // number, one word or one per workgroup), kCbFlags of them
   static constexpr uint32_t kCbFlags = 256;
   uint32_t cb_seq = 0;                  // ... of the last launch
+  uint32_t cb_give_ups = 0;             // one-launch callbacks mixed again because a workgroup gave up at the spread barrier
   bool in_process = false;              // render_locked runs inside wbx_engine_process, which waits for the block: the
                                         // pinned tables need no completion events
   bool gen_skipped = false;             // ... and left the pre-render launch out (expecting an empty queue)
@@ -134,7 +135,7 @@ uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing
   }
   if (e->table_flags && e->h_flags_left && *reinterpret_cast<volatile uint32_t*>(e->h_flags_left) == 0u)
     e->table_flags = false;   // every flag of the table has been cleared by a plan that is over
-  if (!playing || e->table_flags || e->in_process || N == 0u) return 0u;
+  if (!playing || e->table_flags || e->in_process || N == 0u || e->ctx->seg_broken) return 0u;
   if (forced) return forced < K ? forced : 0u;
   if (!e->hs.cut_tracks || K < 128u) return 0u;
   // (also where the one-lane walk would hide behind the previous mix — c3 / 16-bit sessions cut into 5.3- or 20-block clips at
@@ -833,11 +834,18 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance; reads the flags above)
   c->chain_now = render_chains_groups(c, K);
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
-  st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration));
-  if (st != WBX_OK) return cfail(e, st);
   // the sequencer of this render: one lane per track, or — long renders of sessions cut into clips — per (track, segment)
   const uint32_t seg_len = plan_segment_length(e, K, N, playing);
   const uint32_t n_segs = seg_len ? (K + seg_len - 1u) / seg_len : 1u;
+  // (segments: a track whose seam missed is planned again from there, and what its replaced segments queued / took from the
+  //  pool / reserved stays allocated and unused — room for both versions of every row, so that a miss on a session that leans
+  //  on the pre-render pass cannot turn into a capacity error)
+  st = ensure_gen_capacity(c, hs.gen_rows_hint(K, c->masked_rows, ((double)F / (double)c->cfg.sample_rate) / beat_duration) * (seg_len ? 2u : 1u));
+  if (st != WBX_OK) return cfail(e, st);
+  if (seg_len) {
+    st = ensure_pool_slack(c);
+    if (st != WBX_OK) return cfail(e, st);
+  }
   st = ensure_template_capacity(c, std::max(hs.template_hint(K, n_segs), (size_t)2 * N));   // (2 N: the one-launch callback's static pairs)
   if (st != WBX_OK) return cfail(e, st);
 
@@ -1016,8 +1024,10 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->cb_plan = one_launch ? &a : nullptr;
   if (one_launch) {
     c->cb_flag = e->h_status + 8;
+    c->cb_gave_up = e->h_status + 7;
     c->cb_flag_cap = wbx_engine::kCbFlags;
-    c->cb_seq = ++e->cb_seq;
+    if (++e->cb_seq == 0u) ++e->cb_seq;   // (0 is what the completion and election words hold before any launch)
+    c->cb_seq = e->cb_seq;
   }
   st = launch_mix_sum(c, K, N);
   c->cb_plan = nullptr;
@@ -1115,7 +1125,7 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
           if (have < n_flags) {   // the launch never reported: start the ticket count afresh
             st = efail(e, WBX_ERR_DEVICE, "the one-launch callback did not report its block");
             if (c->d_cb_done) (void)hipMemset(c->d_cb_done, 0, kCbDoneWords * sizeof(uint32_t));
-            c->cb_base = 0;
+            c->cb_base = c->cb_base2 = 0;
           }
           break;
         }
@@ -1127,6 +1137,19 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
     if (st == WBX_OK) {
       PB(c).counters_zero = e->h_status[2] == 0u;   // (sum_kernel cleared them unless something was queued)
       e->plan_status_on_host = true;
+    }
+    if (st == WBX_OK && one_launch && e->h_status[7] == e->cb_seq) {
+      // A workgroup of the spread sum gave up waiting for the rest of its grid (the grid was not resident at once: a CU mask
+      // the attribute does not show, a device shared with another process): shares of the master were added from incomplete
+      // group sums.  The launch itself is over (its flag is the LAST workgroup's), the plan is intact: mix and sum the block
+      // again through three launches, and keep to "the last workgroup adds everything" from here on.
+      c->cb_no_spread = true;
+      e->cb_give_ups++;
+      c->zero_status = false;
+      st = launch_mix_sum(c, 1, e->hs.n_tracks());
+      if (st == WBX_OK && sync_main(c) != hipSuccess) st = WBX_ERR_DEVICE;
+      PB(c).counters_zero = false;
+      if (st != WBX_OK) tls_err = c->err;
     }
     if (st == WBX_OK && e->gen_skipped && e->h_status[2] != 0u) {
       // the block did queue records for the pre-render pass: run it now and mix again (the plan is untouched; the
@@ -1226,6 +1249,16 @@ extern "C" wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4])
   out[1] = st[0];
   out[2] = st[1];
   out[3] = e->seg_last_segs;
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_engine_callback_stats(wbx_engine* e, uint64_t out[4]) {
+  if (!e || !out) return WBX_ERR_INVALID;
+  LockGuard g(e->hs.editor_lock);
+  out[0] = e->ctx->cb_launches;
+  out[1] = e->ctx->cb_spread_launches;
+  out[2] = e->cb_give_ups;
+  out[3] = e->ctx->cb_no_spread ? 1u : 0u;
   return WBX_OK;
 }
 

@@ -98,8 +98,15 @@ __device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& 
   if (s > 0u) put(&g.guess[at], gs);
   put(&g.ends[at], en);
   __builtin_amdgcn_s_waitcnt(0);
+  // The ticket's low half counts the segments of the track that are done; its high half collects the XCDs they ran on (one
+  // bit each, or-ed in before the count: the lane that completes the track has everybody's).  What the layout above rests on —
+  // linear workgroup ids dealt round-robin to 8 / 4 / 2 / 1 XCDs — is thereby CHECKED where it matters: a track that is planned
+  // again over rows another L2 may still hold a dirty copy of raises status bit 7, the render reports WBX_ERR_DEVICE and the
+  // engine plans by one lane per track from then on (wbx_engine.hip).
+  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(63508) & 15u;   // HW_REG_XCC_ID (hwreg 20, offset 0, 4 bits)
+  __hip_atomic_fetch_or(g.ticket + t, 0x10000u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t had = __hip_atomic_fetch_add(g.ticket + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (had + 1u != g.n_segs) return;
+  if ((had & 0xFFFFu) + 1u != g.n_segs) return;
   // this lane completed the track: the seams in order.  All stood (nearly always): the track's state for the next render is the
   // last segment's.  One did not: this lane plans the rest of the track again, from the state the segment before really ended
   // with (every other lane of the track is done: nobody writes those rows any more).
@@ -114,6 +121,8 @@ __device__ __forceinline__ void plan_seg_body(const PlanArgs& a, const SegArgs& 
   };
   const uint32_t bad = plan_check_seams(a, t, g.n_segs, g.guess, g.ends, get);
   if (bad < g.n_segs) {   // (rare: the lanes of this wave that are done wait for it)
+    const uint32_t xccs = had >> 16;
+    if (xccs & (xccs - 1u)) raise_status(a.status, 128u);   // the track's segments sat behind more than one L2
     plan_redo_track(a, t, bad, g.seg_len, tv, get(&g.ends[(size_t)t * g.n_segs + bad - 1u]));
     if (g.stats) {
       atomicAdd(g.stats + 0, 1u);
@@ -145,7 +154,7 @@ __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t 
   const int16_t WBX_GLOBAL* b16 = as_global<int16_t>(base);
   const int32_t WBX_GLOBAL* b32 = as_global<int32_t>(base);
   if (sg.speed == 1.0) {
-    const uint32_t idx = (uint32_t)sg.pos + jj;                          // :107
+    const uint32_t idx = u32_of_double_x86(sg.pos) + jj;                 // :107 (the low word, as x86-64 converts)
     switch (sg.format) {
       case FMT_F32: return bf[idx];
       case FMT_I16: {
@@ -164,29 +173,33 @@ __device__ __forceinline__ float sample_at(const DSeg& sg, uint32_t c, uint32_t 
   }
   const double x = __dadd_rn(sg.pos, __dmul_rn((double)(int32_t)jj, sg.speed));   // :50
   const long long ix = (long long)x;                                               // :51
-  const float fx = (float)__dsub_rn(x, (double)ix);                                // :52
+  const float fx = (float)__dsub_rn(x, (double)ix);                                // :52 (negative for x < 0: ix truncates)
+  // Q12: a NEGATIVE playback speed (calc_resize_clip's stretch, clip_edit.h:59-67,110-118) runs the position
+  // below zero; the reference then reads the heap in front of the channel array (sampler.cpp:53-54, undefined).  A tap at
+  // a negative index reads 0 — never memory in front of the clip.
+  const bool ta = ix >= 0, tb = ix >= -1;
   float a, b;
   switch (sg.format) {
     case FMT_F32:
-      a = bf[ix];
-      b = bf[ix + 1];
+      a = ta ? bf[ix] : 0.0f;
+      b = tb ? bf[ix + 1] : 0.0f;
       break;
     case FMT_I16: {
       const float norm = (float)(1.0 / 32767.0);                                   // :9-10
-      a = __fmul_rn(norm, (float)b16[ix]);
-      b = __fmul_rn(norm, (float)b16[ix + 1]);
+      a = __fmul_rn(norm, (float)(ta ? b16[ix] : (int16_t)0));
+      b = __fmul_rn(norm, (float)(tb ? b16[ix + 1] : (int16_t)0));
       break;
     }
     case FMT_I24: {
       const double norm = 1.0 / 8388607.0;                                         // :11-12
-      a = (float)__dmul_rn(norm, (double)b32[ix]);
-      b = (float)__dmul_rn(norm, (double)b32[ix + 1]);
+      a = (float)__dmul_rn(norm, (double)(ta ? b32[ix] : 0));
+      b = (float)__dmul_rn(norm, (double)(tb ? b32[ix + 1] : 0));
       break;
     }
     default: {
       const double norm = 1.0 / 2147483647.0;                                      // :13-14
-      a = (float)__dmul_rn(norm, (double)b32[ix]);
-      b = (float)__dmul_rn(norm, (double)b32[ix + 1]);
+      a = (float)__dmul_rn(norm, (double)(ta ? b32[ix] : 0));
+      b = (float)__dmul_rn(norm, (double)(tb ? b32[ix + 1] : 0));
       break;
     }
   }
@@ -207,7 +220,9 @@ __device__ __forceinline__ f4 render_generic(const DTrackBlock& tb, const DSeg* 
     if (j0 + 4u <= d0 || j0 >= d0 + n) continue;   // none of the lane's frames lies in this segment
     // fp32 segments whose source positions stay below 2^31 (all but multi-hour clips): 32-bit index math, and one
     // 16-B load for a lane whose four frames all lie inside a unity-speed segment
-    const bool small = sg.pos >= 0.0 && sg.pos + (double)n * (sg.speed > 1.0 ? sg.speed : 1.0) < 2147483000.0;
+    // (and a speed above zero: a negative one runs the position below zero, where `fract` is not x - trunc(x) and the
+    //  taps in front of the clip read 0 — sample_at, Q12)
+    const bool small = sg.pos >= 0.0 && sg.speed > 0.0 && sg.pos + (double)n * (sg.speed > 1.0 ? sg.speed : 1.0) < 2147483000.0;
     if (sg.format == FMT_F32 && small) {
       const float WBX_GLOBAL* bf = as_global<float>(c ? sg.src[1] : sg.src[0]);
       if (sg.speed == 1.0) {
@@ -603,22 +618,35 @@ const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int fam
   return launch_mix_fam0(a, n_blocks, variant, s, t0, t1);
 }
 
+// The spread sum's ticket barrier needs every workgroup of the grid resident at once: at most one per CU the process may use.
+// A CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) takes CUs away without the attribute saying so: no spreading then.  (A device
+// shared with another process can still hold workgroups back; the barrier's wait is bounded, a give-up is reported and the
+// block is mixed again through three launches — wbx_engine_process — and the context stops spreading.)
 uint32_t callback_spread_limit() {
   static const uint32_t n_cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     return (uint32_t)(n > 0 ? n : 0);
   }();
-  static const bool no_spread = [] { const char* v = std::getenv("WBX_CB_SPREAD"); return v && v[0] == '0'; }();   // A/B aid
+  static const bool no_spread = [] {
+    const char* v = std::getenv("WBX_CB_SPREAD");   // A/B aid
+    if (v && v[0] == '0') return true;
+    for (const char* name : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK"}) {
+      const char* m = std::getenv(name);
+      if (m && m[0]) return true;
+    }
+    return false;
+  }();
   return no_spread ? 0u : (n_cus < 256u ? n_cus : 256u);
 }
 
-const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s0, uint32_t* done, uint32_t done_base, bool spread,
-                            uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st) {
+const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& s0, uint32_t* done, uint32_t done_base, uint32_t done_base2, bool spread,
+                            uint32_t* gave_up, uint32_t spin_bound, uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st) {
   SumArgs s = s0;
   s.n_blocks = 1u;
   static const bool fenced = [] { const char* v = std::getenv("WBX_CB_FENCED"); return v && v[0] == '1'; }();   // A/B aid
-  CallbackArgs cb{done, spread ? 1u : 0u, done_base, flag, seq, m.n_groups, fenced ? 1u : 0u, dbg};
+  // (the election word: word 1 of the counter block — the counters' own words are multiples of kCbStride)
+  CallbackArgs cb{done, spread ? 1u : 0u, done_base, done_base2, done + 1, gave_up, flag, seq, m.n_groups, fenced ? 1u : 0u, spin_bound, dbg};
   if (family == 1 || family == 3) return launch_callback_fam1(m, p, s, cb, st);   // (3 = 1 without the per-frame taps: one instance serves both)
   if (family == 2) return launch_callback_fam2(m, p, s, cb, st);
   return launch_callback_fam0(m, p, s, cb, window_rows, st);

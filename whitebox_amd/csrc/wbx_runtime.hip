@@ -264,6 +264,21 @@ wbx_status ensure_gen_capacity(wbx_ctx* c, size_t rows) {
   return WBX_OK;
 }
 
+// The overflow pool (stream calls 3.. of a block) at twice its default size, once: a render planned by segments leaves the
+// chunks of replaced segments allocated (grow-only; a host that set wbx_config.max_segments keeps exactly that budget).
+wbx_status ensure_pool_slack(wbx_ctx* c) {
+  if (c->cfg.max_segments) return WBX_OK;
+  const size_t chunks = 2 * std::max<size_t>(1024, (size_t)c->cfg.max_blocks * c->cfg.max_tracks / 8);
+  for (auto& B : c->pb) {
+    if (chunks <= B.pool_chunks) continue;
+    WBX_HIP(c, hipStreamSynchronize(c->plan_stream));
+    WBX_HIP(c, sync_main(c));
+    WBX_HIP(c, B.pool.ensure(chunks * kChunk));
+    B.pool_chunks = (uint32_t)chunks;
+  }
+  return WBX_OK;
+}
+
 // pre-render of the queued generic records of the current plan buffer
 wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
   const uint32_t C = c->cfg.channels, F = c->cfg.block_frames;
@@ -547,7 +562,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     if (!c->d_cb_done) {
       WBX_HIP(c, hipMalloc((void**)&c->d_cb_done, kCbDoneWords * sizeof(uint32_t)));   // (two spread counters: wbx_callback.h)
       WBX_HIP(c, hipMemsetAsync(c->d_cb_done, 0, kCbDoneWords * sizeof(uint32_t), ms));
-      c->cb_base = 0;
+      c->cb_base = c->cb_base2 = 0;
     }
     unsigned long long* cb_dbg = nullptr;
     {
@@ -561,11 +576,17 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     m.partial_through = (std::getenv("WBX_CB_FENCED") && std::getenv("WBX_CB_FENCED")[0] == '1') ? 0u : 1u;
     // every workgroup adds a share of the master when the whole grid is resident at once (at most one workgroup per CU: two
     // fit) and the engine's pinned block has a completion word for each of them
-    const bool spread = !fused && m.n_groups <= callback_spread_limit();
+    const bool spread = !fused && !c->cb_no_spread && m.n_groups <= callback_spread_limit();
     c->cb_flags = 1u;
-    c->mix_kernel_name = launch_callback(m, *c->cb_plan, s, c->d_cb_done, c->cb_base, spread, c->cb_flag, c->cb_seq, mix_family(c),
+    c->mix_kernel_name = launch_callback(m, *c->cb_plan, s, c->d_cb_done, c->cb_base, c->cb_base2, spread, c->cb_gave_up, c->cb_spin_bound, c->cb_flag, c->cb_seq, mix_family(c),
                                          c->has_window_clips || c->has_integer_clips, cb_dbg, ms);
-    if (!fused) c->cb_base += m.n_groups;   // (a one-group block takes no ticket)
+    // (a one-group block takes no ticket; a grid larger than the device — "the last workgroup adds everything" — only the
+    //  first one: the second counter has a base of its own, or the first spread launch after such a block would wait for a
+    //  count that wrapped)
+    if (!fused) c->cb_base += m.n_groups;
+    if (spread) c->cb_base2 += m.n_groups;
+    c->cb_launches++;
+    if (spread) c->cb_spread_launches++;
     c->cb_launched = true;
     // (no event behind it: wbx_engine_process waits for the launch's own word before it returns, nothing can overlap it)
   } else if (!fused) {
@@ -697,6 +718,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     if (ok) ok = hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking) == hipSuccess;
     // measured (tools/ab_alt.sh): with consecutive mixes on alternating streams the two kernels share the device for
     // their whole length (each takes 1.05-1.2 ms instead of 0.74) and the step time does not move — off by default
+    if (const char* sb = std::getenv("WBX_CB_SPIN_BOUND")) c->cb_spin_bound = (uint32_t)std::atoi(sb);   // (tests: 0 forces the give-up path)
     const char* ma = std::getenv("WBX_MIX_ALT");
     c->mix_alternate = ma && ma[0] == '1';
     if (!ok) {
@@ -1410,6 +1432,14 @@ wbx_status wbx::plan_status_to_error(wbx_ctx* c, uint32_t bits) {
   if (bits & 3u) return fail(c, WBX_ERR_OVERFLOW, "segment plan overflow (raise wbx_config.max_segments)");
   if (bits & 8u) return fail(c, WBX_ERR_OVERFLOW, "more boundary / non-fp32 track-blocks than pre-render rows");
   if (bits & 16u) return fail(c, WBX_ERR_OVERFLOW, "plan template array full");
+  if (bits & 128u) {
+    // the segmented sequencer planned a track again over rows its first versions of which were written behind another L2
+    // (the workgroup-id -> XCD layout plan_seg_kernel rests on did not hold on this device): the rows of that render are in
+    // doubt, it says so, and the engine plans by one lane per track from here on
+    c->seg_broken = true;
+    return fail(c, WBX_ERR_DEVICE, "the segmented sequencer's lanes of one track ran on more than one XCD and a seam was planned again: "
+                                   "this render is invalid, later renders are planned by one lane per track");
+  }
   if (bits & 96u) {
     // the chained hand-over rests on in-order workgroup dispatch and on a block's pieces sharing an XCD; a render that saw
     // either fail says so — its results are invalid — and the context walks whole lists from here on (same order of

@@ -34,11 +34,23 @@ __host__ __device__ inline double beat_to_samples(double beat, double sample_rat
   return sec * sample_rate;
 }
 
-// (uint32_t)std::ceil(x) as x86-64 evaluates it: convert through a signed 64-bit integer, keep the low word.
-__host__ __device__ inline uint32_t u32_of_ceil(double x) {
-  double c = ceil(x);
-  return (uint32_t)(uint64_t)(long long)c;
+// Float -> integer conversions the reference leaves to the compiler where the value may be out of range (undefined in C++,
+// deterministic in the compiled engine): stated here as x86-64 performs them, because the device's own conversions SATURATE
+// and the host's do not.  cvttsd2si: truncation towards zero; NaN and anything outside [-2^63, 2^63) give 0x8000000000000000.
+__host__ __device__ inline long long i64_of_double_x86(double x) {
+  if (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) return (long long)0x8000000000000000ull;
+  return (long long)x;
 }
+// (uint64_t)x / (size_t)x — track.cpp:378-379,399-400 `(size_t)(start_offset + sample_pos * speed)`, negative for a clip that
+// plays backwards (quirk Q12): below 2^63 the signed conversion reinterpreted (a negative x wraps to 2^64 + trunc(x)), from
+// 2^63 on the conversion of x - 2^63 with the top bit flipped — the two branches gcc emits
+__host__ __device__ inline uint64_t u64_of_double_x86(double x) {
+  if (x >= 9223372036854775808.0) return (uint64_t)i64_of_double_x86(x - 9223372036854775808.0) ^ 0x8000000000000000ull;
+  return (uint64_t)i64_of_double_x86(x);
+}
+// (uint32_t)x — sampler.cpp:104,107: converted through a signed 64-bit integer, the low word kept
+__host__ __device__ inline uint32_t u32_of_double_x86(double x) { return (uint32_t)(uint64_t)i64_of_double_x86(x); }
+__host__ __device__ inline uint32_t u32_of_ceil(double x) { return u32_of_double_x86(ceil(x)); }
 
 // the plan's status word (PlanArgs::status): tracks raise their bits side by side — on the device an atomic OR (the one-launch
 // callback reads the word in the same launch, from behind another L2: a plain read-modify-write could stay in a cache)
@@ -363,19 +375,19 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
     if (min_time >= start_time) {                                // :357-374 started from the beginning
       double offset_from_start = beat_to_samples(min_time - start_time, sample_rate, beat_duration);
       double sample_offset = sample_position + offset_from_start;
-      uint32_t buffer_offset = mod_buffer((uint64_t)sample_offset, buffer_size);
-      w.on_event(EV_PLAY, buffer_offset, clip->speed, (uint64_t)clip->start_offset, clip);
+      uint32_t buffer_offset = mod_buffer(u64_of_double_x86(sample_offset), buffer_size);
+      w.on_event(EV_PLAY, buffer_offset, clip->speed, u64_of_double_x86(clip->start_offset), clip);
       clear_state_changed(clip, &clips[next_clip], flags_left);
     } else if (start_time > min_time && !st->partially_ended) {  // :375-393 started in the middle
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
-      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      uint64_t sample_offset = u64_of_double_x86(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
       clear_state_changed(clip, &clips[next_clip], flags_left);
     } else if (clip->internal_state_changed && st->partially_ended) {  // :394-419
       double relative_start_time = start_time - min_time;
       double sample_pos = beat_to_samples(relative_start_time, sample_rate, beat_duration);
-      uint64_t sample_offset = (uint64_t)(clip->start_offset + (sample_pos * clip->speed));
+      uint64_t sample_offset = u64_of_double_x86(clip->start_offset + (sample_pos * clip->speed));
       w.on_event(EV_STOP, 0, 0.0, 0, nullptr);
       w.on_event(EV_PLAY, 0, clip->speed, sample_offset, clip);
       clear_state_changed(clip, &clips[next_clip], flags_left);
@@ -384,7 +396,7 @@ __host__ __device__ inline void process_event(BlockWalker& w, DClip* clips, uint
     if (max_time <= end_time) {                                  // :421-434 reaching the end of the clip
       double offset_from_start = beat_to_samples(max_time - start_time, sample_rate, beat_duration);
       double sample_offset = sample_position + offset_from_start;
-      uint32_t buffer_offset = mod_buffer((uint64_t)sample_offset, buffer_size);
+      uint32_t buffer_offset = mod_buffer(u64_of_double_x86(sample_offset), buffer_size);
       w.on_event(EV_STOP, buffer_offset, 0.0, 0, nullptr);
       st->partially_ended = 0;
     } else {                                                     // :435-442

@@ -370,6 +370,13 @@ class Engine:
         _check(self.L.wbx_engine_sequencer_stats(self.h, out), "wbx_engine_sequencer_stats", self.h, True)
         return tuple(int(x) for x in out)
 
+    def callback_stats(self):
+        """(blocks run as one launch, ... with the sum spread over the workgroups, blocks mixed again after a give-up at the
+        spread barrier, 1 when the engine has stopped spreading)"""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.wbx_engine_callback_stats(self.h, out), "wbx_engine_callback_stats", self.h, True)
+        return tuple(int(x) for x in out)
+
     def thread_stats(self):
         """(locked edits the last process / render had seen, per-track cumulative drained parameter messages)"""
         n = len(self.tracks)
