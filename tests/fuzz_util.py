@@ -273,13 +273,15 @@ def wild_session(seed):
     return spec, n_blocks
 
 
-def run_wild_script(seed, spec, n_blocks, e, eng, on_block, edits=True):
+def run_wild_script(seed, spec, n_blocks, e, eng, on_block, edits=True, pieces=False):
     """Plays the session block by block on the oracle `e` and an engine `eng` (whitebox_amd.engine.Engine or
     tests/host_sim.HostSimEngine); with `edits`, 0-2 operations of everything a host can do go between two blocks: parameter
     messages, stop / play, seeks, tempo changes, clip gain / delete / move / resize (shift, stretch — shrinks that leave a
     NEGATIVE speed behind included), adds around the playhead, region deletes, track moves and deletes.  The clip lists must
-    agree bit for bit after every operation; on_block(b, trail) renders and compares one block.  Returns the number of stream
-    calls that ran a tap index below zero (quirk Q12)."""
+    agree bit for bit after every operation; on_block(b, trail) renders and compares one block — with `pieces`,
+    on_block(b, trail, k) renders k = 1 … 16 blocks from block b on (the operations then fall between pieces; from 8 blocks on
+    a piece takes the batch path) and counts the Q12 calls itself.  Returns the number of stream calls that ran a tap index
+    below zero (quirk Q12)."""
     rng = np.random.default_rng(seed * 104729 + 71)
     unit = spec.block / (spec.sample_rate * 60.0 / spec.bpm)
     total = n_blocks * unit
@@ -289,7 +291,10 @@ def run_wild_script(seed, spec, n_blocks, e, eng, on_block, edits=True):
         assert clip_rows(eng.clips(eng.tracks[t])) == clip_rows(e.clips(t)), ("initial clip list", t)
     e.play()
     eng.play()
-    for b in range(n_blocks):
+    rng_k = np.random.default_rng(seed * 31337 + 3)
+    b = -1
+    while b + 1 < n_blocks:
+        b += 1
         for _ in range(int(rng.integers(0, 3)) if edits else 0):
             if nt == 0:
                 break
@@ -339,6 +344,16 @@ def run_wild_script(seed, spec, n_blocks, e, eng, on_block, edits=True):
                 sl = int(rng.integers(0, nt)); e.delete_track(sl); eng.delete_track(sl); nt -= 1
             for tt in range(nt):
                 assert clip_rows(eng.clips(eng.tracks[tt])) == clip_rows(e.clips(tt)), ("clip list", trail[-1], tt)
+        if pieces:
+            k = min(int(rng_k.integers(1, 17)), n_blocks - b)
+            q12 += on_block(b, trail, k) or 0
+            b += k - 1
+            continue
         on_block(b, trail)
-        q12 += sum(1 for sg in e.seglog() if sg[4] < 0 and sg[2] > 0 and sg[3] + (sg[2] - 1) * sg[4] <= -1.0)
+        q12 += q12_calls(e.seglog())
     return q12
+
+
+def q12_calls(seglog):
+    """stream calls of a block's log that run a tap index below zero (quirk Q12)"""
+    return sum(1 for sg in seglog if sg[4] < 0 and sg[2] > 0 and sg[3] + (sg[2] - 1) * sg[4] <= -1.0)

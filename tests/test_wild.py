@@ -198,6 +198,32 @@ def test_host_sequencer_wild_sessions_batched(seed, segments):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", range(1000, 1100))
+def test_host_sequencer_wild_scripts_in_pieces(seed):
+    """the host's operations between RENDERS of 1 … 16 blocks (steady runs, shared templates and the overflow pool across the
+    operations): the stream calls of every piece against the oracle's block-by-block log"""
+    spec, n_blocks = FZ.wild_session(seed)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    sim = HS.build_sim_engine(spec, max_blocks=16, masked_rows=[0, 1, 4][seed % 3])
+
+    def on_piece(b, trail, k):
+        rows, q12 = [], 0
+        for i in range(k):
+            e.process()
+            rows += oracle_rows(e, i)
+            q12 += FZ.q12_calls(e.seglog())
+        sim.render(k)
+        assert plan_rows(sim.fetch_plan()) == rows, (seed, b, k, trail[-4:])
+        return q12
+
+    FZ.run_wild_script(seed, spec, n_blocks, e, sim, on_piece, pieces=True)
+    ph, sp, _ = sim.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
+    e.close()
+    sim.close()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the device
 # ----------------------------------------------------------------------------------------------------------------------
@@ -298,5 +324,39 @@ def test_wild_sessions_batched_on_the_device(seed):
     assert plan_rows(eng.fetch_plan()) == rows
     assert np.array_equal(bits(m), bits(np.stack(oms)))
     assert np.array_equal(pk, np.stack(opk)[..., :spec.channels])
+    e.close()
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBX_WILD_PIECES_FROM", "1000")), int(os.environ.get("WBX_WILD_PIECES_TO", "1040"))))
+def test_wild_scripts_in_pieces_on_the_device(seed):
+    """the wild scripts with the host's operations BETWEEN RENDERS of 1 … 16 blocks (from 8 blocks on the batch path: sequencer
+    on the plan stream, pre-render pass, chained / grouped sums): every block of every piece against the oracle"""
+    from whitebox_amd.engine import build_engine
+    spec, n_blocks = FZ.wild_session(seed)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    eng = build_engine(spec, max_blocks=16)
+
+    def on_piece(b, trail, k):
+        oms, opk, rows, q12 = [], [], [], 0
+        for i in range(k):
+            om, _ = e.process()
+            oms.append(om[:spec.channels])
+            opk.append(e.peaks())
+            rows += oracle_rows(e, i)
+            q12 += FZ.q12_calls(e.seglog())
+        eng.render(k)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert plan_rows(eng.fetch_plan()) == rows, (seed, b, k, trail[-4:])
+        assert np.array_equal(bits(m), bits(np.stack(oms))), (seed, b, k, trail[-4:])
+        nt = len(eng.tracks)
+        assert np.array_equal(pk[:, :nt], np.stack(opk)[:, :nt, :spec.channels]), (seed, b, k, trail[-4:])
+        return q12
+
+    FZ.run_wild_script(seed, spec, n_blocks, e, eng, on_piece, pieces=True)
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == (O.f64_bits(e.playhead), O.f64_bits(e.sample_position))
     e.close()
     eng.close()

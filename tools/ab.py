@@ -110,6 +110,8 @@ def presets(other_lib=None):
     if other_lib:   # head-to-head of two builds of libwbx.so
         P["lib"] = [case(f"{w} {'other' if o else 'this'}", f"WBX_LIB={other_lib}" if o else "", f"--workload {w} {STD}")
                     for w in ("c3", "c4", "i16r", "c2") for o in (0, 1)]
+        P["lib_rev"] = [case(f"{w} {'other' if o else 'this'}", f"WBX_LIB={other_lib}" if o else "", f"--workload {w} {STD}")
+                        for w in ("c4", "c2", "u4096") for o in (1, 0)]
     return P
 
 

@@ -219,7 +219,9 @@ struct MixArgs {
   float* peaks;                 // [K][N][C]
   uint32_t* levels;             // [N][C] running maxima (VUMeter::level) as uint images, or null
   uint32_t n_tracks, n_groups, block_frames, channels;
-  uint32_t tiles;               // ceil(C*F/4 / 256)
+  uint32_t tiles;               // ceil(C*lane_span / 256)
+  uint32_t lane_span;           // lanes the instance gives one channel of one block: F/4 for a block of the instance's own
+                                // size, the next such size above it otherwise (the lanes beyond F/4 clone the last four frames)
   uint32_t n_blocks;            // K (the sub-block instances of the mix kernel cover ceil(K/SB) workgroups per group)
   uint32_t masked_rows;         // rows may be ROW_PAIR / partial-coverage (PlanArgs::masked_rows of the same render)
   uint32_t* chain;              // chained render: [workgroup columns][n_groups] "this piece's running sum is out" words
@@ -282,6 +284,23 @@ struct MipArgs {
   MipNode* tile_nodes;        // [tiles + tiles/4 + 1] the level-5 node of every tile, then scratch of the upper levels
   uint32_t n_tiles;
 };
+
+// The lane space of the instance a block of F = 4 * S4 frames and C channels takes (MixArgs::lane_span): lanes per channel and
+// block.  The instances are cut for blocks of 128 frames (stereo), 256, 512, 1024 ... — what the reference's settings dialog
+// offers (ui/settings.cpp:22-24) — but the block a device back end really opens is its period, realigned to 32 frames
+// (config.cpp:146-149,217-222): 480 frames for WASAPI's 10 ms at 48 kHz, 416 at 44.1 kHz, 960 for 20 ms.  Such a block takes
+// the next shape above it; its surplus lanes clone the block's last four frames (wbx_mix.h).  WBX_RAGGED=0: the general
+// instance of earlier rounds instead (A/B aid).
+inline uint32_t native_lane_span(uint32_t C, uint32_t S4) {
+  const uint32_t lanes = C * S4;
+  const bool exact = ((lanes % 256u == 0u) && (S4 % 64u == 0u)) || (C == 2u && S4 == 32u) ||
+                     (S4 % 64u == 0u && (lanes == 128u || lanes == 64u));
+  if (exact) return S4;
+  if (const char* v = std::getenv("WBX_RAGGED"))
+    if (v[0] == '0') return S4;
+  if (C == 2u) return S4 <= 32u ? 32u : S4 <= 64u ? 64u : S4 <= 128u ? 128u : S4 <= 256u ? 256u : (S4 + 127u) / 128u * 128u;
+  return S4 <= 64u ? 64u : S4 <= 128u ? 128u : S4 <= 256u ? 256u : (S4 + 255u) / 256u * 256u;
+}
 
 // Does a render of n_blocks short blocks (shorter than a 256-lane workgroup) of a session cut into clips take the PACKED
 // masked-row instance (mix_kernel_x) instead of one block per workgroup?  Measured (tools/ab.py packed, profiles/r04_ab_packed.txt):

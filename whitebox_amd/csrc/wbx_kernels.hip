@@ -604,7 +604,7 @@ void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s) {
 // which instance of the hot kernel a render takes: the family's translation unit holds the instances
 // (family 0: fp32 + integer PCM at unity speed; 1: everything; 2: sessions of 16-bit PCM only)
 const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  const uint32_t S4 = a.block_frames >> 2;
+  const uint32_t S4 = a.lane_span;          // (lanes per channel and block of the instance's lane space: F/4, or the next shape above it)
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (family == 3) return launch_mix_fam3(a, n_blocks, variant, s, t0, t1);   // (falls back to family 1 for shapes it has no instance for)

@@ -284,18 +284,31 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   const DGroup grp = a.groups[g];
   const uint32_t F = a.block_frames, C = a.channels, N = a.n_tracks;
   const uint32_t S4 = F >> 2;
-  // SB > 1 (blocks shorter than a workgroup: C*F/4 * SB == 256): the workgroup renders SB consecutive blocks, every
+  // Block sizes between the shapes the instances are cut for (round 5).  A device period is whatever the back end grants — 10 ms
+  // of WASAPI shared mode are 480 frames at 48 kHz, 441 -> 416 at 44.1 kHz once config.cpp:217-222 has realigned them to 32 —
+  // and such a block used to fall to the general instance (lane predicates, records per lane from LDS: 0.29-0.33 of the
+  // roofline against 0.67).  Now the FULL instances serve it: the instance's lane space gives every channel of a block
+  // MixArgs::lane_span lanes (>= F/4: the next shape an instance exists for), and the lanes beyond F/4 CLONE the block's last
+  // four frames — same addresses (cache hits), same values (a maximum does not change), nothing stored.  Every wave still
+  // stays inside one channel of one block, records stay wave-uniform, no lane predicate anywhere in the loops; a block of the
+  // instance's own size has lane_span = F/4 and no clones.
+  const uint32_t Lc = FULL ? a.lane_span : S4;
+  // SB > 1 (blocks shorter than a workgroup: C*Lc * SB == 256): the workgroup renders SB consecutive blocks, every
   // wave stays inside one (sub-block, channel) and reads its own sub-block's records
-  const uint32_t sub = SB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / (C * S4))) : 0u;
+  const uint32_t sub = SB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / (C * Lc))) : 0u;
   const uint32_t rb = sub * kRecs;                 // this wave's records in s_tb
   const uint32_t b = bx * SB + sub;
   const bool bvalid = SB == 1 || b < a.n_blocks;   // the last workgroup of an odd render has an empty sub-block
-  const uint32_t slot = SB > 1 ? tid - sub * (C * S4) : tile * kT + tid;
+  const uint32_t slot = SB > 1 ? tid - sub * (C * Lc) : tile * kT + tid;
   const bool active = FULL ? true : (slot < C * S4);
-  uint32_t c = active ? slot / S4 : 0u;
+  uint32_t c = active ? slot / Lc : 0u;
+  if (FULL && CL == 1 && c >= C) c = C - 1u;                    // (a spare wave behind the last channel's: clones, too)
   if (FULL && CW == 1) c = __builtin_amdgcn_readfirstlane(c);   // CW == 2: lanes 0-31 channel 0, lanes 32-63 channel 1
+  const uint32_t jn = active ? slot - (slot / Lc) * Lc : 0u;    // the lane's place among its channel's lanes
   if (CL == 2) c = 0u;                                          // both channels in every lane: element ch of the arrays below
-  const uint32_t j0 = active ? (slot - c * S4) * 4u : 0u;
+  // `owns`: the lane's four frames are the block's (not a clone of its last four) and this lane stores them
+  const bool owns = FULL ? (jn < S4 && slot < C * Lc) : active;
+  const uint32_t j0 = active ? (jn < S4 ? jn : S4 - 1u) * 4u : 0u;
   // lanes of an aligned `span`-lane group share a channel (span = largest power of two dividing F/4, <= 64)
   uint32_t span = 64u;
   if (!FULL) {
@@ -314,7 +327,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   // MixArgs::init: the running sum of the tracks BEFORE this engine's in the session's track order (another engine's
   // un-clamped master: the previous shard of a multi-GPU chain) — the first group in summation order starts from it instead
   // of the cleared buffer, so the additions continue exactly where that engine stopped
-  if (a.init && g == 0u && active && bvalid) {
+  if (a.init && g == 0u && owns && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++)
       acc.c[ch] = *reinterpret_cast<const f4*>(a.init + ((size_t)b * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0);
@@ -414,6 +427,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   };
   const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);   // FULL: the wave's first frame
   constexpr uint32_t kWF = CW == 2 ? 128u : 256u;   // ... and how many it covers (CW == 2: the 128 frames of the block, once per half-wave)
+  const uint32_t wave_end = wave_base + kWF < F ? wave_base + kWF : F;   // (a block shorter than the instance's lane space ends earlier)
   // Masked rows (EXP).  Frame j0+e of the block is frame (j0+e-d) of the stream call; clamped into the call, so that
   // what the masked-out frames of a lane load stays inside the clip — they are zeroed afterwards.  For a whole-block
   // record (d = 0, n = F) this is j0+e itself.
@@ -999,12 +1013,12 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         constexpr std::integral_constant<bool, MODE != MODE_W> narrow{};
         constexpr std::integral_constant<bool, MODE == MODE_WNU> uni{};
         if (EXP && r.partial) {   // a stream call that covers part of the block (wave-uniform)
-          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
+          if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's 256 frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (G && (fmt != FMT_F32 || k == KIND_UNITY_I32)) {   // 24 / 32-bit PCM (G instances only)
             if constexpr (G) m = partial_any(pre[u], k, fmt, false);
-          } else if (r.d <= wave_base && r.d + r.n >= wave_base + kWF) {   // ... all of this wave's frames
+          } else if (r.d <= wave_base && r.d + r.n >= wave_end) {   // ... all of this wave's frames
             if (k == KIND_WINDOW)
               m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
@@ -1027,10 +1041,10 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         const bool win = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16;
         constexpr std::integral_constant<bool, MODE != MODE_WI> narrow{};
         if (EXP && (LEAN16 || G) && r.partial) {   // a stream call that covers part of the block (wave-uniform)
-          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+          if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-          } else if (r.d <= wave_base && r.d + r.n >= wave_base + kWF) {   // ... all of them
+          } else if (r.d <= wave_base && r.d + r.n >= wave_end) {   // ... all of them
             if (win)
               m = row_window16_shifted(narrow, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
@@ -1047,7 +1061,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         const uint32_t fmt = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format);
         constexpr std::integral_constant<bool, MODE == MODE_MWN> narrow{};
         if (EXP && r.partial) {   // a stream call that covers part of the block
-          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+          if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else {
@@ -1081,8 +1095,8 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         const int k = MODE == MODE_U ? KIND_UNITY : MODE == MODE_I16 ? KIND_UNITY_I16 : MODE == MODE_I32 ? KIND_UNITY_I32
                                                   : __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t fmt = (MODE == MODE_I32 || MODE == MODE_MU) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) : 0u;
-        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_base + kWF)) {   // a stream call that covers part of the block
-          if (r.d >= wave_base + kWF || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
+        if (EXP && r.partial && !(r.d <= wave_base && r.d + r.n >= wave_end)) {   // a stream call that covers part of the block
+          if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (k == KIND_UNITY_I16) {   // ... some: normalise the four loaded samples, then select and mask as for fp32
@@ -1529,7 +1543,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         }
       }
       __syncthreads();
-      if (active && bvalid) {
+      if (owns && bvalid) {
 #pragma unroll
         for (int ch = 0; ch < CL; ch++) {
           const uint32_t* src = reinterpret_cast<const uint32_t*>(
@@ -1635,7 +1649,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         a.fused_status_dst[tid] = a.fused_status_src[tid];
       if (a.fused_zero_status && queued == 0u) a.fused_status_src[tid] = 0u;
     }
-    if (active && bvalid) {
+    if (owns && bvalid) {
 #pragma unroll
       for (int ch = 0; ch < CL; ch++) {
         f4 m = acc.c[ch];
@@ -1656,7 +1670,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           *reinterpret_cast<f4*>(mo) = m;
       }
     }
-  } else if (active && bvalid) {
+  } else if (owns && bvalid) {
 #pragma unroll
     for (int ch = 0; ch < CL; ch++) {
       float* out = a.partial + (((size_t)b * a.n_groups + g) * C + (CL == 2 ? (uint32_t)ch : c)) * F + j0;

@@ -10,7 +10,7 @@ namespace wbx {
 const char* launch_mix_fam0(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const char* name = "";
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
-  const uint32_t S4 = a.block_frames >> 2;
+  const uint32_t S4 = a.lane_span;   // (the instance's lane space: F/4, or the next shape above it)
   const uint32_t lanes = a.channels * S4;   // lanes one block needs
   const bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   if (!full && a.masked_rows) {

@@ -9,7 +9,7 @@ namespace wbx {
 const char* launch_mix_fam2(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const char* name = "";
   const dim3 grid(n_blocks, a.n_groups, a.tiles), block(256);
-  const uint32_t S4 = a.block_frames >> 2;
+  const uint32_t S4 = a.lane_span;   // (the instance's lane space: F/4, or the next shape above it)
   if (variant >= 1000 && a.channels == 2u && S4 == 64u)          // 256-frame stereo blocks: one wave = one block
     WBX_MIX(2, true, 3, 2, 1, 1, 2, 64, grid, dim3(64))
   else if (variant == 1042 && a.channels == 2u && S4 == 128u && a.tiles == 1u)

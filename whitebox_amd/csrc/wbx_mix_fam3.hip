@@ -8,7 +8,7 @@ namespace wbx {
 const char* launch_mix_fam3(const MixArgs& a, uint32_t n_blocks, int variant, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const char* name = "";
   const dim3 grid(n_blocks, a.n_groups, a.tiles);
-  const uint32_t S4 = a.block_frames >> 2;
+  const uint32_t S4 = a.lane_span;   // (the instance's lane space: F/4, or the next shape above it)
   if (variant >= 1000 && a.channels == 2u && S4 == 128u && a.tiles == 1u) {
     // one row per pipeline batch: with two, this family's widest modes spill 84 B per lane at three waves per SIMD
     // (measured, one box: i24r 0.650 -> 0.690 of the roofline, mixr 0.501 -> 0.530, cut into clips +2-3 %; two waves per SIMD

@@ -131,7 +131,7 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 //  columns than resident workgroups several pieces of a block are resident TOGETHER and all but one of them wait — measured
 //  on the one-wave instances, 3072 resident: 0.25 of the roofline at 1024 columns, 0.45 at 2048, against 0.6 unchained)
 static uint32_t blocks_per_workgroup(const wbx_ctx* c, uint32_t K, uint32_t* resident) {
-  const uint32_t C = c->cfg.channels, S4 = c->cfg.block_frames >> 2, lanes = C * S4;
+  const uint32_t C = c->cfg.channels, S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2), lanes = C * S4;   // (the instance's lane space)
   *resident = 1u;
   if ((lanes % 256u == 0u) && (S4 % 64u == 0u)) return 1u;
   const char* e = std::getenv("WBX_MASKED_ROWS");
@@ -319,7 +319,7 @@ int mix_family(const wbx_ctx* c) {
 // rows), fp32 sessions of one clip per track 3-8 % slower (they fetch 1.06 x their bytes instead of 1.02 x) — those keep
 // one channel per wave.
 bool mix_two_channels_per_lane(const wbx_ctx* c) {
-  const uint32_t F = c->cfg.block_frames;
+  const uint32_t F = 4u * native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);   // (the block size of the instance's lane space)
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
   if (c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
   if (!(F == 512u || F == 1024u || F == 256u)) return false;
@@ -339,7 +339,7 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
 // 1: fp32 rows, unity or resampled; 2: also integer PCM at unity speed — sessions whose integer clips all play at the
 // session rate and that hold no resampled clip (those take the instances with the mixed-format window modes).
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
-  const uint32_t S4 = c->cfg.block_frames >> 2, lanes = c->cfg.channels * S4;
+  const uint32_t S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2), lanes = c->cfg.channels * S4;
   bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   // (256-frame stereo blocks: the one-wave instances with both channels per lane, the lean families only)
   if (!full && c->cfg.channels == 2u && S4 == 64u && (mix_family(c) == 0 || mix_family(c) == 2) && mix_two_channels_per_lane(c)) full = true;
@@ -364,7 +364,7 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
 // three launches of earlier rounds (A/B aid; results are identical).
 bool callback_is_one_launch(const wbx_ctx* c) {
   static const bool off = [] { const char* v = std::getenv("WBX_CALLBACK_FUSED"); return v && v[0] == '0'; }();
-  const uint32_t S4 = c->cfg.block_frames >> 2;
+  const uint32_t S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);   // (480-frame stereo blocks take the 512-frame instance)
   return !off && !c->dist && c->cfg.channels * S4 == 256u && (S4 % 64u) == 0u && !c->mix_unroll;
 }
 
@@ -426,7 +426,8 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.n_groups = n_groups;
   m.block_frames = F;
   m.channels = C;
-  m.tiles = ((C * F / 4) + 255u) / 256u;
+  m.lane_span = native_lane_span(C, F >> 2);
+  m.tiles = (C * m.lane_span + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
   // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
