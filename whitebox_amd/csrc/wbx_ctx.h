@@ -330,6 +330,7 @@ int mix_family(const wbx_ctx* c);
 bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 bool callback_is_one_launch(const wbx_ctx* c);
+uint32_t callback_lane_span(const wbx_ctx* c);   // lanes per channel of the one-launch callback's 256-lane workgroup, 0: three launches
 
 // wbx_dist.hip
 float* dist_begin_render(wbx_ctx* c, hipStream_t sum_stream, hipError_t* err);

@@ -362,10 +362,23 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
 // Does a one-block render of wbx_engine_process run as ONE launch (wbx_callback.h)?  Blocks that are exactly one 256-lane
 // workgroup (512-frame stereo, 1024-frame mono: the instances that exist), no multi-GPU exchange.  WBX_CALLBACK_FUSED=0: the
 // three launches of earlier rounds (A/B aid; results are identical).
+// (round 5) ... and every block that FITS one: the callback is a latency path — what counts is one dispatch instead of three, not
+// how many of the workgroup's lanes own frames — so a 128- or 256-frame stereo block (the low-latency settings of
+// ui/settings.cpp:22-24) runs through the same 256-lane instance with lane_span = 256 / C, its surplus lanes cloning the block's
+// last four frames (wbx_mix.h).  WBX_CB_ANY=0: only the shapes whose batch renders take a 256-lane workgroup per block.
+uint32_t callback_lane_span(const wbx_ctx* c) {
+  const uint32_t C = c->cfg.channels, S4 = c->cfg.block_frames >> 2;
+  const uint32_t nat = native_lane_span(C, S4);
+  if (C * nat == 256u && (nat % 64u) == 0u) return nat;
+  const char* v = std::getenv("WBX_CB_ANY");
+  if (v && v[0] == '0') return 0u;
+  if (const char* r = std::getenv("WBX_RAGGED"))
+    if (r[0] == '0') return 0u;
+  return C * S4 <= 256u ? 256u / C : 0u;
+}
 bool callback_is_one_launch(const wbx_ctx* c) {
   static const bool off = [] { const char* v = std::getenv("WBX_CALLBACK_FUSED"); return v && v[0] == '0'; }();
-  const uint32_t S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);   // (480-frame stereo blocks take the 512-frame instance)
-  return !off && !c->dist && c->cfg.channels * S4 == 256u && (S4 % 64u) == 0u && !c->mix_unroll;
+  return !off && !c->dist && callback_lane_span(c) != 0u && !c->mix_unroll;
 }
 
 // where the master of the render about to be issued goes; `writer` is the stream its last writer runs on
@@ -481,6 +494,10 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   // the kernel timer is for batch renders; the one-block callback path skips its three event records
   const bool timed = c->profiling && K > 1;
   const bool one_launch = c->cb_plan != nullptr && K == 1u && m.n_groups != 0u && callback_is_one_launch(c);
+  if (one_launch) {   // (the callback instance's own lane space: one 256-lane workgroup per block)
+    m.lane_span = callback_lane_span(c);
+    m.tiles = 1u;
+  }
   c->cb_launched = false;
   if (m.n_groups && !one_launch) {
     if (timed) {
