@@ -5,8 +5,8 @@ set -u
 O=gpurun_out/${1:-r05_cb}; mkdir -p $O
 for F in 128 256 480 512 64; do
   for ANY in 1 0; do
-    echo "== F=$F WBX_CB_ANY=$ANY"
+    echo "== F=$F WBX_CB_ANY=$ANY" | tee -a $O/callback_block_sizes.txt
     WBX_CB_ANY=$ANY timeout 300 python bench.py --block-frames $F --no-cpu-baseline --no-configs --no-verify --steps 2 --warmup 1 --ramp-steps 2 --latency-blocks 800 2>/dev/null \
-      | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['latency_mode']))"
+      | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['latency_mode']))" | tee -a $O/callback_block_sizes.txt
   done
 done
