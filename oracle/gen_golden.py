@@ -230,10 +230,50 @@ def gen_vu():
     np.savez_compressed(os.path.join(OUT, "vu.npz"), **arrs)
     print("vu.npz:", len(arrs) // 3, "cases")
 
+
+def ingest_inputs():
+    """(name, interleaved [frames][channels]) of the clip-ingest fixture: every storage format load_file hands to
+    deinterleave_samples (I16; I32 = 24- and 32-bit files; F32), 1-6 channels, lengths around the decoder's 1024-frame chunk,
+    extreme integers and float specials (NaN payloads, -0.0, infinities must come through untouched)"""
+    rng = np.random.default_rng(0x1A6E57)
+    out = []
+    for ch in (1, 2, 3, 6):
+        for frames in (1, 5, 1023, 1024, 1025, 2049):
+            if ch > 2 and frames not in (5, 1025):
+                continue
+            i16 = rng.integers(-32768, 32768, (frames, ch)).astype(np.int16)
+            i16[0, 0], i16[-1, -1] = -32768, 32767
+            out.append((f"i16_c{ch}_n{frames}", i16))
+            i32 = rng.integers(-2**31, 2**31, (frames, ch)).astype(np.int32)
+            i32[0, -1], i32[-1, 0] = 2**31 - 1, -2**31
+            out.append((f"i32_c{ch}_n{frames}", i32))
+            f = (rng.standard_normal((frames, ch)) * 0.5).astype(np.float32)
+            sp = np.array([0x7FC00001, 0xFFC12345, 0x7F800000, 0xFF800000, 0x80000000, 0x00000001], np.uint32).view(np.float32)
+            idx = rng.integers(0, frames, 6)
+            f[idx, rng.integers(0, ch, 6)] = sp
+            out.append((f"f32_c{ch}_n{frames}", f))
+    return out
+
+
+def gen_ingest():
+    """tests/golden/ingest.npz from the reference's own deinterleave_samples<T> under load_file's loop
+    (oracle/_ref/libwbref_deint.so)."""
+    if O.ref_deint() is None:
+        raise SystemExit("oracle/_ref/libwbref_deint.so is not built (needs /root/reference)")
+    arrs = {}
+    for name, a in ingest_inputs():
+        planar = O.ref_deinterleave(a)                      # [ch] of frames + 16 (sample_padding) elements
+        bits = {2: np.uint16, 4: np.uint32}[a.dtype.itemsize]
+        arrs[f"{name}.in"] = a.view(bits)
+        arrs[f"{name}.out"] = np.stack(planar).view(bits)
+    np.savez_compressed(os.path.join(OUT, "ingest.npz"), **arrs)
+    print("ingest.npz:", len(arrs) // 2, "cases")
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu"):     # (the other fixtures are untouched)
-        {"mip": gen_mip, "vu": gen_vu}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest"):     # (the other fixtures are untouched)
+        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest}[sys.argv[1]]()
     else:
         main()
         gen_mip()
         gen_vu()
+        gen_ingest()

@@ -1172,7 +1172,7 @@ void wbo_synth_f32(float* dst, size_t frames, uint64_t key, float amp, size_t pa
 
 
 /* ================================================================================================
- * next rows: clip ingest + waveform mip-maps (parity unpinned, see wb_oracle.h)
+ * next rows: clip ingest + waveform mip-maps (both pinned to the reference's own functions, see wb_oracle.h)
  * ================================================================================================ */
 
 /* dsp/sample.cpp:29-43 */

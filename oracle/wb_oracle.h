@@ -221,8 +221,13 @@ void wbo_track_process_event(wbo_engine* e, wbo_track* t, double start_time, dou
                                                                    /* track.cpp:258-451 (audio branch) */
 
 /* ---- next rows: clip ingest and waveform mip-maps ---------------------------------
- * Clip ingest: PARITY UNPINNED — dsp/sample.cpp needs libsndfile/vorbis/dr_mp3 (deinterleave_samples is typed on
- * sf_count_t), absent from the image; the reference holds no test or golden vector for it.
+ * Clip ingest: dsp/sample.cpp as a whole needs libsndfile/vorbis/dr_mp3, absent from the image; its transposition,
+ * deinterleave_samples<T> (:29-43), uses nothing of them but the NAME of libsndfile's count type.  oracle/Makefile cuts the
+ * function out of the file where it lies and ref_deint_driver.cpp compiles the text unmodified inside a class template whose
+ * parameter is called sf_count_t (instantiated at int64_t and int32_t) into _ref/libwbref_deint.so;
+ * tests/test_oracle_vs_ref.py holds wbo_deinterleave to it bit for bit and tests/golden/ingest.npz carries its outputs.
+ * load_file's own lines around it (sf_open / sf_readf_*, :112-197) cannot be built: the 1024-frame loop and the zeroed
+ * 16-frame padding are restated from the text (KAT-pinned).
  * Mip-maps: gfx/waveform_visual.cpp as a whole needs spdlog + the renderer, but its summariser (:9-173) needs only the
  * reference's core/ headers: oracle/Makefile compiles that function from the file where it lies into
  * _ref/libwbref_mip.so (ref_mip_driver.cpp), tests/test_oracle_vs_ref.py holds wbo_mip_summarize to it bit for bit and

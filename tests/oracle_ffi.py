@@ -231,6 +231,42 @@ def ref_mip_level(fmt: str, data: np.ndarray, level: int, quality: int) -> np.nd
     return out
 
 
+_ref_deint = None
+REF_DEINT_PATH = os.path.join(ORACLE_DIR, "_ref", "libwbref_deint.so")
+
+
+def ref_deint() -> Optional[C.CDLL]:
+    """The reference's own deinterleave_samples<T> (oracle/Makefile: cut out of dsp/sample.cpp where it lies and compiled
+    unmodified for any integer count type; None where oracle/_ref was never built)."""
+    global _ref_deint
+    if _ref_deint is None:
+        if not build_ref() or not os.path.exists(REF_DEINT_PATH):
+            return None
+        R = C.CDLL(REF_DEINT_PATH)
+        R.ref_deinterleave.restype = C.c_int64
+        R.ref_deinterleave.argtypes = [c_voidpp, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int]
+        R.ref_deinterleave_f32.restype = C.c_int64
+        R.ref_deinterleave_f32.argtypes = [c_voidpp, C.c_void_p, C.c_int64, C.c_int, C.c_int64]
+        _ref_deint = R
+    return _ref_deint
+
+
+def ref_deinterleave(interleaved: np.ndarray, chunk: int = 1024, count_bits: int = 64, pad: int = 16) -> List[np.ndarray]:
+    """Sample::load_file's loop (sample.cpp:127-142,160-185) around the reference's deinterleave_samples: planar channels of
+    frames + `pad` elements, zeroed first — the padding the resampler's ix + 1 read relies on."""
+    a = np.ascontiguousarray(interleaved)
+    frames, ch = a.shape
+    outs = [np.zeros(frames + pad, dtype=a.dtype) for _ in range(ch)]
+    ptrs = (C.c_void_p * ch)(*[o.ctypes.data for o in outs])
+    R = ref_deint()
+    if a.dtype == np.float32 and count_bits == 64:
+        w = R.ref_deinterleave_f32(ptrs, a.ctypes.data, frames, ch, chunk)
+    else:
+        w = R.ref_deinterleave(ptrs, a.ctypes.data, frames, ch, a.dtype.itemsize, chunk, count_bits)
+    assert w == frames, (w, frames)
+    return outs
+
+
 _ref_vu = None
 REF_VU_PATH = os.path.join(ORACLE_DIR, "_ref", "libwbref_vu.so")
 

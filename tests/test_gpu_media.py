@@ -168,3 +168,27 @@ def test_mipmaps_match_the_reference_fixture():
                 n += 1
         ctx.close()
     assert n == 82
+
+
+def test_ingest_matches_the_reference_fixture():
+    """the device's planar clip storage against tests/golden/ingest.npz — outputs of the reference's own
+    deinterleave_samples<T> under load_file's loop (oracle/gen_golden.py ingest); clips of more than two channels are refused
+    (the path's AudioBuffer is mono / stereo), never mis-read"""
+    from test_oracle_golden import ingest_golden_cases
+    n = 0
+    for name, a, want in ingest_golden_cases():
+        frames, ch = a.shape
+        fmt = name.split("_")[0]
+        ctx = W.MixContext(2)
+        if ch > 2:
+            with pytest.raises(W.WbxError):
+                ctx.clip_upload_interleaved(0, fmt, 48000, a)
+            ctx.close()
+            continue
+        ctx.clip_upload_interleaved(0, fmt, 48000, a)
+        for c in range(ch):
+            got = ctx.clip_download(0, c, frames, DT[fmt])
+            assert np.array_equal(got.view(np.uint8), want[c, :frames].view(np.uint8)), (name, c)
+        ctx.close()
+        n += 1
+    assert n == 36

@@ -293,3 +293,31 @@ def test_clip_chunks_follow_the_reference_pool(oracle, reflib, seed):
     exp = [w - first + 1 if o > 0 else 1 for o, w in zip(ops, want)]
     assert got == exp
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_deinterleave_bit_exact(oracle, seed):
+    """wbo_deinterleave under load_file's loop against the reference's own deinterleave_samples<T> (oracle/_ref/
+    libwbref_deint.so: the function's text cut out of dsp/sample.cpp where it lies and compiled unmodified as a member of a class
+    template whose parameter is named sf_count_t, oracle/Makefile) — every storage format, 1-8 channels, lengths around the
+    decoder's chunk, other chunk sizes, both count types; the 16 padding frames stay zero"""
+    if oracle.ref_deint() is None:
+        pytest.skip("oracle/_ref/libwbref_deint.so not built (no /root/reference here)")
+    rng = np.random.default_rng(5200 + seed)
+    for _ in range(40):
+        ch = int(rng.integers(1, 9))
+        frames = int(rng.choice([1, 2, 1023, 1024, 1025, 2047, 4096, int(rng.integers(1, 20000))]))
+        chunk = int(rng.choice([1024, 1024, 1, 7, 4096]))
+        kind = str(rng.choice(["i16", "i32", "f32"]))
+        if kind == "i16":
+            a = rng.integers(-32768, 32768, (frames, ch)).astype(np.int16)
+        elif kind == "i32":
+            a = rng.integers(-2**31, 2**31, (frames, ch)).astype(np.int32)
+        else:
+            a = rng.integers(0, 2**32, (frames, ch), dtype=np.uint64).astype(np.uint32).view(np.float32)   # any bit pattern
+        got = oracle.oracle_deinterleave(a, chunk)
+        for bits in (64, 32):
+            exp = oracle.ref_deinterleave(a, chunk, bits)
+            for c in range(ch):
+                assert np.array_equal(got[c].view(np.uint8), exp[c][:frames].view(np.uint8)), (kind, ch, frames, chunk, bits, c)
+                assert not exp[c][frames:].view(np.uint8).any()
