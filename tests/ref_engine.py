@@ -1,0 +1,277 @@
+"""Script interface to oracle/_ref/wbref_engine — the reference's OWN clip sequencer and block driver (Track::process_event,
+Track::process, Engine::process ... cut out of engine/track.cpp / engine.cpp where they lie and compiled unmodified:
+oracle/Makefile, oracle/ref_engine_driver.cpp) — and the same script replayed on the oracle.  Test infrastructure only.
+
+A script is a list of operations; `run` operations process blocks.  The reference answers every non-run operation with a
+status: 1 taken, 0 refused (the edit would need Engine::reserve_track_region, which holds a spdlog line and is not in the cut),
+2 bad argument.  The oracle side PREDICTS the refusals with its own restatement of add_to_cliplist's early exits and
+Track::query_clip_by_range, so the prediction is itself compared."""
+import os
+import struct
+import subprocess
+import tempfile
+from typing import List, Optional
+
+import numpy as np
+
+import oracle_ffi as O
+
+EXE = os.path.join(O.ORACLE_DIR, "_ref", "wbref_engine")
+
+
+def available() -> bool:
+    return bool(O.build_ref()) and os.path.exists(EXE)
+
+
+class Script:
+    """operations as tuples; samples as (fmt, channels, rate, frames, [planar arrays incl. 16 pad frames])"""
+
+    def __init__(self, channels=2, block=512, rate=48000, bpm=120.0):
+        self.channels, self.block, self.rate = channels, block, rate
+        self.ops = [("cfg", channels, block, rate), ("bpm", float(bpm))]
+        self.samples = []
+
+    def add_sample(self, fmt, channels, rate, frames, data):
+        self.samples.append((fmt, channels, rate, frames, data))
+        self.ops.append(("sample", len(self.samples) - 1))
+        return len(self.samples) - 1
+
+    def op(self, *a):
+        self.ops.append(tuple(a))
+
+
+def _hx(x: float) -> str:
+    return float(x).hex()
+
+
+def run_reference(s: Script, timeout=60):
+    """-> list of records: ("op", status) | ("run", [block dicts]) | ("clips", [[clip tuples] per track])"""
+    blob, offs = bytearray(), []
+    for fmt, ch, rate, frames, data in s.samples:
+        offs.append(len(blob))
+        for c in range(ch):
+            blob += np.ascontiguousarray(data[c][:frames]).tobytes()
+    lines = []
+    for o in s.ops:
+        k = o[0]
+        if k == "sample":
+            fmt, ch, rate, frames, _ = s.samples[o[1]]
+            lines.append(f"sample {O.FMT[fmt]} {ch} {rate} {frames} {offs[o[1]]}")
+        elif k == "clip":
+            _, t, mn, mx, so, si, sp, g = o
+            lines.append(f"clip {t} {_hx(mn)} {_hx(mx)} {_hx(so)} {si} {_hx(sp)} {_hx(np.float32(g))}")
+        elif k == "gain":
+            lines.append(f"gain {o[1]} {o[2]} {_hx(np.float32(o[3]))}")
+        elif k == "move":
+            lines.append(f"move {o[1]} {o[2]} {_hx(o[3])}")
+        elif k in ("vol", "pan"):
+            lines.append(f"{k} {o[1]} {float(np.float32(o[2]))!r}")
+        elif k in ("bpm", "seek"):
+            lines.append(f"{k} {float(o[1])!r}")
+        else:
+            lines.append(" ".join(str(x) for x in o))
+    with tempfile.TemporaryDirectory() as d:
+        sp, dp, rp = (os.path.join(d, n) for n in ("script.txt", "data.bin", "result.bin"))
+        open(sp, "w").write("\n".join(lines) + "\n")
+        open(dp, "wb").write(bytes(blob))
+        r = subprocess.run([EXE, sp, dp, rp], timeout=timeout, capture_output=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"wbref_engine rc={r.returncode} {r.stderr[-300:]!r}")
+        raw = open(rp, "rb").read()
+    C, F = s.channels, s.block
+    pos, out = 0, []
+
+    def u32():
+        nonlocal pos
+        v = struct.unpack_from("<I", raw, pos)[0]; pos += 4
+        return v
+
+    def f64bits():
+        nonlocal pos
+        v = struct.unpack_from("<Q", raw, pos)[0]; pos += 8
+        return v
+
+    while pos < len(raw):
+        tag = u32()
+        if tag == 0x4F500000:
+            out.append(("op", u32()))
+        elif tag == 0x52554E00:
+            n, blocks = u32(), []
+            for _ in range(n):
+                assert u32() == 0x424C4B00
+                b = {"block": u32()}
+                b["master"] = np.frombuffer(raw, np.uint32, C * F, pos).reshape(C, F).copy(); pos += 4 * C * F
+                b["playhead"], b["sample_position"] = f64bits(), f64bits()
+                tr = []
+                for _t in range(u32()):
+                    ev = []
+                    for _e in range(u32()):
+                        typ, boff = u32(), u32()
+                        time, speed, so = f64bits(), f64bits(), f64bits()
+                        ev.append((typ, boff, time, speed, so))
+                    cur = u32()
+                    spd, soff = f64bits(), f64bits()
+                    lv = (u32(), u32())
+                    tr.append({"events": ev, "current": cur, "speed": spd, "offset": soff, "level": lv})
+                b["tracks"] = tr
+                blocks.append(b)
+            out.append(("run", blocks))
+        elif tag == 0x434C5000:
+            lists = []
+            for _t in range(u32()):
+                cl = []
+                for _c in range(u32()):
+                    mn, mx, so, spd = f64bits(), f64bits(), f64bits(), f64bits()
+                    g, ai = u32(), u32()
+                    cl.append((mn, mx, so, spd, g, ai))
+                lists.append(cl)
+            out.append(("clips", lists))
+        else:
+            raise RuntimeError(f"bad tag {tag:#x} at {pos}")
+    return out
+
+
+def _add_needs_trim(e: O.OracleEngine, t, mn, mx) -> bool:
+    """Engine::add_to_cliplist (engine.cpp:409-461): does the add get past the three early exits AND find clips in its range?"""
+    cl = e.clips(t)
+    if not cl:
+        return False
+    if cl[-1][1] < mn:
+        return False
+    if cl[0][0] > mx:
+        return False
+    f, l = O.C.c_uint32(), O.C.c_uint32()
+    return bool(e.L.wbo_track_query_clip_by_range(e.e, t, O.C.c_double(mn), O.C.c_double(mx), O.C.byref(f), O.C.byref(l)))
+
+
+class Wrapped(Exception):
+    """the session drives the reference into its event_length wrap (track.cpp:669: a write past the block buffer, undefined
+    behaviour in the reference) — nothing to compare"""
+
+
+def run_oracle(s: Script):
+    """the same script on the oracle; same record shapes as run_reference (bit patterns)"""
+    e = O.OracleEngine(s.channels, s.block, s.rate)
+    e.enable_seglog(True)
+    out, block_no = [], 0
+    fb = O.f64_bits
+    for o in s.ops:
+        k, st = o[0], 1
+        if k == "cfg":
+            pass
+        elif k == "bpm":
+            e.set_bpm(o[1])
+        elif k == "seek":
+            e.set_playhead(o[1])
+        elif k == "play":
+            e.play()
+        elif k == "stop":
+            e.stop()
+        elif k == "sample":
+            fmt, ch, rate, frames, data = s.samples[o[1]]
+            e.add_sample(fmt, ch, rate, frames, data)
+        elif k == "track":
+            e.add_track()
+        elif k == "vol":
+            e.set_volume(o[1], o[2])
+        elif k == "pan":
+            e.set_pan(o[1], o[2])
+        elif k == "mute":
+            e.set_mute(o[1], o[2])
+        elif k == "clip":
+            _, t, mn, mx, so, si, sp, g = o
+            if _add_needs_trim(e, t, mn, mx):
+                st = 0
+            else:
+                assert e.add_audio_clip(t, mn, mx, so, si, sp, g) == 0
+        elif k == "delclip":
+            if o[2] >= len(e.clips(o[1])):
+                st = 2
+            else:
+                e.delete_clip(o[1], o[2])
+        elif k == "gain":
+            if o[2] >= len(e.clips(o[1])):
+                st = 2
+            else:
+                e.set_clip_gain(o[1], o[2], o[3])
+        elif k == "move":
+            _, t, i, rel = o
+            cl = e.clips(t)
+            if i >= len(cl):
+                st = 2
+            else:
+                mn, mx = O.C.c_double(), O.C.c_double()
+                e.L.wbo_calc_move_clip(O.C.c_double(cl[i][0]), O.C.c_double(cl[i][1]), O.C.c_double(rel), O.C.c_double(0.0),
+                                       O.C.byref(mn), O.C.byref(mx))
+                f, l = O.C.c_uint32(), O.C.c_uint32()
+                if rel != 0.0 and e.L.wbo_track_query_clip_by_range(e.e, t, mn, mx, O.C.byref(f), O.C.byref(l)):
+                    st = 0
+                else:
+                    e.move_clip(t, i, float(rel))
+        elif k == "deltrack":
+            e.delete_track(o[1])
+        elif k == "movetrack":
+            e.move_track(o[1], o[2])
+        elif k == "solo":
+            e.solo_track(o[1])
+        elif k == "run":
+            blocks = []
+            for _ in range(o[1]):
+                m, _b = e.process()
+                for sg in e.seglog():
+                    if sg[1] + sg[2] > s.block:
+                        raise Wrapped()
+                nt = e.e.contents.n_tracks
+                tr = []
+                for t in range(nt):
+                    T = e.track(t)
+                    ev = [(x.type, x.buffer_offset, fb(x.time), fb(x.speed) if x.type == 2 else 0,
+                           int(x.sample_offset) if x.type == 2 else 0) for x in T.events[:T.n_events]]
+                    tr.append({"events": ev, "current": T.current_event.type, "speed": fb(T.sampler.playback_speed),
+                               "offset": fb(T.sampler.sample_offset), "level": (O.f32_bits(T.level[0]), O.f32_bits(T.level[1]))})
+                blocks.append({"block": block_no, "master": m.view(np.uint32).copy(), "playhead": fb(e.playhead),
+                               "sample_position": fb(e.sample_position), "tracks": tr})
+                block_no += 1
+            out.append(("run", blocks))
+            continue
+        elif k == "clips":
+            nt = e.e.contents.n_tracks
+            out.append(("clips", [[(fb(c[0]), fb(c[1]), fb(c[2]), fb(c[3]), O.f32_bits(c[4]), c[5]) for c in e.clips(t)]
+                                  for t in range(nt)]))
+            continue
+        else:
+            st = 2
+        out.append(("op", st))
+    e.close()
+    return out
+
+
+def compare(ref, orc, what="") -> Optional[str]:
+    """first difference between two record lists, or None"""
+    if len(ref) != len(orc):
+        return f"{what}: {len(ref)} records against {len(orc)}"
+    for i, (r, o) in enumerate(zip(ref, orc)):
+        if r[0] != o[0]:
+            return f"{what}: record {i} kinds {r[0]} / {o[0]}"
+        if r[0] == "op":
+            if r[1] != o[1]:
+                return f"{what}: operation {i} status reference {r[1]} oracle {o[1]}"
+        elif r[0] == "clips":
+            if r[1] != o[1]:
+                return f"{what}: clip lists differ at record {i}: {r[1]} / {o[1]}"
+        else:
+            for br, bo in zip(r[1], o[1]):
+                b = br["block"]
+                for key in ("playhead", "sample_position"):
+                    if br[key] != bo[key]:
+                        return f"{what}: block {b} {key} {br[key]:#x} / {bo[key]:#x}"
+                if len(br["tracks"]) != len(bo["tracks"]):
+                    return f"{what}: block {b} track count"
+                for t, (tr, to) in enumerate(zip(br["tracks"], bo["tracks"])):
+                    for key in ("events", "current", "speed", "offset", "level"):
+                        if tr[key] != to[key]:
+                            return f"{what}: block {b} track {t} {key}: reference {tr[key]} oracle {to[key]}"
+                if not np.array_equal(br["master"], bo["master"]):
+                    d = np.argwhere(br["master"] != bo["master"])
+                    return f"{what}: block {b} master differs at {d[:4].tolist()} ({len(d)} samples)"
+    return None
