@@ -269,11 +269,47 @@ def gen_ingest():
     np.savez_compressed(os.path.join(OUT, "ingest.npz"), **arrs)
     print("ingest.npz:", len(arrs) // 2, "cases")
 
+
+def gen_sequencer():
+    """tests/golden/sequencer.npz from the reference's own sequencer and block driver (oracle/_ref/wbref_engine:
+    Track::process_event / Track::process / Engine::process and the session-building calls, cut out of the reference's sources
+    where they lie and compiled unmodified — oracle/ref_engine_driver.cpp).  Per session: the script (JSON: operations with exact
+    floats, clip audio as keys of whitebox_amd.synth's generator) and the driver's answer file byte for byte (per block: master,
+    playhead, sample_position, every track's AudioEvent list, sampler state and VU level; per operation whether the reference
+    took it; clip lists after edits)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_engine as R
+    import seq_sessions as S
+    if not R.available():
+        raise SystemExit("oracle/_ref/wbref_engine is not built (needs /root/reference)")
+    arrs, n = {}, 0
+    for kind, want in (("static", 10), ("controls", 10), ("edits", 12), ("dense", 8)):
+        got, seed = 0, 1000
+        while got < want:
+            seed += 1
+            s = S.session_script(seed, kind)
+            if s.block % 4 and got % 4:          # three in four sessions in block shapes the product takes (multiples of 4 frames)
+                continue
+            try:
+                orc = R.run_oracle(s)
+            except R.Wrapped:
+                continue                         # the reference writes past its block buffer there: no answer to record
+            raw, ref = R.run_reference(s, want_raw=True)
+            assert R.compare(ref, orc, f"{kind} {seed}") is None
+            name = f"{kind}_{seed}"
+            arrs[f"{name}.script"] = np.frombuffer(R.script_to_json(s).encode(), np.uint8)
+            arrs[f"{name}.answer"] = np.frombuffer(raw, np.uint8)
+            got += 1
+            n += 1
+    np.savez_compressed(os.path.join(OUT, "sequencer.npz"), **arrs)
+    print("sequencer.npz:", n, "sessions")
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest"):     # (the other fixtures are untouched)
-        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest", "sequencer"):     # (the other fixtures are untouched)
+        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest, "sequencer": gen_sequencer}[sys.argv[1]]()
     else:
         main()
         gen_mip()
         gen_vu()
         gen_ingest()
+        gen_sequencer()

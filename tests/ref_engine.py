@@ -31,8 +31,10 @@ class Script:
         self.ops = [("cfg", channels, block, rate), ("bpm", float(bpm))]
         self.samples = []
 
-    def add_sample(self, fmt, channels, rate, frames, data):
-        self.samples.append((fmt, channels, rate, frames, data))
+    def add_sample(self, fmt, channels, rate, frames, data, gen=None):
+        """gen = (seed, seed_track, amp) of whitebox_amd.synth's keyed generator when the data came from it (fixtures store the
+        key, not the audio)"""
+        self.samples.append((fmt, channels, rate, frames, data, gen))
         self.ops.append(("sample", len(self.samples) - 1))
         return len(self.samples) - 1
 
@@ -40,14 +42,43 @@ class Script:
         self.ops.append(tuple(a))
 
 
+def script_to_json(s: Script) -> str:
+    """ops with their floats as hex strings (exact), samples as generator keys"""
+    import json
+    def enc(x):
+        if isinstance(x, (float, np.floating)):
+            return {"f": float(x).hex()}
+        return int(x) if isinstance(x, (int, np.integer)) and not isinstance(x, bool) else x
+    assert all(smp[5] is not None for smp in s.samples)
+    return json.dumps({"channels": s.channels, "block": s.block, "rate": s.rate,
+                       "samples": [[smp[0], smp[1], smp[2], smp[3], list(smp[5][:2]) + [float(smp[5][2]).hex()]] for smp in s.samples],
+                       "ops": [[enc(x) for x in o] for o in s.ops]})
+
+
+def script_from_json(text: str) -> Script:
+    import json
+    from whitebox_amd import synth
+    d = json.loads(text)
+    s = Script(d["channels"], d["block"], d["rate"])
+    s.ops = []
+    for fmt, ch, rate, frames, (seed, seed_track, amp) in d["samples"]:
+        amp = float.fromhex(amp)
+        spec = synth.SessionSpec(name="s", n_tracks=1, seed=seed, samples=[synth.SampleSpec(seed_track, ch, rate, frames, fmt, amp)],
+                                 clips=[], volumes_db=[0.0], pans=[0.0], mutes=[False])
+        s.samples.append((fmt, ch, rate, frames, spec.sample_data(0), (seed, seed_track, amp)))
+    for o in d["ops"]:
+        s.ops.append(tuple(float.fromhex(x["f"]) if isinstance(x, dict) else x for x in o))
+    return s
+
+
 def _hx(x: float) -> str:
     return float(x).hex()
 
 
-def run_reference(s: Script, timeout=60):
+def run_reference(s: Script, timeout=60, want_raw=False):
     """-> list of records: ("op", status) | ("run", [block dicts]) | ("clips", [[clip tuples] per track])"""
     blob, offs = bytearray(), []
-    for fmt, ch, rate, frames, data in s.samples:
+    for fmt, ch, rate, frames, data, _g in s.samples:
         offs.append(len(blob))
         for c in range(ch):
             blob += np.ascontiguousarray(data[c][:frames]).tobytes()
@@ -55,7 +86,7 @@ def run_reference(s: Script, timeout=60):
     for o in s.ops:
         k = o[0]
         if k == "sample":
-            fmt, ch, rate, frames, _ = s.samples[o[1]]
+            fmt, ch, rate, frames = s.samples[o[1]][:4]
             lines.append(f"sample {O.FMT[fmt]} {ch} {rate} {frames} {offs[o[1]]}")
         elif k == "clip":
             _, t, mn, mx, so, si, sp, g = o
@@ -78,7 +109,10 @@ def run_reference(s: Script, timeout=60):
         if r.returncode != 0:
             raise RuntimeError(f"wbref_engine rc={r.returncode} {r.stderr[-300:]!r}")
         raw = open(rp, "rb").read()
-    C, F = s.channels, s.block
+    return (raw, parse_results(raw, s.channels, s.block)) if want_raw else parse_results(raw, s.channels, s.block)
+
+
+def parse_results(raw: bytes, C: int, F: int):
     pos, out = 0, []
 
     def u32():
@@ -168,7 +202,7 @@ def run_oracle(s: Script):
         elif k == "stop":
             e.stop()
         elif k == "sample":
-            fmt, ch, rate, frames, data = s.samples[o[1]]
+            fmt, ch, rate, frames, data = s.samples[o[1]][:5]
             e.add_sample(fmt, ch, rate, frames, data)
         elif k == "track":
             e.add_track()

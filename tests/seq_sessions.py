@@ -28,7 +28,7 @@ def _samples(rng, s: R.Script, seed, n, session_rate, out_channels):
         spec = synth.SessionSpec(name="s", n_tracks=1, seed=seed, samples=[synth.SampleSpec(i, ch, rate, frames, fmt,
                                                                                           0.2 if fmt == "f32" else 1.0)],
                                  clips=[], volumes_db=[0.0], pans=[0.0], mutes=[False])
-        s.add_sample(fmt, ch, rate, frames, spec.sample_data(0))
+        s.add_sample(fmt, ch, rate, frames, spec.sample_data(0), gen=(seed, i, 0.2 if fmt == "f32" else 1.0))
         free.append(not (ch == 1 and out_channels == 2))
     return free
 

@@ -1,0 +1,120 @@
+"""The PRODUCT against the reference's own recorded answers (tests/golden/sequencer.npz: what Track::process_event /
+Track::process / Engine::process of oracle/_ref/wbref_engine — the reference's code, cut out of its sources where they lie and
+compiled unmodified — answered to 40 session scripts; oracle/gen_golden.py sequencer).  Through the C ABI's Engine surface, as
+the audio callback (one wbx_engine_process per block) and as batch renders: master bit for bit, playhead / sample_position bit
+for bit, the running VU maxima, the clip lists after every edit.  Edits the reference's cut could not take (they need
+reserve_track_region) are skipped here exactly where the recording says they were refused."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import whitebox_amd as W
+from whitebox_amd.engine import AudioBuffer, Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    from test_oracle_golden import sequencer_golden_cases
+    return [c for c in sequencer_golden_cases() if c[1].block % 4 == 0]
+
+
+def _replay(s, want, batch):
+    max_run = max([o[1] for o in s.ops if o[0] == "run"] + [1])
+    eng = Engine(8, s.block, s.rate, s.channels, max_blocks=max_run if batch else 1)
+    out = AudioBuffer(s.block, s.channels)
+    level = {}                      # Track object -> running maximum per channel (the reference's VUMeter::level is never read here)
+    wi = 0
+    blocks = 0
+    for o in s.ops:
+        k = o[0]
+        rec = want[wi]
+        wi += 1
+        if k == "run":
+            assert rec[0] == "run" and len(rec[1]) == o[1]
+            if batch:
+                eng.render(o[1])
+                m = eng.ctx.fetch()[0]          # [K][C][F]
+            for b, br in enumerate(rec[1]):
+                if batch:
+                    got = np.ascontiguousarray(m[b]).view(np.uint32)
+                else:
+                    eng.process(None, out, float(s.rate))
+                    got = np.stack([out.get_write_pointer(c) for c in range(s.channels)]).view(np.uint32)
+                    ph, sp, _pl = eng.transport()
+                    assert (O.f64_bits(ph), O.f64_bits(sp)) == (br["playhead"], br["sample_position"]), (br["block"], ph, sp)
+                    lv = eng.levels()
+                    for t, tr in enumerate(eng.tracks):
+                        cur = level.setdefault(tr, np.zeros(2, np.float32))
+                        for c in range(s.channels):
+                            cur[c] = max(cur[c], lv[t, c])
+                        ref_lv = np.array(br["tracks"][t]["level"], np.uint32).view(np.float32)
+                        assert np.array_equal(cur[:s.channels], ref_lv[:s.channels]), (br["block"], t, cur, ref_lv)
+                assert np.array_equal(got, br["master"]), (br["block"], np.argwhere(got != br["master"])[:4].tolist())
+                blocks += 1
+            if batch:
+                ph, sp, _pl = eng.transport()
+                assert (O.f64_bits(ph), O.f64_bits(sp)) == (rec[1][-1]["playhead"], rec[1][-1]["sample_position"])
+            continue
+        if k == "clips":
+            assert rec[0] == "clips" and len(rec[1]) == len(eng.tracks)
+            for t, tr in enumerate(eng.tracks):
+                mine = [(O.f64_bits(c[0]), O.f64_bits(c[1]), O.f64_bits(c[2]), O.f64_bits(c[3]), O.f32_bits(c[4]), c[5])
+                        for c in eng.clips(tr)]
+                assert mine == rec[1][t], (t, mine, rec[1][t])
+            continue
+        assert rec[0] == "op"
+        if rec[1] != 1:
+            continue                # refused by the reference's cut (needs reserve_track_region) or an index out of range
+        if k in ("cfg",):
+            pass
+        elif k == "bpm":
+            eng.set_bpm(o[1])
+        elif k == "seek":
+            eng.set_playhead_position(o[1])
+        elif k == "play":
+            eng.play()
+        elif k == "stop":
+            eng.stop()
+        elif k == "sample":
+            fmt, ch, rate, frames, data = s.samples[o[1]][:5]
+            eng.add_sample(fmt, rate, [np.ascontiguousarray(d[:frames]) for d in data], frames)
+        elif k == "track":
+            eng.add_track("t")
+        elif k == "vol":
+            eng.tracks[o[1]].set_volume(o[2])
+        elif k == "pan":
+            eng.tracks[o[1]].set_pan(o[2])
+        elif k == "mute":
+            eng.tracks[o[1]].set_mute(bool(o[2]))
+        elif k == "clip":
+            _, t, mn, mx, so, si, sp, g = o
+            eng.add_audio_clip(eng.tracks[t], "c", mn, mx, so, si, sp, g)
+        elif k == "delclip":
+            eng.delete_clip(eng.tracks[o[1]], o[2])
+        elif k == "gain":
+            eng.set_clip_gain(eng.tracks[o[1]], o[2], o[3])
+        elif k == "move":
+            eng.move_clip(eng.tracks[o[1]], o[2], o[3])
+        elif k == "deltrack":
+            eng.delete_track(o[1])
+        elif k == "movetrack":
+            eng.move_track(o[1], o[2])
+        elif k == "solo":
+            eng.solo_track(o[1])
+        else:
+            raise AssertionError(k)
+    eng.close()
+    return blocks
+
+
+@pytest.mark.parametrize("batch", [False, True], ids=["callback", "render"])
+def test_product_equals_the_reference_recordings(batch):
+    n = blocks = 0
+    for name, s, want in _cases():
+        try:
+            blocks += _replay(s, want, batch)
+        except AssertionError as e:
+            raise AssertionError(f"{name} ({'render' if batch else 'callback'}): {e}") from e
+        n += 1
+    assert n >= 28 and blocks > 350, (n, blocks)
