@@ -214,11 +214,67 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
         model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+    port = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n_tracks} tracks x {sample_blocks} blocks x {passes} passes ({workload}), "
                       f"{elapsed:.1f} s of CPU work, single thread like the reference's audio thread",
             "host_cpu": model, "host_cores_total": os.cpu_count(),
             "us_per_block": 1e6 * elapsed / blocks_done, "all_cores": best}
+    ref = cpu_reference(workload, n_tracks, sample_blocks, budget_s)
+    if ref is None:
+        return port
+    # the reference's OWN Engine::process timed beside it; the oracle's figure stays in the line as `port`
+    ref.update({"host_cpu": model, "host_cores_total": os.cpu_count(), "all_cores": best,
+                "port": {k: port[k] for k in ("value", "unit", "cores", "kind", "sample", "us_per_block")}})
+    return ref
+
+
+def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
+    """The reference's own Engine::process (oracle/_ref/wbref_engine: Track::process_event / Track::process / Engine::process /
+    Sampler::stream, cut out of the reference's sources where they lie and compiled unmodified, -O2 — oracle/Makefile) on ONE
+    host core, its only thread, over the same bounded sample of the same session.  The executable is prebuilt where
+    /root/reference exists and travels with the tree; nothing of /root/reference is read here.  None where it is absent or the
+    workload needs what the reference does not have (sub-buses) or what the driver's generator does not make (integer PCM)."""
+    import subprocess
+    import tempfile
+    import oracle_ffi as O
+    import ref_engine as R
+    exe = os.path.join(O.ORACLE_DIR, "_ref", "wbref_engine")
+    _, src_rate, n_buses, fmt = WORKLOADS[workload]
+    if not os.path.exists(exe) or n_buses or fmt != "f32":
+        return None
+    seed, amp, tracks = track_layout(workload, n_tracks, 0, 1, sample_blocks)
+    amp32 = float(np.float32(amp))
+    lines = [f"cfg 2 {F} {SR}", "bpm 120.0"]
+    for i, (gt, tfmt, trate, v, p, bus, clips) in enumerate(tracks):
+        frames = int(math.ceil((sample_blocks + 2) * F * (trate / SR))) + 64       # as build_oracle_session
+        lines.append(f"synth 2 {trate} {frames} {seed} {gt} {amp32.hex()}")
+        lines += ["track", f"vol {i} {float(np.float32(v))!r}", f"pan {i} {float(np.float32(p))!r}"]
+        for (a, b, off) in clips:
+            lines.append(f"clip {i} {float(a).hex()} {float(b).hex()} {float(off).hex()} {i} {1.0.hex()} {float(np.float32(1.0)).hex()}")
+    lines.append(f"bench {sample_blocks} {budget_s} 64")
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            sp, dp, rp = (os.path.join(d, n) for n in ("script.txt", "data.bin", "result.bin"))
+            open(sp, "w").write("\n".join(lines) + "\n")
+            open(dp, "wb").close()
+            r = subprocess.run([exe, sp, dp, rp], timeout=budget_s * 4 + 120, capture_output=True)
+            if r.returncode != 0:
+                return None
+            rec = [x for x in R.parse_results(open(rp, "rb").read(), 2, F) if x[0] == "bench"][0][1]
+    except Exception as ex:                                            # a baseline, not the product: never fails the bench
+        print(f"cpu_reference: {ex!r}", file=sys.stderr)
+        return None
+    # what was timed is this session: the first blocks of the first pass against the oracle, bit for bit
+    e = build_oracle_session(workload, n_tracks, 1, sample_blocks)
+    e.play()
+    same = all(np.array_equal(e.process()[0].view(np.uint32), rec["head"][b].view(np.uint32)) for b in range(len(rec["head"])))
+    e.close()
+    blocks_done = rec["blocks"] * rec["passes"]
+    return {"value": blocks_done * F / rec["seconds"], "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": f"{n_tracks} tracks x {rec['blocks']} blocks x {rec['passes']} passes ({workload}), {rec['seconds']:.1f} s of "
+                      f"CPU work in the reference's own Engine::process (oracle/_ref/wbref_engine, g++ -O2), its one audio thread",
+            "us_per_block": 1e6 * rec["seconds"] / blocks_done,
+            "head_blocks_equal_oracle": bool(same)}
 
 
 def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_buses, fmt, seed, amp, passes=64):

@@ -150,6 +150,12 @@ def parse_results(raw: bytes, C: int, F: int):
                 b["tracks"] = tr
                 blocks.append(b)
             out.append(("run", blocks))
+        elif tag == 0x42454E00:
+            n, passes = u32(), u32()
+            secs = struct.unpack_from("<d", raw, pos)[0]; pos += 8
+            cnt = u32()
+            head = np.frombuffer(raw, np.float32, cnt, pos).copy(); pos += 4 * cnt
+            out.append(("bench", {"blocks": n, "passes": passes, "seconds": secs, "head": head.reshape(-1, C, F)}))
         elif tag == 0x434C5000:
             lists = []
             for _t in range(u32()):
