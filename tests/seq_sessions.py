@@ -11,8 +11,11 @@ from whitebox_amd import synth
 
 import ref_engine as R
 
-RATES = [22050, 44100, 48000, 96000]
-SPEEDS = [1.0, 1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 1.0625, 1.9, 0.3, 4.0]
+PLAIN_RATES = [22050, 44100, 48000, 96000]
+PLAIN_SPEEDS = [1.0, 1.0, 1.0, 0.5, 0.8, 0.91875, 0.999, 1.0625, 1.9, 0.3, 4.0]
+WILD_RATES = [8000, 11025, 22050, 44100, 96000, 192000]
+WILD_SPEEDS = [1.0, 0.01, 0.1, 0.9999999, 1.0000001, 3.99, 8.0, 33.0]
+RATES, SPEEDS = PLAIN_RATES, PLAIN_SPEEDS
 
 
 def _samples(rng, s: R.Script, seed, n, session_rate, out_channels):
@@ -43,11 +46,14 @@ def _clip_args(rng, t, si, resample_ok, pos, length, frames):
 def session_script(seed, kind):
     """kind: 'static' (clip layouts only), 'controls' (transport / parameter / track operations between blocks), 'edits' (clip
     adds into free space, deletes aimed at the sounding clip, gains, moves), 'dense' (back-to-back clips, edges on block edges)"""
-    rng = np.random.default_rng([seed, {"static": 1, "controls": 2, "edits": 3, "dense": 4}[kind]])
+    rng = np.random.default_rng([seed, {"static": 1, "controls": 2, "edits": 3, "dense": 4, "wild": 5}[kind]])
+    wild = kind == "wild"           # the corners of what the API accepts, all at once; otherwise an 'edits' script
     out_ch = int(rng.choice([1, 2, 2, 2]))
-    block = int(rng.choice([64, 96, 128, 200, 256, 333, 512, 1024]))
-    rate = int(rng.choice([44100, 48000, 48000, 96000]))
-    bpm = float(rng.choice([120.0, 97.0, 140.5, 61.3, 174.0]))
+    block = int(rng.choice([32, 100, 128, 440, 1000, 2048] if wild else [64, 96, 128, 200, 256, 333, 512, 1024]))
+    rate = int(rng.choice([22050, 32000, 88200, 192000, 48000] if wild else [44100, 48000, 48000, 96000]))
+    bpm = float(rng.choice([20.0, 333.3, 999.0, 120.0] if wild else [120.0, 97.0, 140.5, 61.3, 174.0]))
+    global RATES, SPEEDS
+    RATES, SPEEDS = (WILD_RATES, WILD_SPEEDS) if wild else (PLAIN_RATES, PLAIN_SPEEDS)
     s = R.Script(out_ch, block, rate, bpm)
     n_tracks = int(rng.integers(1, 7))
     n_blocks = int(rng.integers(6, 25))
@@ -69,6 +75,11 @@ def session_script(seed, kind):
         pos = -0.2 * total * rng.random() if rng.random() < 0.3 else total * rng.random() * 0.3
         n_clips = int(rng.integers(0, 5)) if kind != "dense" else int(rng.integers(5, 40))
         for _ in range(n_clips):
+            if wild and rng.random() < 0.4:           # sub-frame and few-frame clips
+                length = float(rng.choice([0.3, 1.0, 2.5, 17.0])) / beat_frames
+                s.op(*_clip_args(rng, t, si, resample_ok[si], pos, length, frames))
+                pos += length + (0.0 if rng.random() < 0.5 else unit * rng.random())
+                continue
             if kind == "dense":
                 length = unit * float(rng.choice([0.2, 0.5, 1.0, 1.0, 2.0, 3.3, float(rng.uniform(0.05, 4))]))
                 if rng.random() < 0.4:
