@@ -270,11 +270,17 @@ def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
     same = all(np.array_equal(e.process()[0].view(np.uint32), rec["head"][b].view(np.uint32)) for b in range(len(rec["head"])))
     e.close()
     blocks_done = rec["blocks"] * rec["passes"]
+    dev = _DEVICE_HEADS.get((workload, n_tracks, 0.0))
+    # the device's verified step against the reference's own Engine::process, directly (bit-exact when the render added in
+    # the reference's order — verify.summation says which)
+    dev_eq = None if dev is None else bool(np.array_equal(dev[:len(rec["head"])].view(np.uint32), rec["head"].view(np.uint32)))
+    dev_rms = None if dev is None else float(np.sqrt(np.mean((dev[:len(rec["head"])].astype(np.float64) - rec["head"]) ** 2)))
     return {"value": blocks_done * F / rec["seconds"], "unit": "frames/s", "cores": 1, "kind": "reference",
             "sample": f"{n_tracks} tracks x {rec['blocks']} blocks x {rec['passes']} passes ({workload}), {rec['seconds']:.1f} s of "
                       f"CPU work in the reference's own Engine::process (oracle/_ref/wbref_engine, g++ -O2), its one audio thread",
             "us_per_block": 1e6 * rec["seconds"] / blocks_done,
-            "head_blocks_equal_oracle": bool(same)}
+            "head_blocks_equal_oracle": bool(same),
+            "device_head_blocks_equal_reference": dev_eq, "device_head_rms_vs_reference": dev_rms}
 
 
 def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_buses, fmt, seed, amp, passes=64):
@@ -326,6 +332,9 @@ def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_bus
             "note": "not the reference's threading (its engine is single-threaded); sub-bus order ignored"}
 
 
+_DEVICE_HEADS = {}   # (workload, tracks, clip_blocks) -> the device's master of blocks 0-3 of the verified step
+
+
 def verify_blocks_of(K, tail):
     """which blocks of a K-block step are compared with the oracle: the first 8; with `tail` also one per 256 and the last 8"""
     head = list(range(min(8, K)))
@@ -363,6 +372,8 @@ def verify_render(eng, host_master, workload, n_tracks, rank, world, K, clip_blo
                                       [(a, b, off, 1.0, 1.0) for (a, b, off) in clips]))
     want = OT.oracle_at_blocks(descs, check, block=F, channels=2, sample_rate=SR, bpm=120.0, n_buses=n_buses * world)
     got = host_master.array[:K * 2 * F].reshape(K, 2, F)[check].copy()
+    if world == 1 and check[:4] == [0, 1, 2, 3]:
+        _DEVICE_HEADS[(workload, n_tracks, float(clip_blocks or 0.0))] = got[:4].copy()   # cpu_reference() compares the reference's own with it
     om = np.stack([want[b][0] for b in check])
     d = got.astype(np.float64) - om.astype(np.float64)
     res["rms"] = float(np.sqrt(np.mean(d * d)))
@@ -897,6 +908,8 @@ def main():
                         "verify_ok": None if ver is None else ver["ok"],
                         "master_bit_exact": None if ver is None else ver["master_bit_exact"],
                         "last_block_checked": None if ver is None else ver["last_block_checked"],
+                        "device_head_equals_reference_engine": line.get("cpu_baseline", {}).get("device_head_blocks_equal_reference"),
+                        "cpu_baseline_kind": line.get("cpu_baseline", {}).get("kind"),
                         "latency_ms_per_block": line.get("latency_mode", {}).get("ms_per_block"),
                         "cpu_baseline_frames_per_s": line.get("cpu_baseline", {}).get("value"),
                         "configs_ok": [k for k in line.get("configs", {}) if line["configs"][k].get("verify", {}).get("ok")],
