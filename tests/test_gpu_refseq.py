@@ -118,3 +118,34 @@ def test_product_equals_the_reference_recordings(batch):
             raise AssertionError(f"{name} ({'render' if batch else 'callback'}): {e}") from e
         n += 1
     assert n >= 28 and blocks > 350, (n, blocks)
+
+
+@pytest.mark.parametrize("kind", ["static", "controls", "edits", "dense", "wild"])
+def test_product_equals_the_live_reference(kind):
+    """the same comparison against the reference executable itself where it travelled with the tree (oracle/_ref/wbref_engine is a
+    prebuilt test artefact like liboracle.so; nothing of /root/reference is read): fresh seeds, scripts of tests/seq_sessions.py
+    run through the reference on the host and replayed on the device — callback for even seeds, batch renders for odd ones.
+    WBX_REFSEQ_GPU_SEEDS widens the range (soak runs)."""
+    import os
+    import ref_engine as R
+    import seq_sessions as S
+    if not R.available():
+        pytest.skip("oracle/_ref/wbref_engine did not travel (built only where /root/reference exists)")
+    n_seeds = int(os.environ.get("WBX_REFSEQ_GPU_SEEDS", "12"))
+    first = int(os.environ.get("WBX_REFSEQ_GPU_FROM", "5000"))
+    done = blocks = 0
+    for seed in range(first, first + n_seeds):
+        s = S.session_script(seed, kind)
+        if s.block % 4:
+            continue                      # the product takes blocks of a multiple of 4 frames
+        try:
+            R.run_oracle(s)               # only to learn whether the script reaches the reference's event_length wrap
+        except R.Wrapped:
+            continue
+        want = R.run_reference(s)
+        try:
+            blocks += _replay(s, want, batch=bool(seed & 1))
+        except AssertionError as e:
+            raise AssertionError(f"{kind} seed {seed} ({'render' if seed & 1 else 'callback'}): {e}") from e
+        done += 1
+    assert done >= n_seeds // 3, (done, n_seeds)
