@@ -217,6 +217,10 @@ int main(int argc, char** argv) {
       std::sscanf(a, "%u %u %u", &c, &f, &r);
       channels = c; frames = f; rate = (double)r;
       E.set_audio_channel_config(0, c, f, r);
+    } else if (!std::strcmp(op, "rate")) {     // rate <r>: the back end reconfigured to another device rate, block shape kept
+      unsigned r; std::sscanf(a, "%u", &r);
+      rate = (double)r;
+      E.set_audio_channel_config(0, channels, frames, r);
     } else if (!std::strcmp(op, "bpm")) {
       double v; std::sscanf(a, "%lf", &v);
       E.set_bpm(v);

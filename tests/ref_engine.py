@@ -203,6 +203,8 @@ def run_oracle(s: Script):
             e.set_bpm(o[1])
         elif k == "seek":
             e.set_playhead(o[1])
+        elif k == "rate":
+            e.e.contents.sample_rate = int(o[1])      # Engine::process is handed the new rate (engine.cpp:1576), nothing else changes
         elif k == "play":
             e.play()
         elif k == "stop":

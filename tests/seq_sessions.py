@@ -18,12 +18,14 @@ WILD_SPEEDS = [1.0, 0.01, 0.1, 0.9999999, 1.0000001, 3.99, 8.0, 33.0]
 RATES, SPEEDS = PLAIN_RATES, PLAIN_SPEEDS
 
 
-def _samples(rng, s: R.Script, seed, n, session_rate, out_channels):
+def _samples(rng, s: R.Script, seed, n, session_rate, out_channels, stereo_only=False):
     """n samples of every storage format; returns per sample whether it may be resampled (Q1)"""
     free = []
     for i in range(n):
         fmt = str(rng.choice(["f32", "f32", "i16", "i24", "i32"]))
         ch = int(rng.integers(1, 3))
+        if stereo_only and out_channels == 2:
+            ch = 2                         # the session rate may change in mid-play: a mono clip would end up resampled (Q1)
         rate = int(rng.choice(RATES + [session_rate] * 3))
         if ch == 1 and out_channels == 2:
             rate = session_rate            # a mono clip in a stereo session: unity path only
@@ -60,7 +62,7 @@ def session_script(seed, kind):
     beat_frames = rate * 60.0 / bpm
     total = n_blocks * block / beat_frames          # beats the session plays
     unit = block / beat_frames                      # beats per block
-    resample_ok = _samples(rng, s, 0x5E90000 + seed, n_tracks, rate, out_ch)
+    resample_ok = _samples(rng, s, 0x5E90000 + seed, n_tracks, rate, out_ch, stereo_only=kind == "controls")
     for t in range(n_tracks):
         s.op("track")
         s.op("vol", t, float(np.float32(rng.uniform(-30, 3))))
@@ -103,9 +105,11 @@ def session_script(seed, kind):
         done += k
         ph = start + done * unit                    # (about: tempo changes move it; good enough to aim edits)
         if kind == "controls":
-            op = int(rng.integers(0, 10))
+            op = int(rng.integers(0, 11))
             t = int(rng.integers(0, ntr))
-            if op == 0:
+            if op == 10:     # the audio back end comes back with another device rate, in mid-play (set_audio_channel_config)
+                s.op("rate", int(rng.choice([44100, 48000, 96000, 22050])))
+            elif op == 0:
                 s.op("vol", t, float(np.float32(rng.uniform(-40, 6))))
             elif op == 1:
                 s.op("pan", t, float(np.float32(rng.uniform(-1, 1))))

@@ -26,6 +26,7 @@ def _replay(s, want, batch):
     level = {}                      # Track object -> running maximum per channel (the reference's VUMeter::level is never read here)
     wi = 0
     blocks = 0
+    rate_now = [s.rate]
     for o in s.ops:
         k = o[0]
         rec = want[wi]
@@ -39,7 +40,7 @@ def _replay(s, want, batch):
                 if batch:
                     got = np.ascontiguousarray(m[b]).view(np.uint32)
                 else:
-                    eng.process(None, out, float(s.rate))
+                    eng.process(None, out, float(rate_now[0]))
                     got = np.stack([out.get_write_pointer(c) for c in range(s.channels)]).view(np.uint32)
                     ph, sp, _pl = eng.transport()
                     assert (O.f64_bits(ph), O.f64_bits(sp)) == (br["playhead"], br["sample_position"]), (br["block"], ph, sp)
@@ -72,6 +73,9 @@ def _replay(s, want, batch):
             eng.set_bpm(o[1])
         elif k == "seek":
             eng.set_playhead_position(o[1])
+        elif k == "rate":
+            eng.set_audio_channel_config(0, s.channels, s.block, int(o[1]))
+            rate_now[0] = int(o[1])
         elif k == "play":
             eng.play()
         elif k == "stop":
