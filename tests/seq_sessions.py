@@ -110,9 +110,9 @@ def session_script(seed, kind):
             if op == 10:     # the audio back end comes back with another device rate, in mid-play (set_audio_channel_config)
                 s.op("rate", int(rng.choice([44100, 48000, 96000, 22050])))
             elif op == 0:
-                s.op("vol", t, float(np.float32(rng.uniform(-40, 6))))
+                s.op("vol", t, float(np.float32(rng.choice([rng.uniform(-40, 6), -72.0, -71.99, -100.0, 0.0, 6.0]))))
             elif op == 1:
-                s.op("pan", t, float(np.float32(rng.uniform(-1, 1))))
+                s.op("pan", t, float(np.float32(rng.choice([rng.uniform(-1, 1), -1.0, 1.0, 0.0]))))
             elif op == 2:
                 s.op("mute", t, int(rng.integers(0, 2)))
             elif op == 3:
