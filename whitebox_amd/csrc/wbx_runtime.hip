@@ -443,6 +443,12 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.tiles = (C * m.lane_span + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
+  {   // one resampling ratio for every window row of this render (layer 2's word; MODE_WNU / WINU: the products fl(j * speed)
+      // hoisted out of the track loop).  WBX_NO_UNIFORM=1: A/B aid.  [Round 3's split of this function lost this line: the
+      // modes were carried but never taken until round 5 — SQ_INSTS_VALU_MUL_F64 of the r03-r05 PMC passes shows it.]
+    static const bool off = [] { const char* v = std::getenv("WBX_NO_UNIFORM"); return v && v[0] == '1'; }();
+    m.uniform_speed = off ? 0.0 : c->uniform_speed;
+  }
   // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
   // master, nothing to continue): the mix workgroup clamps and stores the master itself — the sum kernel is not launched
   // A short render's sum runs on the main stream (and a one-group session's mix stores the master itself): neither may
