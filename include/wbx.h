@@ -282,6 +282,10 @@ wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
 /* The template instance of the dominant kernel that the last render launched, as rocprofv3 prints it
  * ("wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"); "" before the first render. */
 const char* wbx_kernel_name(wbx_ctx* ctx);
+/* The one resampling ratio the last render's mix was told about (MixArgs::uniform_speed: every linearly resampled row of the
+ * render plays at exactly this Sampler::playback_speed_, sampler.h:24 — the hoisted-product chunk modes), 0.0 when the
+ * session holds more than one ratio, none, or the plan came through layer 1.  Introspection, like wbx_kernel_name. */
+double wbx_render_uniform_speed(wbx_ctx* ctx);
 
 /* ---- layer 2: the engine surface -----------------------------------------------------------
  * Mirrors wb::Engine / wb::Track (src/engine/engine.h, track.h).  Beats are doubles as in the

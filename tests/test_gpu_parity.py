@@ -1215,6 +1215,43 @@ def test_kernel_name_follows_the_session(monkeypatch):
     eng.close()
 
 
+def test_one_resampling_ratio_reaches_the_kernel(monkeypatch):
+    """MixArgs::uniform_speed: a session whose resampled clips all play at one ratio in [0.67, 0.999] (44.1 kHz clips in a 48 kHz
+    session) tells the mix so (MODE_WNU / MODE_WINU: the products fl(j * speed) hoisted out of the track loop) — the value the
+    kernel was launched with, bit for bit Sampler::reset_state's expression; a second ratio, or WBX_NO_UNIFORM=1, withdraws it;
+    the master is the same bits either way.  (Rounds 3-4 carried the modes and never took them: the assignment had been lost.)"""
+    spec = synth.make_session("u", 40, n_blocks=8, src_rate=44100)
+    masters = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("WBX_NO_UNIFORM", "1")
+        eng = build_engine(spec, max_blocks=8)
+        eng.play()
+        eng.render(8)
+        m, _, _ = eng.ctx.fetch()
+        masters.append(m.copy())
+        assert eng.ctx.uniform_speed() == (0.0 if off else (44100.0 / 48000.0) * 1.0)
+        eng.close()
+    assert np.array_equal(bits(masters[0]), bits(masters[1]))
+    monkeypatch.delenv("WBX_NO_UNIFORM")
+    # a clip at another ratio: no promise any more
+    spec2 = synth.make_session("u2", 40, n_blocks=8, src_rate=44100)
+    spec2.clips[3].speed = 0.8
+    eng = build_engine(spec2, max_blocks=8)
+    eng.play()
+    eng.render(8)
+    eng.ctx.fetch()
+    assert eng.ctx.uniform_speed() == 0.0
+    eng.close()
+    # ... and a session at the device rate has nothing to hoist
+    eng = build_engine(synth.make_session("u3", 40, n_blocks=8, src_rate=48000), max_blocks=8)
+    eng.play()
+    eng.render(8)
+    eng.ctx.fetch()
+    assert eng.ctx.uniform_speed() == 0.0
+    eng.close()
+
+
 def test_cpp_host_through_the_adapter(tmp_path):
     """A C++ host written against include/wbx_adapter.hpp (reference-shaped Engine/Track/AudioBuffer),
     compiled with plain g++ and linked to libwbx.so, is bit-identical to the oracle."""

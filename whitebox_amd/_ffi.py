@@ -108,6 +108,7 @@ SYMBOLS = {
     "wbx_host_free": (C.c_int, [_vp]),
     "wbx_kernel_time": (C.c_int, [_vp, C.c_int, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "wbx_kernel_name": (C.c_char_p, [_vp]),
+    "wbx_render_uniform_speed": (C.c_double, [_vp]),
     "wbx_tail_time": (C.c_int, [_vp, C.POINTER(_d)]),
     "wbx_engine_create": (C.c_int, [C.POINTER(Config), _pp]),
     "wbx_engine_destroy": (None, [_vp]),

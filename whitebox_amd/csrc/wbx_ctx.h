@@ -236,6 +236,7 @@ struct wbx_ctx {
   uint64_t mix_launches = 0;
   bool profiling = true;
   const char* mix_kernel_name = "";   // the instance launch_mix chose last (wbx_kernel_name)
+  double last_uniform_speed = 0.0;    // MixArgs::uniform_speed of the last launch (wbx_render_uniform_speed)
   int mix_unroll = 0;                 // WBX_MIX_VARIANT=10*U+W forces a kernel variant (results are identical);
                                       // 0 = chosen per render: 24 when resampled or integer-PCM clips are present, else 43
   bool has_window_clips = true;

@@ -616,7 +616,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   };
   // 24/32-bit PCM row (4-byte containers: the fp32 window loads), linear resample: taps a = (float)(norm * (double)src[ix])
   // (sampler.cpp:11-14,53-54), then as fp32
-  auto row_window32 = [&](auto narrow, const Pre& p, uint32_t fmt, double pos, double speed, float cg, const float (&gc)[CL]) {
+  auto row_window32 = [&](auto narrow, auto uni, const Pre& p, uint32_t fmt, double pos, double speed, float cg, const float (&gc)[CL]) {
     const double norm = fmt == FMT_I24 ? 1.0 / 8388607.0 : 1.0 / 2147483647.0;
     Pre f;
 #pragma unroll
@@ -629,7 +629,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
     }
     f.ix0 = p.ix0;
     f.fx0 = p.fx0;
-    return row_window(narrow, f, pos, speed, cg, gc);
+    return row_window_at(narrow, std::false_type{}, uni, f, pos, speed, 0.0, cg, gc);
   };
   // per-frame taps for any playback speed and storage format (sampler.cpp:50-52 for each of the lane's 4 frames):
   // four unaligned loads of the pair {src[ix], src[ix+1]} (8 B; 4 B for 16-bit PCM, kept packed in v) per channel; also
@@ -1028,7 +1028,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           }
         } else if (k == KIND_WINDOW) {
           if (G && fmt != FMT_F32) {   // 24/32-bit PCM through the same window loads (G instances only)
-            if constexpr (G) m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
+            if constexpr (G) m = row_window32(narrow, uni, pre[u], fmt, r.pos, r.speed, cg, gc);
           } else {
             m = row_window_at(narrow, std::false_type{}, uni, pre[u], r.pos, r.speed, 0.0, cg, gc);
           }
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           if (fmt == FMT_F32)
             m = row_window(narrow, pre[u], r.pos, r.speed, cg, gc);
           else
-            m = row_window32(narrow, pre[u], fmt, r.pos, r.speed, cg, gc);
+            m = row_window32(narrow, std::false_type{}, pre[u], fmt, r.pos, r.speed, cg, gc);
         } else if (k == KIND_UNITY_I16) {
           each_i16();
         } else if (k == KIND_UNITY_I32) {
@@ -1495,7 +1495,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
              : (!has_i32 && !has_f32) ? MODE_I16 : has_win ? MODE_MIXED : MODE_MU;
     } else if (has_win || has_win32) {
       // fp32 unity + window rows; in G instances also 24/32-bit PCM unity + window rows (all 4-byte containers)
-      mode = (G || !has_i32) ? (has_wide ? MODE_W : (us > 0.0 && !has_win32) ? MODE_WNU : MODE_WN) : MODE_MIXED;
+      mode = (G || !has_i32) ? (has_wide ? MODE_W : us > 0.0 ? MODE_WNU : MODE_WN) : MODE_MIXED;   // (the position arithmetic does not look at the storage format)
     } else {
       mode = !has_i32 ? MODE_U : !has_f32 ? MODE_I32 : MODE_MU;   // unity rows of several formats
     }

@@ -446,8 +446,9 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   {   // one resampling ratio for every window row of this render (layer 2's word; MODE_WNU / WINU: the products fl(j * speed)
       // hoisted out of the track loop).  WBX_NO_UNIFORM=1: A/B aid.  [Round 3's split of this function lost this line: the
       // modes were carried but never taken until round 5 — SQ_INSTS_VALU_MUL_F64 of the r03-r05 PMC passes shows it.]
-    static const bool off = [] { const char* v = std::getenv("WBX_NO_UNIFORM"); return v && v[0] == '1'; }();
-    m.uniform_speed = off ? 0.0 : c->uniform_speed;
+    const char* v = std::getenv("WBX_NO_UNIFORM");   // (read per launch: tests flip it inside one process)
+    m.uniform_speed = (v && v[0] == '1') ? 0.0 : c->uniform_speed;
+    c->last_uniform_speed = m.uniform_speed;
   }
   // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
   // master, nothing to continue): the mix workgroup clamps and stores the master itself — the sum kernel is not launched
@@ -1635,6 +1636,7 @@ extern "C" wbx_status wbx_host_free(void* p) {
 }
 
 extern "C" const char* wbx_kernel_name(wbx_ctx* c) { return c ? c->mix_kernel_name : ""; }
+extern "C" double wbx_render_uniform_speed(wbx_ctx* c) { return c ? c->last_uniform_speed : 0.0; }
 
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
   if (!c) return WBX_ERR_INVALID;

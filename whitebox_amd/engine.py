@@ -245,6 +245,10 @@ class MixContext:
         """The mix_kernel instance the last render launched, as rocprofv3 prints it."""
         return (self.L.wbx_kernel_name(self.h) or b"").decode()
 
+    def uniform_speed(self) -> float:
+        """MixArgs::uniform_speed of the last render (0.0: no single resampling ratio)."""
+        return float(self.L.wbx_render_uniform_speed(self.h))
+
     def tail_time(self) -> float:
         ms = C.c_double()
         _check(self.L.wbx_tail_time(self.h, C.byref(ms)), "wbx_tail_time", self.h)
