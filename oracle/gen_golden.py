@@ -304,12 +304,51 @@ def gen_sequencer():
     np.savez_compressed(os.path.join(OUT, "sequencer.npz"), **arrs)
     print("sequencer.npz:", n, "sessions")
 
+
+BASELINE_REF_CASES = [   # (name, make_session kwargs, blocks) — BASELINE.json's configs and their seek variants
+    ("c1", dict(n_tracks=8, clip_channels=1, unity_gain=True, seed=0x5EED0001), 8),
+    ("c2", dict(n_tracks=256, seed=0x5EED0002), 8),
+    ("c3", dict(n_tracks=4096, src_rate=44100, seed=0x5EED0003), 4),
+    ("c3seek", dict(n_tracks=512, src_rate=44100, seek=True, seed=0x5EED0013), 8),
+    ("c2seek", dict(n_tracks=256, seek=True, seed=0x5EED0005), 8),
+    ("c5", dict(n_tracks=32768, seed=0x5EED0006), 2),
+]
+
+
+def gen_baseline_ref():
+    """tests/golden/baseline_ref.npz: BASELINE.json's configurations 1, 2, 3 and 5 (and seek variants) rendered by the reference's
+    OWN Engine::process (oracle/_ref/wbref_engine) — per block the master, playhead and sample_position; at the last block every
+    track's VUMeter::level and Sampler::sample_offset_.  The sessions are whitebox_amd.synth.make_session(**kwargs) on every side."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_engine as R
+    from whitebox_amd import synth
+    if not R.available():
+        raise SystemExit("oracle/_ref/wbref_engine is not built (needs /root/reference)")
+    arrs = {}
+    for name, kw, nb in BASELINE_REF_CASES:
+        kw = dict(kw)
+        spec = synth.make_session(name, kw.pop("n_tracks"), n_blocks=nb, **kw)
+        ref = R.run_reference(R.script_from_spec(spec, nb), timeout=300)
+        run = [r for r in ref if r[0] == "run"][0][1]
+        assert all(r[1] == 1 for r in ref if r[0] == "op")          # every clip was taken
+        arrs[f"{name}.master"] = np.stack([b["master"] for b in run])                                   # [blocks][C][F] bit patterns
+        arrs[f"{name}.transport"] = np.array([[b["playhead"], b["sample_position"]] for b in run], np.uint64)
+        last = run[-1]["tracks"]
+        arrs[f"{name}.level"] = np.array([t["level"] for t in last], np.uint32)
+        arrs[f"{name}.offset"] = np.array([t["offset"] for t in last], np.uint64)
+        arrs[f"{name}.events"] = np.array([sum(len(t["events"]) for t in b["tracks"]) for b in run], np.uint32)
+    arrs["cases"] = np.frombuffer(json.dumps([[n, k, b] for n, k, b in BASELINE_REF_CASES]).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "baseline_ref.npz"), **arrs)
+    print("baseline_ref.npz:", len(BASELINE_REF_CASES), "configurations")
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest", "sequencer"):     # (the other fixtures are untouched)
-        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest, "sequencer": gen_sequencer}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest", "sequencer", "baseline"):     # (the other fixtures are untouched)
+        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest, "sequencer": gen_sequencer, "baseline": gen_baseline_ref}[sys.argv[1]]()
     else:
         main()
         gen_mip()
         gen_vu()
         gen_ingest()
         gen_sequencer()
+        gen_baseline_ref()

@@ -71,6 +71,33 @@ def script_from_json(text: str) -> Script:
     return s
 
 
+def script_from_spec(spec, n_blocks: int) -> Script:
+    """a whitebox_amd.synth.SessionSpec (the BASELINE configs, the fuzz generators' sessions ...) as a script: fp32 samples come
+    from the driver's own copy of the keyed generator (`synth` operation: no audio in the script or the data file), other
+    formats through the data file; clips in list order, as build_oracle_engine / build_engine add them"""
+    s = Script(spec.channels, spec.block, spec.sample_rate, spec.bpm)
+    for i, smp in enumerate(spec.samples):
+        if smp.fmt == "f32":
+            s.samples.append(("f32", smp.channels, smp.rate, smp.frames, spec.sample_data(i), (spec.seed, smp.seed_track, smp.amp)))
+            s.ops.append(("synth", len(s.samples) - 1))
+        else:
+            s.add_sample(smp.fmt, smp.channels, smp.rate, smp.frames, spec.sample_data(i), gen=(spec.seed, smp.seed_track, smp.amp))
+    for t in range(spec.n_tracks):
+        s.op("track")
+        s.op("vol", t, float(np.float32(spec.volumes_db[t])))
+        s.op("pan", t, float(np.float32(spec.pans[t])))
+        if spec.mutes[t]:
+            s.op("mute", t, 1)
+    for c in spec.clips:
+        s.op("clip", c.track, float(c.min_beat), float(c.max_beat), float(c.start_offset),
+             c.sample if c.sample is not None else c.track, float(c.speed), float(np.float32(c.gain)))
+    if spec.playhead_start:
+        s.op("seek", float(spec.playhead_start))
+    s.op("play")
+    s.op("run", n_blocks)
+    return s
+
+
 def _hx(x: float) -> str:
     return float(x).hex()
 
@@ -78,8 +105,11 @@ def _hx(x: float) -> str:
 def run_reference(s: Script, timeout=60, want_raw=False):
     """-> list of records: ("op", status) | ("run", [block dicts]) | ("clips", [[clip tuples] per track])"""
     blob, offs = bytearray(), []
-    for fmt, ch, rate, frames, data, _g in s.samples:
+    synth_ops = {o[1] for o in s.ops if o[0] == "synth"}
+    for i, (fmt, ch, rate, frames, data, _g) in enumerate(s.samples):
         offs.append(len(blob))
+        if i in synth_ops:
+            continue                      # generated by the driver from its key
         for c in range(ch):
             blob += np.ascontiguousarray(data[c][:frames]).tobytes()
     lines = []
@@ -88,6 +118,9 @@ def run_reference(s: Script, timeout=60, want_raw=False):
         if k == "sample":
             fmt, ch, rate, frames = s.samples[o[1]][:4]
             lines.append(f"sample {O.FMT[fmt]} {ch} {rate} {frames} {offs[o[1]]}")
+        elif k == "synth":
+            fmt, ch, rate, frames, _d, (seed, kt, amp) = s.samples[o[1]]
+            lines.append(f"synth {ch} {rate} {frames} {seed} {kt} {_hx(np.float32(amp))}")
         elif k == "clip":
             _, t, mn, mx, so, si, sp, g = o
             lines.append(f"clip {t} {_hx(mn)} {_hx(mx)} {_hx(so)} {si} {_hx(sp)} {_hx(np.float32(g))}")
@@ -209,7 +242,7 @@ def run_oracle(s: Script):
             e.play()
         elif k == "stop":
             e.stop()
-        elif k == "sample":
+        elif k in ("sample", "synth"):
             fmt, ch, rate, frames, data = s.samples[o[1]][:5]
             e.add_sample(fmt, ch, rate, frames, data)
         elif k == "track":

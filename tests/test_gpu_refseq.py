@@ -153,3 +153,60 @@ def test_product_equals_the_live_reference(kind):
             raise AssertionError(f"{kind} seed {seed} ({'render' if seed & 1 else 'callback'}): {e}") from e
         done += 1
     assert done >= n_seeds // 3, (done, n_seeds)
+
+
+def _levels_running_max(pk):
+    """per-track running maximum of the block peaks [K][N][C] -> what VUMeter::level holds when nobody read it ([N][2] bit patterns,
+    a mono session's second meter stays 0)"""
+    lv = np.zeros((pk.shape[1], 2), np.float32)
+    lv[:, :pk.shape[2]] = pk.max(axis=0)
+    return lv.view(np.uint32)
+
+
+@pytest.mark.parametrize("which", ["c1", "c2", "c3", "c3seek", "c2seek", "c5"])
+def test_baseline_configs_equal_the_reference_recordings(monkeypatch, which):
+    """BASELINE.json's configurations on the device against what the REFERENCE'S OWN Engine::process rendered
+    (tests/golden/baseline_ref.npz, oracle/gen_golden.py baseline): master bit for bit in the reference's summation order
+    (one group; config 3: chained 128-track pieces; config 5: the chain of 8 engines that WBX_DIST_CHAIN runs across GPUs),
+    playhead and sample_position bit for bit, every track's running VU maximum."""
+    from test_oracle_golden import baseline_ref_cases
+    from whitebox_amd.engine import build_engine
+    for name, spec, K, rec in baseline_ref_cases():
+        if name != which:
+            continue
+        n = spec.n_tracks
+        if name == "c5":
+            from test_dist_gloo import _shard_spec
+            from whitebox_amd.dist import PinnedBuffer, shard_tracks
+            world = 8
+            running = PinnedBuffer(K * 2 * 512)
+            for rank in range(world):
+                first, count = shard_tracks(n, world, rank)
+                eng = build_engine(_shard_spec(spec, first, count), max_blocks=K, group_size=count)
+                eng.ctx.set_clamp(rank == world - 1)
+                eng.ctx.set_master_target(running.ptr)
+                eng.ctx.set_master_init(running.ptr if rank else None)
+                eng.play()
+                eng.render(K)
+                _, pk, _ = eng.ctx.fetch(peaks=True)
+                assert np.array_equal(_levels_running_max(pk), rec["level"][first:first + count]), rank
+                ph, sp, _ = eng.transport()
+                assert (O.f64_bits(ph), O.f64_bits(sp)) == tuple(int(x) for x in rec["transport"][K - 1])
+                eng.close()
+            got = running.array.reshape(K, 2, 512).copy()
+            running.close()
+            assert np.array_equal(got.view(np.uint32), rec["master"])
+            return
+        if n > 512:
+            monkeypatch.setenv("WBX_EXACT_MIN_BLOCKS", str(K))     # the chained order, as renders of >= 1024 blocks take it
+        eng = build_engine(spec, max_blocks=K, group_size=0 if n > 512 else n)
+        eng.play()
+        eng.render(K)
+        m, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(np.ascontiguousarray(m).view(np.uint32), rec["master"]), name
+        ph, sp, _ = eng.transport()
+        assert (O.f64_bits(ph), O.f64_bits(sp)) == tuple(int(x) for x in rec["transport"][K - 1]), name
+        assert np.array_equal(_levels_running_max(pk), rec["level"]), name
+        eng.close()
+        return
+    raise AssertionError(which)
