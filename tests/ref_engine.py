@@ -20,7 +20,14 @@ EXE = os.path.join(O.ORACLE_DIR, "_ref", "wbref_engine")
 
 
 def available() -> bool:
-    return bool(O.build_ref()) and os.path.exists(EXE)
+    if not (bool(O.build_ref()) and os.path.exists(EXE)):
+        return False
+    if not os.access(EXE, os.X_OK):          # (a copy of the tree that dropped the mode bits)
+        try:
+            os.chmod(EXE, 0o755)
+        except OSError:
+            return False
+    return os.access(EXE, os.X_OK)
 
 
 class Script:
