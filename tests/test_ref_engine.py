@@ -67,3 +67,48 @@ def test_refusals_and_takes_are_both_exercised(exe):
                 refused += x == 0
                 bad += x == 2
     assert taken > 100 and refused > 10 and bad > 5, (taken, refused, bad)
+
+
+CUTS = {   # build output under oracle/_ref/ -> the reference source it must be a verbatim, contiguous region of
+    "eng/vu_meter_h_body.inc": "engine/vu_meter.h", "eng/track_h_body.inc": "engine/track.h",
+    "eng/audio_record_h_body.inc": "engine/audio_record.h", "eng/engine_h_body.inc": "engine/engine.h",
+    "eng/track_cpp_body.inc": "engine/track.cpp",
+    "eng/engine_r1.inc": "engine/engine.cpp", "eng/engine_r2.inc": "engine/engine.cpp", "eng/engine_r3.inc": "engine/engine.cpp",
+    "eng/engine_r4.inc": "engine/engine.cpp", "eng/engine_r5.inc": "engine/engine.cpp", "eng/engine_r6.inc": "engine/engine.cpp",
+    "eng/assets_r1.inc": "engine/assets_table.cpp", "eng/assets_r2.inc": "engine/assets_table.cpp",
+    "eng/assets_r3.inc": "engine/assets_table.cpp", "eng/sample_r1.inc": "dsp/sample.cpp",
+    "deinterleave_impl.inc": "dsp/sample.cpp", "mip_impl.inc": "gfx/waveform_visual.cpp", "vu_meter_struct.inc": "engine/vu_meter.h",
+}
+
+
+def test_every_cut_is_a_verbatim_region_of_the_reference(exe):
+    """what oracle/ref_*_driver.cpp compile is the reference's text and nothing else: every build output of the recipe is, byte
+    for byte, ONE contiguous region of the source file it was cut from; regions of one file do not overlap; no `Log::` line
+    survives in a cut except inside track.cpp's own `#if WB_DBG_LOG_*` blocks and audio_record.h's comment"""
+    import re
+    ref_root = "/root/reference/src"
+    ranges = {}
+    for inc, src in CUTS.items():
+        text = open(os.path.join(R.O.ORACLE_DIR, "_ref", inc)).read()
+        whole = open(os.path.join(ref_root, src)).read()
+        at = whole.find(text)
+        if at < 0 and whole.endswith(text[:-1]):     # (a region that runs to the end of a file without a final newline: awk adds one)
+            at = len(whole) - len(text) + 1
+        assert at >= 0 and text.strip(), (inc, "is not a verbatim region of", src)
+        first = whole.count("\n", 0, at) + 1
+        last = first + text.count("\n") - 1
+        ranges.setdefault(src, []).append((first, last, inc))
+        for m in re.finditer(r"^.*Log::.*$", text, re.M):
+            line = m.group(0)
+            if line.lstrip().startswith("//"):
+                continue
+            before = text[:m.start()]
+            depth = len(re.findall(r"^#if", before, re.M)) - len(re.findall(r"^#endif", before, re.M))
+            assert src == "engine/track.cpp" and depth > 0, (inc, line)
+    for src, rs in ranges.items():
+        if src in ("engine/vu_meter.h", "dsp/sample.cpp"):
+            continue            # (two recipes cut these files for two drivers: the struct / the whole body; the transposition / the Sample members)
+        rs.sort()
+        for (a0, a1, _), (b0, b1, _) in zip(rs, rs[1:]):
+            assert a1 < b0, (src, rs)
+    print("\n".join(f"{src}:{a}-{b}  ({inc})" for src, rs in sorted(ranges.items()) for a, b, inc in sorted(rs)))
