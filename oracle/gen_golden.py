@@ -338,6 +338,20 @@ def gen_baseline_ref():
         arrs[f"{name}.level"] = np.array([t["level"] for t in last], np.uint32)
         arrs[f"{name}.offset"] = np.array([t["offset"] for t in last], np.uint64)
         arrs[f"{name}.events"] = np.array([sum(len(t["events"]) for t in b["tracks"]) for b in run], np.uint32)
+    # configuration 4 (64 sub-buses: an extension, the reference has no bus type) as SURVEY A13 defines its oracle: the reference's
+    # own functions composed — one reference Engine per bus (64 x Engine::process over the bus's 64 tracks), the bus sums added in
+    # bus order with the reference's AudioBuffer::mix; recorded: the UN-clamped master, a CRC of every bus sum, two bus sums whole
+    import zlib
+    spec = synth.make_session("c4", 4096, n_buses=64, n_blocks=4, seed=0x5EED0004)
+    ref = R.run_reference(R.script_from_bus_spec(spec, 4), timeout=300)
+    assert all(r[1] == 1 for r in ref if r[0] == "op")
+    rb = [r for r in ref if r[0] == "runbus"][0][1]
+    assert max(b["peak"] for b in rb) < 1.0          # no engine's own clamp touched its bus sum
+    arrs["c4.master_unclamped"] = np.stack([b["master"] for b in rb])
+    arrs["c4.bus_crc"] = np.array([[zlib.crc32(b["buses"][k].tobytes()) for k in range(64)] for b in rb], np.uint32)
+    arrs["c4.bus0"] = np.stack([b["buses"][0] for b in rb])
+    arrs["c4.bus63"] = np.stack([b["buses"][63] for b in rb])
+    arrs["c4.transport"] = np.array([[b["playhead"], b["sample_position"]] for b in rb], np.uint64)
     arrs["cases"] = np.frombuffer(json.dumps([[n, k, b] for n, k, b in BASELINE_REF_CASES]).encode(), np.uint8)
     np.savez_compressed(os.path.join(OUT, "baseline_ref.npz"), **arrs)
     print("baseline_ref.npz:", len(BASELINE_REF_CASES), "configurations")

@@ -39,6 +39,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <ctime>
 #include <functional>
@@ -203,9 +204,14 @@ int main(int argc, char** argv) {
   std::vector<unsigned char> blob((size_t)data_size);
   if (data_size && std::fread(blob.data(), 1, (size_t)data_size, dataf) != (size_t)data_size) return 2;
 
-  Engine& E = g_engine;
+  // engines[0] = the reference's g_engine.  More engines exist only for the sub-bus composition (`bus` / `runbus` below): SURVEY
+  // A13's oracle — "the same composition executed with the reference's AudioBuffer::mix on per-track buffers produced by the
+  // reference Track::process" — is formed from whole Engine::process calls, one engine per bus.
+  std::vector<Engine*> engines{ &g_engine };
+  Engine* cur = &g_engine;
+#define E (*cur)
   uint32_t channels = 2, frames = 512;
-  double rate = 48000.0;
+  double rate = 48000.0, last_bpm = 0.0;
   char line[512], op[32];
   uint32_t block_no = 0;
   while (std::fgets(line, sizeof line, script)) {
@@ -216,21 +222,31 @@ int main(int argc, char** argv) {
       unsigned c, f, r;
       std::sscanf(a, "%u %u %u", &c, &f, &r);
       channels = c; frames = f; rate = (double)r;
-      E.set_audio_channel_config(0, c, f, r);
+      for (auto e : engines) e->set_audio_channel_config(0, c, f, r);
     } else if (!std::strcmp(op, "rate")) {     // rate <r>: the back end reconfigured to another device rate, block shape kept
       unsigned r; std::sscanf(a, "%u", &r);
       rate = (double)r;
       E.set_audio_channel_config(0, channels, frames, r);
     } else if (!std::strcmp(op, "bpm")) {
       double v; std::sscanf(a, "%lf", &v);
-      E.set_bpm(v);
+      last_bpm = v;
+      for (auto e : engines) e->set_bpm(v);
     } else if (!std::strcmp(op, "seek")) {
       double v; std::sscanf(a, "%lf", &v);
       E.set_playhead_position(v);
     } else if (!std::strcmp(op, "play")) {
-      harness_play(E);
+      for (auto e : engines) harness_play(*e);
     } else if (!std::strcmp(op, "stop")) {
-      harness_stop(E);
+      for (auto e : engines) harness_stop(*e);
+    } else if (!std::strcmp(op, "bus")) {      // bus <b>: the operations that follow build the engine that renders sub-bus b
+      unsigned b; std::sscanf(a, "%u", &b);
+      while (engines.size() <= b) {
+        Engine* e = new Engine();
+        e->set_audio_channel_config(0, channels, frames, (uint32_t)rate);
+        if (last_bpm != 0.0) e->set_bpm(last_bpm);
+        engines.push_back(e);
+      }
+      cur = engines[b];
     } else if (!std::strcmp(op, "sample")) {   // sample <AudioFormat> <channels> <rate> <count> <byte offset into the data file>
       unsigned fmt, ch, r; unsigned long long count, off;
       std::sscanf(a, "%u %u %u %llu %llu", &fmt, &ch, &r, &count, &off);
@@ -323,6 +339,32 @@ int main(int argc, char** argv) {
           put_f64(t->sampler.playback_speed_); put_f64(t->sampler.sample_offset_);
           for (int c = 0; c < 2; c++) put(t->level_meter[c].level.load());
         }
+      }
+      continue;
+    } else if (!std::strcmp(op, "runbus")) {   // runbus <n>: n blocks of every engine; master = the buses added in order (AudioBuffer::mix)
+      unsigned n; std::sscanf(a, "%u", &n);
+      AudioBuffer<float> in(frames, channels), master(frames, channels);
+      std::vector<AudioBuffer<float>*> outs;
+      for (size_t b = 0; b < engines.size(); b++) outs.push_back(new AudioBuffer<float>(frames, channels));
+      put_u32(0x52554200u); put_u32(n); put_u32((uint32_t)engines.size());
+      for (unsigned blk = 0; blk < n; blk++) {
+        // every Engine::process ends in the hard clamp (engine.cpp:1627-1636): an engine's output is its bus's un-clamped sum only
+        // while no sample of it reaches +-1 — bus_peak is reported and the test asserts it.  The master written here is the
+        // UN-clamped sum of the buses (the product is asked for the same: wbx_set_clamp(0)); the clamp itself is A10's row.
+        float bus_peak = 0.0f;
+        master.clear();
+        for (size_t b = 0; b < engines.size(); b++) {
+          engines[b]->process(in, *outs[b], rate);
+          master.mix(*outs[b]);                                          // audio_buffer.h:73-82
+        }
+        for (uint32_t c = 0; c < channels; c++) std::fwrite(master.channel_buffers[c], sizeof(float), frames, g_out);
+        for (size_t b = 0; b < engines.size(); b++)
+          for (uint32_t c = 0; c < channels; c++) {
+            std::fwrite(outs[b]->channel_buffers[c], sizeof(float), frames, g_out);
+            for (uint32_t j = 0; j < frames; j++) bus_peak = std::max(bus_peak, std::fabs(outs[b]->channel_buffers[c][j]));
+          }
+        put(bus_peak);
+        put_f64(engines[0]->playhead); put_f64(engines[0]->sample_position);
       }
       continue;
     } else if (!std::strcmp(op, "bench")) {    // bench <blocks> <budget seconds> <max passes>: play, <blocks> x Engine::process, stop — timed

@@ -105,6 +105,34 @@ def script_from_spec(spec, n_blocks: int) -> Script:
     return s
 
 
+def script_from_bus_spec(spec, n_blocks: int) -> Script:
+    """a session with sub-buses (extension A13; config 4) for the driver's `bus` / `runbus` operations: one reference Engine per
+    bus holding that bus's tracks in track order, the buses added in order — SURVEY A13's composition of reference functions"""
+    assert spec.n_buses and spec.track_bus is not None
+    s = Script(spec.channels, spec.block, spec.sample_rate, spec.bpm)
+    for i, smp in enumerate(spec.samples):
+        assert smp.fmt == "f32"
+        s.samples.append(("f32", smp.channels, smp.rate, smp.frames, None, (spec.seed, smp.seed_track, smp.amp)))
+        s.ops.append(("synth", len(s.samples) - 1))
+    for b in range(spec.n_buses):
+        s.op("bus", b)
+        members = [t for t in range(spec.n_tracks) if spec.track_bus[t] == b]
+        local = {t: i for i, t in enumerate(members)}
+        for t in members:
+            s.op("track")
+            s.op("vol", local[t], float(np.float32(spec.volumes_db[t])))
+            s.op("pan", local[t], float(np.float32(spec.pans[t])))
+            if spec.mutes[t]:
+                s.op("mute", local[t], 1)
+        for c in spec.clips:
+            if c.track in local:
+                s.op("clip", local[c.track], float(c.min_beat), float(c.max_beat), float(c.start_offset),
+                     c.sample if c.sample is not None else c.track, float(c.speed), float(np.float32(c.gain)))
+    s.op("play")
+    s.op("runbus", n_blocks)
+    return s
+
+
 def _hx(x: float) -> str:
     return float(x).hex()
 
@@ -190,6 +218,15 @@ def parse_results(raw: bytes, C: int, F: int):
                 b["tracks"] = tr
                 blocks.append(b)
             out.append(("run", blocks))
+        elif tag == 0x52554200:
+            n, nb = u32(), u32()
+            blocks = []
+            for _ in range(n):
+                m = np.frombuffer(raw, np.uint32, C * F, pos).reshape(C, F).copy(); pos += 4 * C * F
+                bus = np.frombuffer(raw, np.uint32, nb * C * F, pos).reshape(nb, C, F).copy(); pos += 4 * nb * C * F
+                peak = struct.unpack_from("<f", raw, pos)[0]; pos += 4
+                blocks.append({"master": m, "buses": bus, "peak": peak, "playhead": f64bits(), "sample_position": f64bits()})
+            out.append(("runbus", blocks))
         elif tag == 0x42454E00:
             n, passes = u32(), u32()
             secs = struct.unpack_from("<d", raw, pos)[0]; pos += 8

@@ -210,3 +210,27 @@ def test_baseline_configs_equal_the_reference_recordings(monkeypatch, which):
         eng.close()
         return
     raise AssertionError(which)
+
+
+def test_config4_equals_the_reference_composition():
+    """configuration 4 on the device against SURVEY A13's oracle formed from the reference's own functions (64 reference engines,
+    one per bus, added with the reference's AudioBuffer::mix: tests/golden/baseline_ref.npz c4.*): the un-clamped master
+    (wbx_set_clamp(0)) and all 64 bus sums bit for bit."""
+    import os
+    import zlib
+    import golden_util as G
+    from whitebox_amd import synth
+    from whitebox_amd.engine import build_engine
+    g = np.load(os.path.join(G.GOLDEN, "baseline_ref.npz"))
+    spec = synth.make_session("c4", 4096, n_buses=64, n_blocks=4, seed=0x5EED0004)
+    eng = build_engine(spec, max_blocks=4)
+    eng.ctx.set_clamp(False)
+    eng.play()
+    eng.render(4)
+    m, _, bus = eng.ctx.fetch(buses=True)
+    assert np.array_equal(np.ascontiguousarray(m).view(np.uint32), g["c4.master_unclamped"])
+    for b in range(4):
+        assert [zlib.crc32(np.ascontiguousarray(bus[b, k]).view(np.uint32).tobytes()) for k in range(64)] == [int(x) for x in g["c4.bus_crc"][b]], b
+    ph, sp, _ = eng.transport()
+    assert (O.f64_bits(ph), O.f64_bits(sp)) == tuple(int(x) for x in g["c4.transport"][3])
+    eng.close()
