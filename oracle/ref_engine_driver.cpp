@@ -309,6 +309,13 @@ int main(int argc, char** argv) {
         // reserve_track_region
         if (rel != 0.0 && tr->query_clip_by_range(mn, mx).has_value()) status = 0; else E.move_clip(tr, c, rel);
       }
+    } else if (!std::strcmp(op, "query")) {    // query <track> <min> <max>: Track::query_clip_by_range (track.cpp:112-157) — what add / move /
+      unsigned t; double mn, mx;               // resize / delete_region hand to reserve_track_region; answered with its own record
+      std::sscanf(a, "%u %la %la", &t, &mn, &mx);
+      auto q = E.tracks[t]->query_clip_by_range(mn, mx);
+      put_u32(0x51525900u); put_u32(q ? 1u : 0u); put_u32(q ? q->first : 0u); put_u32(q ? q->last : 0u);
+      put_f64(q ? q->first_offset : 0.0); put_f64(q ? q->last_offset : 0.0);
+      continue;
     } else if (!std::strcmp(op, "deltrack")) {
       unsigned s; std::sscanf(a, "%u", &s);
       E.delete_track(s);

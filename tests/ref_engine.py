@@ -163,6 +163,8 @@ def run_reference(s: Script, timeout=60, want_raw=False):
             lines.append(f"gain {o[1]} {o[2]} {_hx(np.float32(o[3]))}")
         elif k == "move":
             lines.append(f"move {o[1]} {o[2]} {_hx(o[3])}")
+        elif k == "query":
+            lines.append(f"query {o[1]} {_hx(o[2])} {_hx(o[3])}")
         elif k in ("vol", "pan"):
             lines.append(f"{k} {o[1]} {float(np.float32(o[2]))!r}")
         elif k in ("bpm", "seek"):
@@ -218,6 +220,10 @@ def parse_results(raw: bytes, C: int, F: int):
                 b["tracks"] = tr
                 blocks.append(b)
             out.append(("run", blocks))
+        elif tag == 0x51525900:
+            has, first, last = u32(), u32(), u32()
+            fo, lo = f64bits(), f64bits()
+            out.append(("query", (has, first, last) if has else (0, 0, 0)))
         elif tag == 0x52554200:
             n, nb = u32(), u32()
             blocks = []
@@ -327,6 +333,11 @@ def run_oracle(s: Script):
                     st = 0
                 else:
                     e.move_clip(t, i, float(rel))
+        elif k == "query":
+            f, l = O.C.c_uint32(), O.C.c_uint32()
+            has = int(bool(e.L.wbo_track_query_clip_by_range(e.e, o[1], O.C.c_double(o[2]), O.C.c_double(o[3]), O.C.byref(f), O.C.byref(l))))
+            out.append(("query", (has, f.value, l.value) if has else (0, 0, 0)))
+            continue
         elif k == "deltrack":
             e.delete_track(o[1])
         elif k == "movetrack":
@@ -375,6 +386,9 @@ def compare(ref, orc, what="") -> Optional[str]:
         if r[0] == "op":
             if r[1] != o[1]:
                 return f"{what}: operation {i} status reference {r[1]} oracle {o[1]}"
+        elif r[0] == "query":
+            if r[1] != o[1]:
+                return f"{what}: range query {i}: reference {r[1]} oracle {o[1]}"
         elif r[0] == "clips":
             if r[1] != o[1]:
                 return f"{what}: clip lists differ at record {i}: {r[1]} / {o[1]}"
