@@ -134,6 +134,10 @@ def session_script(seed, kind):
         else:
             op = int(rng.integers(0, 7))
             t = int(rng.integers(0, ntr))
+            for _ in range(int(rng.integers(0, 3))):      # what add / move / resize / delete_region would hand to reserve_track_region:
+                a = float(rng.uniform(-0.1, 1.2)) * total   # Track::query_clip_by_range on ranges that fall in gaps, span clips,
+                b = a + float(rng.choice([rng.uniform(0, 0.5) * total, unit * rng.uniform(0, 2), -unit * rng.uniform(0, 2), 0.0]))   # are empty or INVERTED (Q11)
+                s.op("query", int(rng.integers(0, ntr)), a, b)
             if op <= 1:      # delete a clip (index 0..3: often the one that sounds; out of range -> status 2 on both sides)
                 s.op("delclip", t, int(rng.integers(0, 4)))
             elif op == 2:

@@ -57,6 +57,8 @@ def _replay(s, want, batch):
                 ph, sp, _pl = eng.transport()
                 assert (O.f64_bits(ph), O.f64_bits(sp)) == (rec[1][-1]["playhead"], rec[1][-1]["sample_position"])
             continue
+        if k == "query":
+            continue                # (a question to the reference's Track::query_clip_by_range: the oracle answers it, the engine has no such call)
         if k == "clips":
             assert rec[0] == "clips" and len(rec[1]) == len(eng.tracks)
             for t, tr in enumerate(eng.tracks):
