@@ -58,7 +58,7 @@ def test_refusals_and_takes_are_both_exercised(exe):
         except R.Wrapped:
             continue
         ref = R.run_reference(s)
-        ops = [o for o in s.ops if o[0] != "run" and o[0] != "clips"]
+        ops = [o for o in s.ops if o[0] not in ("run", "clips", "query")]
         st = [r[1] for r in ref if r[0] == "op"]
         assert len(ops) == len(st)
         for o, x in zip(ops, st):
