@@ -240,7 +240,7 @@ def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
     import ref_engine as R
     exe = os.path.join(O.ORACLE_DIR, "_ref", "wbref_engine")
     _, src_rate, n_buses, fmt = WORKLOADS[workload]
-    if not R.available() or n_buses or fmt != "f32":
+    if not R.available(build=False) or n_buses or fmt != "f32":
         return None
     seed, amp, tracks = track_layout(workload, n_tracks, 0, 1, sample_blocks)
     amp32 = float(np.float32(amp))
