@@ -246,6 +246,7 @@ struct wbx_ctx {
   bool has_cut_tracks = true;         // some track holds more than one clip (layer 1: unknown, assume so)
   bool force_g = false;
   bool short_render_now = false;      // the render being issued is shorter than kOverlapMinBlocks (the callback path)
+  uint32_t render_blocks_now = 0;     // ... its length in blocks
   bool has_taps_clips = true;         // ... rows read with per-frame taps (KIND_STRIDE) may occur: the instance must carry MODE_G
   bool has_stride_clips = true;       // fp32 clips played at speed > 0.999, != 1 may occur (layer 1: unknown, assume so)
   bool auto_group = false;            // wbx_config.group_size was 0: the library picks the track-group size

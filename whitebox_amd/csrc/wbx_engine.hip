@@ -831,6 +831,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   c->has_lean16_clips = hs.any_win16_clip && !hs.any_other_window_clip;
   c->has_cut_tracks = hs.cut_tracks != 0 || force_cut_instances();
   c->short_render_now = K < kOverlapMinBlocks;
+  c->render_blocks_now = K;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance; reads the flags above)
   c->chain_now = render_chains_groups(c, K);
   c->masked_rows = mix_takes_masked_rows(c, hs.any_window_clip, hs.any_stride_clip);
@@ -897,6 +898,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   a.flags_left = e->h_flags_left;
   hs.clips_edited = false;
   c->short_render_now = K < kOverlapMinBlocks;
+  c->render_blocks_now = K;
   c->whole_lists_now = render_walks_whole_lists(c, K);   // (enters the choice of the mix instance below)
   c->chain_now = render_chains_groups(c, K);
   // clip boundaries inside a block stay in the hot loop when the mix instance of this render can take them

@@ -318,6 +318,18 @@ int mix_family(const wbx_ctx* c) {
 // integer PCM +2-10 %, sessions cut into clips +5-11 % (2 x at 256 frames, where the other instances have no masked
 // rows), fp32 sessions of one clip per track 3-8 % slower (they fetch 1.06 x their bytes instead of 1.02 x) — those keep
 // one channel per wave.
+// fp32 sessions of one clip per track with resampled clips (c3), chained renders of 2048 blocks and more: the two-channels-per-
+// lane instance with ONE row per pipeline batch, <1,true,3,0,1,1,2,128>.  Round 2 measured these sessions 3 % slower through
+// the CL = 2 instances — at 256-block renders in the grouped order; at 2048 chained blocks, with the one-ratio modes taken
+// again, five alternating runs on one box (profiles/r05_ab_c3_instances.txt) read 0.711 of the roofline for it, 0.701 for
+// <2,true,3,..,2,128>, 0.694 for the one-channel-per-wave <2,true,4,..,1,256>; at 1024 and 256 blocks nothing to choose.
+bool mix_long_chained_window_render(const wbx_ctx* c) {
+  static const bool off = [] { const char* v = std::getenv("WBX_NO_LONG_CL2"); return v && v[0] == '1'; }();   // A/B aid
+  const uint32_t F = 4u * native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);
+  return !off && c->cfg.channels == 2u && F == 512u && c->chain_now && c->render_blocks_now >= 2048u && c->has_window_clips &&
+         !c->has_integer_clips && !c->has_cut_tracks && !c->has_stride_clips && !c->n_buses;
+}
+
 bool mix_two_channels_per_lane(const wbx_ctx* c) {
   const uint32_t F = 4u * native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);   // (the block size of the instance's lane space)
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
@@ -330,6 +342,7 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
   // a render whose workgroups walk whole member lists of many staged chunks: the half-size workgroups of these instances
   // put six of them on a CU, and the walk runs 15 % faster than through the four-wave ones (c3, 1024 blocks: 2.94 vs 3.43 ms)
   if (c->whole_lists_now && !c->chain_now && c->longest_list > 2u * kStage) return true;
+  if (mix_long_chained_window_render(c)) return true;
   return c->has_integer_clips || c->has_cut_tracks;
 }
 
@@ -517,7 +530,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     // event packets between two mixes.  WBX_TIMER_PACKETS=1: the old way, an event record either side (A/B aid)
     static const bool packets = std::getenv("WBX_TIMER_PACKETS") != nullptr;
     if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
-    c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : mix_two_channels_per_lane(c) ? 1023
+    c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : mix_two_channels_per_lane(c) ? (mix_long_chained_window_render(c) ? 1013 : 1023)
                                           : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
                mix_family(c), ms, (timed && !packets) ? c->ev[c->ev_pending][0] : nullptr,
                (timed && !packets) ? c->ev[c->ev_pending][1] : nullptr);
@@ -1419,6 +1432,7 @@ extern "C" wbx_status wbx_submit(wbx_ctx* c, uint32_t K, uint32_t N, const wbx_s
   if (!c->h_pool.empty())
     WBX_HIP(c, hipMemcpyAsync(PB(c).pool.p, c->h_pool.data(), c->h_pool.size() * sizeof(DSeg), hipMemcpyHostToDevice, c->stream));
   c->short_render_now = K < kOverlapMinBlocks;
+  c->render_blocks_now = K;
   c->whole_lists_now = render_walks_whole_lists(c, K);
   c->chain_now = render_chains_groups(c, K);
   (void)pick_mix_stream(c, K, false);   // host-sequenced plans are uploaded on the main stream: their mix follows there
