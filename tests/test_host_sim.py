@@ -344,65 +344,97 @@ def test_two_thread_contract_under_thread_sanitizer():
     assert "WARNING: ThreadSanitizer" not in r.stderr
 
 
+def replay_on_host_sim(name, s, want):
+    """one script (tests/ref_engine.Script) through the product's host code + sequencer source and through the oracle: playhead /
+    sample_position and the clip lists against `want` (the reference's answers, recorded or live), the stream calls of every block
+    against the oracle replaying the same script.  -> blocks compared"""
+    blocks = 0
+    e = O.OracleEngine(s.channels, s.block, s.rate)
+    e.enable_seglog()
+    sim = HS.HostSimEngine(8, s.block, s.rate, s.channels, 1)
+    sim.set_masked_rows(4)
+    wi = 0
+    for o in s.ops:
+        rec = want[wi]
+        wi += 1
+        k = o[0]
+        if k == "run":
+            for br in rec[1]:
+                e.process()
+                sim.render(1)
+                assert [(0,) + r[1:] for r in plan_rows(sim.fetch_plan())] == oracle_rows(e, 0), (name, br["block"])
+                ph, sp, _ = sim.transport()
+                assert (O.f64_bits(ph), O.f64_bits(sp)) == (br["playhead"], br["sample_position"]), (name, br["block"])
+                blocks += 1
+            continue
+        if k == "query":
+            continue
+        if k == "clips":
+            for t, tr in enumerate(sim.tracks):
+                assert FZ.clip_rows(sim.clips(tr)) == rec[1][t], (name, t)
+            continue
+        if rec[1] != 1:
+            continue
+        if k == "bpm": e.set_bpm(o[1]); sim.set_bpm(o[1])
+        elif k == "seek": e.set_playhead(o[1]); sim.set_playhead_position(o[1])
+        elif k == "play": e.play(); sim.play()
+        elif k == "stop": e.stop(); sim.stop()
+        elif k in ("sample", "synth"):
+            fmt, ch, rate, frames, data = s.samples[o[1]][:5]
+            e.add_sample(fmt, ch, rate, frames, data); sim.add_sample_meta(fmt, ch, rate, frames)
+        elif k == "track": e.add_track(); sim.add_track("t")
+        elif k == "vol": e.set_volume(o[1], o[2]); sim.tracks[o[1]].set_volume(o[2])
+        elif k == "pan": e.set_pan(o[1], o[2]); sim.tracks[o[1]].set_pan(o[2])
+        elif k == "mute": e.set_mute(o[1], o[2]); sim.tracks[o[1]].set_mute(o[2])
+        elif k == "clip":
+            _, t, mn, mx, so, si, sp, g = o
+            e.add_audio_clip(t, mn, mx, so, si, sp, g); sim.add_audio_clip(sim.tracks[t], "c", mn, mx, so, si, sp, g)
+        elif k == "delclip": e.delete_clip(o[1], o[2]); sim.delete_clip(sim.tracks[o[1]], o[2])
+        elif k == "gain": e.set_clip_gain(o[1], o[2], o[3]); sim.set_clip_gain(sim.tracks[o[1]], o[2], o[3])
+        elif k == "move": e.move_clip(o[1], o[2], o[3]); sim.move_clip(sim.tracks[o[1]], o[2], o[3])
+        elif k == "deltrack": e.delete_track(o[1]); sim.delete_track(o[1])
+        elif k == "movetrack": e.move_track(o[1], o[2]); sim.move_track(o[1], o[2])
+        elif k == "solo": e.solo_track(o[1]); sim.solo_track(o[1])
+        else: assert k == "cfg", k
+    e.close()
+    sim.close()
+    return blocks
+
+
 def test_host_sequencer_on_the_reference_recordings():
     """tests/golden/sequencer.npz — what the reference's own Track::process_event / Track::process / Engine::process answered to
     40 session scripts (oracle/_ref/wbref_engine, oracle/gen_golden.py sequencer) — replayed through the product's host code +
     sequencer source: playhead / sample_position and the clip lists against the RECORDING, the stream calls of every block
     against the oracle replaying the same script (which test_sequencer_golden holds to the recording event for event)."""
-    import ref_engine as R
     from test_oracle_golden import sequencer_golden_cases
     n = blocks = 0
     for name, s, want in sequencer_golden_cases():
         if s.block % 4 or any(o[0] == "rate" for o in s.ops):     # (the host sim has no reconfiguration call)
             continue
-        e = O.OracleEngine(s.channels, s.block, s.rate)
-        e.enable_seglog()
-        sim = HS.HostSimEngine(8, s.block, s.rate, s.channels, 1)
-        sim.set_masked_rows(4)
-        wi = 0
-        for o in s.ops:
-            rec = want[wi]
-            wi += 1
-            k = o[0]
-            if k == "run":
-                for br in rec[1]:
-                    e.process()
-                    sim.render(1)
-                    assert [(0,) + r[1:] for r in plan_rows(sim.fetch_plan())] == oracle_rows(e, 0), (name, br["block"])
-                    ph, sp, _ = sim.transport()
-                    assert (O.f64_bits(ph), O.f64_bits(sp)) == (br["playhead"], br["sample_position"]), (name, br["block"])
-                    blocks += 1
-                continue
-            if k == "query":
-                continue
-            if k == "clips":
-                for t, tr in enumerate(sim.tracks):
-                    assert FZ.clip_rows(sim.clips(tr)) == rec[1][t], (name, t)
-                continue
-            if rec[1] != 1:
-                continue
-            if k == "bpm": e.set_bpm(o[1]); sim.set_bpm(o[1])
-            elif k == "seek": e.set_playhead(o[1]); sim.set_playhead_position(o[1])
-            elif k == "play": e.play(); sim.play()
-            elif k == "stop": e.stop(); sim.stop()
-            elif k == "sample":
-                fmt, ch, rate, frames, data = s.samples[o[1]][:5]
-                e.add_sample(fmt, ch, rate, frames, data); sim.add_sample_meta(fmt, ch, rate, frames)
-            elif k == "track": e.add_track(); sim.add_track("t")
-            elif k == "vol": e.set_volume(o[1], o[2]); sim.tracks[o[1]].set_volume(o[2])
-            elif k == "pan": e.set_pan(o[1], o[2]); sim.tracks[o[1]].set_pan(o[2])
-            elif k == "mute": e.set_mute(o[1], o[2]); sim.tracks[o[1]].set_mute(o[2])
-            elif k == "clip":
-                _, t, mn, mx, so, si, sp, g = o
-                e.add_audio_clip(t, mn, mx, so, si, sp, g); sim.add_audio_clip(sim.tracks[t], "c", mn, mx, so, si, sp, g)
-            elif k == "delclip": e.delete_clip(o[1], o[2]); sim.delete_clip(sim.tracks[o[1]], o[2])
-            elif k == "gain": e.set_clip_gain(o[1], o[2], o[3]); sim.set_clip_gain(sim.tracks[o[1]], o[2], o[3])
-            elif k == "move": e.move_clip(o[1], o[2], o[3]); sim.move_clip(sim.tracks[o[1]], o[2], o[3])
-            elif k == "deltrack": e.delete_track(o[1]); sim.delete_track(o[1])
-            elif k == "movetrack": e.move_track(o[1], o[2]); sim.move_track(o[1], o[2])
-            elif k == "solo": e.solo_track(o[1]); sim.solo_track(o[1])
-            else: assert k == "cfg", k
-        e.close()
-        sim.close()
+        blocks += replay_on_host_sim(name, s, want)
         n += 1
     assert n >= 24 and blocks > 300, (n, blocks)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("kind", ["static", "controls", "edits", "dense", "wild"])
+def test_host_sequencer_against_the_live_reference(kind):
+    """the same against the reference executable itself (this container): fresh seeds of tests/seq_sessions.py.  WBX_REFSEQ_SEEDS
+    widens the range."""
+    import ref_engine as R
+    import seq_sessions as S
+    if not R.available():
+        pytest.skip("oracle/_ref/wbref_engine not built (no /root/reference here)")
+    n = int(os.environ.get("WBX_REFSEQ_SEEDS", "60"))
+    done = blocks = 0
+    for seed in range(7000, 7000 + n):
+        s = S.session_script(seed, kind)
+        if s.block % 4 or any(o[0] == "rate" for o in s.ops):
+            continue
+        try:
+            R.run_oracle(s)
+        except R.Wrapped:
+            continue
+        blocks += replay_on_host_sim(f"{kind} seed {seed}", s, R.run_reference(s))
+        done += 1
+    assert done >= n // 4, (done, n)
