@@ -2,8 +2,9 @@
 
 The numbers below are the outputs the survey recorded from the reference's own Engine::process /
 Track::process / Sampler::stream compiled and run in the survey container (SURVEY.md §8(a) A8 and
-§8(c) "Seek-math KATs" / "Resampler KAT").  They are the only pin the clip sequencer has (engine.cpp /
-track.cpp cannot be built here without a spdlog stand-in), so every one of them is asserted bit-for-bit.
+§8(c) "Seek-math KATs" / "Resampler KAT"), each asserted bit-for-bit.  Until round 5 they were the only pin the clip sequencer
+had; since then tests/test_ref_engine.py holds the oracle's sequencer to the reference's own compiled code (oracle/_ref/
+wbref_engine) — what stays KAT-pinned is Engine::reserve_track_region, which that build cannot hold.
 """
 import ctypes as C
 
