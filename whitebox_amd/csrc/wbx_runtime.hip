@@ -530,8 +530,14 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     // event packets between two mixes.  WBX_TIMER_PACKETS=1: the old way, an event record either side (A/B aid)
     static const bool packets = std::getenv("WBX_TIMER_PACKETS") != nullptr;
     if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][0], ms));
+    // (unity-speed fp32 sessions: four rows per pipeline batch at three waves per SIMD, <4,true,3,..> — round 2's choice at
+    //  256-block renders; in renders of >= 2048 blocks of large sessions two rows at four waves, <2,true,4,..>, is ahead:
+    //  c4 0.72-0.75 of the roofline against 0.67-0.69, u4096 0.755-0.777 against 0.746-0.763, one box, alternating
+    //  (profiles/r05_ab_c3_instances.txt); 256-track sessions: nothing to choose.  WBX_NO_LONG_24=1: the old choice)
+    static const bool no_long_24 = [] { const char* v = std::getenv("WBX_NO_LONG_24"); return v && v[0] == '1'; }();
+    const bool long_large = !no_long_24 && K >= 2048u && N >= 1024u;
     c->mix_kernel_name = launch_mix(m, K, c->mix_unroll ? c->mix_unroll : mix_two_channels_per_lane(c) ? (mix_long_chained_window_render(c) ? 1013 : 1023)
-                                          : ((c->has_window_clips || c->has_integer_clips) ? 24 : 43),
+                                          : ((c->has_window_clips || c->has_integer_clips || long_large) ? 24 : 43),
                mix_family(c), ms, (timed && !packets) ? c->ev[c->ev_pending][0] : nullptr,
                (timed && !packets) ? c->ev[c->ev_pending][1] : nullptr);
     if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
