@@ -19,7 +19,7 @@
  *     stand-in is written), so oracle/Makefile cuts the regions of those files that hold no Log:: line out of them where they
  *     lie — at function boundaries, into build outputs — and oracle/ref_engine_driver.cpp compiles those texts unmodified
  *     into oracle/_ref/wbref_engine.  tests/test_ref_engine.py compares per block the master, transport, every track's
- *     AudioEvent list, sampler state and VU level, and the clip lists after edits (soak: 98 736 sessions / 1 522 527 blocks, 0
+ *     AudioEvent list, sampler state and VU level, and the clip lists after edits (soak: 296 330 sessions / 4 570 895 blocks, 0
  *     divergences, profiles/r05_refseq_soak.txt); tests/golden/sequencer.npz carries its answers to 40 scripts everywhere.
  *     NOT in the cut (an unconditional Log:: line inside the function): Engine::reserve_track_region (overlap trimming:
  *     KAT-pinned, its arithmetic pinned through clip_edit.h), Engine::play / stop and Track::process_track_messages (a few
