@@ -242,6 +242,20 @@ def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
     _, src_rate, n_buses, fmt = WORKLOADS[workload]
     if not R.available(build=False) or n_buses or fmt != "f32":
         return None
+    # the executable is a prebuilt, untracked file: say which build it is, and refuse one that was not made from the driver
+    # source and the recipe of this tree (oracle/Makefile leaves their hash beside it)
+    import hashlib
+    want = hashlib.sha256(b"".join(open(os.path.join(O.ORACLE_DIR, n), "rb").read()
+                                   for n in ("ref_engine_driver.cpp", "Makefile"))).hexdigest()[:16]
+    try:
+        stamp = open(exe + ".stamp").read().strip()
+    except OSError:
+        stamp = None
+    if stamp != want:
+        print(f"cpu_reference: oracle/_ref/wbref_engine is stale or unstamped (stamp {stamp}, tree {want}): the port is the baseline",
+              file=sys.stderr)
+        return None
+    exe_sha = hashlib.sha256(open(exe, "rb").read()).hexdigest()[:16]
     seed, amp, tracks = track_layout(workload, n_tracks, 0, 1, sample_blocks)
     amp32 = float(np.float32(amp))
     lines = [f"cfg 2 {F} {SR}", "bpm 120.0"]
@@ -280,7 +294,8 @@ def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
                       f"CPU work in the reference's own Engine::process (oracle/_ref/wbref_engine, g++ -O2), its one audio thread",
             "us_per_block": 1e6 * rec["seconds"] / blocks_done,
             "head_blocks_equal_oracle": bool(same),
-            "device_head_blocks_equal_reference": dev_eq, "device_head_rms_vs_reference": dev_rms}
+            "device_head_blocks_equal_reference": dev_eq, "device_head_rms_vs_reference": dev_rms,
+            "ref_driver_recipe_sha16": want, "ref_binary_sha16": exe_sha}
 
 
 def cpu_all_cores(O, L, workload, n_tracks, keep, sample_blocks, src_rate, n_buses, fmt, seed, amp, passes=64):
@@ -578,6 +593,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     gc.enable()
     gc.unfreeze()
     tail_ms = eng.ctx.tail_time()
+    gap_ms, gap_n = eng.ctx.gap_time()
     mix_ms, mix_n = eng.ctx.kernel_time()
     kernel_name = eng.ctx.kernel_name()                 # the instance the library launched (as rocprofv3 names it)
     seq = eng.sequencer_stats()                        # how the sequencer planned: by (track, segment) lanes? seams that missed?
@@ -667,7 +683,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
     alg = algorithmic_bytes_per_block(n_tracks, src_rate, fmt=fmt) * K
     achieved = alg / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0
     return {"dt": dt, "steps": steps, "K": K, "n_tracks": n_tracks, "mix_ms": mix_ms, "mix_n": mix_n, "pre_ms": pre_ms,
-            "pre_n": pre_n, "tail_ms": tail_ms, "enq_max": enq_max, "lat": lat, "lat_small": lat_small, "lat_median": lat_median, "lat_kernel": lat_kernel[0], "alg": alg, "achieved": achieved,
+            "pre_n": pre_n, "tail_ms": tail_ms, "gap_ms": gap_ms, "gap_n": gap_n, "enq_max": enq_max, "lat": lat, "lat_small": lat_small, "lat_median": lat_median, "lat_kernel": lat_kernel[0], "alg": alg, "achieved": achieved,
             "desc": desc, "kernel_name": kernel_name, "src_rate": src_rate, "n_buses": n_buses, "fmt": fmt, "master_peak": master_peak,
             "clip_blocks": clip_blocks, "workload": workload, "verify": ver, "device": dev, "exchange": exch, "summation": summation,
             "session_blocks": session_blocks,
@@ -689,6 +705,7 @@ def roofline_of(r, traffic_table):
             "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command)" if traffic else None,
             "kernel": r["kernel_name"],
             "kernel_ms_avg": r["mix_ms"], "kernel_launches": int(r["mix_n"]), "sum_tail_ms_avg": r["tail_ms"],
+            "mix_gap_ms_avg": r["gap_ms"], "mix_gaps_timed": int(r["gap_n"]),
             # mean over EVERY launch of the run incl. warm-up and ramp: what `rocprofv3 --stats` averages
             "kernel_ms_avg_all_launches": (r["pre_ms"] * r["pre_n"] + r["mix_ms"] * r["mix_n"]) / max(1, r["pre_n"] + r["mix_n"]),
             "kernel_launches_all": int(r["pre_n"] + r["mix_n"]),

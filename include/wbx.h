@@ -279,6 +279,10 @@ wbx_status wbx_kernel_time(wbx_ctx* ctx, int reset, double* mix_ms_avg, uint64_t
 /* Average ms from the end of the mix kernel to the end of the sum kernel over the same launches (launch gap + the
  * group/bus/master sum including its stores to a host-resident master target); read before resetting. */
 wbx_status wbx_tail_time(wbx_ctx* ctx, double* tail_ms_avg);
+/* ... and the mean idle time between two consecutive mix launches (end time stamp of one to start time stamp of the next, over
+ * the pairs timed since the last reset of wbx_kernel_time; *gaps: how many) — what a step spends outside its dominant kernel
+ * while renders run back to back. */
+wbx_status wbx_gap_time(wbx_ctx* ctx, double* gap_ms_avg, uint64_t* gaps);
 /* The template instance of the dominant kernel that the last render launched, as rocprofv3 prints it
  * ("wbx::mix_kernel<2, true, 3, 0, 1, 1, 2, 128>"); "" before the first render. */
 const char* wbx_kernel_name(wbx_ctx* ctx);
@@ -286,6 +290,10 @@ const char* wbx_kernel_name(wbx_ctx* ctx);
  * render plays at exactly this Sampler::playback_speed_, sampler.h:24 — the hoisted-product chunk modes), 0.0 when the
  * session holds more than one ratio, none, or the plan came through layer 1.  Introspection, like wbx_kernel_name. */
 double wbx_render_uniform_speed(wbx_ctx* ctx);
+/* What wbx_create's probe found: the number of XCDs a launch's workgroup ids are dealt to round-robin (8 on MI355X; 4 / 2 / 1 in
+ * other partition modes) — the layout the chained 128-track pieces of long renders and the segmented sequencer rest on — or 0:
+ * not such a layout; the context then walks whole member lists and plans by one lane per track (same results).  Introspection. */
+uint32_t wbx_xcd_count(wbx_ctx* ctx);
 
 /* ---- layer 2: the engine surface -----------------------------------------------------------
  * Mirrors wb::Engine / wb::Track (src/engine/engine.h, track.h).  Beats are doubles as in the
@@ -433,6 +441,20 @@ wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4]);
  *   out[0]  blocks that ran as one launch       out[1]  ... of those, with the sum spread over the workgroups
  *   out[2]  blocks mixed again after a give-up  out[3]  1 when the engine has stopped spreading */
 wbx_status wbx_engine_callback_stats(wbx_engine* e, uint64_t out[4]);
+
+/* Engine::perf_measurer (engine.h:64, core/timing.h:54-67): Engine::process times itself (ScopedPerformanceCounter,
+ * engine.cpp:1577) and ends with perf_measurer.update(duration_ms, audio_buffer_duration_ms) (engine.cpp:1653) — usage moves a
+ * quarter of the way towards duration / period; the UI shows get_usage(), clamped to [0, 1] (ui/control_bar.cpp:54).  Here every
+ * wbx_engine_process / wbx_engine_process_interleaved call feeds its own wall time (launch, device pass, copy-out) and the
+ * period of its block, period_to_ms(buffer_size_to_period(block_frames, sample_rate)) (engine.cpp:52, engine/audio_io.h:187-195).
+ * Any thread.  last_block_ms (may be NULL): what the last update was fed.  Batch renders (wbx_engine_render) do not feed it:
+ * the reference has no such call. */
+wbx_status wbx_engine_perf_usage(wbx_engine* e, double* usage, double* last_block_ms);
+/* the arithmetic behind it, host-only: PerformanceMeasurer::update (timing.h:57-62), ::get_usage (timing.h:64-66),
+ * Engine::audio_buffer_duration_ms (engine.cpp:52) */
+double wbx_calc_perf_update(double usage, double duration_ms, double period_ms);
+double wbx_calc_perf_usage(double usage);
+double wbx_calc_buffer_period_ms(uint32_t buffer_size, uint32_t sample_rate);
 
 /* The plan the device sequencer produced for the last process/render: one record per Sampler::stream
  * call, ordered by (block, track, call).  For seek-math parity checks (bit patterns, not tolerances). */

@@ -197,6 +197,16 @@ struct Engine {
   // never throws — a failed block leaves silence in the output buffer and latches its status here.
   std::atomic<wbx_status> process_status{WBX_OK};
   std::string process_error;   // written by the audio thread only
+  // engine.h:33 / :64 — the block's period in ms (engine.cpp:52) and the load figure process() keeps (engine.cpp:1653):
+  // `g_engine.perf_measurer.get_usage()` of ui/control_bar.cpp:54 reads the same here
+  double audio_buffer_duration_ms = 0;
+  struct PerformanceMeasurer {
+    Engine* owner;
+    double get_usage() const {
+      double u = 0.0;
+      return (owner->h && wbx_engine_perf_usage(owner->h, &u, nullptr) == WBX_OK) ? u : 0.0;
+    }
+  } perf_measurer{this};
 
   // set_audio_channel_config(in, out, buffer_size, sample_rate), engine.cpp:43-57.  The first call creates the device
   // context; later calls (the audio backend was reconfigured) resize it in place — tracks and clips stay, as in the
@@ -217,6 +227,7 @@ struct Engine {
     num_output_channels = output_channels;
     audio_buffer_size = buffer_size;
     audio_sample_rate = sample_rate;
+    audio_buffer_duration_ms = wbx_calc_buffer_period_ms(buffer_size, sample_rate);
   }
   ~Engine() {
     if (h) wbx_engine_destroy(h);

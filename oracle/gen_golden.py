@@ -231,6 +231,44 @@ def gen_vu():
     print("vu.npz:", len(arrs) // 3, "cases")
 
 
+def perf_inputs():
+    """(usage, duration_ms, period_ms) triples for PerformanceMeasurer::update / get_usage and (buffer_size, sample_rate) pairs
+    for Engine::audio_buffer_duration_ms: running averages from idle to overload, sub-microsecond and multi-second blocks,
+    usage outside [0, 1] and non-finite (the clamp's compares), every block size / rate the back ends open"""
+    rng = np.random.default_rng(0x9E2F)
+    u = np.concatenate([[0.0, 1.0, 0.25, -0.5, 2.0, np.inf, -np.inf, np.nan, 5e-324, 1 - 2 ** -53], rng.random(190) * 1.5 - 0.2])
+    d = np.concatenate([[0.0, 10.0, 1e-4, 3.0, 40.0, 1.0, 1.0, 1.0, 5e-324, 10.666666666666666], 10.0 ** (rng.random(190) * 6 - 3)])
+    t = np.concatenate([[10.0, 10.0, 10.666666666666666, 2.9, 5.3, 10.0, 10.0, 10.0, 10.0, 10.666666666666666],
+                        rng.choice([1.3, 2.6, 2.9, 5.3, 5.8, 10.0, 10.6, 10.7, 21.3, 42.7], 190)])
+    sizes = [32, 64, 96, 128, 192, 200, 256, 333, 416, 441, 448, 480, 512, 960, 1000, 1024, 1440, 1920, 2048, 4096, 32768]
+    rates = [8000, 11025, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
+    pairs = np.array([(b, r) for b in sizes for r in rates], np.uint32)
+    return u, d, t, pairs
+
+
+def gen_perf():
+    """tests/golden/perf.npz from the reference's own PerformanceMeasurer (core/timing.h) and period helpers (engine/audio_io.h),
+    both header-only and compiled into oracle/_ref/libwbref.so"""
+    R = O.ref()
+    if R is None:
+        raise SystemExit("oracle/_ref/libwbref.so is not built (needs /root/reference)")
+    u, d, t, pairs = perf_inputs()
+    upd = np.array([R.ref_perf_update(float(a), float(b), float(c)) for a, b, c in zip(u, d, t)])
+    use = np.array([R.ref_perf_get_usage(float(a)) for a in np.concatenate([u, upd])])
+    ms = np.array([R.ref_buffer_duration_ms(int(b), int(r)) for b, r in pairs])
+    # a measurer followed over 400 blocks of a drifting load (the running average's accumulated rounding)
+    rng = np.random.default_rng(0x9E30)
+    durs = 10.0 * (0.3 + 0.25 * np.sin(np.arange(400) / 17.0) + 0.05 * rng.random(400))
+    run, cur = [], 0.0
+    for x in durs:
+        cur = R.ref_perf_update(cur, float(x), 10.666666666666666)
+        run.append(cur)
+    np.savez_compressed(os.path.join(OUT, "perf.npz"), usage=u.view(np.uint64), duration_ms=d.view(np.uint64), period_ms=t.view(np.uint64),
+                        updated=upd.view(np.uint64), clamped=use.view(np.uint64), pairs=pairs, buffer_ms=ms.view(np.uint64),
+                        run_durations=durs.view(np.uint64), run_usage=np.array(run).view(np.uint64))
+    print("perf.npz:", len(u), "updates,", len(pairs), "periods, a run of", len(run))
+
+
 def ingest_inputs():
     """(name, interleaved [frames][channels]) of the clip-ingest fixture: every storage format load_file hands to
     deinterleave_samples (I16; I32 = 24- and 32-bit files; F32), 1-6 channels, lengths around the decoder's 1024-frame chunk,
@@ -357,8 +395,8 @@ def gen_baseline_ref():
     print("baseline_ref.npz:", len(BASELINE_REF_CASES), "configurations")
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest", "sequencer", "baseline"):     # (the other fixtures are untouched)
-        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest, "sequencer": gen_sequencer, "baseline": gen_baseline_ref}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("mip", "vu", "ingest", "sequencer", "baseline", "perf"):     # (the other fixtures are untouched)
+        {"mip": gen_mip, "vu": gen_vu, "ingest": gen_ingest, "sequencer": gen_sequencer, "baseline": gen_baseline_ref, "perf": gen_perf}[sys.argv[1]]()
     else:
         main()
         gen_mip()

@@ -27,8 +27,10 @@
 #include "core/core_math.h"
 #include "core/memory.h"
 #include "core/panning_law.h"
+#include "core/timing.h"
 #include "dsp/dsp_ops.h"
 #include "dsp/sampler.h"
+#include "engine/audio_io.h"
 #include "engine/clip_edit.h"
 
 namespace {
@@ -122,6 +124,25 @@ double ref_shift_clip_content(double start_offset, double speed, double sample_r
   return wb::shift_clip_content(c, relative_pos, beat_duration);
 }
 
+
+// Engine::perf_measurer — what Engine::process ends with (engine.cpp:1577,1653): PerformanceMeasurer::update / get_usage,
+// core/timing.h:54-67 (header-only), on a measurer that starts from `usage`
+double ref_perf_update(double usage, double duration_ms, double target_ms) {
+  wb::PerformanceMeasurer m;
+  m.usage.store(usage);
+  m.update(duration_ms, target_ms);
+  return m.usage.load();
+}
+double ref_perf_get_usage(double usage) {
+  wb::PerformanceMeasurer m;
+  m.usage.store(usage);
+  return m.get_usage();
+}
+// Engine::audio_buffer_duration_ms as set_audio_channel_config computes it (engine.cpp:52): period_to_ms(buffer_size_to_period(..)),
+// engine/audio_io.h:187-195 (header-only)
+double ref_buffer_duration_ms(uint32_t buffer_size, uint32_t sample_rate) {
+  return wb::period_to_ms(wb::buffer_size_to_period(buffer_size, sample_rate));
+}
 
 // math::db_to_linear<float>, core/core_math.h:83-89
 float ref_db_to_linear(float db) { return wb::math::db_to_linear<float>(db); }

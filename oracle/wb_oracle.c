@@ -56,6 +56,27 @@ double wbo_samples_to_beat(double samples, double sample_rate, double beat_durat
   return sec / beat_duration;
 }
 
+/* The load figure Engine::process ends with (engine.cpp:1577 ScopedPerformanceCounter, :1653 perf_measurer.update(duration in
+ * ms, audio_buffer_duration_ms)): PerformanceMeasurer::update, core/timing.h:57-62 — a quarter of the way from the old figure to
+ * this block's duration / period — and get_usage, :64-66 (math::clamp: core_math.h, max(min(x, hi), lo) by compares). */
+double wbo_perf_update(double usage, double duration_ms, double target_ms) {
+  double percentage = duration_ms / target_ms;
+  return usage + 0.25 * (percentage - usage);
+}
+double wbo_perf_get_usage(double usage) {
+  double hi = usage < 1.0 ? usage : 1.0;
+  return hi > 0.0 ? hi : 0.0;
+}
+/* Engine::audio_buffer_duration_ms (engine.cpp:52): period_to_ms(buffer_size_to_period(buffer_size, sample_rate)),
+ * engine/audio_io.h:187-195 — the period in 100-ns units, rounded as math::round does (core_math.h:61-63: truncation of
+ * x +- 0.5 through int64), and back to milliseconds */
+double wbo_buffer_duration_ms(uint32_t buffer_size, uint32_t sample_rate) {
+  const double unit_100_ns = 10000000.0;
+  double x = unit_100_ns * (buffer_size / (double)sample_rate);
+  int64_t period = (int64_t)(double)(int64_t)(x + (x < 0.0 ? -0.5 : 0.5));
+  return 1000.0 * period / unit_100_ns;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * buffers
  * ---------------------------------------------------------------------------------------------- */

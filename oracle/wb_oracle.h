@@ -55,6 +55,9 @@ float wbo_db_to_linear(float db);                                  /* core_math.
 void wbo_pan_coefs(float p, int law, float* left, float* right);   /* panning_law.cpp:9-32 */
 double wbo_beat_to_samples(double beat, double sample_rate, double beat_duration);   /* core_math.h:209-212 */
 double wbo_samples_to_beat(double samples, double sample_rate, double beat_duration); /* core_math.h:204-207 */
+double wbo_perf_update(double usage, double duration_ms, double target_ms);          /* core/timing.h:57-62 (engine.cpp:1653) */
+double wbo_perf_get_usage(double usage);                                              /* core/timing.h:64-66 */
+double wbo_buffer_duration_ms(uint32_t buffer_size, uint32_t sample_rate);            /* engine/audio_io.h:187-195 (engine.cpp:52) */
 
 /* ---- buffers (planar fp32, AudioBuffer<float> semantics) ------------------------------------ */
 void wbo_clear(float* const* ch, uint32_t n_channels, uint32_t n_samples);                  /* audio_buffer.h:67-71 */

@@ -67,6 +67,11 @@ int main() {
   if (out.n_samples != F || out.n_channels != C) return 2;
   if (g_engine.process_status.load() != WBX_OK) return 3;
   wbo_engine_destroy(o);
+  {   // the load figure Engine::process keeps (engine.cpp:1653; ui/control_bar.cpp:54 reads g_engine.perf_measurer.get_usage())
+    const double u = g_engine.perf_measurer.get_usage();
+    if (!(u > 0.0 && u <= 1.0)) return 9;
+    if (g_engine.audio_buffer_duration_ms != wbo_buffer_duration_ms(F, SR)) return 9;   // engine.cpp:52
+  }
 
   // meters: the maxima since the last read, as the host's own VUMeter::update takes them (vu_meter.h:32-33)
   g_engine.fetch_levels();

@@ -101,6 +101,12 @@ def lib() -> C.CDLL:
         L.wbo_beat_to_samples.argtypes = [C.c_double] * 3
         L.wbo_samples_to_beat.restype = C.c_double
         L.wbo_samples_to_beat.argtypes = [C.c_double] * 3
+        L.wbo_perf_update.restype = C.c_double
+        L.wbo_perf_update.argtypes = [C.c_double] * 3
+        L.wbo_perf_get_usage.restype = C.c_double
+        L.wbo_perf_get_usage.argtypes = [C.c_double]
+        L.wbo_buffer_duration_ms.restype = C.c_double
+        L.wbo_buffer_duration_ms.argtypes = [C.c_uint32, C.c_uint32]
         L.wbo_lower_bound_max_time.restype = C.c_uint32
         L.wbo_lower_bound_max_time.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_double]
         L.wbo_deinterleave.restype = C.c_size_t
@@ -181,6 +187,12 @@ def ref() -> Optional[C.CDLL]:
         R.ref_beat_to_samples.argtypes = [C.c_double] * 3
         R.ref_samples_to_beat.restype = C.c_double
         R.ref_samples_to_beat.argtypes = [C.c_double] * 3
+        R.ref_perf_update.restype = C.c_double
+        R.ref_perf_update.argtypes = [C.c_double] * 3
+        R.ref_perf_get_usage.restype = C.c_double
+        R.ref_perf_get_usage.argtypes = [C.c_double]
+        R.ref_buffer_duration_ms.restype = C.c_double
+        R.ref_buffer_duration_ms.argtypes = [C.c_uint32, C.c_uint32]
         R.ref_apply_gain.argtypes = [c_f32p, C.c_uint32, C.c_float]
         R.ref_find_abs_maximum.restype = C.c_float
         R.ref_find_abs_maximum.argtypes = [c_f32p, C.c_uint32]

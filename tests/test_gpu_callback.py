@@ -256,3 +256,124 @@ def test_callback_give_up_at_the_spread_barrier_mixes_the_block_again(monkeypatc
     assert launches == 5 and spread == 1 and give_ups == 1 and off == 1     # block 0 gave up; blocks 1-4: the last workgroup adds
     e.close()
     eng.close()
+
+
+def _dense_boundary_session(n_tracks, n_blocks, block=512):
+    """fp32 tracks cut into clips of 0.23 blocks with gaps: four or five stream calls in most track-blocks — records in the
+    sequencer's overflow pool and in the pre-render queue from block 0 on (the plan counters [0], [2], [3] are all in use)"""
+    beat_frames = 48000 * 60.0 / 120.0
+    total = (n_blocks + 1) * block
+    samples, clips, vols, pans = [], [], [], []
+    for t in range(n_tracks):
+        samples.append(synth.SampleSpec(seed_track=t, channels=2, rate=[48000, 44100][t % 2], frames=int(total * 1.2) + 400, fmt="f32", amp=0.02))
+        v, p = synth.track_params(0xD0B, t)
+        vols.append(float(v))
+        pans.append(float(p))
+        L = 0.23 * block
+        pos, k = -((t * 37) % 101) / 101.0 * L, 0
+        while pos < total:
+            a, b = max(pos, 0.0), pos + L * (0.6 if (t + k) % 3 == 0 else 1.0)
+            if b > a:
+                clips.append(synth.ClipSpec(t, a / beat_frames, b / beat_frames, start_offset=a * 0.9, gain=[1.0, 0.5, 1.7][k % 3]))
+            pos += L
+            k += 1
+    return synth.SessionSpec(name="dense", n_tracks=n_tracks, seed=0xD0B, samples=samples, clips=clips, volumes_db=vols, pans=pans,
+                             mutes=[False] * n_tracks, block=block)
+
+
+@pytest.mark.parametrize("n_tracks", [300, 900])
+def test_callback_give_up_with_the_plan_counters_in_use(monkeypatch, n_tracks):
+    """(advisor, round 5) The give-up path on a block whose sequencer lanes allocate overflow-pool chunks and queue pre-render
+    records: workgroup 0 of the spread launch gives up at once (WBX_CB_SPIN_BOUND=0) while other workgroups are still planning —
+    it must neither publish nor clear the plan's counters (two tracks would share a pool chunk, status bits would be lost); the
+    launch's reporter hands them to the host, un-cleared, and the block comes out right: stream calls, peaks and master equal
+    to the oracle's in the give-up block and in every block after it."""
+    monkeypatch.setenv("WBX_CB_SPIN_BOUND", "0")
+    spec = _dense_boundary_session(n_tracks, 5)
+    e = O.build_oracle_engine(spec)
+    e.enable_seglog()
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    e.play()
+    eng.play()
+    for b in range(4):
+        om, _ = e.process()
+        eng.process(None, out, float(spec.sample_rate))
+        m = np.stack(out.channel_buffers)
+        d = m.astype(np.float64) - om.astype(np.float64)
+        assert float(np.sqrt(np.mean(d * d))) <= RMS_TOL, b
+        _, pk, _ = eng.ctx.fetch(peaks=True)
+        assert np.array_equal(pk[0], e.peaks()[:, :spec.channels]), b
+        rows = oracle_rows(e, 0)
+        assert max(sum(1 for r in rows if r[1] == t) for t in range(0, n_tracks, 7)) >= 3      # (the session does what it says)
+        assert plan_rows(eng.fetch_plan()) == rows, b
+    launches, spread, give_ups, off = eng.callback_stats()
+    assert give_ups == 1 and off == 1, (launches, spread, give_ups, off)
+    e.close()
+    eng.close()
+
+
+def test_callback_give_up_does_not_lose_a_plan_overflow(monkeypatch):
+    """(advisor, round 5) ... and a status bit raised in the give-up block reaches the caller: 1100 tracks that each need an
+    overflow-pool chunk against the 1024 chunks a max_blocks = 1 engine has — the block that gave up at the spread barrier and
+    was mixed again reports WBX_ERR_OVERFLOW (-8) like any other (the redo's sum used to drop the already-cleared device
+    counters over the host's copy: the overflow of exactly that block was never seen)."""
+    monkeypatch.setenv("WBX_CB_SPIN_BOUND", "0")
+    spec = _dense_boundary_session(1100, 3)
+    eng = build_engine(spec, max_blocks=1)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    eng.play()
+    with pytest.raises(W.WbxError) as ei:
+        eng.process(None, out, float(spec.sample_rate))
+    assert ei.value.status == -8 and "overflow" in str(ei.value), str(ei.value)
+    assert eng.callback_stats()[2] == 1           # (it was the give-up block)
+    eng.close()
+
+
+def test_xcd_layout_probe_and_its_fallback(monkeypatch):
+    """wbx_create probes the workgroup-id -> XCD layout the chained pieces and the segmented sequencer rest on (MI355X: 8 XCDs,
+    round-robin); a device where it does not hold (WBX_XCD_PROBE_FAIL=1 plays one) walks whole member lists and plans by one lane
+    per track from its first render — same results, no WBX_ERR_DEVICE on the way"""
+    spec = synth.make_session("xcd", 300, src_rate=44100, n_blocks=64, seed=0xC5B3)
+    monkeypatch.setenv("WBX_EXACT_MIN_BLOCKS", "32")
+    masters = {}
+    for fail in ("0", "1"):
+        monkeypatch.setenv("WBX_XCD_PROBE_FAIL", fail)
+        eng = build_engine(spec, max_blocks=64)
+        assert eng.ctx.xcd_count() == (8 if fail == "0" else 0)
+        eng.play()
+        eng.render(64)
+        m, _, _ = eng.ctx.fetch()
+        order = eng.ctx.render_order(64)
+        assert order[2] is True and (order[0] > 1) == (fail == "0"), order     # the reference's order either way; chained only with the layout
+        masters[fail] = m.copy()
+        eng.close()
+    assert np.array_equal(bits(masters["0"]), bits(masters["1"]))
+
+
+def test_perf_measurer_follows_the_callback():
+    """Engine::perf_measurer (engine.cpp:1577,1653; core/timing.h:54-67): every wbx_engine_process call feeds its own wall time
+    and the block's period (engine.cpp:52).  The durations are the box's, the arithmetic is the reference's: the running figure
+    the engine reports equals the oracle's PerformanceMeasurer statements replayed over the durations it reports, bit for bit;
+    batch renders do not feed it."""
+    spec = synth.make_session("perf", 64, src_rate=44100, n_blocks=40, seed=0xC5B4)
+    eng = build_engine(spec, max_blocks=8)
+    out = W.AudioBuffer(spec.block, spec.channels)
+    L = O.lib()
+    period = L.wbo_buffer_duration_ms(spec.block, spec.sample_rate)
+    assert O.f64_bits(period) == O.f64_bits(W.lib().wbx_calc_buffer_period_ms(spec.block, spec.sample_rate)) and abs(period - 10.6667) < 1e-3
+    assert eng.perf_usage() == (0.0, 0.0)
+    eng.play()
+    cur = 0.0
+    for b in range(24):
+        eng.process(None, out, float(spec.sample_rate))
+        usage, last_ms = eng.perf_usage()
+        assert 0.0 < last_ms < 5000.0, (b, last_ms)
+        cur = L.wbo_perf_update(cur, last_ms, period)
+        assert O.f64_bits(usage) == O.f64_bits(L.wbo_perf_get_usage(cur)), (b, usage, cur)
+        if b == 11:
+            eng.render(8)                    # (a batch render in between: not a callback, no update)
+            eng.ctx.fetch()
+            assert eng.perf_usage() == (usage, last_ms)
+    assert 0.0 < usage < 1.0                 # a 64-track block takes a few dozen microseconds of its 10.7 ms
+    eng.close()

@@ -63,3 +63,35 @@ def test_bench_algorithmic_bytes_match_survey_figures():
     assert abs(b.algorithmic_bytes_per_block(4096, 44100) - (512 * 32768 * 0.91875 + extra)) < 1e-3
     assert abs(b.algorithmic_bytes_per_block(4096, 48000, fmt="i16") - (512 * 16384 + extra)) < 1e-6
     assert abs(512 * 32768 / 1e6 - 16.78) < 0.01 and abs(512 * 32768 * 0.91875 / 1e6 - 15.41) < 0.01
+
+
+def test_perf_measurer_arithmetic_matches_reference_golden():
+    """The product's load-figure arithmetic (wbx_calc_perf_update / wbx_calc_perf_usage / wbx_calc_buffer_period_ms: what
+    wbx_engine_process feeds Engine::perf_measurer with, engine.cpp:52,1653) against the outputs of the reference's own
+    PerformanceMeasurer (core/timing.h:54-67) and period helpers (engine/audio_io.h:187-195) — tests/golden/perf.npz, fp64 bit
+    patterns; host-only entry points, no device"""
+    g = np.load(os.path.join(G.GOLDEN, "perf.npz"))
+    L = W.lib()
+    u, d, t = (g[k].view(np.float64) for k in ("usage", "duration_ms", "period_ms"))
+    upd = np.array([L.wbx_calc_perf_update(float(a), float(b), float(c)) for a, b, c in zip(u, d, t)])
+    assert np.array_equal(upd.view(np.uint64), g["updated"])
+    use = np.array([L.wbx_calc_perf_usage(float(a)) for a in np.concatenate([u, upd])])
+    assert np.array_equal(use.view(np.uint64), g["clamped"])
+    ms = np.array([L.wbx_calc_buffer_period_ms(int(b), int(r)) for b, r in g["pairs"]])
+    assert np.array_equal(ms.view(np.uint64), g["buffer_ms"])
+    cur, run = 0.0, []
+    for x in g["run_durations"].view(np.float64):
+        cur = L.wbx_calc_perf_update(cur, float(x), 10.666666666666666)
+        run.append(cur)
+    assert np.array_equal(np.array(run).view(np.uint64), g["run_usage"])
+
+
+def test_perf_measurer_arithmetic_matches_oracle_random(oracle):
+    Lo, L = oracle.lib(), W.lib()
+    rng = np.random.default_rng(78)
+    for _ in range(3000):
+        u, d, t = float(rng.random() * 1.4 - 0.2), float(10.0 ** (rng.random() * 6 - 3)), float(rng.uniform(0.5, 50.0))
+        assert O.f64_bits(L.wbx_calc_perf_update(u, d, t)) == O.f64_bits(Lo.wbo_perf_update(u, d, t))
+        assert O.f64_bits(L.wbx_calc_perf_usage(u)) == O.f64_bits(Lo.wbo_perf_get_usage(u))
+        b, r = int(rng.integers(1, 8193)) * 4, int(rng.choice([8000, 22050, 44100, 48000, 96000, 192000]))
+        assert O.f64_bits(L.wbx_calc_buffer_period_ms(b, r)) == O.f64_bits(Lo.wbo_buffer_duration_ms(b, r))

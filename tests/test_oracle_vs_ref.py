@@ -321,3 +321,26 @@ def test_deinterleave_bit_exact(oracle, seed):
             for c in range(ch):
                 assert np.array_equal(got[c].view(np.uint8), exp[c][:frames].view(np.uint8)), (kind, ch, frames, chunk, bits, c)
                 assert not exp[c][frames:].view(np.uint8).any()
+
+
+def test_perf_measurer_and_block_period_bit_exact(oracle, reflib):
+    """The load figure Engine::process ends with (engine.cpp:1577,1653): the oracle's statements against the reference's own
+    PerformanceMeasurer::update / get_usage (core/timing.h:54-67) and period_to_ms(buffer_size_to_period()) (engine/audio_io.h:
+    187-195, what engine.cpp:52 stores in audio_buffer_duration_ms) — both header-only, compiled into oracle/_ref/libwbref.so —
+    on random loads (fp64 bit patterns), non-finite and out-of-range figures, a measurer followed over 2000 blocks, and every
+    block size from 4 to 4096 frames at ten device rates"""
+    L = oracle.lib()
+    rng = np.random.default_rng(0xBEEF)
+    for _ in range(4000):
+        u = float(rng.choice([rng.random() * 1.5 - 0.2, 0.0, 1.0, np.inf, -np.inf, np.nan, 5e-324], p=[0.88, 0.02, 0.02, 0.02, 0.02, 0.02, 0.02]))
+        d, t = float(10.0 ** (rng.random() * 7 - 4)), float(rng.choice([1.3, 2.9, 5.3, 10.0, 10.666666666666666, 21.3]))
+        assert oracle.f64_bits(L.wbo_perf_update(u, d, t)) == oracle.f64_bits(reflib.ref_perf_update(u, d, t)), (u, d, t)
+        assert oracle.f64_bits(L.wbo_perf_get_usage(u)) == oracle.f64_bits(reflib.ref_perf_get_usage(u)), u
+    a = b = 0.0
+    for i in range(2000):
+        d = 10.0 * (0.4 + 0.3 * np.sin(i / 23.0)) + float(rng.random())
+        a, b = L.wbo_perf_update(a, d, 10.666666666666666), reflib.ref_perf_update(b, d, 10.666666666666666)
+        assert oracle.f64_bits(a) == oracle.f64_bits(b), i
+    for rate in (8000, 11025, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000):
+        for size in range(4, 4097, 4):
+            assert oracle.f64_bits(L.wbo_buffer_duration_ms(size, rate)) == oracle.f64_bits(reflib.ref_buffer_duration_ms(size, rate)), (size, rate)

@@ -109,7 +109,9 @@ SYMBOLS = {
     "wbx_kernel_time": (C.c_int, [_vp, C.c_int, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "wbx_kernel_name": (C.c_char_p, [_vp]),
     "wbx_render_uniform_speed": (C.c_double, [_vp]),
+    "wbx_xcd_count": (_u32, [_vp]),
     "wbx_tail_time": (C.c_int, [_vp, C.POINTER(_d)]),
+    "wbx_gap_time": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "wbx_engine_create": (C.c_int, [C.POINTER(Config), _pp]),
     "wbx_engine_destroy": (None, [_vp]),
     "wbx_engine_set_audio_channel_config": (C.c_int, [_vp, _u32, _u32, _u32]),
@@ -157,6 +159,10 @@ SYMBOLS = {
     "wbx_engine_thread_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u32]),
     "wbx_engine_sequencer_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "wbx_engine_callback_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "wbx_engine_perf_usage": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wbx_calc_perf_update": (C.c_double, [C.c_double] * 3),
+    "wbx_calc_perf_usage": (C.c_double, [C.c_double]),
+    "wbx_calc_buffer_period_ms": (C.c_double, [_u32, _u32]),
     "wbx_engine_fetch_plan": (C.c_int, [_vp, C.POINTER(PlanRecord), _sz, C.POINTER(_sz)]),
 }
 

@@ -37,7 +37,8 @@ struct CallbackArgs {
   uint32_t base2;      // ... the second one (only spread launches arrive there: it has a base of its own)
   uint32_t* elect;     // device word: the launch number of the last launch whose reporter has been chosen (not spread: of the
                        // workgroups that see the full count, the first to swap its launch's number in adds and reports);
-                       // elect[1]: the number of the last launch in which a workgroup gave up at the spread barrier
+                       // elect[1]: the number of the last launch in which a workgroup gave up at the spread barrier;
+                       // elect[2]: ... in which workgroup 0 did, and therefore left the plan's counters to the reporter
   uint32_t* gave_up;   // pinned host: `seq` — written in front of `flag` — when a workgroup of this launch gave up at the spread barrier
   uint32_t* flag;      // pinned host: `seq` once master and status are out.  (One word per workgroup, the host waiting for all of
                        // them, was tried instead of the second ticket: 3 us less on the device, 6 us more until the audio thread
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
       uint32_t n = cb_arrive(cb.done, wg, tid) - cb.base;
       if (cb.spread) {   // wait for the others (all resident: the host spreads only grids of at most one workgroup per CU)
         uint32_t spins = 0u;
-        // (bounded: ~50 ms, a thousand times what the slowest workgroup of a block takes; a give-up is reported — status bit 5 —
-        //  never a hang: the host mixes the block again through three launches and the context stops spreading)
+        // (bounded: ~50 ms, a thousand times what the slowest workgroup of a block takes; a give-up is reported — elect[1] and
+        //  the pinned gave_up word, below — never a hang: the host mixes the block again through three launches and the context
+        //  stops spreading)
         while (n < cb.n_wgs && spins < cb.spin_bound) {
           __builtin_amdgcn_s_sleep(1);
           n = cb_total(cb.done, tid) - cb.base;
@@ -193,9 +195,14 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
       for (uint32_t slot = first; slot < n_slots; slot += step) add_slot(slot, nullptr);
     }
     // the plan's counters go to the host with workgroup 0's share (spread: beside the others' sums, not behind the second
-    // ticket) / with the last workgroup's master
+    // ticket) / with the last workgroup's master.  Only a workgroup that has SEEN the full count may touch them: every
+    // sequencer lane of the launch is then over, the counters are final and clearing them takes nothing from a plan_track
+    // still running.  Workgroup 0 of a spread launch that gave up at the barrier leaves them alone and says so (elect[2]);
+    // the launch's reporter — behind the second ticket, where every workgroup is through — copies them instead, uncleared.
     if (!cb.spread || wg == 0u) {
-      if (s.status_dst && tid < 4u) {   // (as sum_kernel does: the plan's counters for the host, cleared for the buffer's next plan)
+      if (cb.spread && s_ticket != cb.n_wgs) {
+        if (tid == 0u) __hip_atomic_store(cb.elect + 2, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (s.status_dst && tid < 4u) {   // (as sum_kernel does: the plan's counters for the host, cleared for the buffer's next plan)
         const uint32_t queued = __hip_atomic_load(s.status_src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(s.status_dst + tid, __hip_atomic_load(s.status_src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -214,6 +221,12 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     }
   }
   if (!report) return;
+  // (a spread launch whose workgroup 0 gave up: the counters have not gone out — every workgroup is past its second ticket
+  //  now, so they are final; copied, not cleared: the host mixes this block again and clears them itself)
+  if (cb.spread && !a.fused_master && s.status_dst && tid < 4u &&
+      __hip_atomic_load(cb.elect + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cb.seq)
+    __hip_atomic_store(s.status_dst + tid, __hip_atomic_load(s.status_src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   // master and status (pinned host memory) went out as system-scope stores: once this workgroup's are acknowledged — every
   // wave's — they are on their way to the host in front of its flag
   if (cb.fenced) __threadfence_system();

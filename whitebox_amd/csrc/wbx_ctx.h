@@ -35,6 +35,7 @@ void launch_clamp_into(const float* src, float* dst, size_t n, int clamp, hipStr
 void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t F, uint32_t C, int fmt, hipStream_t s);
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s);
 void launch_levels_take(uint32_t* levels, uint32_t* dst, uint32_t n, hipStream_t s);
+bool probe_xcd_layout(hipStream_t s, uint32_t* n_xcds);   // workgroup ids round-robin over 8 / 4 / 2 / 1 XCDs? (wbx_kernels.hip)
 void launch_deinterleave(const void* src, void* dst0, void* dst1, uint64_t frames, uint32_t channels, uint32_t elem,
                          hipStream_t s);
 void launch_mip(const MipArgs& a, int format, int bits, hipStream_t s);
@@ -182,6 +183,10 @@ struct wbx_ctx {
   // host memory and needs few CUs).  sum_pending: a sum has been issued that the main stream has not waited for yet.
   hipStream_t sum_stream = nullptr;
   hipEvent_t mix_done[kRing] = {}, sum_done[kRing] = {};
+  // recorded right behind the sum KERNEL, in front of the copy that takes a staged master to host memory: from here on the
+  // partial buffer may be written again.  What the next user of the buffer waits for (round 6) — sum_done lies behind the
+  // copy, 8 MB over PCIe per 2048-block render: a 256-track session's plans waited 0.3 ms for it and its mixes 0.07 ms for them
+  hipEvent_t partial_free[kRing] = {};
   bool sum_valid[kRing] = {};
   int sum_pending = -1;
   uint32_t render_seq = 0;
@@ -210,6 +215,21 @@ struct wbx_ctx {
   uint64_t cb_launches = 0, cb_spread_launches = 0;   // one-launch callbacks issued / ... with the spread sum
   bool seg_broken = false;            // plan_seg_kernel found its XCD layout broken (status bit 7): one lane per track from then on
   uint32_t cb_spin_bound = 40000;     // polls of the spread barrier before a workgroup gives up (~50 ms; WBX_CB_SPIN_BOUND, read at wbx_create)
+  // A/B switches read ONCE, at wbx_create (a test sets the variable and creates a new context): the audio callback never calls
+  // getenv, and what a context decides at plan time (masked rows, lane space) cannot disagree with what it launches
+  uint32_t n_xcds = 0;                // the XCD layout probe of wbx_create: 8 / 4 / 2 / 1, or 0 — not round-robin: no chained pieces
+                                      // (chain_broken), no segmented sequencer (seg_broken) from the start
+  bool knob_ragged_off = false;       // WBX_RAGGED=0: blocks between the instances' shapes take the general instance
+  bool knob_cb_any_off = false;       // WBX_CB_ANY=0: the one-launch callback only for blocks that are exactly one 256-lane workgroup
+  bool knob_no_uniform = false;       // WBX_NO_UNIFORM=1: MixArgs::uniform_speed withheld (the one-ratio modes off)
+  bool knob_masked_rows_off = false;  // WBX_MASKED_ROWS=0: every clip boundary through the pre-render pass
+  bool knob_chain_off = false;        // WBX_CHAIN=0: long renders walk whole member lists instead of chaining 128-track pieces
+  bool knob_no_lean16 = false;        // WBX_NO_LEAN16: sessions of 16-bit PCM only through family 1
+  bool knob_no_fam3 = false;          // WBX_NO_FAM3: resampled-integer sessions through family 1
+  bool knob_no_cl2 = false;           // WBX_NO_CL2: never both channels of a frame in one lane
+  bool knob_cb_fenced = false;        // WBX_CB_FENCED=1: release / acquire fences in the one-launch callback
+  bool knob_partial_free_off = false; // WBX_PARTIAL_FREE=0: a partial buffer's next user waits for sum_done (behind the master's copy-out), as until round 5
+  int knob_packed_x = -1;             // WBX_PACKED_X=0|1: the packed masked-row instances off / on for every shape (-1: the library's choice)
   bool cb_no_spread = false;          // a spread launch gave up waiting for the whole grid (not resident at once: a CU mask, a
                                       // device shared with another process): the context keeps to "the last workgroup adds"
   uint32_t cb_flags = 1;              // completion words the launch writes (one, or one per workgroup: cb_flag[0 .. cb_flags))
@@ -232,6 +252,8 @@ struct wbx_ctx {
   hipEvent_t ev[kEventRing][3]{};       // before the mix, after the mix, after the sum
   int ev_pending = 0;
   double mix_ms_total = 0.0;
+  double gap_ms_total = 0.0;           // end of one mix -> start of the next, consecutive launches of one drain (wbx_gap_time)
+  uint64_t gap_count = 0;
   double tail_ms_total = 0.0;          // mix end -> sum end (launch gap + sum kernel incl. its PCIe stores)
   uint64_t mix_launches = 0;
   bool profiling = true;
@@ -332,6 +354,7 @@ int mix_family(const wbx_ctx* c);
 bool mix_two_channels_per_lane(const wbx_ctx* c);
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips);
 bool callback_is_one_launch(const wbx_ctx* c);
+inline uint32_t lane_span_of(const wbx_ctx* c) { return native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2, c->knob_ragged_off); }
 uint32_t callback_lane_span(const wbx_ctx* c);   // lanes per channel of the one-launch callback's 256-lane workgroup, 0: three launches
 
 // wbx_dist.hip

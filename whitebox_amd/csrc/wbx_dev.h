@@ -244,6 +244,7 @@ struct MixArgs {
   unsigned long long* dbg_clock;   // diagnostic (WBX_DBG_CLOCK=1): [workgroups][4] start / end wall-clock ticks, HW_ID, XCC_ID, or null
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
+  int packed_x;                 // WBX_PACKED_X as the context read it at creation (-1: unset; packed_masked_variant)
 };
 
 constexpr uint32_t kSumGridBlocks = 512;   // blocks in flight of one sum launch (x its tiles = waves)
@@ -291,13 +292,13 @@ struct MipArgs {
 // (config.cpp:146-149,217-222): 480 frames for WASAPI's 10 ms at 48 kHz, 416 at 44.1 kHz, 960 for 20 ms.  Such a block takes
 // the next shape above it; its surplus lanes clone the block's last four frames (wbx_mix.h).  WBX_RAGGED=0: the general
 // instance of earlier rounds instead (A/B aid).
-inline uint32_t native_lane_span(uint32_t C, uint32_t S4) {
+// (`ragged_off`: WBX_RAGGED=0 as the context read it when it was created — the audio callback never calls getenv, and the
+//  plan-time and launch-time choices of one context cannot disagree)
+inline uint32_t native_lane_span(uint32_t C, uint32_t S4, bool ragged_off) {
   const uint32_t lanes = C * S4;
   const bool exact = ((lanes % 256u == 0u) && (S4 % 64u == 0u)) || (C == 2u && S4 == 32u) ||
                      (S4 % 64u == 0u && (lanes == 128u || lanes == 64u));
-  if (exact) return S4;
-  if (const char* v = std::getenv("WBX_RAGGED"))
-    if (v[0] == '0') return S4;
+  if (exact || ragged_off) return S4;
   if (C == 2u) return S4 <= 32u ? 32u : S4 <= 64u ? 64u : S4 <= 128u ? 128u : S4 <= 256u ? 256u : (S4 + 127u) / 128u * 128u;
   return S4 <= 64u ? 64u : S4 <= 128u ? 128u : S4 <= 256u ? 256u : (S4 + 255u) / 256u * 256u;
 }
@@ -306,9 +307,10 @@ inline uint32_t native_lane_span(uint32_t C, uint32_t S4) {
 // masked-row instance (mix_kernel_x) instead of one block per workgroup?  Measured (tools/ab.py packed, profiles/r04_ab_packed.txt):
 // 128-frame stereo (four blocks per workgroup) +5-9 % over the one-wave instance; 256-frame stereo / 512-frame mono (two blocks)
 // 6-13 % BEHIND theirs — those keep one block per workgroup.  Renders of a few blocks: one workgroup per block is the shorter
-// chain.  WBX_PACKED_X=0|1: A/B aid, tests (1 = every shape that has a packed instance).
-inline int packed_masked_variant(uint32_t n_blocks, bool stereo128) {
-  if (const char* v = std::getenv("WBX_PACKED_X")) return std::atoi(v) != 0 ? 1 : 0;   // (per launch of a batch render: tests flip it)
+// chain.  WBX_PACKED_X=0|1: A/B aid, tests (1 = every shape that has a packed instance) — `forced` is what the context read
+// when it was created (-1: unset), handed to the launchers as MixArgs::packed_x.
+inline int packed_masked_variant(uint32_t n_blocks, bool stereo128, int forced) {
+  if (forced >= 0) return forced;
   return (stereo128 && n_blocks >= 8u) ? 1 : 0;
 }
 

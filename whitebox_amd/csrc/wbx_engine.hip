@@ -16,6 +16,7 @@ using namespace wbx;
 struct wbx_engine {
   wbx_ctx* ctx = nullptr;
   HostSession hs;
+  int knob_plan_seg = -1;               // WBX_PLAN_SEG, read once at wbx_engine_create: 0 off, n > 0 segments of n blocks, -1 unset
   // pinned host buffers the plan kernel reads in place (one 16-B / 8-B read per lane): state patches and per-track
   // gains reach the device without a copy and, above all, without a stream synchronisation that would drain the
   // renders the audio thread has run ahead by.  Rings of three; a buffer is refilled only after the plan kernel that
@@ -128,11 +129,8 @@ wbx_status cfail(wbx_engine* e, wbx_status s) {
 // r04_ab_seglen.txt: 256 tracks best at 32-64 blocks — 16 and 128 are 9-15 % slower —, 4096 tracks x 2048 short blocks at 512).
 // WBX_PLAN_SEG=0: off; =<n>: segments of n blocks (A/B aid, tests).
 uint32_t plan_segment_length(wbx_engine* e, uint32_t K, uint32_t N, bool playing) {
-  uint32_t forced = 0u;
-  if (const char* v = std::getenv("WBX_PLAN_SEG")) {
-    if (v[0] == '0' && v[1] == 0) return 0u;
-    forced = (uint32_t)std::atoi(v);
-  }
+  if (e->knob_plan_seg == 0) return 0u;   // (WBX_PLAN_SEG as wbx_engine_create read it: the audio thread never calls getenv)
+  const uint32_t forced = e->knob_plan_seg > 0 ? (uint32_t)e->knob_plan_seg : 0u;
   if (e->table_flags && e->h_flags_left && *reinterpret_cast<volatile uint32_t*>(e->h_flags_left) == 0u)
     e->table_flags = false;   // every flag of the table has been cleared by a plan that is over
   if (!playing || e->table_flags || e->in_process || N == 0u || e->ctx->seg_broken) return 0u;
@@ -170,6 +168,11 @@ extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out)
   e->ctx = c;
   e->hs.max_tracks = cfg->max_tracks;
   e->hs.dst_rate = cfg->sample_rate;
+  if (const char* v = std::getenv("WBX_PLAN_SEG")) e->knob_plan_seg = std::max(0, std::atoi(v));
+  if (const char* v = std::getenv("WBX_PLAN_LANES")) {   // tuning knob; measured on c3 cut into clips of 5.3 / 20 blocks:
+    const int n = std::atoi(v);                          // 64, 32, 16 and 8 tracks per wave within 2 % of each other
+    if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16 || n == 32 || n == 64) e->hs.plan_lanes_knob = (uint32_t)n;
+  }
   c->owner = e;
   c->sample_in_use = sample_in_use_cb;
   if (hipStreamCreateWithFlags(&e->levels_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -862,7 +865,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
   {
     const int pp = (int)(c->render_seq % kRing);
     if (plan_beside && c->sum_valid[pp]) {   // ... and the sum that read the partial buffer this render's mix will write
-      WBX_EHIP(e, hipStreamWaitEvent(ps, c->sum_done[pp], 0));
+      WBX_EHIP(e, hipStreamWaitEvent(ps, c->knob_partial_free_off ? c->sum_done[pp] : c->partial_free[pp], 0));   // (the sum KERNEL: not the copy-out of its master behind it)
       c->partial_wait_done = true;
     }
   }
@@ -1074,9 +1077,19 @@ extern "C" wbx_status wbx_engine_process_interleaved(wbx_engine* e, int out_form
 
 namespace {
 
+wbx_status process_block_locked(wbx_engine* e, float* const* out_planar, int out_format, void* out_il);
+
 wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format, void* out_il) {
-  wbx_ctx* c = e->ctx;
+  const auto t_in = std::chrono::steady_clock::now();   // ScopedPerformanceCounter, engine.cpp:1577
   LockGuard g(e->hs.editor_lock);   // held for the whole block, like editor_lock in Engine::process (engine.cpp:1587-1651)
+  const wbx_status st = process_block_locked(e, out_planar, out_format, out_il);
+  // perf_measurer.update(duration, audio_buffer_duration_ms), engine.cpp:1653 (there behind the unlock; one writer either way)
+  e->hs.perf_update(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(), e->ctx->cfg.block_frames);
+  return st;
+}
+
+wbx_status process_block_locked(wbx_engine* e, float* const* out_planar, int out_format, void* out_il) {
+  wbx_ctx* c = e->ctx;
   if (c->master_target || c->dist) {   // the caller redirected the master: leave it there and fetch the ordinary way
     if (out_format) return efail(e, WBX_ERR_UNSUPPORTED, "wbx_engine_process_interleaved: not with a redirected master / a multi-GPU exchange");
     wbx_status st = render_locked(e, 1);
@@ -1143,12 +1156,17 @@ wbx_status process_block(wbx_engine* e, float* const* out_planar, int out_format
     if (st == WBX_OK && one_launch && e->h_status[7] == e->cb_seq) {
       // A workgroup of the spread sum gave up waiting for the rest of its grid (the grid was not resident at once: a CU mask
       // the attribute does not show, a device shared with another process): shares of the master were added from incomplete
-      // group sums.  The launch itself is over (its flag is the LAST workgroup's), the plan is intact: mix and sum the block
-      // again through three launches, and keep to "the last workgroup adds everything" from here on.
+      // group sums.  The launch itself is over (its flag is the LAST workgroup's) and the plan is intact — the counters were
+      // copied, and cleared, only by a workgroup that had seen every sequencer lane finished (workgroup 0 with the full count,
+      // else the reporter, which does not clear: wbx_callback.h) —: mix and sum the block again through three launches, and
+      // keep to "the last workgroup adds everything" from here on.  h_status holds the plan's counters already; this sum must
+      // not drop the device's copy over them (workgroup 0 may have cleared it: an overflow bit of this block would be lost).
       c->cb_no_spread = true;
       e->cb_give_ups++;
       c->zero_status = false;
+      c->status_dst = nullptr;
       st = launch_mix_sum(c, 1, e->hs.n_tracks());
+      c->status_dst = e->h_status;
       if (st == WBX_OK && sync_main(c) != hipSuccess) st = WBX_ERR_DEVICE;
       PB(c).counters_zero = false;
       if (st != WBX_OK) tls_err = c->err;
@@ -1254,6 +1272,23 @@ extern "C" wbx_status wbx_engine_sequencer_stats(wbx_engine* e, uint64_t out[4])
   return WBX_OK;
 }
 
+// Engine::perf_measurer.get_usage() (core/timing.h:64-66; read by ui/control_bar.cpp:54): the share of its period the audio
+// callback has been taking, an exponential average over wbx_engine_process / _process_interleaved calls, clamped to [0, 1].
+// Any thread.  last_block_ms (optional): the wall time of the last call, what the last update was fed.
+extern "C" wbx_status wbx_engine_perf_usage(wbx_engine* e, double* usage, double* last_block_ms) {
+  if (!e || !usage) return WBX_ERR_INVALID;
+  *usage = e->hs.perf_get_usage();
+  if (last_block_ms) {
+    LockGuard g(e->hs.editor_lock);
+    *last_block_ms = e->hs.last_block_ms;
+  }
+  return WBX_OK;
+}
+// the arithmetic behind it, host-only (tests hold it to the reference's PerformanceMeasurer and period helpers bit for bit)
+extern "C" double wbx_calc_perf_update(double usage, double duration_ms, double period_ms) { return HostSession::perf_step(usage, duration_ms, period_ms); }
+extern "C" double wbx_calc_perf_usage(double usage) { return HostSession::perf_clamped(usage); }
+extern "C" double wbx_calc_buffer_period_ms(uint32_t buffer_size, uint32_t sample_rate) { return HostSession::buffer_period_ms(buffer_size, sample_rate); }
+
 extern "C" wbx_status wbx_engine_callback_stats(wbx_engine* e, uint64_t out[4]) {
   if (!e || !out) return WBX_ERR_INVALID;
   LockGuard g(e->hs.editor_lock);
@@ -1296,11 +1331,7 @@ extern "C" wbx_status wbx_engine_fetch_plan(wbx_engine* e, wbx_plan_record* out,
   if (used) WBX_EHIP(e, hipMemcpy(pool.data(), PB(c).pool.p, pool.size() * sizeof(DSeg), hipMemcpyDeviceToHost));
   const size_t n = plan_records(K, N, rows.data(), tmpl.data(), tmpl.size(), pool.data(), used, out, cap);
   *n_out = n;
-  if (pc[1] & 3u) return efail(e, WBX_ERR_OVERFLOW, "segment plan overflow");
-  if (pc[1] & 16u) return efail(e, WBX_ERR_OVERFLOW, "plan template array full");
-  if (pc[1] & 96u) {
-    c->chain_broken = true;
-    return efail(e, WBX_ERR_DEVICE, "a chained workgroup lost its predecessor's running sum (wait gave up / another XCD): this render is invalid");
-  }
-  return WBX_OK;
+  // (every status bit the way wbx_fetch reports it — bit 7, the segmented sequencer's XCD check, included; bit 3, "more
+  //  boundary rows than pre-render rows", concerns the audio, not the records handed out here)
+  return cfail(e, plan_status_to_error(c, pc[1] & ~8u));
 }

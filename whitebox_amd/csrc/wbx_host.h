@@ -166,6 +166,34 @@ struct HostSession {
   uint64_t edit_seq = 0;                // locked edits completed so far (UI thread, under the lock)
   uint64_t render_edit_seq = 0;         // edit_seq as the last process / render saw it
 
+  // ---- the load figure of the audio thread: Engine::perf_measurer (engine.h:64; core/timing.h:54-67) ----
+  // Engine::process starts a counter (engine.cpp:1577) and ends with perf_measurer.update(its duration in ms,
+  // audio_buffer_duration_ms) (:1653); the UI reads get_usage() (ui/control_bar.cpp:54).  Here: the wall time of one
+  // wbx_engine_process call — launch, device pass, copy-out — against the block's period.  One writer (the audio thread),
+  // any reader; the arithmetic lives in static functions so that tests hold it to the reference's bit for bit.
+  std::atomic<double> perf_usage{0.0};
+  double last_block_ms = 0.0;               // the duration the last update was fed (under the editor lock)
+  static double buffer_period_ms(uint32_t buffer_size, uint32_t sample_rate) {   // engine.cpp:52 through audio_io.h:187-195
+    constexpr double kHundredNsPerSecond = 1e7;
+    const double units = kHundredNsPerSecond * (buffer_size / (double)sample_rate);
+    const int64_t period = (int64_t)(units + (units < 0.0 ? -0.5 : 0.5));         // math::round: truncation of x +- 0.5
+    return 1000.0 * (double)period / kHundredNsPerSecond;
+  }
+  static double perf_step(double usage, double duration_ms, double period_ms) {  // timing.h:57-61
+    const double share = duration_ms / period_ms;
+    return usage + 0.25 * (share - usage);
+  }
+  static double perf_clamped(double usage) {                                       // timing.h:64-66 (math::clamp to [0, 1])
+    const double capped = usage < 1.0 ? usage : 1.0;
+    return capped > 0.0 ? capped : 0.0;
+  }
+  void perf_update(double duration_ms, uint32_t buffer_size) {
+    last_block_ms = duration_ms;
+    perf_usage.store(perf_step(perf_usage.load(std::memory_order_relaxed), duration_ms, buffer_period_ms(buffer_size, dst_rate)),
+                     std::memory_order_release);
+  }
+  double perf_get_usage() const { return perf_clamped(perf_usage.load(std::memory_order_acquire)); }
+
   double uniform_window_speed() const { return window_speed > 0.0 ? window_speed : 0.0; }
   uint32_t n_tracks() const { return (uint32_t)tracks.size(); }
   bool valid_track(uint32_t t) const { return t < tracks.size(); }
@@ -562,13 +590,10 @@ struct HostSession {
   // (a ROW_PAIR block takes two templates; every track may strand part of a reservation of `reserve` templates)
   // tracks per wave of the plan kernel: a session cut into many clips meets a clip boundary every few blocks on every
   // track, and a wave runs the (long) boundary path whenever ANY of its tracks does
+  uint32_t plan_lanes_knob = 0;   // WBX_PLAN_LANES as the engine read it when it was created (0: unset)
   uint32_t plan_lanes(uint32_t K) const {
     (void)K;
-    if (const char* e = std::getenv("WBX_PLAN_LANES")) {   // tuning knob; measured on c3 cut into clips of 5.3 / 20 blocks:
-      const int v = std::atoi(e);                          // 64, 32, 16 and 8 tracks per wave within 2 % of each other
-      if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
-    }
-    return 64u;
+    return plan_lanes_knob ? plan_lanes_knob : 64u;
   }
   static uint32_t template_reserve(uint32_t K) { return K >= 64u ? 32u : K >= 8u ? 8u : 1u; }
   // (lanes: lanes per track of the sequencer — more than one when it is cut along the time axis; every lane may strand a

@@ -644,7 +644,7 @@ const char* launch_callback(const MixArgs& m, const PlanArgs& p, const SumArgs& 
                             uint32_t* gave_up, uint32_t spin_bound, uint32_t* flag, uint32_t seq, int family, bool window_rows, unsigned long long* dbg, hipStream_t st) {
   SumArgs s = s0;
   s.n_blocks = 1u;
-  static const bool fenced = [] { const char* v = std::getenv("WBX_CB_FENCED"); return v && v[0] == '1'; }();   // A/B aid
+  const bool fenced = m.partial_through == 0u;   // WBX_CB_FENCED=1 (A/B aid), as the context read it
   // (the election word: word 1 of the counter block — the counters' own words are multiples of kCbStride)
   CallbackArgs cb{done, spread ? 1u : 0u, done_base, done_base2, done + 1, gave_up, flag, seq, m.n_groups, fenced ? 1u : 0u, spin_bound, dbg};
   if (family == 1 || family == 3) return launch_callback_fam1(m, p, s, cb, st);   // (3 = 1 without the per-frame taps: one instance serves both)
@@ -694,6 +694,37 @@ void launch_convert(const float* master, void* dst, uint32_t n_blocks, uint32_t 
 
 void launch_levels_take(uint32_t* levels, uint32_t* dst, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(levels_take_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, levels, dst, n);
+}
+
+// The layout two hand-overs rest on — a launch's linear workgroup ids dealt round-robin to 8 / 4 / 2 / 1 XCDs, so that the
+// 128-track pieces of a block (chained renders) and the segments of a track (plan_seg_kernel) meet behind ONE L2 — probed
+// once per context: workgroup i of a small 1-D grid notes the XCD it runs on.  -> true when ids repeat with a period of
+// 8, 4, 2 or 1 (MI355X: 8); anything else (a 6-XCD part, a partition mode that deals differently) and the context walks
+// whole member lists and plans by one lane per track from the start, instead of finding out in its first long render.
+__global__ __launch_bounds__(64) void xcc_probe_kernel(uint32_t* out) {
+  if (threadIdx.x == 0u) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg(63508) & 15u;   // HW_REG_XCC_ID
+}
+bool probe_xcd_layout(hipStream_t s, uint32_t* n_xcds) {
+  constexpr uint32_t kProbe = 64;
+  uint32_t* d = nullptr;
+  uint32_t h[kProbe];
+  *n_xcds = 0;
+  if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3(kProbe), dim3(64), 0, s, d);
+  const bool ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return false;
+  for (uint32_t period : {1u, 2u, 4u, 8u}) {
+    bool fits = true, distinct = true;
+    for (uint32_t i = period; i < kProbe && fits; i++) fits = h[i] == h[i - period];
+    for (uint32_t i = 0; i < period && distinct; i++)
+      for (uint32_t j = 0; j < i; j++) distinct = distinct && h[i] != h[j];
+    if (fits && distinct) {
+      *n_xcds = period;
+      return true;
+    }
+  }
+  return false;
 }
 
 void launch_synth(void* dst, uint64_t frames, uint64_t key, float amp, int fmt, hipStream_t s) {

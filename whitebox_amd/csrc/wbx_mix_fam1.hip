@@ -15,7 +15,7 @@ const char* launch_mix_fam1(const MixArgs& a, uint32_t n_blocks, hipStream_t s, 
   if (!full && a.masked_rows) {
     // short blocks of a session cut into clips, renders of 8 blocks and more: the packed instances that take masked rows
     const bool st128 = S4 == 32u && a.channels == 2u, two = S4 % 64u == 0u && lanes == 128u, four = S4 == 64u && lanes == 64u;
-    const int x = packed_masked_variant(n_blocks, st128);
+    const int x = packed_masked_variant(n_blocks, st128, a.packed_x);
     if (x && (st128 || two || four)) {
       const uint32_t sb = st128 ? 4u : 256u / lanes;
       const dim3 gx((n_blocks + sb - 1u) / sb, a.n_groups, 1);

@@ -48,6 +48,12 @@ void drain_events(wbx_ctx* c) {
       c->mix_ms_total += ms;
       c->mix_launches++;
       if (hipEventElapsedTime(&ms, c->ev[i][1], c->ev[i][2]) == hipSuccess) c->tail_ms_total += ms;
+      // the idle time between two consecutive mixes (end of one to start of the next, the kernels' own time stamps): what a
+      // step spends outside its dominant kernel while the device runs back to back
+      if (i > 0 && hipEventElapsedTime(&ms, c->ev[i - 1][1], c->ev[i][0]) == hipSuccess && ms >= 0.0f && ms < 50.0f) {
+        c->gap_ms_total += ms;
+        c->gap_count++;
+      }
     }
   }
   c->ev_pending = 0;
@@ -131,15 +137,14 @@ void build_routing(wbx_ctx* c, uint32_t n_tracks) {
 //  columns than resident workgroups several pieces of a block are resident TOGETHER and all but one of them wait — measured
 //  on the one-wave instances, 3072 resident: 0.25 of the roofline at 1024 columns, 0.45 at 2048, against 0.6 unchained)
 static uint32_t blocks_per_workgroup(const wbx_ctx* c, uint32_t K, uint32_t* resident) {
-  const uint32_t C = c->cfg.channels, S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2), lanes = C * S4;   // (the instance's lane space)
+  const uint32_t C = c->cfg.channels, S4 = lane_span_of(c), lanes = C * S4;   // (the instance's lane space)
   *resident = 1u;
   if ((lanes % 256u == 0u) && (S4 % 64u == 0u)) return 1u;
-  const char* e = std::getenv("WBX_MASKED_ROWS");
   const bool short_ok = (C == 2u && S4 == 32u) || (S4 % 64u == 0u && lanes == 128u) || (S4 == 64u && lanes == 64u);
   const uint32_t packed = (C == 2u && S4 == 32u) ? 4u : (S4 % 64u == 0u && (lanes == 128u || lanes == 64u)) ? 256u / lanes : 1u;
   const int fam = mix_family(c);
-  if (short_ok && c->has_cut_tracks && !(e && e[0] == '0')) {   // masked rows ...
-    if (!(fam == 2 && C == 2u && S4 == 64u) && packed_masked_variant(K, C == 2u && S4 == 32u)) return packed;   // ... in the packed instances
+  if (short_ok && c->has_cut_tracks && !c->knob_masked_rows_off) {   // masked rows ...
+    if (!(fam == 2 && C == 2u && S4 == 64u) && packed_masked_variant(K, C == 2u && S4 == 32u, c->knob_packed_x)) return packed;   // ... in the packed instances
     *resident = lanes <= 64u ? 3u : 2u;
     return 1u;                                                   // ... in the one-block-per-workgroup instances
   }
@@ -161,11 +166,10 @@ bool render_walks_whole_lists(const wbx_ctx* c, uint32_t K) {
 // one long walk per workgroup ends when its slowest shader engine does (profiles/r03_wg_clocks.txt: 25-40 % behind the mean).
 // WBX_CHAIN=0: walk the lists whole.
 bool render_chains_groups(const wbx_ctx* c, uint32_t K) {
-  const char* e = std::getenv("WBX_CHAIN");
   // (a reported hand-over failure: whole-list walks from then on.  WBX_MIX_ALT=1 runs two renders' mixes side by side, and
   //  the words of both would share d_chain with only the epoch to tell them apart: render i+1's pieces overwrite words
   //  render i's successors still poll — no chaining there)
-  const bool off = (e && e[0] == '0') || c->chain_broken || c->mix_alternate;
+  const bool off = c->knob_chain_off || c->chain_broken || c->mix_alternate;
   // (K a multiple of 32: every instance's grid then has an x extent that is a multiple of 8, which keeps the pieces of a
   //  block on one XCD — what the chain's L2-level hand-over rests on; other lengths walk the lists whole)
   return render_walks_whole_lists(c, K) && !off && c->longest_list > c->cfg.group_size && (K % 32u) == 0u;
@@ -306,9 +310,9 @@ wbx_status launch_pre_render(wbx_ctx* c, uint32_t K, hipStream_t on) {
 // speeds up to 0.999 or not at all
 int mix_family(const wbx_ctx* c) {
   if (c->force_g) return 1;
-  if (c->has_lean16_clips && !c->has_non16_clips && !std::getenv("WBX_NO_LEAN16")) return 2;
+  if (c->has_lean16_clips && !c->has_non16_clips && !c->knob_no_lean16) return 2;
   if (c->has_stride_clips || (c->has_window_clips && c->has_integer_clips))
-    return (c->has_taps_clips || std::getenv("WBX_NO_FAM3")) ? 1 : 3;   // (3 = 1 without the per-frame taps)
+    return (c->has_taps_clips || c->knob_no_fam3) ? 1 : 3;   // (3 = 1 without the per-frame taps)
   return 0;
 }
 
@@ -325,15 +329,15 @@ int mix_family(const wbx_ctx* c) {
 // <2,true,3,..,2,128>, 0.694 for the one-channel-per-wave <2,true,4,..,1,256>; at 1024 and 256 blocks nothing to choose.
 bool mix_long_chained_window_render(const wbx_ctx* c) {
   static const bool off = [] { const char* v = std::getenv("WBX_NO_LONG_CL2"); return v && v[0] == '1'; }();   // A/B aid
-  const uint32_t F = 4u * native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);
+  const uint32_t F = 4u * lane_span_of(c);
   return !off && c->cfg.channels == 2u && F == 512u && c->chain_now && c->render_blocks_now >= 2048u && c->has_window_clips &&
          !c->has_integer_clips && !c->has_cut_tracks && !c->has_stride_clips && !c->n_buses;
 }
 
 bool mix_two_channels_per_lane(const wbx_ctx* c) {
-  const uint32_t F = 4u * native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2);   // (the block size of the instance's lane space)
+  const uint32_t F = 4u * lane_span_of(c);   // (the block size of the instance's lane space)
   if (c->mix_unroll) return c->mix_unroll >= 1000;   // WBX_MIX_VARIANT
-  if (c->cfg.channels != 2u || std::getenv("WBX_NO_CL2")) return false;
+  if (c->cfg.channels != 2u || c->knob_no_cl2) return false;
   if (!(F == 512u || F == 1024u || F == 256u)) return false;
   // the callback path (a handful of workgroups, each a chain of dependent rows): a wave per channel half — four waves share
   // the chain instead of two (measured, 4096 / 64 tracks: 16-bit resampled 53 -> 51 / 55 -> 49 us, cut into clips 63 -> 58 /
@@ -352,7 +356,7 @@ bool mix_two_channels_per_lane(const wbx_ctx* c) {
 // 1: fp32 rows, unity or resampled; 2: also integer PCM at unity speed — sessions whose integer clips all play at the
 // session rate and that hold no resampled clip (those take the instances with the mixed-format window modes).
 uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_clips) {
-  const uint32_t S4 = native_lane_span(c->cfg.channels, c->cfg.block_frames >> 2), lanes = c->cfg.channels * S4;
+  const uint32_t S4 = lane_span_of(c), lanes = c->cfg.channels * S4;
   bool full = (lanes % 256u == 0u) && (S4 % 64u == 0u);
   // (256-frame stereo blocks: the one-wave instances with both channels per lane, the lean families only)
   if (!full && c->cfg.channels == 2u && S4 == 64u && (mix_family(c) == 0 || mix_family(c) == 2) && mix_two_channels_per_lane(c)) full = true;
@@ -362,8 +366,7 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
   if (!full && c->has_cut_tracks &&
       ((c->cfg.channels == 2u && S4 == 32u) || (S4 % 64u == 0u && lanes == 128u) || (S4 == 64u && lanes == 64u)))
     full = true;
-  if (const char* e = std::getenv("WBX_MASKED_ROWS"))
-    if (e[0] == '0') return 0u;   // A/B aid: send every boundary row through the pre-render pass
+  if (c->knob_masked_rows_off) return 0u;   // WBX_MASKED_ROWS=0, A/B aid: send every boundary row through the pre-render pass
   if (!full) return 0u;
   if (mix_family(c) == 1 || mix_family(c) == 3) return 4u;   // the everything family: every row kind it streams, also as a masked row
   if (mix_family(c) == 2) return 3u;   // sessions of 16-bit PCM only: also their resampled rows
@@ -381,12 +384,9 @@ uint32_t mix_takes_masked_rows(const wbx_ctx* c, bool window_clips, bool stride_
 // last four frames (wbx_mix.h).  WBX_CB_ANY=0: only the shapes whose batch renders take a 256-lane workgroup per block.
 uint32_t callback_lane_span(const wbx_ctx* c) {
   const uint32_t C = c->cfg.channels, S4 = c->cfg.block_frames >> 2;
-  const uint32_t nat = native_lane_span(C, S4);
+  const uint32_t nat = lane_span_of(c);
   if (C * nat == 256u && (nat % 64u) == 0u) return nat;
-  const char* v = std::getenv("WBX_CB_ANY");
-  if (v && v[0] == '0') return 0u;
-  if (const char* r = std::getenv("WBX_RAGGED"))
-    if (r[0] == '0') return 0u;
+  if (c->knob_cb_any_off || c->knob_ragged_off) return 0u;
   return C * S4 <= 256u ? 256u / C : 0u;
 }
 bool callback_is_one_launch(const wbx_ctx* c) {
@@ -423,7 +423,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   if (!c->cur_mix_stream) c->cur_mix_stream = c->stream;
   hipStream_t ms = c->cur_mix_stream;             // the main stream, or the alternate one (pick_mix_stream)
   const int pk = ms == c->stream ? 0 : 1;         // its peaks buffer
-  if (c->sum_valid[pp] && !c->partial_wait_done) WBX_HIP(c, hipStreamWaitEvent(ms, c->sum_done[pp], 0));
+  if (c->sum_valid[pp] && !c->partial_wait_done) WBX_HIP(c, hipStreamWaitEvent(ms, c->knob_partial_free_off ? c->sum_done[pp] : c->partial_free[pp], 0));
   c->partial_wait_done = false;
   m.partial = c->d_partial2[pp].p;
   m.peaks = c->d_peaks[pk].p;
@@ -452,15 +452,15 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.n_groups = n_groups;
   m.block_frames = F;
   m.channels = C;
-  m.lane_span = native_lane_span(C, F >> 2);
+  m.lane_span = lane_span_of(c);
+  m.packed_x = c->knob_packed_x;
   m.tiles = (C * m.lane_span + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
   {   // one resampling ratio for every window row of this render (layer 2's word; MODE_WNU / WINU: the products fl(j * speed)
       // hoisted out of the track loop).  WBX_NO_UNIFORM=1: A/B aid.  [Round 3's split of this function lost this line: the
       // modes were carried but never taken until round 5 — SQ_INSTS_VALU_MUL_F64 of the r03-r05 PMC passes shows it.]
-    const char* v = std::getenv("WBX_NO_UNIFORM");   // (read per launch: tests flip it inside one process)
-    m.uniform_speed = (v && v[0] == '1') ? 0.0 : c->uniform_speed;
+    m.uniform_speed = c->knob_no_uniform ? 0.0 : c->uniform_speed;
     c->last_uniform_speed = m.uniform_speed;
   }
   // A short render of a session that is one group (the callback configuration up to 64 tracks; no sub-buses, planar fp32
@@ -617,7 +617,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
         cb_dbg = c->d_dbg.p;
       }
     }
-    m.partial_through = (std::getenv("WBX_CB_FENCED") && std::getenv("WBX_CB_FENCED")[0] == '1') ? 0u : 1u;
+    m.partial_through = c->knob_cb_fenced ? 0u : 1u;
     // every workgroup adds a share of the master when the whole grid is resident at once (at most one workgroup per CU: two
     // fit) and the engine's pinned block has a completion word for each of them
     const bool spread = !fused && !c->cb_no_spread && m.n_groups <= callback_spread_limit();
@@ -636,6 +636,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   } else if (!fused) {
     launch_sum(s, K, ss);
   }
+  if (sum_beside) WBX_HIP(c, hipEventRecord(c->partial_free[pp], ss));   // (in front of the staged master's copy: wbx_ctx.h)
   if (stage_bytes) WBX_HIP(c, hipMemcpyAsync(master_home, master_dst, stage_bytes, hipMemcpyDeviceToHost, ss));
   if (m.n_groups && timed) {
     WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][2], ss));
@@ -757,12 +758,37 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     bool ok = hipStreamCreateWithPriority(&c->sum_stream, hipStreamNonBlocking, (sp && sp[0] == 'l') ? lo : hi) == hipSuccess;
     for (int i = 0; i < kRing && ok; i++)
       ok = hipEventCreateWithFlags(&c->mix_done[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&c->partial_free[i], hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking) == hipSuccess;
     // measured (tools/ab_alt.sh): with consecutive mixes on alternating streams the two kernels share the device for
     // their whole length (each takes 1.05-1.2 ms instead of 0.74) and the step time does not move — off by default
     if (const char* sb = std::getenv("WBX_CB_SPIN_BOUND")) c->cb_spin_bound = (uint32_t)std::atoi(sb);   // (tests: 0 forces the give-up path)
+    {   // the A/B switches the render path consults (wbx_ctx.h: read once, here)
+      auto is = [](const char* name, char what) { const char* v = std::getenv(name); return v && v[0] == what; };
+      c->knob_ragged_off = is("WBX_RAGGED", '0');
+      c->knob_cb_any_off = is("WBX_CB_ANY", '0');
+      c->knob_no_uniform = is("WBX_NO_UNIFORM", '1');
+      c->knob_masked_rows_off = is("WBX_MASKED_ROWS", '0');
+      c->knob_chain_off = is("WBX_CHAIN", '0');
+      c->knob_no_lean16 = std::getenv("WBX_NO_LEAN16") != nullptr;
+      c->knob_no_fam3 = std::getenv("WBX_NO_FAM3") != nullptr;
+      c->knob_no_cl2 = std::getenv("WBX_NO_CL2") != nullptr;
+      c->knob_cb_fenced = is("WBX_CB_FENCED", '1');
+      c->knob_partial_free_off = is("WBX_PARTIAL_FREE", '0');
+      if (const char* v = std::getenv("WBX_PACKED_X")) c->knob_packed_x = std::atoi(v) != 0 ? 1 : 0;
+    }
+    // the workgroup-id -> XCD layout the chained pieces and the segmented sequencer rest on, probed before anything relies on it
+    // (WBX_XCD_PROBE_FAIL=1: tests take the fallback path)
+    if (ok) {
+      const char* pf = std::getenv("WBX_XCD_PROBE_FAIL");
+      if (!probe_xcd_layout(c->stream, &c->n_xcds) || (pf && pf[0] == '1')) {
+        c->n_xcds = 0;
+        c->chain_broken = true;
+        c->seg_broken = true;
+      }
+    }
     const char* ma = std::getenv("WBX_MIX_ALT");
     c->mix_alternate = ma && ma[0] == '1';
     if (!ok) {
@@ -829,6 +855,7 @@ extern "C" void wbx_destroy(wbx_ctx* c) {
   for (int i = 0; i < kRing; i++) {
     if (c->mix_done[i]) (void)hipEventDestroy(c->mix_done[i]);
     if (c->sum_done[i]) (void)hipEventDestroy(c->sum_done[i]);
+    if (c->partial_free[i]) (void)hipEventDestroy(c->partial_free[i]);
   }
   for (auto& P : c->d_partial2) P.release();
   c->d_master.release();
@@ -1657,6 +1684,7 @@ extern "C" wbx_status wbx_host_free(void* p) {
 
 extern "C" const char* wbx_kernel_name(wbx_ctx* c) { return c ? c->mix_kernel_name : ""; }
 extern "C" double wbx_render_uniform_speed(wbx_ctx* c) { return c ? c->last_uniform_speed : 0.0; }
+extern "C" uint32_t wbx_xcd_count(wbx_ctx* c) { return c ? c->n_xcds : 0u; }
 
 extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg, uint64_t* mix_launches) {
   if (!c) return WBX_ERR_INVALID;
@@ -1669,7 +1697,19 @@ extern "C" wbx_status wbx_kernel_time(wbx_ctx* c, int reset, double* mix_ms_avg,
     c->mix_ms_total = 0.0;
     c->tail_ms_total = 0.0;
     c->mix_launches = 0;
+    c->gap_ms_total = 0.0;
+    c->gap_count = 0;
   }
+  return WBX_OK;
+}
+
+extern "C" wbx_status wbx_gap_time(wbx_ctx* c, double* gap_ms_avg, uint64_t* gaps) {
+  if (!c || !gap_ms_avg) return WBX_ERR_INVALID;
+  WBX_HIP(c, join_sum(c));
+  WBX_HIP(c, sync_main(c));
+  drain_events(c);
+  *gap_ms_avg = c->gap_count ? c->gap_ms_total / (double)c->gap_count : 0.0;
+  if (gaps) *gaps = c->gap_count;
   return WBX_OK;
 }
 

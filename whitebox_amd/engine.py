@@ -245,6 +245,10 @@ class MixContext:
         """The mix_kernel instance the last render launched, as rocprofv3 prints it."""
         return (self.L.wbx_kernel_name(self.h) or b"").decode()
 
+    def xcd_count(self) -> int:
+        """XCDs the workgroup ids of a launch are dealt to round-robin (wbx_create's probe); 0: no such layout"""
+        return int(self.L.wbx_xcd_count(self.h))
+
     def uniform_speed(self) -> float:
         """MixArgs::uniform_speed of the last render (0.0: no single resampling ratio)."""
         return float(self.L.wbx_render_uniform_speed(self.h))
@@ -253,6 +257,12 @@ class MixContext:
         ms = C.c_double()
         _check(self.L.wbx_tail_time(self.h, C.byref(ms)), "wbx_tail_time", self.h)
         return ms.value
+
+    def gap_time(self):
+        """(mean idle time in ms between two consecutive mix launches since the last kernel_time(reset=True), pairs timed)"""
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self.L.wbx_gap_time(self.h, C.byref(ms), C.byref(n)), "wbx_gap_time", self.h)
+        return ms.value, int(n.value)
 
 
 class Track:
@@ -380,6 +390,13 @@ class Engine:
         out = (C.c_uint64 * 4)()
         _check(self.L.wbx_engine_callback_stats(self.h, out), "wbx_engine_callback_stats", self.h, True)
         return tuple(int(x) for x in out)
+
+    def perf_usage(self):
+        """(Engine::perf_measurer.get_usage() — the callback's share of its period, exponential average, clamped to [0, 1] —,
+        the wall time in ms of the last process call)"""
+        u, d = C.c_double(), C.c_double()
+        _check(self.L.wbx_engine_perf_usage(self.h, C.byref(u), C.byref(d)), "wbx_engine_perf_usage", self.h, True)
+        return u.value, d.value
 
     def thread_stats(self):
         """(locked edits the last process / render had seen, per-track cumulative drained parameter messages)"""
