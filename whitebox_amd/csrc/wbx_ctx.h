@@ -229,6 +229,7 @@ struct wbx_ctx {
   bool knob_no_cl2 = false;           // WBX_NO_CL2: never both channels of a frame in one lane
   bool knob_cb_fenced = false;        // WBX_CB_FENCED=1: release / acquire fences in the one-launch callback
   bool knob_partial_free_off = false; // WBX_PARTIAL_FREE=0: a partial buffer's next user waits for sum_done (behind the master's copy-out), as until round 5
+  unsigned dev_event_flags = 0x2;     // hipEventDisableTiming [| hipEventReleaseToDevice]: events only other streams of this device wait for
   int knob_packed_x = -1;             // WBX_PACKED_X=0|1: the packed masked-row instances off / on for every shape (-1: the library's choice)
   bool cb_no_spread = false;          // a spread launch gave up waiting for the whole grid (not resident at once: a CU mask, a
                                       // device shared with another process): the context keeps to "the last workgroup adds"
@@ -337,7 +338,7 @@ hipError_t join_sum(wbx_ctx* c);
 hipError_t join_alt(wbx_ctx* c);
 hipError_t sync_main(wbx_ctx* c);          // the host waits for the main stream and every mix / sum beside it
 hipStream_t pick_mix_stream(wbx_ctx* c, uint32_t K, bool alternate);
-void drain_events(wbx_ctx* c);
+void drain_events(wbx_ctx* c, int upto = 0);
 wbx_status upload_tables(wbx_ctx* c, uint32_t n_tracks);
 wbx_status ensure_result_buffers(wbx_ctx* c, uint32_t K, uint32_t N);
 wbx_status ensure_template_capacity(wbx_ctx* c, size_t n);

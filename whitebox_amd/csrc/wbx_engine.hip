@@ -176,7 +176,7 @@ extern "C" wbx_status wbx_engine_create(const wbx_config* cfg, wbx_engine** out)
   c->owner = e;
   c->sample_in_use = sample_in_use_cb;
   if (hipStreamCreateWithFlags(&e->levels_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&e->levels_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->levels_ev, e->ctx->dev_event_flags) != hipSuccess ||
       hipHostMalloc((void**)&e->h_levels, (size_t)cfg->max_tracks * 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
     wbx_engine_destroy(e);
     return WBX_ERR_OOM;
@@ -694,8 +694,8 @@ wbx_status ensure_pinned_tables(wbx_engine* e, uint32_t N) {
     e->patch_cap[i] = cap;
     e->patch_valid[i] = false;
     e->gains_valid[i] = false;
-    if (!e->patch_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->patch_done[i], hipEventDisableTiming));
-    if (!e->gains_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->gains_done[i], hipEventDisableTiming));
+    if (!e->patch_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->patch_done[i], e->ctx->dev_event_flags));
+    if (!e->gains_done[i]) WBX_EHIP(e, hipEventCreateWithFlags(&e->gains_done[i], e->ctx->dev_event_flags));
   }
   e->gains_cap = cap;
   e->gains_slot = -1;
@@ -939,7 +939,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
       WBX_EHIP(e, hipHostMalloc((void**)&e->h_times[ts], (size_t)K * sizeof(DBlockTime), hipHostMallocDefault));
       e->times_cap[ts] = K;
     }
-    if (!e->times_done[ts]) WBX_EHIP(e, hipEventCreateWithFlags(&e->times_done[ts], hipEventDisableTiming));
+    if (!e->times_done[ts]) WBX_EHIP(e, hipEventCreateWithFlags(&e->times_done[ts], e->ctx->dev_event_flags));
     block_times(a, e->h_times[ts]);   // wbx_seq.h: the source the device compiles
     launch_times_copy(e->h_times[ts], B.times.p, K, ps);
     WBX_EHIP(e, hipEventRecord(e->times_done[ts], ps));
@@ -949,7 +949,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     // (found by the random-pieces test once it left renders unfetched: a batch render's plan, on the idle plan stream,
     //  overtook the plan of a short render still queued on the main stream behind earlier mixes and read the state before
     //  that one had written it)
-    if (!e->plan_handover) WBX_EHIP(e, hipEventCreateWithFlags(&e->plan_handover, hipEventDisableTiming));
+    if (!e->plan_handover) WBX_EHIP(e, hipEventCreateWithFlags(&e->plan_handover, e->ctx->dev_event_flags));
     WBX_EHIP(e, hipEventRecord(e->plan_handover, e->last_plan_stream));
     WBX_EHIP(e, hipStreamWaitEvent(ps, e->plan_handover, 0));
   }
@@ -977,7 +977,7 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     // one lane per (track, segment); the lane that completes a track checks its seams; the seam states live in one buffer
     const size_t per = (size_t)N * n_segs;
     if (e->seam_stream && e->seam_stream != ps) {   // (its last user ran on the other stream)
-      if (!e->seam_done) WBX_EHIP(e, hipEventCreateWithFlags(&e->seam_done, hipEventDisableTiming));
+      if (!e->seam_done) WBX_EHIP(e, hipEventCreateWithFlags(&e->seam_done, e->ctx->dev_event_flags));
       WBX_EHIP(e, hipEventRecord(e->seam_done, e->seam_stream));
       WBX_EHIP(e, hipStreamWaitEvent(ps, e->seam_done, 0));
     }

@@ -41,8 +41,12 @@ hipStream_t pick_mix_stream(wbx_ctx* c, uint32_t K, bool alternate) {
   return c->cur_mix_stream;
 }
 
-void drain_events(wbx_ctx* c) {
-  for (int i = 0; i < c->ev_pending; i++) {
+// the kernel timer's pending launches -> the totals; `upto` > 0: only the oldest `upto` of them (a full ring: the newer half
+// stays pending, so the submitting thread never waits for the launch it has just issued — waiting for THAT drained the whole
+// run-ahead every 64 renders: ~9 us per step of a 0.4 ms render)
+void drain_events(wbx_ctx* c, int upto) {
+  const int n = (upto > 0 && upto < c->ev_pending) ? upto : c->ev_pending;
+  for (int i = 0; i < n; i++) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) {
       c->mix_ms_total += ms;
@@ -56,7 +60,9 @@ void drain_events(wbx_ctx* c) {
       }
     }
   }
-  c->ev_pending = 0;
+  for (int i = n; i < c->ev_pending; i++)   // (the handles change places: every slot keeps three valid events)
+    for (int k = 0; k < 3; k++) std::swap(c->ev[i - n][k], c->ev[i][k]);
+  c->ev_pending -= n;
 }
 
 // Routing tables.  `order`: the direct tracks in index order, then the members of bus 0, bus 1, ... — the order the sums
@@ -521,9 +527,9 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   c->cb_launched = false;
   if (m.n_groups && !one_launch) {
     if (timed) {
-      if (c->ev_pending == kEventRing) {
-        WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing - 1][1]));
-        drain_events(c);
+      if (c->ev_pending == kEventRing) {   // the older half: 32 launches behind the newest, over long ago
+        WBX_HIP(c, hipEventSynchronize(c->ev[kEventRing / 2 - 1][2]));
+        drain_events(c, kEventRing / 2);
       }
     }
     // the timer's two events ride on the kernel's own dispatch packet (start / end time stamps of the kernel itself): no
@@ -718,6 +724,12 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (const char* u = std::getenv("WBX_EXACT_MIN_BLOCKS")) c->exact_min_blocks = (uint32_t)std::atoi(u);   // 0: never
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
   if (const char* u = std::getenv("WBX_KERNEL_TIMER")) c->profiling = std::atoi(u) != 0;   // 0: no HIP-event kernel timer
+  // Events whose only waiters are other streams of this device (or a host that waits for "done" and reads nothing the device
+  // wrote): released to the DEVICE — the default, a release to the system behind every marker, cost a 256-track session 5 % of
+  // its step (0.447 -> 0.422 ms per 2048-block render: three markers between two mixes).  Results leave through sum_done and
+  // the callback's own system-scope stores, which keep the system scope.  WBX_EVENT_SCOPE=system: as until round 5 (A/B aid).
+  const unsigned scope = [] { const char* es = std::getenv("WBX_EVENT_SCOPE"); return (es && es[0] == 's') ? 0u : (unsigned)hipEventReleaseToDevice; }();
+  c->dev_event_flags = hipEventDisableTiming | scope;
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {
@@ -728,8 +740,9 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     c->own_stream = true;
   }
   for (int i = 0; i < kEventRing; i++) {
-    if (hipEventCreate(&c->ev[i][0]) != hipSuccess || hipEventCreate(&c->ev[i][1]) != hipSuccess ||
-        hipEventCreate(&c->ev[i][2]) != hipSuccess) {
+    // (timing events: only their time stamps are read — no release to the system behind the kernel that carries them)
+    if (hipEventCreateWithFlags(&c->ev[i][0], scope) != hipSuccess || hipEventCreateWithFlags(&c->ev[i][1], scope) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev[i][2], scope) != hipSuccess) {
       wbx_destroy(c);
       return WBX_ERR_DEVICE;
     }
@@ -755,11 +768,12 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
     const char* so = std::getenv("WBX_SUM_OVERLAP");
     c->sum_overlap = !(so && so[0] == '0');
     const char* sp = std::getenv("WBX_SUM_PRIO");
+    const unsigned dev_ev = c->dev_event_flags;
     bool ok = hipStreamCreateWithPriority(&c->sum_stream, hipStreamNonBlocking, (sp && sp[0] == 'l') ? lo : hi) == hipSuccess;
     for (int i = 0; i < kRing && ok; i++)
-      ok = hipEventCreateWithFlags(&c->mix_done[i], hipEventDisableTiming) == hipSuccess &&
+      ok = hipEventCreateWithFlags(&c->mix_done[i], dev_ev) == hipSuccess &&
            hipEventCreateWithFlags(&c->sum_done[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&c->partial_free[i], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&c->partial_free[i], dev_ev) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking) == hipSuccess;
     // measured (tools/ab_alt.sh): with consecutive mixes on alternating streams the two kernels share the device for
@@ -801,7 +815,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   for (auto& B : c->pb) {
     B.pool_chunks = (uint32_t)chunks;
     if (B.pool.ensure(chunks * kChunk) != hipSuccess || hipMalloc((void**)&B.counters, 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipEventCreateWithFlags(&B.planned, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&B.planned, c->dev_event_flags) != hipSuccess) {
       wbx_destroy(c);
       return WBX_ERR_OOM;
     }
@@ -1662,7 +1676,7 @@ extern "C" wbx_status wbx_pace(wbx_ctx* c, uint32_t max_ahead) {
   if (!c || max_ahead == 0 || max_ahead >= kPaceRing) return WBX_ERR_INVALID;
   (void)hipSetDevice(c->cfg.device);
   const uint32_t slot = (uint32_t)(c->pace_seq % kPaceRing);
-  if (!c->pace_ev[slot]) WBX_HIP(c, hipEventCreateWithFlags(&c->pace_ev[slot], hipEventDisableTiming));
+  if (!c->pace_ev[slot]) WBX_HIP(c, hipEventCreateWithFlags(&c->pace_ev[slot], c->dev_event_flags));   // (the host waits for "done", reads nothing)
   WBX_HIP(c, hipEventRecord(c->pace_ev[slot], c->cur_mix_stream ? c->cur_mix_stream : c->stream));
   if (c->pace_seq >= max_ahead) WBX_HIP(c, hipEventSynchronize(c->pace_ev[(c->pace_seq - max_ahead) % kPaceRing]));
   c->pace_seq++;
