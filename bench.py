@@ -545,7 +545,6 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
 
     L = W.lib()
     state = {"done": 0}
-    pace_every = max(1, int(os.environ.get("WBX_BENCH_PACE_EVERY", "1")))   # (experiment aid: an event record per N steps)
 
     result_rank = dist.result_rank if dist is not None else 0   # who holds the summed master (chain mode: the last rank)
 
@@ -559,9 +558,7 @@ def run_workload(W, synth, args, workload, rank, world, *, n_tracks, K, steps, w
             dist.exchange(host_master.ptr if rank == result_rank else None)   # asynchronous, beside the next renders
         # keep the submitting thread at most 12 steps ahead of the device: far deeper, the HIP runtime stalls a
         # launch until its queue has drained (tens of ms) and the device then idles
-        state["steps"] = state.get("steps", 0) + 1
-        if state["steps"] % pace_every == 0:
-            L.wbx_pace(eng.ctx.h, max(1, 12 // pace_every))
+        L.wbx_pace(eng.ctx.h, 12)
         state["done"] += K
 
     def drain():

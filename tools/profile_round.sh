@@ -5,13 +5,13 @@
 # 256-block renders.  Counters are never combined with trace domains other than --kernel-trace.
 # usage (on the GPU box): tools/profile_round.sh [tag]      -> gpurun_out/<tag>/ ; then tools/refresh_profiles.sh <tag> <round>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q -n 4 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?" >> $O/bench_default.err
 B="--no-cpu-baseline --no-configs"
 for W in c4 c2 u4096 i16 i16r i24r d96 mixfmt mixr; do
@@ -48,6 +48,12 @@ for M in reduce ordered chain; do
   timeout 300 python bench.py --force-dist-path --dist-mode $M $B > $O/bench_dist1_$M.json 2>> $O/bench_default.err
 done
 timeout 300 python tools/longrun_probe.py c3 2048 4 > $O/longrun_probe.txt 2>&1
+# round 6: a 256-track session over 200 steps (a step is 0.4 ms: over 20 the one drain at the end is 4 % of the measurement), and
+# what releasing the internal events to the device instead of the system is worth there (alternating)
+for rep in 1 2 3; do
+  timeout 200 python bench.py --workload c2 --steps 200 $B > $O/bench_c2_steps200_$rep.json 2>> $O/bench_default.err
+  WBX_EVENT_SCOPE=system timeout 200 python bench.py --workload c2 --steps 200 $B > $O/bench_c2_steps200_sysscope_$rep.json 2>> $O/bench_default.err
+done
 cd /tmp
 kt() {   # name, bench args...
   n=$1; shift
