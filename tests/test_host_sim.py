@@ -427,7 +427,8 @@ def test_host_sequencer_against_the_live_reference(kind):
         pytest.skip("oracle/_ref/wbref_engine not built (no /root/reference here)")
     n = int(os.environ.get("WBX_REFSEQ_SEEDS", "60"))
     done = blocks = 0
-    for seed in range(7000, 7000 + n):
+    first = int(os.environ.get("WBX_REFSEQ_FROM", "7000"))      # (soak runs: a seed range no earlier run has seen)
+    for seed in range(first, first + n):
         s = S.session_script(seed, kind)
         if s.block % 4 or any(o[0] == "rate" for o in s.ops):
             continue

@@ -15,6 +15,7 @@ import seq_sessions as S
 pytestmark = pytest.mark.ref
 
 N = int(os.environ.get("WBX_REFSEQ_SEEDS", "60"))
+FROM = int(os.environ.get("WBX_REFSEQ_FROM", "0"))       # soak runs: a seed range no earlier run has seen
 
 
 @pytest.fixture(scope="module")
@@ -42,7 +43,7 @@ def _differential(kind, seeds):
 
 @pytest.mark.parametrize("kind", ["static", "controls", "edits", "dense", "wild"])
 def test_oracle_sequencer_equals_the_reference(exe, kind):
-    compared, wrapped, blocks = _differential(kind, range(N))
+    compared, wrapped, blocks = _differential(kind, range(FROM, FROM + N))
     assert compared >= N * (0.5 if kind in ("dense", "wild") else 0.8), (compared, wrapped)
     print(f"{kind}: {compared} sessions / {blocks} blocks equal, {wrapped} left out (event_length wrap)")
 
