@@ -525,6 +525,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
     m.tiles = 1u;
   }
   c->cb_launched = false;
+  bool by_kernel_event = false;
   if (m.n_groups && !one_launch) {
     if (timed) {
       if (c->ev_pending == kEventRing) {   // the older half: 32 launches behind the newest, over long ago
@@ -548,11 +549,16 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
                (timed && !packets) ? c->ev[c->ev_pending][1] : nullptr);
     if (timed && packets) WBX_HIP(c, hipEventRecord(c->ev[c->ev_pending][1], ms));
     if (c->dist) WBX_HIP(c, dist_mix_issued(c, ms));
+    // (round 6) When the kernel carries the timer's stop event and its sum runs on another stream, THAT event is what the sum
+    // stream waits for, and mix_done — what later plans wait for — is recorded over there: no marker packet behind the mix on
+    // its own stream, where the next mix queues (every packet between two mixes is a round trip of the command processor to
+    // the queue in host memory, behind whatever the copy engine is posting).  WBX_MIX_MARKER=1: the marker, as until round 5.
+    by_kernel_event = timed && !packets && !c->knob_mix_marker && !c->dist && !c->mix_alternate && ms == c->stream && sum_beside;
   }
   // the plan buffer is free as soon as the MIX has read it: releasing it before the sum lets the next plan run
   // beside sum_kernel (the GPU is nearly idle there) instead of competing with the next mix for CU slots — started
   // together with a mix, the one-wave-per-track plan kernel is starved until that mix drains
-  if (!one_launch) WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));   // (one launch: recorded behind it, below)
+  if (!one_launch && !by_kernel_event) WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));   // (one launch: recorded behind it, below)
   if (ms != c->stream) c->alt_pending = pp;
   // A master bound for pinned host memory leaves a batch render through a device staging buffer and the copy engine.  Stored
   // by the sum kernel itself, its megabytes of posted writes fill the GPU's upstream queue in a few microseconds and drain at
@@ -595,7 +601,14 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   s.status_src = c->status_dst ? PB(c).counters : nullptr;
   s.status_dst = c->status_dst;
   s.zero_status = (c->status_dst && c->zero_status) ? 1u : 0u;
-  if (ss != ms) WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  if (by_kernel_event && ss != ms) {
+    WBX_HIP(c, hipStreamWaitEvent(ss, c->ev[c->ev_pending][1], 0));   // the kernel's own completion ...
+    WBX_HIP(c, hipEventRecord(c->mix_done[pp], ss));                   // ... and, over here, "the mix has read its plan buffer"
+  } else if (by_kernel_event) {
+    WBX_HIP(c, hipEventRecord(c->mix_done[pp], ms));
+  } else if (ss != ms) {
+    WBX_HIP(c, hipStreamWaitEvent(ss, c->mix_done[pp], 0));   // (an earlier pending sum is ordered before this one by ss)
+  }
 
   if (c->n_buses && !buses_alias && !c->buses_clean) {
     // buses without member groups must read as zero; every bus that has members is rewritten by each render, so the
@@ -791,6 +804,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
       c->knob_no_cl2 = std::getenv("WBX_NO_CL2") != nullptr;
       c->knob_cb_fenced = is("WBX_CB_FENCED", '1');
       c->knob_partial_free_off = is("WBX_PARTIAL_FREE", '0');
+      c->knob_mix_marker = is("WBX_MIX_MARKER", '1');
       if (const char* v = std::getenv("WBX_PACKED_X")) c->knob_packed_x = std::atoi(v) != 0 ? 1 : 0;
     }
     // the workgroup-id -> XCD layout the chained pieces and the segmented sequencer rest on, probed before anything relies on it
@@ -1677,7 +1691,10 @@ extern "C" wbx_status wbx_pace(wbx_ctx* c, uint32_t max_ahead) {
   (void)hipSetDevice(c->cfg.device);
   const uint32_t slot = (uint32_t)(c->pace_seq % kPaceRing);
   if (!c->pace_ev[slot]) WBX_HIP(c, hipEventCreateWithFlags(&c->pace_ev[slot], c->dev_event_flags));   // (the host waits for "done", reads nothing)
-  WBX_HIP(c, hipEventRecord(c->pace_ev[slot], c->cur_mix_stream ? c->cur_mix_stream : c->stream));
+  // (behind the last render's sum when that runs on its own stream: no marker between two mixes; WBX_MIX_MARKER=1: on the mix stream)
+  hipStream_t where = c->cur_mix_stream ? c->cur_mix_stream : c->stream;
+  if (!c->knob_mix_marker && c->sum_pending >= 0 && c->sum_stream && !c->dist) where = c->sum_stream;
+  WBX_HIP(c, hipEventRecord(c->pace_ev[slot], where));
   if (c->pace_seq >= max_ahead) WBX_HIP(c, hipEventSynchronize(c->pace_ev[(c->pace_seq - max_ahead) % kPaceRing]));
   c->pace_seq++;
   return WBX_OK;
