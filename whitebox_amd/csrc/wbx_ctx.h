@@ -20,7 +20,7 @@
 
 namespace wbx {
 void launch_plan(const PlanArgs& a, hipStream_t s);
-void launch_times_copy(const DBlockTime* host_pinned, DBlockTime* dev, uint32_t n_blocks, hipStream_t s);
+void launch_times_copy(const DBlockTime* host_pinned, DBlockTime* dev, uint32_t n_blocks, uint32_t* zero_counters, hipStream_t s);
 void launch_gen(const GenArgs& a, uint32_t max_grid, hipStream_t s);
 void launch_plan_segments(const PlanArgs& a, const SegArgs& g, bool beside, hipStream_t s);
 const char* launch_mix(const MixArgs& a, uint32_t n_blocks, int variant, int family, hipStream_t s, hipEvent_t t0 = nullptr,

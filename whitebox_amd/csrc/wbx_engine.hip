@@ -869,7 +869,10 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
       c->partial_wait_done = true;
     }
   }
-  if (!B.counters_zero) WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
+  // the plan's four counters start from zero: cleared by the kernel that brings the transport table in front of the plan when
+  // there is one (below), else by a memset — a 16-byte fill is a launch of its own, ~50 us beside a running mix, at the head of
+  // the chain fill -> table -> plan -> pre-render that a short render's mix waits for
+  bool need_zero = !B.counters_zero;
   B.counters_zero = false;
   e->plan_status_on_host = false;
   const double sample_rate = (double)c->cfg.sample_rate;
@@ -941,10 +944,13 @@ wbx_status render_locked(wbx_engine* e, uint32_t K) {
     }
     if (!e->times_done[ts]) WBX_EHIP(e, hipEventCreateWithFlags(&e->times_done[ts], e->ctx->dev_event_flags));
     block_times(a, e->h_times[ts]);   // wbx_seq.h: the source the device compiles
-    launch_times_copy(e->h_times[ts], B.times.p, K, ps);
+    static const bool by_memset = [] { const char* v = std::getenv("WBX_COUNTERS_MEMSET"); return v && v[0] == '1'; }();   // A/B aid
+    launch_times_copy(e->h_times[ts], B.times.p, K, (need_zero && !by_memset) ? B.counters : nullptr, ps);
+    if (!by_memset) need_zero = false;
     WBX_EHIP(e, hipEventRecord(e->times_done[ts], ps));
     e->times_valid[ts] = true;
   }
+  if (need_zero) WBX_EHIP(e, hipMemsetAsync(B.counters, 0, 4 * sizeof(uint32_t), ps));
   if (e->last_plan_stream && e->last_plan_stream != ps) {
     // (found by the random-pieces test once it left renders unfetched: a batch render's plan, on the idle plan stream,
     //  overtook the plan of a short render still queued on the main stream behind earlier mixes and read the state before

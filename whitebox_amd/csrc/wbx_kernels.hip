@@ -137,9 +137,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // the host's table of per-block transport records (pinned memory) -> device memory, in front of a batch render's plan.  A
 // kernel of our own, not hipMemcpyAsync: the runtime's host-to-device path made the submitting thread wait for the stream
 // (measured: the renders of a 256-track session then ran one after the other instead of overlapped)
-__global__ __launch_bounds__(256) void times_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+// (`zero`: the plan buffer's four counters, cleared here instead of by a memset launch of their own — or null)
+__global__ __launch_bounds__(256) void times_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, uint32_t* zero) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n16) dst[i] = src[i];
+  if (zero && i < 4u) zero[i] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,10 +570,10 @@ __global__ __launch_bounds__(256) void synth_kernel(void* dst, uint64_t frames, 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from wbx_runtime.hip)
 // ------------------------------------------------------------------------------------------------
-void launch_times_copy(const DBlockTime* host_pinned, DBlockTime* dev, uint32_t n_blocks, hipStream_t s) {
+void launch_times_copy(const DBlockTime* host_pinned, DBlockTime* dev, uint32_t n_blocks, uint32_t* zero_counters, hipStream_t s) {
   const uint32_t n16 = n_blocks * (uint32_t)(sizeof(DBlockTime) / 16u);
   hipLaunchKernelGGL(times_copy_kernel, dim3((n16 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const uint4*>(host_pinned),
-                     reinterpret_cast<uint4*>(dev), n16);
+                     reinterpret_cast<uint4*>(dev), n16, zero_counters);
 }
 
 void launch_plan(const PlanArgs& a, hipStream_t s) {
