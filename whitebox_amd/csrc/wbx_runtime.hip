@@ -738,9 +738,9 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
   if (const char* u = std::getenv("WBX_FORCE_G")) c->force_g = std::atoi(u) != 0;   // A/B aid: always the G instances
   if (const char* u = std::getenv("WBX_KERNEL_TIMER")) c->profiling = std::atoi(u) != 0;   // 0: no HIP-event kernel timer
   // Events whose only waiters are other streams of this device (or a host that waits for "done" and reads nothing the device
-  // wrote): released to the DEVICE — the default, a release to the system behind every marker, cost a 256-track session 5 % of
-  // its step (0.447 -> 0.422 ms per 2048-block render: three markers between two mixes).  Results leave through sum_done and
-  // the callback's own system-scope stores, which keep the system scope.  WBX_EVENT_SCOPE=system: as until round 5 (A/B aid).
+  // wrote): released to the DEVICE — a marker's default release is to the system.  (No measurable effect by itself; the A/Bs
+  // that seemed to show one were reading the copy engine's two speeds: EXPERIMENTS.md.)  Results leave through sum_done and the
+  // callback's own system-scope stores, which keep the system scope.  WBX_EVENT_SCOPE=system: as until round 5 (A/B aid).
   const unsigned scope = [] { const char* es = std::getenv("WBX_EVENT_SCOPE"); return (es && es[0] == 's') ? 0u : (unsigned)hipEventReleaseToDevice; }();
   c->dev_event_flags = hipEventDisableTiming | scope;
   if (cfg->stream) {
