@@ -231,6 +231,7 @@ struct wbx_ctx {
   bool knob_partial_free_off = false; // WBX_PARTIAL_FREE=0: a partial buffer's next user waits for sum_done (behind the master's copy-out), as until round 5
   unsigned dev_event_flags = 0x2;     // hipEventDisableTiming [| hipEventReleaseToDevice]: events only other streams of this device wait for
   bool knob_mix_marker = false;       // WBX_MIX_MARKER=1: mix_done and the pace event as markers on the mix stream (as until round 5)
+  bool knob_fast_partial_off = false; // WBX_FAST_PARTIAL=0: every partial stream call through the clamped masked arithmetic (as until round 5)
   int knob_packed_x = -1;             // WBX_PACKED_X=0|1: the packed masked-row instances off / on for every shape (-1: the library's choice)
   bool cb_no_spread = false;          // a spread launch gave up waiting for the whole grid (not resident at once: a CU mask, a
                                       // device shared with another process): the context keeps to "the last workgroup adds"

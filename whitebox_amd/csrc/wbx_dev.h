@@ -245,6 +245,8 @@ struct MixArgs {
   double uniform_speed;         // > 0: every linearly resampled row of this render plays at exactly this speed, which lies
                                 // in [0.67, 0.999] (one resampling ratio in the whole session); 0: no such promise
   int packed_x;                 // WBX_PACKED_X as the context read it at creation (-1: unset; packed_masked_variant)
+  uint32_t fast_partial;        // partial stream calls that start >= 4 samples into their clip: the unmasked arithmetic + frame
+                                // masks instead of the clamped per-frame form (wbx_mix.h fast_part; WBX_FAST_PARTIAL=0: off)
 };
 
 constexpr uint32_t kSumGridBlocks = 512;   // blocks in flight of one sum launch (x its tiles = waves)

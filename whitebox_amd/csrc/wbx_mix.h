@@ -439,6 +439,25 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
   // all-ones when frame j0+e lies inside [d, d+n), zero otherwise
   auto frame_mask = [&](uint32_t e, uint32_t d, uint32_t n) { return (uint32_t)0 - (uint32_t)((j0 + e - d) < n); };
   auto and_mask = [&](float v, uint32_t m) { return __uint_as_float(__float_as_uint(v) & m); };
+  // (round 6) The cheap form of a masked row.  A partial stream call that starts at least four samples into its clip — every clip
+  // of a track cut into back-to-back clips but the one that opens its sample — can be rendered by the UNMASKED arithmetic of a
+  // call that covers the whole wave (frame j of the block is frame j - d of the call: one subtraction in the position) followed by
+  // the frame masks: a lane that straddles the call's start keeps its own, negative, call frame, so its frames inside the call
+  // sit where that arithmetic expects them, and what its frames in front of the call read lies inside the clip (>= pos - 3
+  // samples >= 1); frames behind the call's end read at most five samples past it: the clip's 16 frames of padding.  Lanes
+  // wholly outside the call load at its first / last frame and are masked to +0.0 whatever they compute.  The values of the
+  // frames inside the call are those of the clamped form bit for bit (same position expression: pos + fl((j - d) * speed)).
+  // Calls that start within the first four samples keep the clamped form (row_*_masked below).  wave-uniform.
+  auto fast_part = [&](const URec& r) {
+    return EXP && a.fast_partial != 0u && r.partial && __double2hiint(r.pos) >= 0x40100000;   // pos >= 4.0 (pos is never negative here)
+  };
+  auto part_cf0 = [&](const URec& r) {   // the call frame a partial row's loads start from
+    if (fast_part(r)) {
+      const int x = (int)j0 - (int)r.d, hi = (int)r.n - 1;
+      return ((int)j0 + 3 < (int)r.d) ? 0 : (x < hi ? x : hi);
+    }
+    return call_frame(0u, r.d, r.n);
+  };
 
   // ---- per-row arithmetic (each returns the 4 frames of one track AFTER clip gain and track gain) ----
   // fp32 row at unity speed: sampler.cpp:151-152, track.cpp:731
@@ -782,6 +801,17 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
                                  const float (&gc)[CL]) {
     return row_window_masked(unpack16(p, unity), pos, speed, unity, d, n, cg, gc);
   };
+  // frames outside the stream call [d, d + n) contribute an exact +0.0
+  auto mask_row = [&](Row& m, uint32_t d, uint32_t n) {
+    const uint32_t k0 = frame_mask(0u, d, n), k1 = frame_mask(1u, d, n), k2 = frame_mask(2u, d, n), k3 = frame_mask(3u, d, n);
+#pragma unroll
+    for (int ch = 0; ch < CL; ch++) {
+      m.c[ch].x = and_mask(m.c[ch].x, k0);
+      m.c[ch].y = and_mask(m.c[ch].y, k1);
+      m.c[ch].z = and_mask(m.c[ch].z, k2);
+      m.c[ch].w = and_mask(m.c[ch].w, k3);
+    }
+  };
   // accumulate a row; pk[ch] = the lane's max |m| of channel ch
   auto add_row = [&](const Row& m0, float (&pk)[CL]) {
 #pragma unroll
@@ -862,7 +892,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         double prod0;
         const bool part = EXP && r.partial;
         if (part)
-          prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
+          prod0 = __dmul_rn((double)part_cf0(r), r.speed);
         else if (MODE == MODE_WNU)   // whole-block rows of a one-ratio chunk: the hoisted product for the resampled ones, j * 1.0
           prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW ? up0 : j0d;   // for the unity ones — no multiply
         else
@@ -871,7 +901,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
       } else if constexpr (MODE == MODE_WI || MODE == MODE_WIN || MODE == MODE_WINU) {
         double prod0;
         if (EXP && (LEAN16 || G) && r.partial)    // the lane's first frame inside the stream call (partial 16-bit window rows)
-          prod0 = __dmul_rn((double)call_frame(0u, r.d, r.n), r.speed);
+          prod0 = __dmul_rn((double)part_cf0(r), r.speed);
         else if (MODE == MODE_WINU)   // one-ratio chunk: the hoisted product for the resampled rows, j * 1.0 for the unity ones
           prod0 = __builtin_amdgcn_readfirstlane((int)r.kind) == KIND_WINDOW_I16 ? up0 : j0d;
         else
@@ -905,7 +935,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         // low half; the rest is its neighbour's samples or the clip's padding), so the loads stay straight-line
         typedef float f4a2 __attribute__((ext_vector_type(4), aligned(2)));
         // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
-        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
+        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)part_cf0(r) : j0);   // (a negative call frame wraps back: pos >= 4 there)
         const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
         if (active) {
 #pragma unroll
@@ -916,7 +946,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         }
       } else {
         // sampler.cpp:107 (EXP: the lane's frame inside the stream call — j0 itself for a whole-block record)
-        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0);
+        const uint32_t off = (uint32_t)r.pos + ((EXP && r.partial) ? (uint32_t)part_cf0(r) : j0);   // (a negative call frame wraps back: pos >= 4 there)
 #pragma unroll
         for (int ch = 0; ch < CL; ch++) {
           if (MODE == MODE_I16) {
@@ -1018,11 +1048,13 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (G && (fmt != FMT_F32 || k == KIND_UNITY_I32)) {   // 24 / 32-bit PCM (G instances only)
             if constexpr (G) m = partial_any(pre[u], k, fmt, false);
-          } else if (r.d <= wave_base && r.d + r.n >= wave_end) {   // ... all of this wave's frames
+          } else if (const bool all = r.d <= wave_base && r.d + r.n >= wave_end; all || fast_part(r)) {
+            // ... all of this wave's frames — or some, of a call that starts deep enough in its clip: the same arithmetic + masks
             if (k == KIND_WINDOW)
               m = row_window_at(narrow, std::true_type{}, std::false_type{}, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
               each_f32();
+            if (!all) mask_row(m, r.d, r.n);
           } else {
             m = row_window_masked(pre[u], r.pos, r.speed, k != KIND_WINDOW, r.d, r.n, cg, gc);
           }
@@ -1044,11 +1076,12 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-          } else if (r.d <= wave_base && r.d + r.n >= wave_end) {   // ... all of them
+          } else if (const bool all = r.d <= wave_base && r.d + r.n >= wave_end; all || fast_part(r)) {   // ... all of them (or: see fast_part)
             if (win)
               m = row_window16_shifted(narrow, pre[u], r.pos, r.speed, (double)r.d, cg, gc);
             else
               each_i16();
+            if (!all) mask_row(m, r.d, r.n);
           } else {
             m = row_window16_masked(pre[u], r.pos, r.speed, !win, r.d, r.n, cg, gc);
           }
@@ -1099,6 +1132,14 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
           if (r.d >= wave_end || r.d + r.n <= wave_base) {   // ... none of this wave's frames: an exact +0.0
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          } else if (fast_part(r)) {   // ... some, of a call that starts deep enough in its clip: the plain row + masks
+            if (k == KIND_UNITY_I16)
+              each_i16();
+            else if (k == KIND_UNITY_I32)
+              each_i32(fmt);
+            else
+              each_f32();
+            mask_row(m, r.d, r.n);
           } else if (k == KIND_UNITY_I16) {   // ... some: normalise the four loaded samples, then select and mask as for fp32
             each([&](const Win& w, float g) {
               return row_f32_masked(norm_i16(__float_as_int(w.v.x), __float_as_int(w.v.y)), r.d, r.n, cg, g);

@@ -460,6 +460,7 @@ wbx_status launch_mix_sum(wbx_ctx* c, uint32_t K, uint32_t N) {
   m.channels = C;
   m.lane_span = lane_span_of(c);
   m.packed_x = c->knob_packed_x;
+  m.fast_partial = c->knob_fast_partial_off ? 0u : 1u;
   m.tiles = (C * m.lane_span + 255u) / 256u;
   m.n_blocks = K;
   m.masked_rows = c->masked_rows ? 1u : 0u;
@@ -805,6 +806,7 @@ extern "C" wbx_status wbx_create(const wbx_config* cfg, wbx_ctx** out) {
       c->knob_cb_fenced = is("WBX_CB_FENCED", '1');
       c->knob_partial_free_off = is("WBX_PARTIAL_FREE", '0');
       c->knob_mix_marker = is("WBX_MIX_MARKER", '1');
+      c->knob_fast_partial_off = is("WBX_FAST_PARTIAL", '0');
       if (const char* v = std::getenv("WBX_PACKED_X")) c->knob_packed_x = std::atoi(v) != 0 ? 1 : 0;
     }
     // the workgroup-id -> XCD layout the chained pieces and the segmented sequencer rest on, probed before anything relies on it
