@@ -2056,3 +2056,22 @@ def test_instance_selection(kw, block, expect):
     assert eng.ctx.kernel_name() == expect
     assert np.array_equal(bits(m), bits(om)) and np.array_equal(pk, opk[:, :, :spec.channels])
     eng.close()
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+@pytest.mark.parametrize("block,channels,fmt", [(512, 2, "f32"), (512, 2, "i16"), (256, 2, "f32"), (128, 2, "f32"), (1024, 1, "f32")])
+def test_masked_rows_with_the_boundary_at_every_frame(monkeypatch, fast, block, channels, fmt):
+    """The clip boundary walks through the block three frames per block (clips of 1 + 3/F blocks, touching or with gaps): over the
+    render it sits at every lane position — on a lane's first frame, inside a lane, one frame in front of a wave's end — and the
+    calls at block edges are one, two, three frames long (shorter than a lane).  Round 6's cheap form of a masked row (wbx_mix.h
+    fast_part: the unmasked arithmetic of a whole-wave call + frame masks, for calls that start >= 4 samples into their clip) and
+    the clamped form (WBX_FAST_PARTIAL=0; also what the first clip of every track takes: it opens its sample) both give the
+    oracle's stream calls, peaks and master bit for bit."""
+    monkeypatch.setenv("WBX_FAST_PARTIAL", fast)
+    n_blocks = 200 if block >= 512 else 120
+    spec = _boundary_session(24, n_blocks, block, 1.0 + 3.0 / block, channels)
+    if fmt != "f32":
+        for smp in spec.samples:
+            smp.fmt, smp.amp = fmt, 1.0
+        spec.volumes_db = [v - 30.0 for v in spec.volumes_db]
+    check_against_oracle(spec, n_blocks, group_size=24, expect_exact=True)
