@@ -221,10 +221,17 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     }
   }
   if (!report) return;
+  // the two give-up words of this launch — "some workgroup gave up" (elect[1]) and "workgroup 0 did, the counters have not gone
+  // out" (elect[2]) — in ONE round trip (lanes 0 and 1 of the first wave), in front of the wait that is due anyway
+  uint32_t gave = 0u, wg0_gave = 0u;
+  if (cb.spread && !a.fused_master && tid < 64u) {
+    const uint32_t w = tid < 2u ? __hip_atomic_load(cb.elect + 1u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    gave = (uint32_t)__builtin_amdgcn_readlane((int)w, 0) == cb.seq ? 1u : 0u;
+    wg0_gave = (uint32_t)__builtin_amdgcn_readlane((int)w, 1) == cb.seq ? 1u : 0u;
+  }
   // (a spread launch whose workgroup 0 gave up: the counters have not gone out — every workgroup is past its second ticket
   //  now, so they are final; copied, not cleared: the host mixes this block again and clears them itself)
-  if (cb.spread && !a.fused_master && s.status_dst && tid < 4u &&
-      __hip_atomic_load(cb.elect + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cb.seq)
+  if (wg0_gave && s.status_dst && tid < 4u)
     __hip_atomic_store(s.status_dst + tid, __hip_atomic_load(s.status_src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   // master and status (pinned host memory) went out as system-scope stores: once this workgroup's are acknowledged — every
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0u) {
-    if (cb.spread && cb.gave_up && __hip_atomic_load(cb.elect + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cb.seq) {
+    if (gave && cb.gave_up) {
       __hip_atomic_store(cb.gave_up, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __builtin_amdgcn_s_waitcnt(0);   // (on its way to the host in front of the flag)
     }
