@@ -183,10 +183,39 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
           if (s.out_il && C > 1u) s_part[1][ls * ng + g] = *reinterpret_cast<const f4*>(src + F);
         }
         __syncthreads();
-        const uint32_t my = wg + (k0 + tid) * cb.n_wgs;
-        if (tid < spr && my < n_slots) {
-          const PartialFromLds lds{{&s_part[0][tid * ng], &s_part[(s.out_il && C > 1u) ? 1 : 0][tid * ng]}, s.out_il ? F : 0xFFFFFFFFu};
-          add_slot(my, &lds);
+        if (!s.out_il && !s.n_buses && !s.chain && ng >= 32u) {
+          // (round 6) the usual block — planar fp32 master, no sub-buses — of a session of many groups: a slot's FOUR frames go
+          // to four lanes, one dependent chain of ng additions each, instead of one lane issuing all 4 * ng of them (a 4096-track
+          // block: 256 group sums, ~3 us of one lane's instruction issue behind the barrier, a quarter of that this way).  The
+          // same additions in the same order per sample as sum_block; the quad's first lane stores the 16 bytes.
+          if (tid < 64u) {
+            const uint32_t q = tid >> 2, k = tid & 3u;
+            const uint32_t my = wg + (k0 + q) * cb.n_wgs;
+            const bool own = q < spr && my < n_slots;
+            const float* col = reinterpret_cast<const float*>(&s_part[0][(own ? q : 0u) * ng]) + k;   // group g's sum of this frame: col[4 * g]
+            float acc = 0.0f;
+            constexpr int kAhead = 32;
+            for (uint32_t g0 = 0u; g0 < ng; g0 += kAhead) {
+              float v[kAhead];
+#pragma unroll
+              for (int i = 0; i < kAhead; i++) v[i] = col[4u * (g0 + i < ng ? g0 + i : ng - 1u)];   // (clamped: straight-line reads)
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < kAhead; i++)
+                if (g0 + i < ng) acc = __fadd_rn(acc, v[i]);                                         // audio_buffer.h:73-82, group order
+            }
+            if (s.clamp) acc = acc > 1.0f ? 1.0f : (acc < -1.0f ? -1.0f : acc);                      // engine.cpp:1627-1636 (compares: NaN passes)
+            const uint32_t base = tid & ~3u;
+            const float y = __shfl(acc, (int)base + 1, 64), z = __shfl(acc, (int)base + 2, 64), w = __shfl(acc, (int)base + 3, 64);
+            if (own && k == 0u)
+              store_u4_system(s.master + (size_t)my * 4u, uint4{__float_as_uint(acc), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)});
+          }
+        } else {
+          const uint32_t my = wg + (k0 + tid) * cb.n_wgs;
+          if (tid < spr && my < n_slots) {
+            const PartialFromLds lds{{&s_part[0][tid * ng], &s_part[(s.out_il && C > 1u) ? 1 : 0][tid * ng]}, s.out_il ? F : 0xFFFFFFFFu};
+            add_slot(my, &lds);
+          }
         }
         __syncthreads();
       }
