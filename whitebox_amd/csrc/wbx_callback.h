@@ -37,8 +37,7 @@ struct CallbackArgs {
   uint32_t base2;      // ... the second one (only spread launches arrive there: it has a base of its own)
   uint32_t* elect;     // device word: the launch number of the last launch whose reporter has been chosen (not spread: of the
                        // workgroups that see the full count, the first to swap its launch's number in adds and reports);
-                       // elect[1]: the number of the last launch in which a workgroup gave up at the spread barrier;
-                       // elect[2]: ... in which workgroup 0 did, and therefore left the plan's counters to the reporter
+                       // (give-ups at the spread barrier travel with the second tickets: kCbGaveUp / kCbGaveUp0)
   uint32_t* gave_up;   // pinned host: `seq` — written in front of `flag` — when a workgroup of this launch gave up at the spread barrier
   uint32_t* flag;      // pinned host: `seq` once master and status are out.  (One word per workgroup, the host waiting for all of
                        // them, was tried instead of the second ticket: 3 us less on the device, 6 us more until the audio thread
@@ -55,6 +54,9 @@ struct CallbackArgs {
 // apart (different memory channels): workgroup w adds to word w % kCbLanes, and whoever needs the total reads all of them —
 // lanes 0..15 of a wave, one load each, one round trip — and adds them up.  tid < 64 must call these together.
 constexpr uint32_t kCbLanes = 16, kCbStride = 64;
+// the second ticket's total: arrivals in its low ten bits (at most 256 workgroups spread), workgroups that had given up at the
+// barrier in the next ten, "workgroup 0 was one of them" above
+constexpr uint32_t kCbGaveUp = 1u << 10, kCbGaveUp0 = 1u << 20;
 __device__ __forceinline__ uint32_t cb_total(const uint32_t* cnt, uint32_t lane) {
   uint32_t v = lane < kCbLanes ? __hip_atomic_load(cnt + lane * kCbStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   v += (uint32_t)__shfl_xor((int)v, 8, 64);
@@ -65,9 +67,9 @@ __device__ __forceinline__ uint32_t cb_total(const uint32_t* cnt, uint32_t lane)
 }
 // arrive, then the total as it stands once this workgroup's own arrival is through (the workgroup whose arrival is the
 // last one to complete sees them all)
-__device__ __forceinline__ uint32_t cb_arrive(uint32_t* cnt, uint32_t wg, uint32_t lane) {
+__device__ __forceinline__ uint32_t cb_arrive(uint32_t* cnt, uint32_t wg, uint32_t lane, uint32_t inc = 1u) {
   uint32_t old = 0u;
-  if (lane == 0u) old = __hip_atomic_fetch_add(cnt + (wg % kCbLanes) * kCbStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0u) old = __hip_atomic_fetch_add(cnt + (wg % kCbLanes) * kCbStride, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);   // (the returned value orders the reads below behind the arrival)
   asm volatile("" ::"s"(old) : "memory");
   return cb_total(cnt, lane);
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
   // dword (agent-scope loads) cost 56 us.
   __shared__ uint32_t s_ticket;
   bool report = true;   // this workgroup writes the flag
+  uint32_t second_total = 0u;   // spread: the second counter as this workgroup's arrival found it (count + give-up markers)
   if (!a.fused_master) {
     if (cb.fenced) __threadfence();
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged ...
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
           n = cb_total(cb.done, tid) - cb.base;
           spins++;
         }
-        // (a give-up: noted in a device word — written through, acknowledged before this workgroup takes its second ticket —
-        //  which the workgroup that reports the launch hands to the host)
-        if (tid == 0u && n < cb.n_wgs) __hip_atomic_store(cb.elect + 1, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a give-up — n < n_wgs in s_ticket — travels with this workgroup's SECOND ticket: kCbGaveUp on top of its arrival, and
+        //  kCbGaveUp0 when it is workgroup 0, whose plan counters then have not gone out; the workgroup that reports the launch
+        //  reads both out of the total it takes anyway — no word of its own, no extra round trip behind the second ticket)
       }
       if (tid == 0u) s_ticket = n;
     }
@@ -226,11 +229,11 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     // the plan's counters go to the host with workgroup 0's share (spread: beside the others' sums, not behind the second
     // ticket) / with the last workgroup's master.  Only a workgroup that has SEEN the full count may touch them: every
     // sequencer lane of the launch is then over, the counters are final and clearing them takes nothing from a plan_track
-    // still running.  Workgroup 0 of a spread launch that gave up at the barrier leaves them alone and says so (elect[2]);
+    // still running.  Workgroup 0 of a spread launch that gave up at the barrier leaves them alone and says so (its second ticket);
     // the launch's reporter — behind the second ticket, where every workgroup is through — copies them instead, uncleared.
     if (!cb.spread || wg == 0u) {
       if (cb.spread && s_ticket != cb.n_wgs) {
-        if (tid == 0u) __hip_atomic_store(cb.elect + 2, cb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (nothing: its second ticket says so)
       } else if (s.status_dst && tid < 4u) {   // (as sum_kernel does: the plan's counters for the host, cleared for the buffer's next plan)
         const uint32_t queued = __hip_atomic_load(s.status_src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(s.status_dst + tid, __hip_atomic_load(s.status_src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
@@ -241,23 +244,24 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
     if (cb.spread) {   // whoever stores its share last reports (its own stores and, through the ticket, everybody's are acknowledged)
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
+      const bool gave_up_here = s_ticket != cb.n_wgs;   // (the first ticket's count as this workgroup left the barrier)
+      __syncthreads();                                 // (every wave has read s_ticket before it is written again)
       if (tid < 64u) {
-        const uint32_t n = cb_arrive(cb.done + kCbLanes * kCbStride, wg, tid) - cb.base2;
+        const uint32_t inc = 1u + (gave_up_here ? kCbGaveUp + (wg == 0u ? kCbGaveUp0 : 0u) : 0u);
+        const uint32_t n = cb_arrive(cb.done + kCbLanes * kCbStride, wg, tid, inc) - cb.base2;
         if (tid == 0u) s_ticket = n;
       }
       __syncthreads();
-      report = s_ticket == cb.n_wgs;   // (two may see it: both write the same word, the status went out with workgroup 0's share)
+      // (two may see the full count: both write the same words, the status went out with workgroup 0's share.  A launch with a
+      //  give-up leaves the marker bits in the counter for good — the context never spreads again: this counter is not read any more)
+      report = (s_ticket & (kCbGaveUp - 1u)) == cb.n_wgs;
+      second_total = s_ticket;
     }
   }
   if (!report) return;
-  // the two give-up words of this launch — "some workgroup gave up" (elect[1]) and "workgroup 0 did, the counters have not gone
-  // out" (elect[2]) — in ONE round trip (lanes 0 and 1 of the first wave), in front of the wait that is due anyway
-  uint32_t gave = 0u, wg0_gave = 0u;
-  if (cb.spread && !a.fused_master && tid < 64u) {
-    const uint32_t w = tid < 2u ? __hip_atomic_load(cb.elect + 1u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    gave = (uint32_t)__builtin_amdgcn_readlane((int)w, 0) == cb.seq ? 1u : 0u;
-    wg0_gave = (uint32_t)__builtin_amdgcn_readlane((int)w, 1) == cb.seq ? 1u : 0u;
-  }
+  // did a workgroup of this launch give up at the barrier — did workgroup 0, whose plan counters then have not gone out?  Both
+  // came with the second tickets (a spread launch; 0 otherwise)
+  const uint32_t gave = (second_total / kCbGaveUp) & (kCbGaveUp - 1u), wg0_gave = second_total / kCbGaveUp0;
   // (a spread launch whose workgroup 0 gave up: the counters have not gone out — every workgroup is past its second ticket
   //  now, so they are final; copied, not cleared: the host mixes this block again and clears them itself)
   if (wg0_gave && s.status_dst && tid < 4u)
