@@ -228,6 +228,23 @@ def cpu_baseline(workload, n_tracks, budget_s=12.0):
     return ref
 
 
+def ref_engine_stamp(exe, oracle_dir):
+    """(is `exe` the build of this tree's driver source + recipe?, the tree's hash, the stamp oracle/Makefile left beside the
+    executable or None, the executable's own hash or None)"""
+    import hashlib
+    want = hashlib.sha256(b"".join(open(os.path.join(oracle_dir, n), "rb").read()
+                                   for n in ("ref_engine_driver.cpp", "Makefile"))).hexdigest()[:16]
+    try:
+        stamp = open(exe + ".stamp").read().strip()
+    except OSError:
+        stamp = None
+    try:
+        exe_sha = hashlib.sha256(open(exe, "rb").read()).hexdigest()[:16]
+    except OSError:
+        exe_sha = None
+    return stamp == want and exe_sha is not None, want, stamp, exe_sha
+
+
 def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
     """The reference's own Engine::process (oracle/_ref/wbref_engine: Track::process_event / Track::process / Engine::process /
     Sampler::stream, cut out of the reference's sources where they lie and compiled unmodified, -O2 — oracle/Makefile) on ONE
@@ -244,18 +261,11 @@ def cpu_reference(workload, n_tracks, sample_blocks, budget_s):
         return None
     # the executable is a prebuilt, untracked file: say which build it is, and refuse one that was not made from the driver
     # source and the recipe of this tree (oracle/Makefile leaves their hash beside it)
-    import hashlib
-    want = hashlib.sha256(b"".join(open(os.path.join(O.ORACLE_DIR, n), "rb").read()
-                                   for n in ("ref_engine_driver.cpp", "Makefile"))).hexdigest()[:16]
-    try:
-        stamp = open(exe + ".stamp").read().strip()
-    except OSError:
-        stamp = None
-    if stamp != want:
+    ok, want, stamp, exe_sha = ref_engine_stamp(exe, O.ORACLE_DIR)
+    if not ok:
         print(f"cpu_reference: oracle/_ref/wbref_engine is stale or unstamped (stamp {stamp}, tree {want}): the port is the baseline",
               file=sys.stderr)
         return None
-    exe_sha = hashlib.sha256(open(exe, "rb").read()).hexdigest()[:16]
     seed, amp, tracks = track_layout(workload, n_tracks, 0, 1, sample_blocks)
     amp32 = float(np.float32(amp))
     lines = [f"cfg 2 {F} {SR}", "bpm 120.0"]

@@ -116,3 +116,33 @@ def test_rccl_transport_lines_are_recognised(tmp_path):
     assert got["kinds"] == ["net:IB", "p2p", "shm", "socket"] and got["lines"] == 5
     assert got["peers"] == {"1": ["p2p"], "2": ["shm"], "3": ["socket"], "4": ["net:IB"]}
     assert bench.parse_rccl_transports(str(tmp_path / "absent.log"), 0)["kinds"] == []
+
+
+def test_a_stale_reference_executable_is_refused(tmp_path):
+    """bench.py's CPU baseline times oracle/_ref/wbref_engine, a prebuilt, untracked file that travels with the tree: it is taken
+    only when the stamp oracle/Makefile left beside it is the hash of THIS tree's driver source + recipe (advisor, round 5) — a
+    build of an older driver, an unstamped copy or a missing file fall back to the port."""
+    import hashlib
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_stamp", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    od = tmp_path / "oracle"
+    (od / "_ref").mkdir(parents=True)
+    (od / "ref_engine_driver.cpp").write_text("// driver v2\n")
+    (od / "Makefile").write_text("all:\n")
+    exe = od / "_ref" / "wbref_engine"
+    want = hashlib.sha256(b"// driver v2\nall:\n").hexdigest()[:16]
+    assert b.ref_engine_stamp(str(exe), str(od)) == (False, want, None, None)                 # nothing there
+    exe.write_bytes(b"\x7fELF...")
+    assert b.ref_engine_stamp(str(exe), str(od))[:3] == (False, want, None)                   # unstamped
+    (od / "_ref" / "wbref_engine.stamp").write_text("0123456789abcdef\n")
+    assert b.ref_engine_stamp(str(exe), str(od))[:3] == (False, want, "0123456789abcdef")     # built from another driver / recipe
+    (od / "_ref" / "wbref_engine.stamp").write_text(want + "\n")
+    ok, w, st, sha = b.ref_engine_stamp(str(exe), str(od))
+    assert ok and st == want and sha == hashlib.sha256(b"\x7fELF...").hexdigest()[:16]
+    # ... and the tree's own executable, where it has been built, carries the tree's stamp
+    real = os.path.join(root, "oracle", "_ref", "wbref_engine")
+    if os.path.exists(real):
+        assert b.ref_engine_stamp(real, os.path.join(root, "oracle"))[0]
