@@ -916,7 +916,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
         const int k = __builtin_amdgcn_readfirstlane((int)r.kind);
         const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.format) == FMT_I16 ? 1u : 2u;
         // (EXP: a partial stream call starts at the lane's first frame INSIDE the call, clamped into it)
-        const uint32_t cf0 = (EXP && r.partial) ? (uint32_t)call_frame(0u, r.d, r.n) : j0;
+        const uint32_t cf0 = (EXP && r.partial) ? (uint32_t)part_cf0(r) : j0;   // (may be a negative frame: fast_part)
         const double x0 = __dadd_rn(r.pos, __dmul_rn((EXP && r.partial) ? (double)(int32_t)cf0 : j0d, r.speed));   // sampler.cpp:50
         const bool win = k == KIND_WINDOW || k == KIND_WINDOW_I16;
         const int ix0 = win ? (int)x0 : (int)((uint32_t)r.pos + cf0);                     // :51 / :107
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
       // normalised to fp32 (the linear path's normalisers sampler.cpp:9-14 for window rows, the unity path's with their
       // clamp :109-144 for unity rows), then the general masked arithmetic.  `packed16`: the 16-bit samples arrived packed
       // (v.x, v.y = samples 0..3, w4 = sample 4 in its low half)
-      auto partial_any = [&](const Pre& p, int k, uint32_t fmt, bool packed16) {
+      auto partial_any = [&](auto narrow, const Pre& p, int k, uint32_t fmt, bool packed16) {
         const bool unity = k == KIND_UNITY || k == KIND_UNITY_I16 || k == KIND_UNITY_I32;
         Pre f = p;
         if (packed16) {
@@ -1025,6 +1025,17 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
               f.w[ch].w4 = (float)__dmul_rn(norm, (double)__float_as_int(p.w[ch].w4));
             }
           }
+        }
+        if (fast_part(r)) {   // the cheap form (fast_part above): the unmasked arithmetic of a whole-wave call + frame masks
+          Row mm;
+          if (unity) {
+#pragma unroll
+            for (int ch = 0; ch < CL; ch++) mm.c[ch] = row_f32(f.w[ch].v, cg, gc[ch]);
+          } else {
+            mm = row_window_at(narrow, std::true_type{}, std::false_type{}, f, r.pos, r.speed, (double)r.d, cg, gc);
+          }
+          if (!(r.d <= wave_base && r.d + r.n >= wave_end)) mask_row(mm, r.d, r.n);
+          return mm;
         }
         return row_window_masked(f, r.pos, r.speed, unity, r.d, r.n, cg, gc);
       };
@@ -1047,7 +1058,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
 #pragma unroll
             for (int ch = 0; ch < CL; ch++) m.c[ch] = f4{0.0f, 0.0f, 0.0f, 0.0f};
           } else if (G && (fmt != FMT_F32 || k == KIND_UNITY_I32)) {   // 24 / 32-bit PCM (G instances only)
-            if constexpr (G) m = partial_any(pre[u], k, fmt, false);
+            if constexpr (G) m = partial_any(narrow, pre[u], k, fmt, false);
           } else if (const bool all = r.d <= wave_base && r.d + r.n >= wave_end; all || fast_part(r)) {
             // ... all of this wave's frames — or some, of a call that starts deep enough in its clip: the same arithmetic + masks
             if (k == KIND_WINDOW)
@@ -1104,7 +1115,7 @@ __device__ __forceinline__ void mix_body(const MixArgs& a) {
 #pragma unroll
               for (int ch = 0; ch < CL; ch++) q.w[ch].w4 = pre[u].w[ch].v.z;   // the fifth sample of a 16-bit window: low half of the third dword
             }
-            m = partial_any(q, k, fmt, p16);
+            m = partial_any(narrow, q, k, fmt, p16);
           }
         } else if (k == KIND_WINDOW_I16) {
           Pre q = pre[u];
