@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void callback_kernel(MixArgs a, PlanArgs p,
       uint32_t n = cb_arrive(cb.done, wg, tid) - cb.base;
       if (cb.spread) {   // wait for the others (all resident: the host spreads only grids of at most one workgroup per CU)
         uint32_t spins = 0u;
-        // (bounded: ~50 ms, a thousand times what the slowest workgroup of a block takes; a give-up is reported — elect[1] and
-        //  the pinned gave_up word, below — never a hang: the host mixes the block again through three launches and the context
-        //  stops spreading)
+        // (bounded: ~50 ms, a thousand times what the slowest workgroup of a block takes; a give-up is reported — with the second
+        //  ticket and the pinned gave_up word, below — never a hang: the host mixes the block again through three launches and
+        //  the context stops spreading)
         while (n < cb.n_wgs && spins < cb.spin_bound) {
           __builtin_amdgcn_s_sleep(1);
           n = cb_total(cb.done, tid) - cb.base;
